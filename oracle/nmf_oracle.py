@@ -1,0 +1,450 @@
+"""CPU oracle for the proxmin NMF/CMF hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement of the algorithm that `proxmin.nmf.nmf()` runs in the
+reference (pmelchior/proxmin v0.6.12), specialised to the two-block problem X = (A, S):
+
+    minimise  1/2 * || Y - A S ||_F^2     subject to prox_A / prox_S / proxs_g constraints
+
+It exists so that the HIP path in `proxmin_amd/` can be checked against something that was
+itself pinned to the reference: `tests/golden/make_golden.py` imports the real reference in the
+build container, runs it on seeded inputs, and commits the inputs + outputs as `.npz` fixtures;
+`tests/test_oracle_golden.py` checks THIS file against those fixtures (fp64, ~1e-12).
+Parity status: PINNED (fixtures generated from the reference itself, see tests/golden/README.md).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  Nothing under `proxmin_amd/` imports it, and the product path never falls back to it.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+Constraints are described by *prox specs* -- plain tuples, e.g. ("plus",), ("unity_plus", 0),
+("soft", 0.01, "relative") -- rather than by Python callables, so that the oracle shares no
+code with either the reference or the product package.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# proximal operators                                   (proxmin/operators.py:20-160)
+# --------------------------------------------------------------------------------------
+
+PROX_NAMES = (
+    "id", "zero", "plus", "unity", "unity_plus", "min", "max",
+    "hard", "hard_plus", "soft", "soft_plus",
+)
+
+
+def _threshold(step, thresh, kind):
+    """operators.py:4-14 + the `type` switch repeated in :62-66, :79-83, :120-124, :145-149.
+
+    "relative": the threshold is multiplied by the step the solver hands to the prox
+    (a scalar for pgm/bsdmm, a (K,) / (K,1) array for adaprox); "absolute": used as is.
+    """
+    if kind not in ("relative", "absolute"):
+        raise AssertionError(kind)
+    return thresh * step if kind == "relative" else thresh
+
+
+def apply_prox(X, step, spec):
+    """Evaluate one proximal operator, returning a NEW array (the reference mutates in place
+    and returns its argument; every caller on the nmf() path immediately stores the result,
+    so value semantics are equivalent).  `spec` is None/("id",) or one of PROX_NAMES.
+    """
+    if spec is None:
+        return np.array(X, copy=True)
+    name = spec[0]
+    if name == "id":                                   # operators.py:20-23
+        return np.array(X, copy=True)
+    if name == "zero":                                 # operators.py:26-30
+        return np.zeros_like(X)
+    if name == "plus":                                 # operators.py:33-38  X[X<0] = 0
+        return np.where(X < 0, np.zeros((), X.dtype), X)
+    if name == "unity":                                # operators.py:41-45  rescale, no guard
+        axis = spec[1] if len(spec) > 1 else 0
+        return (X / np.sum(X, axis=axis, keepdims=True)).astype(X.dtype, copy=False)
+    if name == "unity_plus":                           # operators.py:48-52  plus, then unity
+        axis = spec[1] if len(spec) > 1 else 0
+        P = np.where(X < 0, np.zeros((), X.dtype), X)
+        return (P / np.sum(P, axis=axis, keepdims=True)).astype(X.dtype, copy=False)
+    thresh = spec[1] if len(spec) > 1 else 0
+    kind = spec[2] if len(spec) > 2 else "relative"
+    t = _threshold(step, thresh, kind)
+    if name == "min":                                  # operators.py:55-68  X[X-t<0] = t
+        return np.where(X - t < 0, t, X).astype(X.dtype, copy=False)
+    if name == "max":                                  # operators.py:71-84  X[X-t>0] = t
+        return np.where(X - t > 0, t, X).astype(X.dtype, copy=False)
+    if name == "hard":                                 # operators.py:109-124 |X|<t -> 0
+        return np.where(np.abs(X) < t, 0, X).astype(X.dtype, copy=False)
+    if name == "hard_plus":                            # operators.py:127-135
+        H = np.where(np.abs(X) < t, 0, X)
+        return np.where(H < 0, 0, H).astype(X.dtype, copy=False)
+    if name == "soft":                                 # operators.py:138-150 sign*max(|X|-t,0)
+        mag = np.abs(X) - t
+        return (np.sign(X) * np.where(mag < 0, 0, mag)).astype(X.dtype, copy=False)
+    if name == "soft_plus":                            # operators.py:153-160
+        mag = np.abs(X) - t
+        Sx = np.sign(X) * np.where(mag < 0, 0, mag)
+        return np.where(Sx < 0, 0, Sx).astype(X.dtype, copy=False)
+    raise ValueError("unknown prox spec %r" % (spec,))
+
+
+def apply_prox_sequence(X, step, specs, repeat=1):
+    """operators.AlternatingProjections.__call__ (operators.py:203-211): the list is applied
+    LAST-to-first, `repeat` times."""
+    out = np.array(X, copy=True)
+    for _ in range(repeat):
+        for spec in reversed(list(specs)):
+            out = apply_prox(out, step, spec)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# likelihood, gradient, step rules                          (proxmin/nmf.py:13-93)
+# --------------------------------------------------------------------------------------
+
+def half_sq_residual(A, S, Y):
+    """nmf.log_likelihood with W=1 (nmf.py:13-25): 1/2 * sum (Y - A S)^2."""
+    D = Y - A @ S
+    return np.sum(D * D) / 2
+
+
+def residual_gradients(A, S, Y):
+    """nmf.grad_likelihood with W=1 (nmf.py:28-41): R = A S - Y; (R S^T, A^T R)."""
+    R = A @ S
+    R -= Y
+    return R @ S.T, A.T @ R
+
+
+def gram_lambda_max(L):
+    """utils.get_spectral_norm for a dense L (utils.py:14-35): largest eigenvalue of L^T L.
+    The reference calls the general `eigvals` and takes the real part of the max; L^T L is
+    symmetric PSD so the symmetric solver returns the same number to rounding."""
+    G = L.T @ L
+    return np.linalg.eigvalsh(G)[-1]
+
+
+def lipschitz_steps(A, S):
+    """nmf.step_pgm, W==1 branch (nmf.py:44-65): (1/lmax(S S^T), 1/lmax(A^T A))."""
+    return 1 / gram_lambda_max(S.T), 1 / gram_lambda_max(A)
+
+
+def adaprox_steps(A, S):
+    """nmf.step_adaprox (nmf.py:91-93): per-component steps, shapes (K,) and (K,1)."""
+    return np.mean(A, axis=0) / 10, S.mean(axis=1)[:, None] / 10
+
+
+def nesterov_omegas(n, accelerated=True):
+    """utils.NesterovAccelerator (utils.py:193-206): the omega returned at the n first reads.
+    First read returns 0 (t=1), then (t-1)/t_next with t_next = (1+sqrt(4t^2+1))/2."""
+    out, t = [], 1.0
+    for _ in range(n):
+        if not accelerated:
+            out.append(0.0)
+            continue
+        t_next = 0.5 * (1 + math.sqrt(4 * t * t + 1))
+        out.append((t - 1) / t_next)
+        t = t_next
+    return out
+
+
+class BBStepper:
+    """utils.BarzilaiBorweinStepper (utils.py:209-241), returning a tuple (the reference
+    returns an ndarray for it>=1 which two-block pgm cannot consume)."""
+
+    def __init__(self, kind=1, init_r=0.1):
+        assert kind in (1, 2)
+        self.kind, self.r = kind, init_r
+
+    def step(self, X, it, grads):
+        nb = len(X)
+        if it == 0:                                                    # utils.py:218-222
+            self.delta = [np.inf] * nb
+            self.prevX = [x.copy() for x in X]
+            self.prevG = grads
+            return tuple(self.r * np.max(np.abs(X[j])) / np.max(np.abs(grads[j])) for j in range(nb))
+        dX = [X[j] - self.prevX[j] for j in range(nb)]                 # utils.py:225-226
+        dG = [grads[j] - self.prevG[j] for j in range(nb)]
+        self.prevX = [x.copy() for x in X]
+        self.prevG = grads
+        out = []
+        for j in range(nb):
+            ss, sy, yy = np.sum(dX[j] ** 2), np.sum(dX[j] * dG[j]), np.sum(dG[j] ** 2)
+            a = ss / sy if self.kind == 1 else sy / yy                 # utils.py:231-234
+            if it <= 3:                                                # utils.py:237-238
+                self.delta[j] = min(self.delta[j], math.sqrt(ss))
+            stab = self.delta[j] / math.sqrt(np.sum(grads[j] ** 2))    # utils.py:239
+            out.append(min(abs(a), stab))                              # utils.py:241
+        return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
+# PGM / FISTA                                          (proxmin/algorithms.py:12-144)
+# --------------------------------------------------------------------------------------
+
+def _sumsq(x):
+    return (x ** 2).sum()                               # utils.l2sq, utils.py:257-260
+
+
+def pgm_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, accelerated=False,
+            backtracking=False, max_iter=1000, e_rel=1e-3, callback=None, trace=None):
+    """`nmf(Y, A, S, algorithm=pgm, ...)` (nmf.py:150-162 -> algorithms.py:12-144).
+
+    A and S are updated in place.  `step`: None -> lipschitz_steps evaluated at the
+    (extrapolated) point, like the reference's default; or a callable (A, S, it, grads) ->
+    (sA, sS).  Returns (converged(2), (gA, gS), (sA, sS), n_iter) -- the reference returns
+    the first three (algorithms.py:144); n_iter is what it logs (:140).
+    `trace`, if a list, receives (A.copy(), S.copy()) BEFORE each update, i.e. what the
+    reference's callback sees (algorithms.py:90).
+    """
+    X = [A, S]
+    specs = [prox_A, prox_S]
+    e = (e_rel, e_rel) if np.isscalar(e_rel) else tuple(e_rel)
+    T = [1.0, 1.0]
+    omegas = nesterov_omegas(max_iter, accelerated)
+    prev = None
+    conv = (False, False)
+    G = St = None
+    f_prev = None
+    n_done = 0
+    for it in range(max_iter):
+        n_done = it + 1
+        if trace is not None:
+            trace.append((A.copy(), S.copy()))
+        if callback is not None:
+            try:
+                callback(A, S, it=it)
+            except StopIteration:
+                break
+        om = omegas[it]                                                # algorithms.py:93
+        if om > 0:
+            E = [X[j] + om * (X[j] - prev[j]) for j in range(2)]       # :95
+        else:
+            E = [X[j].copy() for j in range(2)]                        # :96-99 (alias/copy)
+        prev = [x.copy() for x in X]                                   # :102
+        G = residual_gradients(E[0], E[1], Y)                          # :105
+        St = lipschitz_steps(E[0], E[1]) if step is None else tuple(step(E[0], E[1], it, G))  # :106
+        for j in range(2):                                             # :107-108
+            X[j][:] = apply_prox(E[j] - T[j] * St[j] * G[j], T[j] * St[j], specs[j])
+        if backtracking:                                               # :110-127
+            f_now = half_sq_residual(A, S, Y)
+            if it == 0:
+                f_prev = half_sq_residual(prev[0], prev[1], Y)
+
+            def quad():
+                return sum(np.sum((X[j] - prev[j]) * G[j]) + 0.5 / (T[j] * St[j]) * np.sum((X[j] - prev[j]) ** 2)
+                           for j in range(2))
+            while f_now > f_prev + quad():
+                jmax = int(np.argmax([np.max(np.abs(St[j] * G[j])) / np.max(np.abs(prev[j])) for j in range(2)]))
+                T[jmax] /= 2
+                X[jmax][:] = apply_prox(E[jmax] - T[jmax] * St[jmax] * G[jmax], T[jmax] * St[jmax], specs[jmax])
+                f_now = half_sq_residual(A, S, Y)
+            f_prev = f_now
+        conv = tuple(bool(_sumsq(X[j] - prev[j]) <= e[j] ** 2 * _sumsq(X[j])) for j in range(2))  # :130-133
+        if all(conv):
+            break
+    return conv, G, St, n_done
+
+
+# --------------------------------------------------------------------------------------
+# adaptive proximal gradient (Adam family)             (proxmin/algorithms.py:147-423)
+# --------------------------------------------------------------------------------------
+
+SCHEMES = ("adam", "nadam", "amsgrad", "padam", "adamx", "radam")
+
+
+def moment_update(scheme, it, G, M, V, Vhat, b1, b2, eps, p):
+    """The six `_*_phi_psi` functions (algorithms.py:147-245).  M and V are updated in place;
+    Vhat is updated in place when it is an array and left alone when it is None (the
+    reference rebinds a LOCAL name in that case, :176-177/:193-194/:210-211, so a cold start
+    never accumulates a running maximum).  `b1` is the per-iteration array (:327-330).
+    Returns (Phi, Psi)."""
+    b1t = b1[it]
+    M[:] = (1 - b1t) * G + b1t * M                                     # e.g. :149
+    V[:] = (1 - b2) * (G ** 2) + b2 * V                                # e.g. :150
+    t = it + 1
+    if scheme == "adam":                                               # :147-156
+        return M / (1 - b1t ** t), np.sqrt(V / (1 - b2 ** t)) + eps
+    if scheme == "nadam":                                              # :158-167
+        return (b1t * M + (1 - b1t) * G) / (1 - b1t ** t), np.sqrt(V / (1 - b2 ** t)) + eps
+    if scheme in ("amsgrad", "padam", "adamx"):                        # :170-221
+        if Vhat is None:
+            cap = V
+        else:
+            if scheme == "adamx":
+                factor = (1 - b1t) ** 2 / (1 - b1[it - 1]) ** 2        # :213 (b1[-1] at it=0)
+                Vhat[:] = np.maximum(factor * Vhat, V)
+            else:
+                Vhat[:] = np.maximum(Vhat, V)
+            cap = Vhat
+        if eps > 0:
+            cap = np.maximum(cap, eps)                                 # eps applied to V, not sqrt(V)
+        Psi = cap ** p if scheme == "padam" else np.sqrt(cap)
+        return M, Psi
+    if scheme == "radam":                                              # :224-245
+        rho_inf = 2 / (1 - b2) - 1
+        Phi = M / (1 - b1t ** t)
+        rho = rho_inf - 2 * t * b2 ** t / (1 - b2 ** t)
+        if rho > 4:
+            Psi = np.sqrt(V / (1 - b2 ** t))
+            Psi = Psi / np.sqrt((rho - 4) * (rho - 2) * rho_inf / (rho_inf - 4) / (rho_inf - 2) / rho)
+        else:
+            Psi = np.ones(G.shape, G.dtype)
+        if eps > 0:
+            Psi = np.maximum(Psi, np.sqrt(eps))
+        return Phi, Psi
+    raise AssertionError(scheme)
+
+
+def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="adam",
+                b1=0.9, b2=0.999, eps=1e-8, check_convergence=True, p=0.25, max_iter=1000,
+                e_rel=1e-3, prox_max_iter=1000, M=None, V=None, Vhat=None, callback=None,
+                trace=None):
+    """`nmf(Y, A, S, algorithm=adaprox, ...)` (nmf.py:164-176 -> algorithms.py:248-423).
+
+    Returns (converged, M, V, Vhat, n_iter, sub_iters) -- the reference returns the first
+    four (:423) and logs the last two (:415-417).  prox spec None skips the sub-iteration
+    loop entirely (:380)."""
+    X = [A, S]
+    specs = [prox_A, prox_S]
+    e = (e_rel, e_rel) if np.isscalar(e_rel) else tuple(e_rel)
+    if not hasattr(b1, "__iter__"):
+        b1 = np.array((b1,) * max_iter)                                # :327-328
+    assert len(b1) == max_iter
+    scheme = scheme.lower()
+    assert scheme in SCHEMES
+    if M is None:
+        M = [np.zeros(x.shape, x.dtype) for x in X]                    # :348-349
+    if V is None:
+        V = [np.zeros(x.shape, x.dtype) for x in X]                    # :352-353
+    if Vhat is None:
+        Vhat = [None, None]                                            # :356-357
+    sub = [0, 0]
+    conv = (None, None)
+    n_done = 0
+    for it in range(max_iter):
+        n_done = it + 1
+        if trace is not None:
+            trace.append((A.copy(), S.copy()))
+        if callback is not None:
+            try:
+                callback(A, S, it=it)
+            except StopIteration:
+                break
+        G = residual_gradients(A, S, Y)                                # :369 (Jacobi: both at old X)
+        alpha = adaprox_steps(A, S) if step is None else tuple(step(A, S, it))   # :370
+        prev = [x.copy() for x in X] if check_convergence else None   # :371-372
+        for j in range(2):
+            Phi, Psi = moment_update(scheme, it, G[j], M[j], V[j], Vhat[j], b1, b2, eps, p)
+            X[j][:] -= alpha[j] * Phi / Psi                            # :378
+            if specs[j] is not None:
+                z = X[j].copy()                                        # :383
+                gamma = alpha[j] / np.max(Psi)                         # :384
+                tau = 0
+                for tau in range(1, prox_max_iter + 1):                # :386-393
+                    z_new = apply_prox(z - gamma / alpha[j] * Psi * (z - X[j]), gamma, specs[j])
+                    done = _sumsq(z_new - z) <= e[j] ** 2 * _sumsq(z)
+                    z = z_new
+                    if done:
+                        break
+                sub[j] += tau
+                X[j][:] = z                                            # :400
+        if check_convergence:                                          # :403-410
+            conv = tuple(bool(_sumsq(X[j] - prev[j]) <= e[j] ** 2 * _sumsq(X[j])) for j in range(2))
+            if all(conv):
+                break
+    if not check_convergence:
+        conv = (None, None)                                            # :420-421
+    return conv, M, V, Vhat, n_done, sub
+
+
+# --------------------------------------------------------------------------------------
+# block-SDMM                      (proxmin/algorithms.py:653-850, proxmin/utils.py:244-391)
+# --------------------------------------------------------------------------------------
+
+def _l2(x):
+    return math.sqrt(float((x ** 2).sum()))             # utils.l2, utils.py:263-266
+
+
+def bsdmm_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), proxs_g=None, max_iter=1000,
+              e_rel=1e-3, e_abs=0, callback=None, trace=None, state=None):
+    """`nmf(Y, A, S, algorithm=bsdmm, proxs_g=...)` (nmf.py:178-203 -> algorithms.py:653-850)
+    for the only configuration nmf() can reach without crashing: step=None, Ls=None (identity
+    adapters, spectral norm 1: utils.py:56-59,70-74), steps_g_update="steps_f".
+
+    proxs_g: None, or [gA, gS] where each entry is None or a list of prox specs.
+    Returns (converged(list of 2 bools), n_iter).  If `state` is a dict it receives the final
+    Z and U lists (lost by the reference) for kernel-level comparisons."""
+    X = [A, S]
+    specs_f = [prox_A, prox_S]
+    if proxs_g is None:
+        proxs_g = [None, None]
+    proxs_g = [None if g is None else list(g) for g in proxs_g]
+    er = [e_rel] * 2 if np.isscalar(e_rel) else list(e_rel)
+    ea = [e_abs] * 2 if np.isscalar(e_abs) else list(e_abs)
+    nblk = 2
+    ncon = [0 if g is None else len(g) for g in proxs_g]
+    # utils.initZU (utils.py:244-254): Z_i = copy of X, U_i = 0
+    Z = [[X[j].copy() for _ in range(max(ncon[j], 0))] if proxs_g[j] is not None else X[j].copy() for j in range(2)]
+    U = [[np.zeros_like(X[j]) for _ in range(ncon[j])] if proxs_g[j] is not None else np.zeros_like(X[j]) for j in range(2)]
+    conv = [None, None]
+    it = 0
+    while it < max_iter:                                               # algorithms.py:800
+        if trace is not None:
+            trace.append((A.copy(), S.copy()))
+        if callback is not None:
+            callback(A, S, it=it)                                      # no StopIteration handler (:802)
+        for j in range(2):                                             # Gauss-Seidel (:805)
+            sf = lipschitz_steps(X[0], X[1])[j]                        # nmf.py:187-193, slack == 1
+            Gj = residual_gradients(X[0], X[1], Y)[j]                  # nmf.py:181-185 (current Xs)
+            n_el = X[j].size
+            if proxs_g[j] is None:                                     # utils.py:319-327
+                old = X[j].copy()
+                X[j][:] = apply_prox(X[j] - sf * Gj, sf, specs_f[j])
+                Z[j][:] = X[j]
+                lR = 0.0
+                lS = _l2(X[j] - old)
+                # get_variable_errors with step_g=None (utils.py:349-363); U stays 0
+                e_pri = math.sqrt(Z[j].size) * ea[j] + er[j] * max(_l2(X[j]), _l2(Z[j]))
+                e_dual = math.sqrt(n_el) * ea[j] + er[j] * _l2(U[j])
+                conv[j] = (lR <= e_pri) and (lS <= e_dual)
+            else:
+                sg = [sf * 1 * nblk * ncon[j]] * ncon[j]               # get_step_g, utils.py:269-279
+                dX = np.sum([sf / sg[i] * (X[j] - Z[j][i] + U[j][i]) for i in range(ncon[j])], axis=0)  # utils.py:330-336
+                X[j][:] = apply_prox((X[j] - dX) - sf * Gj, sf, specs_f[j])   # utils.py:338 + nmf.py:185
+                ok = True
+                for i in range(ncon[j]):                               # do_the_mm, utils.py:295-304
+                    Znew = apply_prox(X[j] + U[j][i], sg[i], proxs_g[j][i])
+                    R = X[j] - Znew
+                    Sd = -1 / sg[i] * (Znew - Z[j][i])
+                    Z[j][i][:] = Znew
+                    U[j][i][:] += R
+                    e_pri = math.sqrt(Z[j][i].size) * ea[j] + er[j] * max(_l2(X[j]), _l2(Z[j][i]))
+                    e_dual = math.sqrt(n_el) * ea[j] + er[j] * _l2(U[j][i] / sg[i])
+                    ok &= (_l2(R) <= e_pri) and (_l2(Sd) <= e_dual)    # utils.py:386-390
+                conv[j] = bool(ok)
+        it += 1
+        if all(conv):
+            break
+    if state is not None:
+        state["Z"], state["U"] = Z, U
+    return [bool(c) for c in conv], it
+
+
+# --------------------------------------------------------------------------------------
+# seeded synthetic problems
+# --------------------------------------------------------------------------------------
+
+def synthetic_problem(M, N, K, dtype=np.float32, unity_S=False, seed=1234, noise=0.01):
+    """The generator every parity test / bench leg uses (the reference has no generator on
+    this path; examples/unmixing.py:102-115 is the model).  Returns Y, A0, S0."""
+    rng = np.random.default_rng(seed)
+    At = rng.random((M, K), dtype=np.float32) if dtype == np.float32 else rng.random((M, K))
+    St = rng.random((K, N), dtype=np.float32) if dtype == np.float32 else rng.random((K, N))
+    if unity_S:
+        St /= St.sum(0, keepdims=True)
+    Y = (At @ St + noise * rng.standard_normal((M, N))).astype(dtype)
+    A0 = rng.random((M, K)).astype(dtype)
+    S0 = rng.random((K, N)).astype(dtype)
+    if unity_S:
+        S0 /= S0.sum(0, keepdims=True)
+    return Y, A0, S0
