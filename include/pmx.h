@@ -1,0 +1,215 @@
+/*
+ * pmx.h -- C ABI of libpmx.so, the MI355X (gfx950) engine behind proxmin_amd.nmf.nmf().
+ *
+ * The reference (pmelchior/proxmin) has no FFI: its boundary is Python callables.  This header
+ * is the boundary a maintainer of the reference would bind with ctypes to move the
+ * `proxmin.nmf.nmf()` path onto the GPU (see INTEGRATION.md for the stub).  Every entry point
+ * names the reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C types only; device memory is owned by the context unless stated otherwise;
+ *   - every function returns PMX_OK (0) or a negative PMX_E_* code; pmx_last_error() gives text;
+ *   - factors are float32 on the device.  A is M x K row-major.  S (K x N in the reference) is
+ *     held TRANSPOSED as St = S^T, N x K row-major, so that both blocks are tall matrices with
+ *     K contiguous components per row (host wrappers transpose on upload/download);
+ *   - "block" j: 0 = A, 1 = S, exactly the order of X = [A, S] in proxmin/nmf.py:147;
+ *   - all launches go to the context's stream; calls that return results synchronise it.
+ */
+#ifndef PMX_H
+#define PMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------- */
+enum {
+    PMX_OK = 0,
+    PMX_E_INVALID = -1,     /* bad argument (the reference would `assert`)                   */
+    PMX_E_HIP = -2,         /* a HIP runtime call failed                                      */
+    PMX_E_NOMEM = -3,
+    PMX_E_UNSUPPORTED = -4, /* valid in the reference but not implemented on the device       */
+    PMX_E_STATE = -5        /* call order (e.g. run before Y/factors were set)                */
+};
+
+/* ---- Y storage / contraction arithmetic ---------------------------------------------- */
+enum {
+    PMX_MODE_F32 = 0,   /* Y fp32 in HBM, A@S / R@S^T / A^T@R on v_mfma_f32_32x32x2_f32 (exact f32) */
+    PMX_MODE_BF16 = 1,  /* Y bf16 in HBM, operands rounded to bf16, fp32 accumulate                  */
+    PMX_MODE_BF16X3 = 2 /* Y fp32 in HBM, operands split hi+lo bf16 (3 MFMA passes), fp32 accumulate */
+};
+
+/* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */
+enum {
+    PMX_PROX_NONE = -1,      /* prox=None: adaprox skips the sub-iteration loop (algorithms.py:380) */
+    PMX_PROX_ID = 0,         /* prox_id          operators.py:20  */
+    PMX_PROX_ZERO = 1,       /* prox_zero        operators.py:26  */
+    PMX_PROX_PLUS = 2,       /* prox_plus        operators.py:33  */
+    PMX_PROX_UNITY = 3,      /* prox_unity       operators.py:41  (axis given in pmx_prox.unit)      */
+    PMX_PROX_UNITY_PLUS = 4, /* prox_unity_plus  operators.py:48  */
+    PMX_PROX_MIN = 5,        /* prox_min         operators.py:55  */
+    PMX_PROX_MAX = 6,        /* prox_max         operators.py:71  */
+    PMX_PROX_HARD = 7,       /* prox_hard        operators.py:109 */
+    PMX_PROX_HARD_PLUS = 8,  /* prox_hard_plus   operators.py:127 */
+    PMX_PROX_SOFT = 9,       /* prox_soft        operators.py:138 */
+    PMX_PROX_SOFT_PLUS = 10  /* prox_soft_plus   operators.py:153 */
+};
+
+/* One proximal operator.  `unit` says which sum prox_unity* normalises by, in DEVICE layout:
+ * 0 = along the K components of one row (numpy axis=1 for A, axis=0 for S),
+ * 1 = along the rows, per component     (numpy axis=0 for A, axis=1 for S).
+ * `relative` = 1 is the reference's type="relative" (threshold multiplied by the step the
+ * solver passes to the prox, operators.py:4-14), 0 is type="absolute". */
+typedef struct pmx_prox {
+    int32_t op;
+    int32_t unit;
+    float thresh;
+    int32_t relative;
+} pmx_prox;
+
+#define PMX_MAX_SEQ 4 /* AlternatingProjections of up to 4 built-ins (operators.py:187-211) */
+#define PMX_MAX_G 4   /* constraints per block for bsdmm                                      */
+
+/* A (possibly composite) operator: seq[0..n-1] applied in the order stored, `repeat` times.
+ * (The host wrapper reverses AlternatingProjections' list, which applies last-to-first.) */
+typedef struct pmx_proxseq {
+    int32_t n;      /* 0 => PMX_PROX_NONE */
+    int32_t repeat; /* >= 1 */
+    pmx_prox seq[PMX_MAX_SEQ];
+} pmx_proxseq;
+
+/* ---- adaprox moment schemes: proxmin/algorithms.py:147-245 ----------------------------- */
+enum { PMX_ADAM = 0, PMX_NADAM = 1, PMX_AMSGRAD = 2, PMX_PADAM = 3, PMX_ADAMX = 4, PMX_RADAM = 5 };
+
+/* ---- device buffers addressable through pmx_upload / pmx_download ---------------------- */
+enum {
+    PMX_BUF_A = 0,   /* M x K                         */
+    PMX_BUF_ST = 1,  /* N x K  (S transposed)         */
+    PMX_BUF_GA = 2,  /* last gradient wrt A, M x K    (pgm return value, algorithms.py:144) */
+    PMX_BUF_GST = 3, /* last gradient wrt S^T, N x K  */
+    PMX_BUF_MA = 4, PMX_BUF_MST = 5,   /* adaprox first moments  (algorithms.py:348-349)  */
+    PMX_BUF_VA = 6, PMX_BUF_VST = 7,   /* adaprox second moments (algorithms.py:352-353)  */
+    PMX_BUF_VHA = 8, PMX_BUF_VHST = 9, /* adaprox Vhat (only when warm-started, :356-359) */
+    PMX_BUF_Z0 = 16, /* + block*PMX_MAX_G + i : bsdmm Z_i of block (utils.py:244-254)     */
+    PMX_BUF_U0 = 32  /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
+};
+
+typedef struct pmx_ctx pmx_ctx;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int pmx_abi_version(void);
+const char* pmx_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails) */
+int pmx_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------------
+ * One context = one nmf() call's device state on one GPU: Y (M x N, this rank's rows), the
+ * factors and the solver state.  `stream` is a hipStream_t to launch on (e.g. torch's current
+ * stream) or NULL to create a private one.  Replaces the closure set-up of nmf.py:146-148. */
+int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, int64_t K, int mode, void* stream);
+int pmx_ctx_destroy(pmx_ctx* ctx);
+int pmx_ctx_sync(pmx_ctx* ctx);
+
+/* Y: copy from host (row-major float32, leading dimension ld elements) or adopt/convert a
+ * device buffer (float32, row-major).  With PMX_MODE_BF16 the data is converted to bf16 on
+ * the device.  `copy`=0 adopts the fp32 device pointer without copying (caller keeps it
+ * alive).  Y is read-only for the solvers (nmf.py:116). */
+int pmx_set_Y_host(pmx_ctx* ctx, const float* Y, int64_t ld);
+int pmx_set_Y_device(pmx_ctx* ctx, const float* dY, int64_t ld, int copy);
+
+/* raw float32 transfers host <-> one of the PMX_BUF_* arrays (count = number of floats) */
+int pmx_upload(pmx_ctx* ctx, int buf, const float* host, int64_t count);
+int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
+/* device address of a buffer (for zero-copy interop, e.g. torch.distributed on the comm buffer) */
+int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
+
+/* ---- single operations (unit parity tests, and what the reference exposes as functions) --- */
+/* nmf.grad_likelihood, W=1 (nmf.py:28-41): gradients at the current A, St into GA / GST.     */
+int pmx_grad(pmx_ctx* ctx);
+/* nmf.log_likelihood, W=1 (nmf.py:13-25): 1/2 sum (Y - A S)^2 at the current factors.        */
+int pmx_loglike(pmx_ctx* ctx, double* out);
+/* nmf.step_pgm, W==1 branch (nmf.py:44-65): out[0] = 1/lmax(S S^T), out[1] = 1/lmax(A^T A). */
+int pmx_step_pgm(pmx_ctx* ctx, double out[2]);
+/* nmf.step_adaprox (nmf.py:91-93): out[0..K) = mean(A,0)/10, out[K..2K) = mean(S,1)/10.      */
+int pmx_step_adaprox(pmx_ctx* ctx, float* out);
+/* apply one operator to a device buffer in place, as `prox(X, step)` would (operators.py).
+ * step_k: K per-component steps (scalar steps: K copies). block selects rows (M or N).        */
+int pmx_prox_apply(pmx_ctx* ctx, int buf, const pmx_proxseq* prox, const float* step_k);
+/* context-free variant: `prox(X, step)` on a HOST array X (rows x K float32, K <= 128, updated in
+ * place): copies to the device, runs the operator kernel, copies back.  This is what calling
+ * proxmin.operators.prox_* directly on an ndarray maps to. */
+int pmx_prox_array(int device, float* X, int64_t rows, int K, const pmx_proxseq* prox, const float* step_k);
+
+/* ---- solvers ------------------------------------------------------------------------------
+ * Each *_run advances at most `n_iter` iterations from the current device state and returns
+ * after the stream is idle.  They can be called repeatedly (the host wrapper calls them with
+ * n_iter=1 when a user callback wants to see every iterate, algorithms.py:90/368/802).       */
+
+typedef struct pmx_pgm_params { /* algorithms.pgm arguments, algorithms.py:12-23 */
+    pmx_proxseq prox[2];
+    int32_t accelerated;  /* Nesterov/FISTA extrapolation (utils.py:193-206) */
+    float step_scale;     /* multiplies the Lipschitz steps of nmf.step_pgm (1 = reference default) */
+    int32_t use_fixed_steps; /* 1: use fixed_steps[] instead of the Lipschitz rule (user `step`) */
+    double fixed_steps[2];
+    double e_rel[2];      /* algorithms.py:66-68 */
+} pmx_pgm_params;
+
+typedef struct pmx_result {
+    int32_t iterations;   /* iterations executed by THIS call                                 */
+    int32_t total_iterations; /* since pmx_*_begin                                             */
+    int32_t stopped;      /* 1 if the convergence test ended the run (algorithms.py:134)      */
+    int32_t converged[2]; /* last evaluated per-block test                                    */
+    double steps[2];      /* pgm/bsdmm: last step sizes (algorithms.py:144)                   */
+    int64_t sub_iterations[2]; /* adaprox: accumulated proximal sub-iterations (:398)         */
+} pmx_result;
+
+int pmx_pgm_begin(pmx_ctx* ctx, const pmx_pgm_params* p);
+int pmx_pgm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
+
+typedef struct pmx_adaprox_params { /* algorithms.adaprox arguments, algorithms.py:248-265 */
+    pmx_proxseq prox[2];
+    int32_t scheme;
+    double b2, eps, p;
+    int32_t check_convergence;
+    int32_t prox_max_iter;
+    int32_t warm_vhat;    /* 1: Vhat buffers were uploaded (true AMSGrad/PAdam/AdamX running max) */
+    int32_t use_fixed_steps; /* 1: alpha = fixed_alpha (user `step` returning constants)       */
+    double fixed_alpha[2];
+    double e_rel[2];
+} pmx_adaprox_params;
+
+int pmx_adaprox_begin(pmx_ctx* ctx, const pmx_adaprox_params* p, int warm_moments);
+/* b1: n_iter values b1[it] for the iterations of this call (algorithms.py:327-330);
+ * b1_prev: b1[it-1] for the first of them (adamx, :213; the reference reads b1[-1] at it=0). */
+int pmx_adaprox_run(pmx_ctx* ctx, int n_iter, const double* b1, double b1_prev, pmx_result* res);
+
+typedef struct pmx_bsdmm_params { /* algorithms.bsdmm as reachable from nmf(), algorithms.py:653-666 */
+    pmx_proxseq prox_f[2];              /* prox_A, prox_S inside prox_f (nmf.py:181-185)       */
+    int32_t n_g[2];                     /* constraints per block; 0 = proxs_g[j] is None       */
+    pmx_proxseq prox_g[2][PMX_MAX_G];
+    double e_rel[2], e_abs[2];
+} pmx_bsdmm_params;
+
+int pmx_bsdmm_begin(pmx_ctx* ctx, const pmx_bsdmm_params* p);
+int pmx_bsdmm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
+
+/* ---- row-sharded multi-GPU --------------------------------------------
+ * With rows of Y/A split over ranks, an iteration is: phase 0 (local K1 + pack the values that
+ * need a cross-rank sum into the comm buffer), one all-reduce(sum) of the comm buffer done by the
+ * caller (torch.distributed / RCCL), phase 1 (update).  world > 1 only changes which kernels read
+ * the comm buffer; the kernels are the same ones the *_run entry points launch. */
+int pmx_set_world(pmx_ctx* ctx, int rank, int world, int64_t M_global);
+int pmx_comm_buffer(pmx_ctx* ctx, void** dptr, int64_t* count_floats);
+int pmx_pgm_phase(pmx_ctx* ctx, int phase);
+int pmx_adaprox_phase(pmx_ctx* ctx, int phase, double b1_it, double b1_prev);
+int pmx_iter_result(pmx_ctx* ctx, pmx_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMX_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libpmx.so (the C ABI declared in include/pmx.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950) and
+lives next to this file.  There is NO CPU fallback: if the library is missing, or no MI355X is
+visible, the package fails loudly at the first call that needs the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmx.so")
+
+MAX_SEQ = 4
+MAX_G = 4
+MAXK = 128
+ABI_VERSION = 1
+
+# enums (include/pmx.h)
+MODE_F32, MODE_BF16, MODE_BF16X3 = 0, 1, 2
+PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "max": 6,
+        "hard": 7, "hard_plus": 8, "soft": 9, "soft_plus": 10}
+SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}
+BUF_A, BUF_ST, BUF_GA, BUF_GST, BUF_MA, BUF_MST, BUF_VA, BUF_VST, BUF_VHA, BUF_VHST = range(10)
+BUF_Z0, BUF_U0 = 16, 32
+
+
+class Prox(C.Structure):
+    _fields_ = [("op", C.c_int32), ("unit", C.c_int32), ("thresh", C.c_float), ("relative", C.c_int32)]
+
+
+class ProxSeq(C.Structure):
+    _fields_ = [("n", C.c_int32), ("repeat", C.c_int32), ("seq", Prox * MAX_SEQ)]
+
+
+class PgmParams(C.Structure):
+    _fields_ = [("prox", ProxSeq * 2), ("accelerated", C.c_int32), ("step_scale", C.c_float),
+                ("use_fixed_steps", C.c_int32), ("fixed_steps", C.c_double * 2), ("e_rel", C.c_double * 2)]
+
+
+class Result(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("total_iterations", C.c_int32), ("stopped", C.c_int32),
+                ("converged", C.c_int32 * 2), ("steps", C.c_double * 2), ("sub_iterations", C.c_int64 * 2)]
+
+
+class AdaproxParams(C.Structure):
+    _fields_ = [("prox", ProxSeq * 2), ("scheme", C.c_int32), ("b2", C.c_double), ("eps", C.c_double),
+                ("p", C.c_double), ("check_convergence", C.c_int32), ("prox_max_iter", C.c_int32),
+                ("warm_vhat", C.c_int32), ("use_fixed_steps", C.c_int32), ("fixed_alpha", C.c_double * 2),
+                ("e_rel", C.c_double * 2)]
+
+
+class BsdmmParams(C.Structure):
+    _fields_ = [("prox_f", ProxSeq * 2), ("n_g", C.c_int32 * 2), ("prox_g", (ProxSeq * MAX_G) * 2),
+                ("e_rel", C.c_double * 2), ("e_abs", C.c_double * 2)]
+
+
+_SIGNATURES = {
+    "pmx_abi_version": (C.c_int, []),
+    "pmx_last_error": (C.c_char_p, []),
+    "pmx_device_count": (C.c_int, []),
+    "pmx_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "pmx_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "pmx_ctx_sync": (C.c_int, [C.c_void_p]),
+    "pmx_set_Y_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_set_Y_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "pmx_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "pmx_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "pmx_grad": (C.c_int, [C.c_void_p]),
+    "pmx_loglike": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pmx_step_pgm": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pmx_step_adaprox": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pmx_prox_apply": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ProxSeq), C.c_void_p]),
+    "pmx_prox_array": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(ProxSeq), C.c_void_p]),
+    "pmx_pgm_begin": (C.c_int, [C.c_void_p, C.POINTER(PgmParams)]),
+    "pmx_pgm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
+    "pmx_adaprox_begin": (C.c_int, [C.c_void_p, C.POINTER(AdaproxParams), C.c_int]),
+    "pmx_adaprox_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.POINTER(Result)]),
+    "pmx_bsdmm_begin": (C.c_int, [C.c_void_p, C.POINTER(BsdmmParams)]),
+    "pmx_bsdmm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
+    "pmx_set_world": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64]),
+    "pmx_comm_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "pmx_pgm_phase": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_adaprox_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "pmx_iter_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class PmxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpmx.so (once) and attach the signatures.  Raises if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmxError("libpmx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). proxmin_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pmx_abi_version() != ABI_VERSION:
+        raise PmxError("libpmx.so ABI %d != expected %d; rebuild" % (lib.pmx_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().pmx_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise AssertionError(msg)          # the reference validates arguments with `assert`
+        if rc == -4:
+            raise NotImplementedError(msg)
+        raise PmxError("libpmx error %d: %s" % (rc, msg))
+
+
+def require_gpu():
+    lib = load()
+    if lib.pmx_device_count() < 1:
+        raise PmxError("no HIP device visible: proxmin_amd runs only on an MI355X (gfx950); there is no CPU path")
+    return lib

@@ -1,0 +1,285 @@
+"""Solver back-ends of the nmf() path with the reference's signatures (proxmin/algorithms.py:
+pgm :12-23, adaprox :248-265, bsdmm :653-666).  They are the objects `nmf()` compares `algorithm`
+against by identity (nmf.py:141) and the host-side drivers of the device kernel chains.
+
+Scope: the gradient must be the NMF likelihood gradient built by `proxmin_amd.nmf` (a
+`functools.partial(nmf.grad_likelihood, Y=..., W=1)`) -- that is what carries Y to the device --
+and constraints must be operators from `proxmin_amd.operators`.  Generic user `grad` callables are
+outside this build's scope and raise NotImplementedError (no silent CPU fallback).
+"""
+from __future__ import annotations
+
+import logging
+from functools import partial
+
+import numpy as np
+
+from . import _lib, operators, utils
+from .engine import DeviceNMF
+
+logger = logging.getLogger("proxmin")
+
+
+# ---------------------------------------------------------------------------------------------
+def _problem_from_grad(X, grad):
+    from . import nmf as _nmf
+
+    if not (isinstance(grad, partial) and grad.func is _nmf.grad_likelihood and not grad.args):
+        raise NotImplementedError("only the NMF likelihood gradient (functools.partial(proxmin_amd.nmf.grad_likelihood, Y=Y)) "
+                                  "can run on the device; generic `grad` callables are out of scope")
+    kw = grad.keywords
+    _nmf._check_W(kw.get("W", 1))
+    X = utils._as_tuple(X)
+    assert len(X) == 2, "X must be [A, S]"
+    A, S = X
+    Y = np.asarray(kw["Y"])
+    assert A.ndim == 2 and S.ndim == 2 and A.shape[1] == S.shape[0]
+    assert Y.shape == (A.shape[0], S.shape[1]), "Y must be M x N"
+    return Y, A, S
+
+
+def _prox_pair(prox, n=2):
+    prox = utils._as_tuple(prox)
+    if len(prox) == 1:
+        prox = prox * n
+    assert len(prox) == n
+    return prox
+
+
+def _e_rel_pair(e_rel):
+    if np.isscalar(e_rel):
+        e_rel = (e_rel,) * 2
+    assert len(e_rel) == 2
+    return tuple(float(e) for e in e_rel)
+
+
+def _write_back(dev, A, S):
+    dA, dS = dev.get_factors()
+    A[...] = dA
+    S[...] = dS
+
+
+def _wants_iterates(callback):
+    return callback is not None and not isinstance(callback, utils.NullCallback)
+
+
+# ---------------------------------------------------------------------------------------------
+def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None, e_rel=1e-6, max_iter=1000, callback=None):
+    """Proximal Gradient Method / FISTA for the two NMF blocks (algorithms.py:12-144).
+
+    Returns (converged, gradient, step) like the reference.  `step`: the default rule
+    (`partial(nmf.step_pgm, W=1)` / `nmf.step_pgm`), `nmf.scaled_step_pgm(c)` or
+    `nmf.constant_step(a, b)`.
+    """
+    from . import nmf as _nmf
+
+    Y, A, S = _problem_from_grad(X, grad)
+    prox = _prox_pair(prox)
+    # prox=None means prox_id in pgm (algorithms.py:63-64)
+    seqs = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]
+    e_rel = _e_rel_pair(e_rel)
+    assert backtracking is False or f is not None
+    if backtracking:
+        raise NotImplementedError("backtracking line search is not implemented on the device yet")
+    scale, fixed = 1.0, None
+    if isinstance(step, _nmf.scaled_step_pgm):
+        scale = step.scale
+    elif isinstance(step, _nmf.constant_step):
+        fixed = step.steps
+    elif step is _nmf.step_pgm or (isinstance(step, partial) and step.func is _nmf.step_pgm):
+        pass
+    else:
+        raise NotImplementedError("user-defined `step` callables are not supported on the device; use "
+                                  "nmf.scaled_step_pgm(c) or nmf.constant_step(a, b)")
+
+    with DeviceNMF(A.shape[0], S.shape[1], A.shape[1]) as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=fixed, e_rel=e_rel)
+        res = None
+        it_done = 0
+        if _wants_iterates(callback):
+            for it in range(max_iter):
+                try:
+                    callback(A, S, it=it)                       # algorithms.py:90 (pre-update iterate)
+                except StopIteration:
+                    break
+                res = dev.pgm_run(1)
+                _write_back(dev, A, S)
+                it_done = res.total_iterations
+                if res.stopped:
+                    break
+        else:
+            res = dev.pgm_run(max_iter)
+            it_done = res.total_iterations
+            _write_back(dev, A, S)
+        dt = A.dtype
+        G = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
+    converged = tuple(bool(c) for c in res.converged) if res is not None else (False, False)
+    steps = (dt.type(res.steps[0]), dt.type(res.steps[1])) if res is not None else (None, None)
+    logger.info("Completed {0} iterations".format(it_done))
+    if not all(converged):
+        logger.warning("Solution did not converge")
+    return converged, G, steps
+
+
+# ---------------------------------------------------------------------------------------------
+def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8, check_convergence=True, p=0.25,
+            e_rel=1e-6, max_iter=1000, prox_max_iter=1000, M=None, V=None, Vhat=None, callback=None):
+    """Adaptive proximal gradient method, Adam family (algorithms.py:248-423).
+
+    Returns (converged, M, V, Vhat).  As in the reference, a cold start returns Vhat = [None, None]
+    even for amsgrad/padam/adamx (the running maximum is only kept when Vhat arrays are passed in).
+    """
+    from . import nmf as _nmf
+
+    Y, A, S = _problem_from_grad(X, grad)
+    prox = _prox_pair(prox)
+    seqs = [operators.device_proxseq(q, j) for j, q in enumerate(prox)]
+    e_rel = _e_rel_pair(e_rel)
+    if not hasattr(b1, "__iter__"):
+        b1 = np.array((b1,) * max_iter)
+    b1 = np.asarray(b1, dtype=np.float64)
+    assert len(b1) == max_iter
+    assert (b1 >= 0).all() and (b1 < 1).all()
+    assert b2 >= 0 and b2 < 1
+    assert eps >= 0
+    assert p > 0 and p <= 0.5
+    scheme = scheme.lower()
+    assert scheme in ["adam", "nadam", "adamx", "amsgrad", "padam", "radam"]
+    fixed = None
+    if isinstance(step, _nmf.constant_step):
+        fixed = step.steps
+    elif step is not _nmf.step_adaprox:
+        raise NotImplementedError("user-defined `step` callables are not supported on the device; use nmf.constant_step(a, b)")
+
+    Xs = (A, S)
+    warm = M is not None or V is not None
+    if M is not None:
+        assert len(M) == 2 and all(m.shape == x.shape for x, m in zip(Xs, M))
+    if V is not None:
+        assert len(V) == 2 and all(v.shape == x.shape for x, v in zip(Xs, V))
+    if Vhat is not None:
+        assert len(Vhat) == 2 and all(vh.shape == x.shape for x, vh in zip(Xs, Vhat))
+
+    with DeviceNMF(A.shape[0], S.shape[1], A.shape[1]) as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        for j in range(2):
+            if warm:
+                dev.put(_lib.BUF_MA, j, M[j] if M is not None else np.zeros(Xs[j].shape, np.float32))
+                dev.put(_lib.BUF_VA, j, V[j] if V is not None else np.zeros(Xs[j].shape, np.float32))
+            if Vhat is not None:
+                dev.put(_lib.BUF_VHA, j, Vhat[j])
+        dev.adaprox_begin(seqs, scheme=scheme, b2=b2, eps=eps, p=p, check_convergence=check_convergence,
+                          prox_max_iter=prox_max_iter, warm_moments=warm, warm_vhat=Vhat is not None,
+                          fixed_alpha=fixed, e_rel=e_rel)
+        res = None
+        it_done = 0
+        if max_iter > 0:
+            if _wants_iterates(callback):
+                for it in range(max_iter):
+                    try:
+                        callback(A, S, it=it)                   # algorithms.py:368
+                    except StopIteration:
+                        break
+                    res = dev.adaprox_run(b1[it:it + 1], b1[it - 1])   # b1[-1] at it = 0, like algorithms.py:213
+                    _write_back(dev, A, S)
+                    it_done = res.total_iterations
+                    if res.stopped:
+                        break
+            else:
+                res = dev.adaprox_run(b1, b1[-1])
+                it_done = res.total_iterations
+                _write_back(dev, A, S)
+        dt = A.dtype
+        outM = tuple(np.ascontiguousarray(dev.get(_lib.BUF_MA, j)).astype(dt) for j in range(2))
+        outV = tuple(np.ascontiguousarray(dev.get(_lib.BUF_VA, j)).astype(dt) for j in range(2))
+        if M is not None:
+            for j in range(2):
+                M[j][...] = outM[j]
+            outM = M
+        if V is not None:
+            for j in range(2):
+                V[j][...] = outV[j]
+            outV = V
+        if Vhat is not None:
+            for j in range(2):
+                Vhat[j][...] = dev.get(_lib.BUF_VHA, j)
+            outVhat = Vhat
+        else:
+            outVhat = [None] * 2
+    sub = [int(res.sub_iterations[0]), int(res.sub_iterations[1])] if res is not None else [0, 0]
+    logger.info("Completed {0} iterations and {1} sub-iterations".format(it_done, sub))
+    if check_convergence:
+        converged = tuple(bool(c) for c in res.converged) if res is not None else (False, False)
+        if not all(converged):
+            logger.warning("Solution did not converge")
+    else:
+        converged = (None,) * 2
+    return converged, outM, outV, outVhat
+
+
+# ---------------------------------------------------------------------------------------------
+def bsdmm(X, proxs_f, steps_f_cb, proxs_g=None, steps_g=None, Ls=None, update_order=None, steps_g_update="steps_f",
+          max_iter=1000, e_rel=1e-6, e_abs=0, callback=None):
+    """Block-Simultaneous Direction Method of Multipliers (algorithms.py:653-850).
+
+    On the device this solver is reachable through `nmf.nmf(..., algorithm=bsdmm, proxs_g=...)`,
+    which is how the reference builds `proxs_f` / `steps_f_cb` from the NMF gradient
+    (nmf.py:178-203).  A direct call with user closures cannot be mapped to kernels.
+    """
+    raise NotImplementedError("call bsdmm through proxmin_amd.nmf.nmf(..., algorithm=bsdmm, proxs_g=...); "
+                              "generic proxs_f / steps_f_cb closures are out of scope of the device path")
+
+
+def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=None, steps_g_update="steps_f",
+               max_iter=1000, e_rel=1e-6, e_abs=0, callback=None):
+    """The bsdmm branch of nmf() (nmf.py:178-203 -> algorithms.py:653-850): step_f = step_pgm,
+    identity linear operators, steps_g from steps_f (algorithms.py:815-819)."""
+    Y, A, S = _problem_from_grad(X, grad)
+    N = 2
+    if proxs_g is None:
+        proxs_g = [None] * N
+    assert len(proxs_g) == N
+    steps_g_update = steps_g_update.lower()
+    assert steps_g_update in ["steps_f", "fixed", "relative"]
+    if steps_g_update != "steps_f" and steps_g is not None:
+        raise NotImplementedError("steps_g_update='%s' with explicit steps_g is not implemented on the device" % steps_g_update)
+    if Ls is not None and any(L is not None for L in np.ravel(np.array(Ls, dtype=object))):
+        raise NotImplementedError("linear operators Ls are not implemented on the device (identity only)")
+    if update_order is not None and list(update_order) != [0, 1]:
+        raise NotImplementedError("only the default update order (A, then S) is implemented on the device")
+    er = [e_rel] * N if np.isscalar(e_rel) else list(e_rel)
+    ea = [e_abs] * N if np.isscalar(e_abs) else list(e_abs)
+    seq_f = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]
+    seq_g = []
+    for j in range(N):
+        g = proxs_g[j]
+        if g is None:
+            seq_g.append(None)
+            continue
+        if not hasattr(g, "__iter__"):
+            g = [g]
+        seq_g.append([operators.device_proxseq(q if q is not None else operators.prox_id, j) for q in g])
+
+    with DeviceNMF(A.shape[0], S.shape[1], A.shape[1]) as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea)
+        res = None
+        if _wants_iterates(callback):
+            for it in range(max_iter):
+                callback(A, S, it=it)                           # no StopIteration handler (algorithms.py:802)
+                res = dev.bsdmm_run(1)
+                _write_back(dev, A, S)
+                if res.stopped:
+                    break
+        else:
+            res = dev.bsdmm_run(max_iter)
+            _write_back(dev, A, S)
+    converged = [bool(c) for c in res.converged] if res is not None else [None, None]
+    logger.info("Completed {0} iterations".format(res.total_iterations if res is not None else 0))
+    if not all(converged):
+        logger.warning("Solution did not converge")
+    return converged

@@ -1,0 +1,337 @@
+// K1: fused residual-gradient kernel (the O(MNK) part of the nmf() hot path).
+//
+// Restates proxmin/nmf.py:39-41 (grad_likelihood, W=1) and nmf.py:25 (log_likelihood):
+//     R = A S - Y ;  gA = R S^T ;  gS = A^T R ;  loss = 1/2 sum R^2
+// with ONE pass over Y.  R never leaves the chip: each workgroup computes a 128 x BN tile of A S on
+// the matrix cores, subtracts the Y tile it streams from HBM, parks R in LDS, and feeds it straight
+// back into the two gradient contractions.  S is held transposed (St, N x K), so both outputs are
+// "tall" (rows x K) and the kernel is symmetric in A and St.
+//
+// F32 mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 157 TFLOP/s peak on MI355X).
+//
+// Work decomposition (8 wavefronts = 512 threads per workgroup, one workgroup per CU):
+//   region  = RP row panels (128 rows each, run-time) x CB column blocks (BN columns each)
+//   step    = one 128 x BN block of Y:
+//       GEMM1  P = A_panel (128 x KP) . St_blk^T (KP x BN)        -> 32x32 tiles, accumulators
+//              R = P - Y                                          -> LDS  Rl[128][BN+1]
+//       GEMM2  gA_panel (128 x KP) += R (128 x BN) . St_blk (BN x KP)   accumulates over the CB blocks
+//       GEMM3  gSt_blk (BN x KP)   += R^T (BN x 128) . A_panel (128 x KP) accumulates over the RP panels
+//   gA accumulators are flushed once per row panel into slab (column-region) of `slabA`,
+//   gSt accumulators once per workgroup into slab (row-region) of `slabS`; the update kernels sum the
+//   slabs in a fixed order (deterministic, no float atomics).
+//
+// LDS images are row-major with an odd leading dimension (KP+1 / BN+1) so that every ds_read_b32 /
+// ds_write_b32 pattern used below (lanes walk rows, or lanes walk columns) is bank-conflict free.
+#include "pmx_common.h"
+
+struct GradArgs {
+    const float* Y;      // M x N (ldY)
+    int64_t ldY;
+    const float* A;      // M x K
+    const float* St;     // N x K
+    float* slabA;        // [nSlabA][M][K]
+    float* slabS;        // [nSlabS][N][K]
+    double* lossPart;    // [gridDim.x * gridDim.y]
+    const DevStatus* status;
+    int M, N, K;
+    int RP;              // row panels per workgroup
+    int doA, doS;        // which gradients are wanted (bsdmm needs one at a time, nmf.py:181-185)
+};
+
+template <int KP> struct GradCfg;
+template <> struct GradCfg<32>  { static constexpr int BN = 128, G1T = 2, G2T = 1, G2SPLIT = 2, G3T = 1, G3SPLIT = 2; };
+template <> struct GradCfg<64>  { static constexpr int BN = 128, G1T = 2, G2T = 1, G2SPLIT = 1, G3T = 1, G3SPLIT = 1; };
+template <> struct GradCfg<128> { static constexpr int BN = 64,  G1T = 1, G2T = 2, G2SPLIT = 1, G3T = 1, G3SPLIT = 1; };
+
+constexpr int GRAD_BM = 128;
+constexpr int GRAD_CB = 4;
+constexpr int GRAD_THREADS = 512;
+
+// C/D layout of a 32x32 MFMA tile: register i of lane l holds (row, col) =
+// ((i&3) + 8*(i>>2) + 4*(l>>5), l&31)
+__device__ __forceinline__ int tile_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+template <int KP>
+__global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
+    using C = GradCfg<KP>;
+    constexpr int BN = C::BN;
+    constexpr int LDK = KP + 1;   // Al / Sl leading dimension
+    constexpr int LDR = BN + 1;   // Rl leading dimension
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Al = lds;                       // [128][LDK]
+    float* Sl = Al + GRAD_BM * LDK;        // [BN][LDK]
+    float* Rl = Sl + BN * LDK;             // [128][LDR]
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;          // wave 0..7
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    const int M = a.M, N = a.N, K = a.K;
+    const int rowRegion = blockIdx.x, colRegion = blockIdx.y;
+    const int row0 = rowRegion * a.RP * GRAD_BM;
+    const int col0 = colRegion * GRAD_CB * BN;
+
+    // ---- per-wave tile assignment --------------------------------------------------------------
+    const int g1_mt = w >> 1;                                      // GEMM1 row tile (all KP)
+    const int g1_nt0 = (C::G1T == 2) ? 2 * (w & 1) : (w & 1);       // first column tile
+    const int g2_mt = w >> 1;                                      // GEMM2 output row tile
+    const int g2_kt0 = (KP == 128) ? 2 * (w & 1) : ((KP == 64) ? (w & 1) : 0);
+    const int g2_half = (C::G2SPLIT == 2) ? (w & 1) : 0;           // which half of the inner n range
+    int g3_nt, g3_kt, g3_half;
+    if (KP == 128) { g3_nt = w >> 2; g3_kt = w & 3; g3_half = 0; }
+    else if (KP == 64) { g3_nt = w >> 1; g3_kt = w & 1; g3_half = 0; }
+    else { g3_nt = w >> 1; g3_kt = 0; g3_half = w & 1; }
+    constexpr int G2_INNER = BN / C::G2SPLIT;        // inner n length per wave
+    constexpr int G3_INNER = GRAD_BM / C::G3SPLIT;   // inner m length per wave
+
+    f32x16 accS[GRAD_CB];
+#pragma unroll
+    for (int cb = 0; cb < GRAD_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
+    f32x16 accA[C::G2T];
+
+    float lossAcc = 0.f;
+
+    // valid extent of this workgroup's region (uniform)
+    int nrp = (M - row0 + GRAD_BM - 1) / GRAD_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    int ncb = (N - col0 + BN - 1) / BN;
+    if (ncb > GRAD_CB) ncb = GRAD_CB;
+    const int nsteps = nrp * ncb;
+
+    // The P accumulators double as the landing zone of the Y tile: Y for step s+1 is requested right
+    // after step s has parked its residual in LDS and flies during GEMM2/GEMM3 of step s; GEMM1 then
+    // accumulates A S on top of -Y, so R = A S - Y needs no extra registers and no subtraction pass.
+    // Out-of-range rows/columns yield 0 and meet zero-padded operands, so their residual is exactly 0.
+    f32x16 p[C::G1T];
+    // per-lane element offset inside a 128 x BN block (32-bit); the block origin and the per-register
+    // row offsets are wave-uniform and stay in SGPRs
+    const int laneRow = g1_mt * 32 + 4 * hi;
+    const int laneCol = g1_nt0 * 32 + l31;
+    const int laneOff = laneRow * (int)a.ldY + laneCol;
+    auto request_Y = [&](int prow0, int bcol0) {
+        const float* blk = a.Y + (int64_t)prow0 * a.ldY + bcol0;
+        if (prow0 + GRAD_BM <= M && bcol0 + BN <= N) {   // interior block (uniform branch)
+#pragma unroll
+            for (int t = 0; t < C::G1T; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float* rowp = blk + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + t * 32;
+                    p[t][i] = rowp[laneOff];
+                }
+        } else {                                           // edge block: clamp the address, select 0
+            const int rmax = M - 1 - prow0, cmax = N - 1 - bcol0;   // >= 0
+#pragma unroll
+            for (int t = 0; t < C::G1T; ++t) {
+                const int lc = laneCol + t * 32;
+                const int cc = lc < cmax ? lc : cmax;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int lr = laneRow + (i & 3) + 8 * (i >> 2);
+                    const int rr = lr < rmax ? lr : rmax;
+                    const float v = blk[(int64_t)rr * a.ldY + cc];
+                    p[t][i] = (lr <= rmax && lc <= cmax) ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto flush_gA = [&](int prow0) {
+        const int slab = colRegion * C::G2SPLIT + g2_half;
+        float* dst = a.slabA + (int64_t)slab * M * K;
+#pragma unroll
+        for (int t = 0; t < C::G2T; ++t) {
+            const int kk = (g2_kt0 + t) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gr = prow0 + g2_mt * 32 + tile_row(i, lane);
+                if (gr < M && kk < K) dst[(int64_t)gr * K + kk] = accA[t][i];
+            }
+        }
+    };
+
+    if (nsteps > 0) request_Y(row0, col0);
+    int rp = 0, cb = 0;
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const int prow0 = row0 + rp * GRAD_BM;
+        const int bcol0 = col0 + cb * BN;
+        __syncthreads();   // previous step's readers of Al / Sl / Rl are done
+        if (cb == 0) {     // new row panel (uniform)
+            // ---- stage the A panel: Al[m][k] = A[prow0+m][k], zero padded -----------------------
+#pragma unroll 4
+            for (int e = tid; e < GRAD_BM * KP; e += GRAD_THREADS) {
+                const int m = e / KP, k = e - m * KP;
+                float v = 0.f;
+                if (prow0 + m < M && k < K) v = a.A[(int64_t)(prow0 + m) * K + k];
+                Al[m * LDK + k] = v;
+            }
+#pragma unroll
+            for (int t = 0; t < C::G2T; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accA[t][i] = 0.f;
+        }
+        // ---- stage the St block: Sl[n][k] = St[bcol0+n][k] --------------------------------------
+#pragma unroll 4
+        for (int e = tid; e < BN * KP; e += GRAD_THREADS) {
+            const int n = e / KP, k = e - n * KP;
+            float v = 0.f;
+            if (bcol0 + n < N && k < K) v = a.St[(int64_t)(bcol0 + n) * K + k];
+            Sl[n * LDK + k] = v;
+        }
+        __syncthreads();
+        // ---- GEMM1: P = A S accumulated on top of -Y ---------------------------------------------
+#pragma unroll
+        for (int t = 0; t < C::G1T; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[t][i] = -p[t][i];
+        {
+            const float* ap = Al + (g1_mt * 32 + l31) * LDK + hi * (KP / 2);
+            const float* bp = Sl + (g1_nt0 * 32 + l31) * LDK + hi * (KP / 2);
+#pragma unroll 8
+            for (int s = 0; s < KP / 2; ++s) {
+                const float av = ap[s];
+#pragma unroll
+                for (int t = 0; t < C::G1T; ++t) {
+                    const float bv = bp[t * 32 * LDK + s];
+                    p[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, p[t], 0, 0, 0);
+                }
+            }
+        }
+        // ---- loss, park R in LDS ---------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < C::G1T; ++t) {
+            const int lc = (g1_nt0 + t) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int lr = g1_mt * 32 + tile_row(i, lane);
+                const float r = p[t][i];
+                lossAcc += r * r;
+                Rl[lr * LDR + lc] = r;
+            }
+        }
+        __syncthreads();
+        // ---- request the next step's Y tile (lands during GEMM2/GEMM3) ---------------------------
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        if (step + 1 < nsteps) request_Y(row0 + nrp_ * GRAD_BM, col0 + ncb_ * BN);
+        // ---- GEMM2: gA(rows of this panel) += R . St_blk ----------------------------------------
+        if (a.doA) {
+            const float* rq = Rl + (g2_mt * 32 + l31) * LDR + g2_half * G2_INNER + hi * (G2_INNER / 2);
+            const float* sp = Sl + (g2_half * G2_INNER + hi * (G2_INNER / 2)) * LDK + g2_kt0 * 32 + l31;
+#pragma unroll 8
+            for (int s = 0; s < G2_INNER / 2; ++s) {
+                const float av = rq[s];
+#pragma unroll
+                for (int t = 0; t < C::G2T; ++t) {
+                    const float bv = sp[s * LDK + t * 32];
+                    accA[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accA[t], 0, 0, 0);
+                }
+            }
+        }
+        // ---- GEMM3: gSt(rows of this column block) += R^T . A_panel -----------------------------
+        if (a.doS) {
+            const float* rq = Rl + (g3_half * G3_INNER + hi * (G3_INNER / 2)) * LDR + g3_nt * 32 + l31;
+            const float* aq = Al + (g3_half * G3_INNER + hi * (G3_INNER / 2)) * LDK + g3_kt * 32 + l31;
+            // the accumulator of column block cb must be addressed statically to stay in registers:
+            // uniform switch around the (small) MFMA loop instead of unrolling the whole step
+#define GEMM3_INTO(ACC)                                                                       \
+    _Pragma("unroll 8") for (int s = 0; s < G3_INNER / 2; ++s)                                \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(rq[s * LDR], aq[s * LDK], ACC, 0, 0, 0);
+            switch (cb) {
+                case 0: GEMM3_INTO(accS[0]) break;
+                case 1: GEMM3_INTO(accS[1]) break;
+                case 2: GEMM3_INTO(accS[2]) break;
+                default: GEMM3_INTO(accS[3]) break;
+            }
+#undef GEMM3_INTO
+        }
+        // ---- end of a row panel: flush gA -------------------------------------------------------
+        if (cb + 1 == ncb) {
+            if (a.doA) flush_gA(prow0);
+        }
+        cb = ncb_;
+        rp = nrp_;
+    }
+    // ---- flush gSt: slab = rowRegion (x split) ------------------------------------------------------
+    if (a.doS) {
+        const int slab = rowRegion * C::G3SPLIT + g3_half;
+        float* dst = a.slabS + (int64_t)slab * N * K;
+        const int kk = g3_kt * 32 + l31;
+#pragma unroll
+        for (int cb = 0; cb < GRAD_CB; ++cb) {
+            const int bcol0 = col0 + cb * BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gn = bcol0 + g3_nt * 32 + tile_row(i, lane);
+                if (gn < N && kk < K) dst[(int64_t)gn * K + kk] = accS[cb][i];
+            }
+        }
+    }
+    // ---- loss partial (one double per workgroup) ---------------------------------------------------
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if (lane == 0) lds[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < GRAD_THREADS / 64; ++i) s += (double)lds[i];
+            a.lossPart[blockIdx.y * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// host-side launcher -----------------------------------------------------------------------------
+struct GradPlan {
+    int KP, BN, RP, gridX, gridY, nSlabA, nSlabS;
+    size_t ldsBytes;
+};
+
+GradPlan grad_plan_f32(int64_t M, int64_t N, int64_t K) {
+    GradPlan p{};
+    p.KP = K <= 32 ? 32 : (K <= 64 ? 64 : 128);
+    p.BN = p.KP == 128 ? 64 : 128;
+    const int splitA = p.KP == 32 ? 2 : 1, splitS = p.KP == 32 ? 2 : 1;
+    const int64_t panels = (M + GRAD_BM - 1) / GRAD_BM;
+    p.gridY = (int)((N + (int64_t)GRAD_CB * p.BN - 1) / ((int64_t)GRAD_CB * p.BN));
+    // aim for >= 2 workgroups per CU, but keep the number of gSt slabs (= row regions) small
+    int64_t wantX = (512 + p.gridY - 1) / p.gridY;
+    if (wantX < 1) wantX = 1;
+    if (wantX > panels) wantX = panels;
+    p.RP = (int)((panels + wantX - 1) / wantX);
+    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    p.nSlabA = p.gridY * splitA;
+    p.nSlabS = p.gridX * splitS;
+    p.ldsBytes = sizeof(float) * ((size_t)GRAD_BM * (p.KP + 1) + (size_t)p.BN * (p.KP + 1) + (size_t)GRAD_BM * (p.BN + 1));
+    return p;
+}
+
+hipError_t grad_launch_f32(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
+    dim3 grid(p.gridX, p.gridY), block(GRAD_THREADS);
+    hipError_t e;
+    switch (p.KP) {
+        case 32:
+            e = hipFuncSetAttribute((const void*)k_grad_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_grad_f32<32>, grid, block, p.ldsBytes, stream, a);
+            break;
+        case 64:
+            e = hipFuncSetAttribute((const void*)k_grad_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_grad_f32<64>, grid, block, p.ldsBytes, stream, a);
+            break;
+        default:
+            e = hipFuncSetAttribute((const void*)k_grad_f32<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_grad_f32<128>, grid, block, p.ldsBytes, stream, a);
+            break;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,189 @@
+// Lipschitz step rule of the PGM / bSDMM back-ends, on the device.
+//
+// Restates nmf.step_pgm (W == 1 branch, proxmin/nmf.py:44-65) -> utils.get_spectral_norm
+// (proxmin/utils.py:14-35):   step_A = 1 / lmax(S S^T),   step_S = 1 / lmax(A^T A).
+// With St = S^T both are 1 / lmax(X^T X) of a tall X (rows x K):
+//   k_gram_partial : per-workgroup K x K partial Gram matrices (fp32 products, fp32 accumulation over
+//                    at most a few hundred rows)
+//   k_gram_reduce  : fixed-order sum of the partials in fp64
+//   k_eig          : largest eigenvalue of the symmetric PSD K x K matrix by power iteration
+//                    (warm-started from the previous iteration's eigenvector; the reference calls
+//                    LAPACK `eigvals` and takes the max), final Rayleigh quotient in fp64.
+// No host round trip: the step sizes land in DevStatus::step and are read by the update kernels.
+#include "pmx_common.h"
+
+constexpr int GRAM_BLOCKS = 128;
+constexpr int GRAM_THREADS = 256;
+constexpr int GRAM_CHUNK = 32;     // rows staged per LDS tile
+
+struct GramArgs {
+    const float* X[2];     // factor f: 0 = A (M x K), 1 = St (N x K)
+    int64_t rows[2];
+    int K;
+    float* part;           // [2][GRAM_BLOCKS][KP*KP]
+    const DevStatus* status;
+    int want[2];           // compute factor f?
+};
+
+template <int KP>
+__global__ __launch_bounds__(GRAM_THREADS) void k_gram_partial(GramArgs a) {
+    constexpr int TS = KP / 16;                 // per-thread micro tile (TS x TS)
+    __shared__ float xs[GRAM_CHUNK][KP + 1];
+    if (chain_halted(a.status)) return;
+    const int f = blockIdx.y;
+    if (!a.want[f]) return;
+    const int K = a.K;
+    const int64_t rows = a.rows[f];
+    const float* X = a.X[f];
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    float acc[TS][TS];
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int jx = 0; jx < TS; ++jx) acc[i][jx] = 0.f;
+    const int64_t per = (rows + GRAM_BLOCKS - 1) / GRAM_BLOCKS;
+    const int64_t r0 = (int64_t)blockIdx.x * per;
+    const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+    for (int64_t rb = r0; rb < r1; rb += GRAM_CHUNK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < GRAM_CHUNK * KP; e += GRAM_THREADS) {
+            const int rr = e / KP, k = e - rr * KP;
+            float v = 0.f;
+            if (rb + rr < r1 && k < K) v = X[(rb + rr) * K + k];
+            xs[rr][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < GRAM_CHUNK; ++rr) {
+            float av[TS], bv[TS];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) av[i] = xs[rr][ti + 16 * i];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) bv[i] = xs[rr][tj + 16 * i];
+#pragma unroll
+            for (int i = 0; i < TS; ++i)
+#pragma unroll
+                for (int jx = 0; jx < TS; ++jx) acc[i][jx] += av[i] * bv[jx];
+        }
+    }
+    float* out = a.part + ((int64_t)f * GRAM_BLOCKS + blockIdx.x) * KP * KP;
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int jx = 0; jx < TS; ++jx) out[(ti + 16 * i) * KP + tj + 16 * jx] = acc[i][jx];
+}
+
+struct GramReduceArgs {
+    const float* part;     // [2][GRAM_BLOCKS][KP*KP]
+    double* G;             // [2][KP*KP]
+    int KP;
+    const DevStatus* status;
+    int want[2];
+};
+__global__ __launch_bounds__(256) void k_gram_reduce(GramReduceArgs a) {
+    if (chain_halted(a.status)) return;
+    const int f = blockIdx.y;
+    if (!a.want[f]) return;
+    const int n = a.KP * a.KP;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + e;
+    double s = 0.0;
+    for (int b = 0; b < GRAM_BLOCKS; ++b) s += (double)p[(int64_t)b * n];
+    a.G[(int64_t)f * n + e] = s;
+}
+
+struct EigArgs {
+    const double* G;       // [2][KP*KP]  (factor f)
+    int KP, K;
+    DevStatus* status;
+    int want[2];
+    double scale;          // step = scale / lmax   (user `step = c * step_pgm` support)
+    int max_iter;
+};
+// one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
+// lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
+__global__ __launch_bounds__(256) void k_eig(EigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+    __shared__ double vec[MAXK], wv[MAXK], red[8];
+    DevStatus* st = a.status;
+    if (chain_halted(st)) return;
+    const int f = blockIdx.x;
+    if (!a.want[f]) return;
+    const int KP = a.KP, K = a.K, ld = KP + 1;
+    const double* G = a.G + (int64_t)f * KP * KP;
+    const int t = threadIdx.x;
+    for (int e = t; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
+    // warm start (all-ones on the first call: the Perron vector of a non-negative Gram matrix is positive)
+    if (t < K) {
+        double v0 = st->eigvec[f][t];
+        vec[t] = v0;
+    }
+    __syncthreads();
+    double lam_prev = -1.0, lam = 0.0;
+    int it = 0, calm = 0;
+    for (; it < a.max_iter; ++it) {
+        // w = G v
+        if (t < K) {
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += g[t * ld + k] * (float)vec[k];
+            wv[t] = (double)s;
+        }
+        __syncthreads();
+        // norm
+        double p = (t < K) ? wv[t] * wv[t] : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        if ((t & 63) == 0) red[t >> 6] = p;
+        __syncthreads();
+        const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+        lam = nrm;                         // |G v| with |v| = 1 -> lmax
+        __syncthreads();
+        if (nrm == 0.0 || !(nrm == nrm)) break;   // zero / NaN matrix
+        if (t < K) vec[t] = wv[t] / nrm;
+        __syncthreads();
+        if (fabs(lam - lam_prev) <= 1e-7 * lam) {
+            if (++calm >= 2) { ++it; break; }
+        } else calm = 0;
+        lam_prev = lam;
+    }
+    // Rayleigh quotient in fp64 with the fp64 Gram matrix (error quadratic in the eigenvector error)
+    if (t < K) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += G[t * KP + k] * vec[k];
+        wv[t] = s;
+    }
+    __syncthreads();
+    double num = (t < K) ? wv[t] * vec[t] : 0.0, den = (t < K) ? vec[t] * vec[t] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o); den += __shfl_xor(den, o); }
+    __syncthreads();
+    if ((t & 63) == 0) { red[t >> 6] = num; red[4 + (t >> 6)] = den; }
+    __syncthreads();
+    if (t == 0) {
+        const double n = red[0] + red[1] + red[2] + red[3], d = red[4] + red[5] + red[6] + red[7];
+        double l = (d > 0.0) ? n / d : lam;
+        if (!(lam == lam)) l = lam;
+        st->lam[f] = l;
+        st->step[1 - f] = a.scale / l;     // 1/0 -> inf like the reference
+        st->eig_iters[f] = it;
+    }
+    if (t < K) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vec[t] : 1.0;
+}
+
+void launch_gram(const GramArgs& a, int KP, hipStream_t s) {
+    dim3 grid(GRAM_BLOCKS, 2);
+    if (KP == 32) hipLaunchKernelGGL(k_gram_partial<32>, grid, dim3(GRAM_THREADS), 0, s, a);
+    else if (KP == 64) hipLaunchKernelGGL(k_gram_partial<64>, grid, dim3(GRAM_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_gram_partial<128>, grid, dim3(GRAM_THREADS), 0, s, a);
+}
+void launch_gram_reduce(const GramReduceArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3((a.KP * a.KP + 255) / 256, 2), dim3(256), 0, s, a);
+}
+hipError_t launch_eig(const EigArgs& a, hipStream_t s) {
+    const size_t lds = sizeof(float) * a.KP * (a.KP + 1);
+    hipError_t e = hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eig, dim3(2), dim3(256), lds, s, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,884 @@
+// Factor-sized kernels of the nmf() hot path: everything that is O((M+N)K) per iteration.
+//
+//   - gradient-slab folding, PGM / FISTA update           (proxmin/algorithms.py:93-108,130-135)
+//   - adaprox moment schemes, update, proximal sub-iterations (algorithms.py:147-245, :369-410)
+//   - block-SDMM primal/dual update and residual norms     (proxmin/utils.py:295-391)
+//   - the proximal operators themselves                    (proxmin/operators.py:20-160)
+//
+// Both blocks are tall row-major matrices with K components per row (A: M x K, St = S^T: N x K), so
+// one set of kernels serves both.  A row is handled by LPR = 32 lanes (half a wavefront), lane l owning
+// components l, l+32, l+64, l+96; the row sums inside prox_unity / prox_unity_plus are wavefront
+// shuffles (5 xor steps), never LDS or atomics.  Reductions over the whole factor (norms for the
+// stopping tests, max Psi, column sums) are written as one double per workgroup and folded by the next
+// kernel in the chain in a fixed order, so results are deterministic.
+//
+// Control flow lives on the device: every kernel first reads DevStatus::halt (set by a single-block
+// "decide" kernel when the run converged or needs more proximal sub-iterations than were enqueued)
+// and becomes a no-op once it is set; the host enqueues chains of iterations without synchronising.
+#include "pmx_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_sum32(float v) {   // sum over the 32 lanes that share a row
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-wide sum of NV doubles; thread 0 writes dst[i * stride]
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* dst, int64_t stride, double* scratch /* >= NV*4 */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * 4 + w] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dst[i * stride] = scratch[i * 4 + 0] + scratch[i * 4 + 1] + scratch[i * 4 + 2] + scratch[i * 4 + 3];
+}
+
+// fold one slot's EW_BLOCKS partials (every thread returns the same value; fixed order)
+__device__ __forceinline__ double fold_partials(const double* part, double* scratch) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < EW_BLOCKS; i += EW_THREADS) v += part[i];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+__device__ __forceinline__ double fold_partials_max(const double* part, double* scratch) {
+    double v = -1.0;
+    for (int i = threadIdx.x; i < EW_BLOCKS; i += EW_THREADS) v = fmax(v, part[i]);
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
+__device__ __forceinline__ double* part_ptr(double* partials, int slot, int blk) {
+    return partials + ((int64_t)slot * 2 + blk) * EW_BLOCKS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// proximal operators on one row held across 32 lanes          (proxmin/operators.py:20-160)
+// v[c] is component l32 + 32c; ok[c] says whether that component exists (< K).
+// sk[c] is the step the solver passes for that component (scalar steps: all equal).
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__device__ __forceinline__ void prox_one(float (&v)[NC], const bool (&ok)[NC], const pmx_prox& p, const float (&sk)[NC]) {
+    switch (p.op) {
+        case PMX_PROX_ID: break;
+        case PMX_PROX_ZERO:
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = 0.f;
+            break;
+        case PMX_PROX_PLUS:                                     // X[X<0] = 0
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = v[c] < 0.f ? 0.f : v[c];
+            break;
+        case PMX_PROX_UNITY:
+        case PMX_PROX_UNITY_PLUS: {                             // X / sum(X, axis)   (no zero guard)
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (p.op == PMX_PROX_UNITY_PLUS) v[c] = v[c] < 0.f ? 0.f : v[c];
+                s += ok[c] ? v[c] : 0.f;
+            }
+            s = row_sum32(s);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = v[c] / s;
+            break;
+        }
+        default: {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float t = p.relative ? p.thresh * sk[c] : p.thresh;   // operators.py:4-14
+                float x = v[c];
+                switch (p.op) {
+                    case PMX_PROX_MIN: x = (x - t < 0.f) ? t : x; break;             // operators.py:66-68
+                    case PMX_PROX_MAX: x = (x - t > 0.f) ? t : x; break;             // operators.py:82-84
+                    case PMX_PROX_HARD: x = (fabsf(x) < t) ? 0.f : x; break;         // operators.py:125-127
+                    case PMX_PROX_HARD_PLUS: x = (fabsf(x) < t) ? 0.f : x; x = x < 0.f ? 0.f : x; break;
+                    case PMX_PROX_SOFT:
+                    case PMX_PROX_SOFT_PLUS: {                                       // sign(X) * plus(|X| - t)
+                        float m = fabsf(x) - t;
+                        m = m < 0.f ? 0.f : m;
+                        const float sg = (float)(x > 0.f) - (float)(x < 0.f);
+                        x = sg * m;
+                        if (p.op == PMX_PROX_SOFT_PLUS) x = x < 0.f ? 0.f : x;
+                        break;
+                    }
+                    default: break;
+                }
+                v[c] = x;
+            }
+        }
+    }
+}
+
+template <int NC>
+__device__ __forceinline__ void prox_row(float (&v)[NC], const bool (&ok)[NC], const ProxSeq& ps, const float (&sk)[NC]) {
+    for (int r = 0; r < ps.repeat; ++r)
+        for (int q = 0; q < ps.n; ++q) prox_one<NC>(v, ok, ps.seq[q], sk);
+}
+
+// row iteration: half-wave h of the grid handles rows h, h + H, h + 2H, ...
+#define ROW_LOOP_BEGIN(rows)                                                                     \
+    const int l32 = threadIdx.x & 31;                                                            \
+    const int64_t hw_ = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 5;                    \
+    const int64_t nhw_ = ((int64_t)EW_BLOCKS * EW_THREADS) >> 5;                                   \
+    for (int64_t r = hw_; r < (rows); r += nhw_) {
+#define ROW_LOOP_END }
+
+struct SlabRef {
+    const float* base;   // [n][rows][K]
+    int n;
+};
+
+template <int NC>
+__device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], const SlabRef& s, int64_t rows, int K, int64_t r, int l32) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    const int64_t stride = rows * K;
+    const float* p = s.base + r * K + l32;
+    for (int i = 0; i < s.n; ++i) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) g[c] += p[c * 32];
+        p += stride;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fold gradient slabs into G (pmx_grad; also used by tests)
+// ------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    SlabRef slab[2];
+    float* G[2];
+    int64_t rows[2];
+    int K;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_fold(FoldArgs a) {
+    const int j = blockIdx.y;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float g[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        load_grad<NC>(g, ok, a.slab[j], rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) a.G[j][r * K + l32 + 32 * c] = g[c];
+    ROW_LOOP_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone prox (operators.* called on an array)
+// ------------------------------------------------------------------------------------------------
+struct ProxArgs {
+    float* X;
+    int64_t rows;
+    int K;
+    ProxSeq prox;
+    float stepk[MAXK];
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_prox_apply(ProxArgs a) {
+    const int K = a.K;
+    ROW_LOOP_BEGIN(a.rows)
+        bool ok[NC];
+        float v[NC], sk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int kk = l32 + 32 * c;
+            ok[c] = kk < K;
+            v[c] = ok[c] ? a.X[r * K + kk] : 0.f;
+            sk[c] = ok[c] ? a.stepk[kk] : 0.f;
+        }
+        prox_row<NC>(v, ok, a.prox, sk);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) a.X[r * K + l32 + 32 * c] = v[c];
+    ROW_LOOP_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGM / FISTA update                                      (proxmin/algorithms.py:93-108,130-133)
+//   X_new = prox(Xe - s G, s);  Xe_next = X_new + omega_next (X_new - X_old)
+// ------------------------------------------------------------------------------------------------
+struct PgmArgs {
+    float* X[2];        // current iterate (updated in place)
+    float* Xe[2];       // extrapolated point (== X when not accelerated)
+    float* G[2];        // gradient output (returned by pgm, algorithms.py:144)
+    SlabRef slab[2];
+    int64_t rows[2];
+    int K;
+    ProxSeq prox[2];
+    DevStatus* status;
+    double* partials;
+    int accelerated;
+    float omega_next;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
+    __shared__ double scratch[16];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    const float s = (float)a.status->step[j];
+    const ProxSeq& px = a.prox[j];
+    float* X = a.X[j];
+    float* Xe = a.Xe[j];
+    float d2 = 0.f, n2 = 0.f;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float g[NC], xo[NC], v[NC], sk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        load_grad<NC>(g, ok, a.slab[j], rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t e = r * K + l32 + 32 * c;
+            xo[c] = ok[c] ? X[e] : 0.f;
+            const float xe = a.accelerated ? (ok[c] ? Xe[e] : 0.f) : xo[c];
+            v[c] = xe - s * g[c];
+            sk[c] = s;
+        }
+        prox_row<NC>(v, ok, px, sk);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (ok[c]) {
+                const int64_t e = r * K + l32 + 32 * c;
+                X[e] = v[c];
+                a.G[j][e] = g[c];
+                if (a.accelerated) Xe[e] = v[c] + a.omega_next * (v[c] - xo[c]);
+                const float d = v[c] - xo[c];
+                d2 += d * d;
+                n2 += v[c] * v[c];
+            }
+        }
+    ROW_LOOP_END
+    double red[2] = {(double)d2, (double)n2};
+    // SL_DIFF2 and SL_NORM2 are adjacent slots: stride between them = 2 * EW_BLOCKS doubles
+    block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+}
+
+// single-block decision kernel shared by pgm and adaprox outer tests (algorithms.py:130-135,403-410)
+struct DecideArgs {
+    DevStatus* status;
+    double* partials;
+    double e_rel[2];
+    int check;          // evaluate the convergence test
+};
+__global__ __launch_bounds__(EW_THREADS) void k_pgm_decide(DecideArgs a) {
+    __shared__ double scratch[8];
+    if (chain_halted(a.status)) return;
+    double d[2], n[2];
+    for (int j = 0; j < 2; ++j) {
+        d[j] = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
+        n[j] = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+    }
+    if (threadIdx.x == 0) {
+        DevStatus* st = a.status;
+        int all = 1;
+        for (int j = 0; j < 2; ++j) {
+            const int c = d[j] <= a.e_rel[j] * a.e_rel[j] * n[j];
+            st->conv[j] = c;
+            st->norms[j][0] = d[j];
+            st->norms[j][1] = n[j];
+            all &= c;
+        }
+        st->it_done += 1;
+        if (a.check && all) {
+            st->stopped = 1;
+            st->reason = HALT_CONVERGED;
+            __threadfence();
+            st->halt = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (adaprox step rule, nmf.py:91-93) -- partial per workgroup
+// ------------------------------------------------------------------------------------------------
+struct ColsumArgs {
+    const float* X[2];
+    int64_t rows[2];
+    int K;
+    double* colpart;      // [2][EW_BLOCKS][MAXK]
+    const DevStatus* status;
+};
+template <int NC>
+__device__ __forceinline__ void colsum_store(const float (&cs)[NC], double* colpart, int j, float* sm /* [8][MAXK] */) {
+    const int hwi = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sm[hwi * MAXK + l32 + 32 * c] = cs[c];
+    __syncthreads();
+    if (threadIdx.x < 32 * NC) {
+        double s = 0.0;
+        for (int h = 0; h < EW_THREADS / 32; ++h) s += (double)sm[h * MAXK + threadIdx.x];
+        colpart[((int64_t)j * EW_BLOCKS + blockIdx.x) * MAXK + threadIdx.x] = s;
+    }
+}
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_colsum(ColsumArgs a) {
+    __shared__ float sm[(EW_THREADS / 32) * MAXK];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int K = a.K;
+    float cs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cs[c] = 0.f;
+    ROW_LOOP_BEGIN(a.rows[j])
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (l32 + 32 * c < K) cs[c] += a.X[j][r * K + l32 + 32 * c];
+    ROW_LOOP_END
+    colsum_store<NC>(cs, a.colpart, j, sm);
+}
+
+// alpha_k = mean_k / 10 from the column-sum partials (single block)
+struct AlphaArgs {
+    DevStatus* status;
+    const double* colpart;
+    int64_t rows_global[2];   // divisor of the mean (global M for a row-sharded A)
+    int K;
+    int use_fixed;
+    float fixed[2];
+};
+__device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
+    const int t = threadIdx.x;
+    for (int j = 0; j < 2; ++j) {
+        if (t < a.K) {
+            float al;
+            if (a.use_fixed) al = a.fixed[j];
+            else {
+                double s = 0.0;
+                const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + t;
+                for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
+                al = (float)(s / (double)a.rows_global[j]) / 10.f;
+            }
+            a.status->alpha[j][t] = al;
+        }
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void k_alpha_init(AlphaArgs a) {
+    if (chain_halted(a.status)) return;
+    compute_alpha(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaprox: moments + update                      (proxmin/algorithms.py:147-245, :369-378)
+// ------------------------------------------------------------------------------------------------
+struct MomentArgs {
+    float* X[2];
+    float* Xp[2];       // copy of the pre-update iterate (only when check_convergence)
+    float* Mm[2];
+    float* Vv[2];
+    float* Vh[2];       // nullptr unless warm-started (algorithms.py:356-359)
+    float* Psi[2];      // written when the block has a prox (sub-iterations need it)
+    SlabRef slab[2];
+    int64_t rows[2];
+    int K;
+    DevStatus* status;
+    double* partials;
+    int scheme;
+    int it;
+    double b1t, b1prev, b2, eps, p;
+    int check_convergence;
+    int has_prox[2];
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
+    __shared__ double scratch[8];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    float* X = a.X[j];
+    float* Mm = a.Mm[j];
+    float* Vv = a.Vv[j];
+    float* Vh = a.Vh[j];
+    const double b1 = a.b1t;
+    const float c1 = (float)(1.0 - a.b2), c2 = (float)a.b2;   // python floats are weak scalars: fp32 arithmetic
+    const double t = (double)(a.it + 1);
+    const double bias1 = 1.0 - pow(b1, t);                     // 1 - b1[it]**t
+    const float bias2 = (float)(1.0 - pow(a.b2, t));           // 1 - b2**t
+    const float epsf = (float)a.eps;
+    // radam scalars (algorithms.py:224-245)
+    const double rho_inf = 2.0 / (1.0 - a.b2) - 1.0;
+    const double rho = rho_inf - 2.0 * t * pow(a.b2, t) / (1.0 - pow(a.b2, t));
+    const float rfac = rho > 4.0 ? (float)sqrt((rho - 4.0) * (rho - 2.0) * rho_inf / (rho_inf - 4.0) / (rho_inf - 2.0) / rho) : 1.f;
+    const float adamx_factor = (float)(((1.0 - b1) * (1.0 - b1)) / ((1.0 - a.b1prev) * (1.0 - a.b1prev)));
+    float alpha[NC];
+    {
+        const int l32_ = threadIdx.x & 31;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) alpha[c] = (l32_ + 32 * c < K) ? a.status->alpha[j][l32_ + 32 * c] : 0.f;
+    }
+    float maxpsi = -1.f;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float g[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        load_grad<NC>(g, ok, a.slab[j], rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (!ok[c]) continue;
+            const int64_t e = r * K + l32 + 32 * c;
+            const float gg = g[c];
+            // b1[it] is a NumPy float64 scalar in the reference, so M is formed in fp64 and rounded on store
+            const float m = (float)((1.0 - b1) * (double)gg + b1 * (double)Mm[e]);
+            const float v = c1 * (gg * gg) + c2 * Vv[e];
+            Mm[e] = m;
+            Vv[e] = v;
+            double upd;   // alpha * Phi / Psi
+            float psi;
+            switch (a.scheme) {
+                case PMX_ADAM:
+                    psi = sqrtf(v / bias2) + epsf;
+                    upd = (double)alpha[c] * ((double)m / bias1) / (double)psi;
+                    break;
+                case PMX_NADAM:
+                    psi = sqrtf(v / bias2) + epsf;
+                    upd = (double)alpha[c] * ((b1 * (double)m + (1.0 - b1) * (double)gg) / bias1) / (double)psi;
+                    break;
+                case PMX_RADAM:
+                    psi = rho > 4.0 ? sqrtf(v / bias2) / rfac : 1.f;
+                    if (epsf > 0.f) psi = fmaxf(psi, sqrtf(epsf));
+                    upd = (double)alpha[c] * ((double)m / bias1) / (double)psi;
+                    break;
+                default: {   // amsgrad / padam / adamx (algorithms.py:170-221)
+                    float cap = v;
+                    if (Vh != nullptr) {
+                        const float old = Vh[e];
+                        cap = fmaxf(a.scheme == PMX_ADAMX ? adamx_factor * old : old, v);
+                        Vh[e] = cap;
+                    }
+                    if (epsf > 0.f) cap = fmaxf(cap, epsf);
+                    psi = a.scheme == PMX_PADAM ? powf(cap, (float)a.p) : sqrtf(cap);
+                    upd = (double)(alpha[c] * m / psi);
+                }
+            }
+            const float xo = X[e];
+            if (a.check_convergence) a.Xp[j][e] = xo;
+            X[e] = (float)((double)xo - upd);
+            if (a.has_prox[j]) a.Psi[j][e] = psi;
+            maxpsi = fmaxf(maxpsi, psi);
+        }
+    ROW_LOOP_END
+    // NaN-propagating max like np.max: fmaxf drops NaNs, so flag them explicitly
+    double mv = (double)maxpsi;
+    mv = wave_max(mv);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mv;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        part_ptr(a.partials, SL_MAXPSI, j)[blockIdx.x] = fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaprox: one proximal sub-iteration pass                 (proxmin/algorithms.py:383-400)
+//   z_new = prox(z - gamma/alpha * Psi * (z - X), gamma);  stop when |z_new - z|^2 <= e^2 |z|^2
+// Pass t (0-based) is launched as its own kernel; before doing any work it evaluates the stopping
+// test of pass t-1 from that pass's per-workgroup partial sums (all workgroups fold them in the same
+// order and reach the same verdict; workgroup 0 publishes it for the host and for later kernels).
+// ------------------------------------------------------------------------------------------------
+struct SubArgs {
+    float* X[2];
+    float* Psi[2];
+    float* zb[2][2];
+    int64_t rows[2];
+    int K;
+    ProxSeq prox[2];
+    DevStatus* status;
+    double* partials;
+    double e_rel[2];
+    int t;               // pass index within this iteration
+    int prox_max_iter;
+    int has_prox[2];
+};
+
+// If the loop of block j finished BEFORE pass t, returns the number of passes it took (tau >= 1);
+// otherwise returns 0.  Uniform across the workgroup (and across workgroups).
+__device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, double* scratch) {
+    if (a.t == 0) return 0;
+    __shared__ int pub;
+    if (threadIdx.x == 0) pub = a.status->sub_done[j] ? a.status->sub_tau[j] : 0;   // published by an earlier kernel
+    __syncthreads();
+    const int tau_pub = pub;
+    if (tau_pub > 0) return tau_pub;
+    const int par = (a.t - 1) & 1;
+    const double d = fold_partials(part_ptr(a.partials, par ? SL_SUB_D1 : SL_SUB_D, j), scratch);
+    const double n = fold_partials(part_ptr(a.partials, par ? SL_SUB_N1 : SL_SUB_N, j), scratch);
+    const bool done = (d <= a.e_rel[j] * a.e_rel[j] * n) || (a.t >= a.prox_max_iter);
+    if (done && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.status->sub_tau[j] = a.t;
+        __threadfence();
+        a.status->sub_done[j] = 1;
+    }
+    return done ? a.t : 0;
+}
+
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_ada_sub(SubArgs a) {
+    __shared__ double scratch[16];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    if (!a.has_prox[j]) return;
+    if (sub_finished_before(a, j, scratch) > 0) return;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    const double maxpsi = fold_partials_max(part_ptr(a.partials, SL_MAXPSI, j), scratch);
+    const float* zc = a.t == 0 ? a.X[j] : a.zb[j][(a.t - 1) & 1];
+    float* zn = a.zb[j][a.t & 1];
+    float gam[NC], rat[NC];
+    {
+        const int l32_ = threadIdx.x & 31;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int kk = l32_ + 32 * c;
+            const float al = kk < K ? a.status->alpha[j][kk] : 0.f;
+            gam[c] = al / (float)maxpsi;          // gamma = Alpha / max(Psi)      algorithms.py:384
+            rat[c] = gam[c] / al;                 // gamma / Alpha (NaN if alpha == 0, as in the reference)
+        }
+    }
+    float d2 = 0.f, n2 = 0.f;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float z[NC], v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t e = r * K + l32 + 32 * c;
+            ok[c] = l32 + 32 * c < K;
+            z[c] = ok[c] ? zc[e] : 0.f;
+            const float x = ok[c] ? a.X[j][e] : 0.f;
+            const float psi = ok[c] ? a.Psi[j][e] : 0.f;
+            v[c] = z[c] - rat[c] * psi * (z[c] - x);
+        }
+        prox_row<NC>(v, ok, a.prox[j], gam);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (ok[c]) {
+                zn[r * K + l32 + 32 * c] = v[c];
+                const float d = v[c] - z[c];
+                d2 += d * d;
+                n2 += z[c] * z[c];
+            }
+        }
+    ROW_LOOP_END
+    double red[2] = {(double)d2, (double)n2};
+    const int par = a.t & 1;
+    block_sum_store<2>(red, part_ptr(a.partials, par ? SL_SUB_D1 : SL_SUB_D, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaprox: finish an iteration -- X <- z, outer norms, column sums   (algorithms.py:400-410)
+// `t` = number of sub-iteration passes enqueued so far for this iteration.
+// ------------------------------------------------------------------------------------------------
+struct FinishArgs {
+    SubArgs s;
+    float* Xp[2];
+    double* colpart;
+    int check_convergence;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
+    __shared__ double scratch[16];
+    __shared__ float sm[(EW_THREADS / 32) * MAXK];
+    if (chain_halted(a.s.status)) return;
+    const int j = blockIdx.y;
+    const int64_t rows = a.s.rows[j];
+    const int K = a.s.K;
+    DevStatus* st = a.s.status;
+    const float* src = a.s.X[j];
+    if (a.s.has_prox[j]) {
+        const int tau = sub_finished_before(a.s, j, scratch);
+        if (tau == 0) {
+            // more passes are needed than were enqueued: leave everything untouched; k_ada_decide halts
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->need_sub[j] = 1;
+            return;
+        }
+        src = a.s.zb[j][(tau - 1) & 1];
+    }
+    float* X = a.s.X[j];
+    float d2 = 0.f, n2 = 0.f;
+    float cs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cs[c] = 0.f;
+    ROW_LOOP_BEGIN(rows)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (l32 + 32 * c < K) {
+                const int64_t e = r * K + l32 + 32 * c;
+                const float x = src[e];
+                X[e] = x;
+                if (a.check_convergence) {
+                    const float d = x - a.Xp[j][e];
+                    d2 += d * d;
+                    n2 += x * x;
+                }
+                cs[c] += x;
+            }
+        }
+    ROW_LOOP_END
+    double red[2] = {(double)d2, (double)n2};
+    block_sum_store<2>(red, part_ptr(a.s.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    colsum_store<NC>(cs, a.colpart, j, sm);
+}
+
+// single-block end-of-iteration kernel for adaprox
+struct AdaDecideArgs {
+    AlphaArgs al;
+    double* partials;
+    double e_rel[2];
+    int check_convergence;
+    int has_prox[2];
+};
+__global__ __launch_bounds__(EW_THREADS) void k_ada_decide(AdaDecideArgs a) {
+    __shared__ double scratch[8];
+    DevStatus* st = a.al.status;
+    if (chain_halted(st)) return;
+    __shared__ int need;
+    if (threadIdx.x == 0) need = st->need_sub[0] | st->need_sub[1];
+    __syncthreads();
+    if (need) {   // the enqueued proximal sub-iterations did not suffice: stop the chain, the host resumes
+        if (threadIdx.x == 0) {
+            st->reason = HALT_NEED_SUB;
+            __threadfence();
+            st->halt = 1;
+        }
+        return;
+    }
+    double d[2] = {0, 0}, n[2] = {0, 0};
+    if (a.check_convergence)
+        for (int j = 0; j < 2; ++j) {
+            d[j] = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
+            n[j] = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+        }
+    compute_alpha(a.al);   // step sizes for the NEXT iteration from the updated factors (nmf.py:93)
+    if (threadIdx.x == 0) {
+        int all = 1;
+        for (int j = 0; j < 2; ++j) {
+            const int c = a.check_convergence ? (d[j] <= a.e_rel[j] * a.e_rel[j] * n[j]) : 0;
+            st->conv[j] = c;
+            st->norms[j][0] = d[j];
+            st->norms[j][1] = n[j];
+            all &= c;
+            const int tau = a.has_prox[j] ? st->sub_tau[j] : 0;
+            st->sub_total[j] += tau;
+            st->last_tau[j] = tau;
+            st->sub_done[j] = 0;
+            st->sub_tau[j] = 0;
+        }
+        st->it_done += 1;
+        if (a.check_convergence && all) {
+            st->stopped = 1;
+            st->reason = HALT_CONVERGED;
+            __threadfence();
+            st->halt = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-SDMM: update of one block                       (proxmin/utils.py:295-346, nmf.py:181-185)
+// ------------------------------------------------------------------------------------------------
+struct BsdmmArgs {
+    float* X;
+    SlabRef slab;
+    float* Z[PMX_MAX_G];
+    float* U[PMX_MAX_G];
+    int64_t rows;
+    int K;
+    int j;               // block
+    int n_g;             // number of constraints (0: proxs_g[j] is None)
+    ProxSeq prox_f;
+    ProxSeq prox_g[PMX_MAX_G];
+    DevStatus* status;
+    double* partials;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
+    __shared__ double scratch[4 * (2 + 4 * PMX_MAX_G)];
+    if (chain_halted(a.status)) return;
+    const int j = a.j;
+    const int K = a.K;
+    const float sf = (float)a.status->step[j];
+    // get_step_g (utils.py:269-279): step_f * ||L||^2 * N_blocks * M_constraints, identity L
+    const float sg = sf * 1.f * 2.f * (float)a.n_g;
+    const float w = a.n_g > 0 ? sf / sg : 0.f;         // step_f / step_g[i]
+    const float nisg = a.n_g > 0 ? -1.f / sg : 0.f;    // -1 / step_g
+    float d2 = 0.f, x2 = 0.f;
+    float r2[PMX_MAX_G], s2[PMX_MAX_G], z2[PMX_MAX_G], u2[PMX_MAX_G];
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_G; ++i) r2[i] = s2[i] = z2[i] = u2[i] = 0.f;
+    ROW_LOOP_BEGIN(a.rows)
+        bool ok[NC];
+        float g[NC], xo[NC], v[NC], sk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        load_grad<NC>(g, ok, a.slab, a.rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t e = r * K + l32 + 32 * c;
+            xo[c] = ok[c] ? a.X[e] : 0.f;
+            float dx = 0.f;
+            for (int i = 0; i < a.n_g; ++i)             // utils.py:330-336
+                if (ok[c]) dx += w * (xo[c] - a.Z[i][e] + a.U[i][e]);
+            v[c] = (xo[c] - dx) - sf * g[c];            // utils.py:338 + nmf.py:185
+            sk[c] = sf;
+        }
+        prox_row<NC>(v, ok, a.prox_f, sk);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) {
+                a.X[r * K + l32 + 32 * c] = v[c];
+                const float d = v[c] - xo[c];
+                d2 += d * d;
+                x2 += v[c] * v[c];
+            }
+        for (int i = 0; i < a.n_g; ++i) {               // do_the_mm, utils.py:295-304
+            float zn[NC], zo[NC], uo[NC], sgk[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int64_t e = r * K + l32 + 32 * c;
+                zo[c] = ok[c] ? a.Z[i][e] : 0.f;
+                uo[c] = ok[c] ? a.U[i][e] : 0.f;
+                zn[c] = v[c] + uo[c];
+                sgk[c] = sg;
+            }
+            prox_row<NC>(zn, ok, a.prox_g[i], sgk);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) {
+                    const int64_t e = r * K + l32 + 32 * c;
+                    const float rr = v[c] - zn[c];
+                    const float sd = nisg * (zn[c] - zo[c]);
+                    const float un = uo[c] + rr;
+                    a.Z[i][e] = zn[c];
+                    a.U[i][e] = un;
+                    r2[i] += rr * rr;
+                    s2[i] += sd * sd;
+                    z2[i] += zn[c] * zn[c];
+                    const float us = un / sg;
+                    u2[i] += us * us;
+                }
+        }
+    ROW_LOOP_END
+    double red[2 + 4 * PMX_MAX_G];
+    red[0] = d2;
+    red[1] = x2;
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_G; ++i) {
+        red[2 + 4 * i + 0] = r2[i];
+        red[2 + 4 * i + 1] = s2[i];
+        red[2 + 4 * i + 2] = z2[i];
+        red[2 + 4 * i + 3] = u2[i];
+    }
+    // slots: SL_DIFF2, SL_NORM2, then SL_G0.. ; consecutive slots are 2*EW_BLOCKS doubles apart, but
+    // SL_G0 is not adjacent to SL_NORM2, so store in two groups
+    double head[2] = {red[0], red[1]};
+    block_sum_store<2>(head, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    double tail[4 * PMX_MAX_G];
+#pragma unroll
+    for (int i = 0; i < 4 * PMX_MAX_G; ++i) tail[i] = red[2 + i];
+    block_sum_store<4 * PMX_MAX_G>(tail, part_ptr(a.partials, SL_G0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+}
+
+// check_constraint_convergence for block j (utils.py:349-391), and end-of-iteration bookkeeping
+struct BsdmmDecideArgs {
+    DevStatus* status;
+    double* partials;
+    int j;
+    int n_g;
+    int64_t size;        // X.size == Z.size (identity L)
+    double e_rel, e_abs;
+    int last_block;      // 1 for the second block: closes the iteration (algorithms.py:841-844)
+};
+__global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) {
+    __shared__ double scratch[8];
+    if (chain_halted(a.status)) return;
+    const int j = a.j;
+    const double d2 = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
+    const double x2 = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+    double q[4 * PMX_MAX_G];
+    for (int i = 0; i < 4 * a.n_g; ++i) q[i] = fold_partials(part_ptr(a.partials, SL_G0 + i, j), scratch);
+    if (threadIdx.x == 0) {
+        DevStatus* st = a.status;
+        const double sq = sqrt((double)a.size);
+        int conv = 1;
+        if (a.n_g == 0) {
+            // utils.py:319-327: R = 0, S = X_new - X_old, Z = X, U = 0, step_g = None
+            const double e_pri = sq * a.e_abs + a.e_rel * sqrt(x2);
+            const double e_dual = sq * a.e_abs + a.e_rel * 0.0;
+            conv = (0.0 <= e_pri) && (sqrt(d2) <= e_dual);
+        } else {
+            for (int i = 0; i < a.n_g; ++i) {
+                const double lR = sqrt(q[4 * i + 0]), lS = sqrt(q[4 * i + 1]);
+                const double e_pri = sq * a.e_abs + a.e_rel * fmax(sqrt(x2), sqrt(q[4 * i + 2]));
+                const double e_dual = sq * a.e_abs + a.e_rel * sqrt(q[4 * i + 3]);
+                conv &= (lR <= e_pri) && (lS <= e_dual);
+            }
+        }
+        st->conv[j] = conv;
+        st->norms[j][0] = d2;
+        st->norms[j][1] = x2;
+        if (a.last_block) {
+            st->it_done += 1;
+            if (st->conv[0] && st->conv[1]) {
+                st->stopped = 1;
+                st->reason = HALT_CONVERGED;
+                __threadfence();
+                st->halt = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch wrappers (NC dispatch)
+// ------------------------------------------------------------------------------------------------
+#define DISPATCH_NC(K, KERNEL, grid, stream, args)                                               \
+    do {                                                                                         \
+        if ((K) <= 32) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(EW_THREADS), 0, stream, args);    \
+        else if ((K) <= 64) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(EW_THREADS), 0, stream, args); \
+        else hipLaunchKernelGGL(KERNEL<4>, grid, dim3(EW_THREADS), 0, stream, args);              \
+    } while (0)
+
+void launch_fold(const FoldArgs& a, int nblocks_y, hipStream_t s) { DISPATCH_NC(a.K, k_fold, dim3(EW_BLOCKS, nblocks_y), s, a); }
+void launch_prox_apply(const ProxArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_prox_apply, dim3(EW_BLOCKS), s, a); }
+void launch_pgm_update(const PgmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pgm_update, dim3(EW_BLOCKS, 2), s, a); }
+void launch_pgm_decide(const DecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pgm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_colsum(const ColsumArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colsum, dim3(EW_BLOCKS, 2), s, a); }
+void launch_alpha_init(const AlphaArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_alpha_init, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_ada_moment(const MomentArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_moment, dim3(EW_BLOCKS, 2), s, a); }
+void launch_ada_sub(const SubArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_sub, dim3(EW_BLOCKS, 2), s, a); }
+void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, k_ada_finish, dim3(EW_BLOCKS, 2), s, a); }
+void launch_ada_decide(const AdaDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ada_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }
+void launch_bsdmm_decide(const BsdmmDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bsdmm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }

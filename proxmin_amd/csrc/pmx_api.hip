@@ -1,0 +1,923 @@
+// libpmx: context management, kernel chains and the C ABI declared in include/pmx.h.
+//
+// Host-side mirror of the reference's solver loops (proxmin/algorithms.py pgm :87-138,
+// adaprox :365-413, bsdmm :800-844) as *kernel chains*: the host enqueues whole iterations on one HIP
+// stream without synchronising; convergence tests and the data-dependent length of adaprox's proximal
+// sub-iteration loop are resolved on the device through DevStatus (see pmx_common.h).  The host only
+// synchronises at the end of a chunk of iterations, reads DevStatus back, and resumes if a chain
+// stopped early.
+//
+// Single translation unit: the kernels are included below.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+
+#include "pmx_common.h"
+#include "k_grad.hip"
+#include "k_update.hip"
+#include "k_gram.hip"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void pmx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define FAIL(code, ...)            \
+    do {                           \
+        pmx_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+
+enum Algo { ALG_NONE = 0, ALG_PGM, ALG_ADAPROX, ALG_BSDMM };
+
+struct pmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t M = 0, N = 0, K = 0;
+    int KP = 0, mode = PMX_MODE_F32;
+    int64_t rows[2] = {0, 0};
+
+    // data
+    const float* Y = nullptr;
+    float* Yown = nullptr;
+    int64_t ldY = 0;
+    bool haveY = false;
+
+    float* X[2] = {nullptr, nullptr};      // A, St
+    float* G[2] = {nullptr, nullptr};
+    float* Xe[2] = {nullptr, nullptr};     // pgm accelerated
+    float* Xp[2] = {nullptr, nullptr};     // adaprox X_
+    float* Mm[2] = {nullptr, nullptr};
+    float* Vv[2] = {nullptr, nullptr};
+    float* Vh[2] = {nullptr, nullptr};
+    float* Psi[2] = {nullptr, nullptr};
+    float* zb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* Zg[2][PMX_MAX_G] = {};
+    float* Ug[2][PMX_MAX_G] = {};
+    float* tmp[2] = {nullptr, nullptr};    // scratch for pmx_prox_apply on arbitrary rows
+
+    // K1
+    GradPlan plan{};
+    float* slab[2] = {nullptr, nullptr};
+    double* lossPart = nullptr;
+
+    // reductions / control
+    double* partials = nullptr;            // [SL_COUNT][2][EW_BLOCKS]
+    double* colpart = nullptr;             // [2][EW_BLOCKS][MAXK]
+    float* gramPart = nullptr;             // [2][GRAM_BLOCKS][KP*KP]
+    double* gramG = nullptr;               // [2][KP*KP]
+    DevStatus* dstatus = nullptr;
+    DevStatus* hstatus = nullptr;          // pinned mirror
+
+    // solver state
+    Algo algo = ALG_NONE;
+    pmx_pgm_params pgm{};
+    pmx_adaprox_params ada{};
+    pmx_bsdmm_params bsd{};
+    int it = 0;                            // iterations enqueued AND completed (host view)
+    double nest_t = 1.0;                   // NesterovAccelerator.t (utils.py:195)
+    float omega_cur = 0.f;
+    int nsub_guess = 2;
+    std::vector<void*> allocs;
+
+    // multi-GPU
+    int rank = 0, world = 1;
+    int64_t M_global = 0;
+};
+
+static int dalloc(pmx_ctx* c, void** p, size_t bytes, bool zero = true) {
+    if (*p) return PMX_OK;
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) FAIL(PMX_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    c->allocs.push_back(*p);
+    if (zero) HIP_CHECK(hipMemsetAsync(*p, 0, bytes ? bytes : 16, c->stream));
+    return PMX_OK;
+}
+template <class T>
+static int dallocT(pmx_ctx* c, T** p, size_t count, bool zero = true) { return dalloc(c, (void**)p, count * sizeof(T), zero); }
+
+static ProxSeq to_dev(const pmx_proxseq& p) {
+    ProxSeq d{};
+    d.n = p.n;
+    d.repeat = p.repeat < 1 ? 1 : p.repeat;
+    for (int i = 0; i < PMX_MAX_SEQ; ++i) d.seq[i] = p.seq[i];
+    return d;
+}
+static int check_prox(const pmx_proxseq& p, const char* what) {
+    if (p.n < 0 || p.n > PMX_MAX_SEQ) FAIL(PMX_E_INVALID, "%s: bad operator count %d", what, p.n);
+    for (int i = 0; i < p.n; ++i) {
+        const pmx_prox& q = p.seq[i];
+        if (q.op < PMX_PROX_ID || q.op > PMX_PROX_SOFT_PLUS) FAIL(PMX_E_INVALID, "%s: unknown prox op %d", what, q.op);
+        if ((q.op == PMX_PROX_UNITY || q.op == PMX_PROX_UNITY_PLUS) && q.unit != 0)
+            FAIL(PMX_E_UNSUPPORTED, "%s: prox_unity along the row dimension (numpy axis=0 on A / axis=1 on S) is not implemented on the device", what);
+    }
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_abi_version(void) { return PMX_ABI_VERSION; }
+extern "C" const char* pmx_last_error(void) { return g_err; }
+extern "C" int pmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, int64_t K, int mode, void* stream) {
+    if (!out) FAIL(PMX_E_INVALID, "out is NULL");
+    if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    if (K > MAXK) FAIL(PMX_E_UNSUPPORTED, "K=%lld > %d components is not supported", (long long)K, MAXK);
+    if (M > (1ll << 30) || N > (1ll << 30)) FAIL(PMX_E_UNSUPPORTED, "dimension too large");
+    if (mode != PMX_MODE_F32) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) FAIL(PMX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_CHECK(hipSetDevice(device));
+    pmx_ctx* c = new pmx_ctx();
+    c->device = device;
+    c->M = M; c->N = N; c->K = K;
+    c->rows[0] = M; c->rows[1] = N;
+    c->M_global = M;
+    c->mode = mode;
+    c->KP = K <= 32 ? 32 : (K <= 64 ? 64 : 128);
+    if (stream) c->stream = (hipStream_t)stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; FAIL(PMX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    c->plan = grad_plan_f32(M, N, K);
+    int rc = PMX_OK;
+    for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
+        rc = dallocT(c, &c->X[j], (size_t)c->rows[j] * K);
+        if (rc == PMX_OK) rc = dallocT(c, &c->G[j], (size_t)c->rows[j] * K);
+    }
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->plan.nSlabA * M * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * N * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)c->plan.gridX * c->plan.gridY);
+    if (rc == PMX_OK) rc = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
+    if (rc == PMX_OK) rc = dallocT(c, &c->colpart, (size_t)2 * EW_BLOCKS * MAXK);
+    if (rc == PMX_OK) rc = dallocT(c, &c->gramPart, (size_t)2 * GRAM_BLOCKS * c->KP * c->KP);
+    if (rc == PMX_OK) rc = dallocT(c, &c->gramG, (size_t)2 * c->KP * c->KP);
+    if (rc == PMX_OK) rc = dallocT(c, &c->dstatus, 1);
+    if (rc == PMX_OK) {
+        hipError_t e = hipHostMalloc((void**)&c->hstatus, sizeof(DevStatus), hipHostMallocDefault);
+        if (e != hipSuccess) { pmx_set_error("hipHostMalloc: %s", hipGetErrorString(e)); rc = PMX_E_NOMEM; }
+    }
+    if (rc != PMX_OK) { pmx_ctx_destroy(c); return rc; }
+    *out = c;
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_destroy(pmx_ctx* c) {
+    if (!c) return PMX_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->hstatus) hipHostFree(c->hstatus);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_sync(pmx_ctx* c) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
+    if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    HIP_CHECK(hipSetDevice(c->device));
+    int rc = dallocT(c, &c->Yown, (size_t)c->M * c->N, false);
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipMemcpy2DAsync(c->Yown, c->N * sizeof(float), Y, ld * sizeof(float), c->N * sizeof(float), c->M, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->Y = c->Yown;
+    c->ldY = c->N;
+    c->haveY = true;
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int copy) {
+    if (!c || !dY) FAIL(PMX_E_INVALID, "NULL argument");
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    HIP_CHECK(hipSetDevice(c->device));
+    if (copy) {
+        int rc = dallocT(c, &c->Yown, (size_t)c->M * c->N, false);
+        if (rc != PMX_OK) return rc;
+        HIP_CHECK(hipMemcpy2DAsync(c->Yown, c->N * sizeof(float), dY, ld * sizeof(float), c->N * sizeof(float), c->M, hipMemcpyDeviceToDevice, c->stream));
+        c->Y = c->Yown;
+        c->ldY = c->N;
+    } else {
+        c->Y = dY;
+        c->ldY = ld;
+    }
+    c->haveY = true;
+    return PMX_OK;
+}
+
+static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool create) {
+    int j;
+    float** p = nullptr;
+    if (buf >= PMX_BUF_A && buf <= PMX_BUF_VHST) {
+        j = buf & 1;
+        switch (buf >> 1) {
+            case 0: p = &c->X[j]; break;
+            case 1: p = &c->G[j]; break;
+            case 2: p = &c->Mm[j]; break;
+            case 3: p = &c->Vv[j]; break;
+            case 4: p = &c->Vh[j]; break;
+        }
+    } else if (buf >= PMX_BUF_Z0 && buf < PMX_BUF_Z0 + 2 * PMX_MAX_G) {
+        j = (buf - PMX_BUF_Z0) / PMX_MAX_G;
+        p = &c->Zg[j][(buf - PMX_BUF_Z0) % PMX_MAX_G];
+    } else if (buf >= PMX_BUF_U0 && buf < PMX_BUF_U0 + 2 * PMX_MAX_G) {
+        j = (buf - PMX_BUF_U0) / PMX_MAX_G;
+        p = &c->Ug[j][(buf - PMX_BUF_U0) % PMX_MAX_G];
+    } else FAIL(PMX_E_INVALID, "unknown buffer id %d", buf);
+    *count = c->rows[j] * c->K;
+    if (!*p) {
+        if (!create) FAIL(PMX_E_STATE, "buffer %d has not been created yet", buf);
+        int rc = dallocT(c, p, (size_t)*count);
+        if (rc != PMX_OK) return rc;
+    }
+    *slot = p;
+    return PMX_OK;
+}
+
+extern "C" int pmx_upload(pmx_ctx* c, int buf, const float* host, int64_t count) {
+    if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    float** slot; int64_t n;
+    int rc = buf_lookup(c, buf, &slot, &n, true);
+    if (rc != PMX_OK) return rc;
+    if (count != n) FAIL(PMX_E_INVALID, "buffer %d holds %lld floats, got %lld", buf, (long long)n, (long long)count);
+    HIP_CHECK(hipMemcpyAsync(*slot, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_download(pmx_ctx* c, int buf, float* host, int64_t count) {
+    if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    float** slot; int64_t n;
+    int rc = buf_lookup(c, buf, &slot, &n, false);
+    if (rc != PMX_OK) return rc;
+    if (count != n) FAIL(PMX_E_INVALID, "buffer %d holds %lld floats, got %lld", buf, (long long)n, (long long)count);
+    HIP_CHECK(hipMemcpyAsync(host, *slot, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_buffer_ptr(pmx_ctx* c, int buf, void** dptr, int64_t* count) {
+    if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
+    float** slot; int64_t n;
+    int rc = buf_lookup(c, buf, &slot, &n, true);
+    if (rc != PMX_OK) return rc;
+    *dptr = *slot;
+    if (count) *count = n;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// building blocks of the chains
+// ------------------------------------------------------------------------------------------------
+static int read_status(pmx_ctx* c) {
+    HIP_CHECK(hipMemcpyAsync(c->hstatus, c->dstatus, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+static int reset_status(pmx_ctx* c) {
+    DevStatus s;
+    memset(&s, 0, sizeof(s));
+    for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < MAXK; ++k) s.eigvec[f][k] = 1.0;
+    memcpy(c->hstatus, &s, sizeof(s));
+    HIP_CHECK(hipMemcpyAsync(c->dstatus, c->hstatus, sizeof(DevStatus), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+// clear `halt` (and adaprox's need_sub flags) before resuming a chain
+static int clear_halt(pmx_ctx* c) {
+    static const int zeros[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->halt, zeros, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));   // halt, reason
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->need_sub[0], zeros, sizeof(int) * 2, hipMemcpyHostToDevice, c->stream));
+    return PMX_OK;
+}
+
+static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS) {
+    GradArgs g{};
+    g.Y = c->Y; g.ldY = c->ldY;
+    g.A = A; g.St = St;
+    g.slabA = c->slab[0]; g.slabS = c->slab[1];
+    g.lossPart = c->lossPart;
+    g.status = c->dstatus;
+    g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
+    g.RP = c->plan.RP;
+    g.doA = doA; g.doS = doS;
+    HIP_CHECK(grad_launch_f32(c->plan, g, c->stream));
+    return PMX_OK;
+}
+
+static SlabRef slab_ref(pmx_ctx* c, int j) {
+    SlabRef s;
+    s.base = c->slab[j];
+    s.n = j == 0 ? c->plan.nSlabA : c->plan.nSlabS;
+    return s;
+}
+
+// Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
+static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale) {
+    GramArgs g{};
+    g.X[0] = A; g.X[1] = St;
+    g.rows[0] = c->M; g.rows[1] = c->N;
+    g.K = (int)c->K;
+    g.part = c->gramPart;
+    g.status = c->dstatus;
+    g.want[0] = wantStepS;   // factor 0 (A)  -> step of block 1 (S)
+    g.want[1] = wantStepA;   // factor 1 (St) -> step of block 0 (A)
+    launch_gram(g, c->KP, c->stream);
+    GramReduceArgs r{};
+    r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
+    r.want[0] = g.want[0]; r.want[1] = g.want[1];
+    launch_gram_reduce(r, c->stream);
+    EigArgs e{};
+    e.G = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+    e.want[0] = g.want[0]; e.want[1] = g.want[1];
+    e.scale = scale;
+    e.max_iter = 2000;
+    HIP_CHECK(launch_eig(e, c->stream));
+    return PMX_OK;
+}
+
+static int require_ready(pmx_ctx* c) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (!c->haveY) FAIL(PMX_E_STATE, "Y has not been set");
+    HIP_CHECK(hipSetDevice(c->device));
+    return PMX_OK;
+}
+
+static void fill_result(pmx_ctx* c, pmx_result* r, int it_before) {
+    if (!r) return;
+    const DevStatus* s = c->hstatus;
+    r->iterations = s->it_done - it_before;
+    r->total_iterations = s->it_done;
+    r->stopped = s->stopped;
+    r->converged[0] = s->conv[0];
+    r->converged[1] = s->conv[1];
+    r->steps[0] = s->step[0];
+    r->steps[1] = s->step[1];
+    r->sub_iterations[0] = s->sub_total[0];
+    r->sub_iterations[1] = s->sub_total[1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// single operations
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_grad(pmx_ctx* c) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+    rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
+    if (rc != PMX_OK) return rc;
+    FoldArgs f{};
+    for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
+    f.K = (int)c->K;
+    launch_fold(f, 2, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!out) FAIL(PMX_E_INVALID, "out is NULL");
+    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+    rc = enqueue_grad(c, c->X[0], c->X[1], 0, 0);
+    if (rc != PMX_OK) return rc;
+    const int n = c->plan.gridX * c->plan.gridY;
+    std::vector<double> h(n);
+    HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += h[i];
+    *out = 0.5 * s;
+    return PMX_OK;
+}
+
+extern "C" int pmx_step_pgm(pmx_ctx* c, double out[2]) {
+    if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+    int rc = enqueue_steps(c, c->X[0], c->X[1], true, true, 1.0);
+    if (rc != PMX_OK) return rc;
+    rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    out[0] = c->hstatus->step[0];
+    out[1] = c->hstatus->step[1];
+    return PMX_OK;
+}
+
+static AlphaArgs alpha_args(pmx_ctx* c) {
+    AlphaArgs a{};
+    a.status = c->dstatus;
+    a.colpart = c->colpart;
+    a.rows_global[0] = c->M_global;
+    a.rows_global[1] = c->N;
+    a.K = (int)c->K;
+    a.use_fixed = 0;
+    return a;
+}
+
+static int enqueue_alpha_from_factors(pmx_ctx* c, const AlphaArgs& al) {
+    ColsumArgs cs{};
+    cs.X[0] = c->X[0]; cs.X[1] = c->X[1];
+    cs.rows[0] = c->M; cs.rows[1] = c->N;
+    cs.K = (int)c->K;
+    cs.colpart = c->colpart;
+    cs.status = c->dstatus;
+    launch_colsum(cs, c->stream);
+    launch_alpha_init(al, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
+    if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+    int rc = enqueue_alpha_from_factors(c, alpha_args(c));
+    if (rc != PMX_OK) return rc;
+    rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    memcpy(out, c->hstatus->alpha[0], sizeof(float) * c->K);
+    memcpy(out + c->K, c->hstatus->alpha[1], sizeof(float) * c->K);
+    return PMX_OK;
+}
+
+extern "C" int pmx_prox_apply(pmx_ctx* c, int buf, const pmx_proxseq* prox, const float* step_k) {
+    if (!c || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    int rc = check_prox(*prox, "prox_apply");
+    if (rc != PMX_OK) return rc;
+    float** slot; int64_t n;
+    rc = buf_lookup(c, buf, &slot, &n, false);
+    if (rc != PMX_OK) return rc;
+    ProxArgs a{};
+    a.X = *slot;
+    a.rows = n / c->K;
+    a.K = (int)c->K;
+    a.prox = to_dev(*prox);
+    for (int k = 0; k < c->K; ++k) a.stepk[k] = step_k[k];
+    launch_prox_apply(a, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const pmx_proxseq* prox, const float* step_k) {
+    if (!X || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
+    if (rows <= 0 || K <= 0 || K > MAXK) FAIL(PMX_E_INVALID, "bad shape rows=%lld K=%d", (long long)rows, K);
+    int rc = check_prox(*prox, "prox_array");
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipSetDevice(device));
+    float* d = nullptr;
+    const size_t bytes = (size_t)rows * K * sizeof(float);
+    HIP_CHECK(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemcpy(d, X, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ProxArgs a{};
+        a.X = d;
+        a.rows = rows;
+        a.K = K;
+        a.prox = to_dev(*prox);
+        for (int k = 0; k < K; ++k) a.stepk[k] = step_k[k];
+        launch_prox_apply(a, nullptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(X, d, bytes, hipMemcpyDeviceToHost);
+    }
+    hipFree(d);
+    if (e != hipSuccess) FAIL(PMX_E_HIP, "prox_array: %s", hipGetErrorString(e));
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGM / FISTA                                             (proxmin/algorithms.py:12-144)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!p) FAIL(PMX_E_INVALID, "params is NULL");
+    for (int j = 0; j < 2; ++j) {
+        rc = check_prox(p->prox[j], j ? "prox_S" : "prox_A");
+        if (rc != PMX_OK) return rc;
+    }
+    c->pgm = *p;
+    c->algo = ALG_PGM;
+    c->it = 0;
+    c->nest_t = 1.0;
+    c->omega_cur = 0.f;
+    rc = reset_status(c);
+    if (rc != PMX_OK) return rc;
+    if (p->accelerated) {
+        for (int j = 0; j < 2; ++j) {
+            rc = dallocT(c, &c->Xe[j], (size_t)c->rows[j] * c->K, false);
+            if (rc != PMX_OK) return rc;
+            // omega = 0 on the first read (utils.py:201-203): the first extrapolated point is X itself
+            HIP_CHECK(hipMemcpyAsync(c->Xe[j], c->X[j], c->rows[j] * c->K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        // consume the first omega (== 0) like `accel.omega` at it = 0
+        const double t1 = 0.5 * (1.0 + sqrt(4.0 * c->nest_t * c->nest_t + 1.0));
+        c->nest_t = t1;
+    }
+    return PMX_OK;
+}
+
+// omega that the NEXT iteration will read (utils.py:198-206)
+static float next_omega(pmx_ctx* c) {
+    if (!c->pgm.accelerated) return 0.f;
+    const double t = c->nest_t;
+    const double t1 = 0.5 * (1.0 + sqrt(4.0 * t * t + 1.0));
+    const double om = (t - 1.0) / t1;
+    c->nest_t = t1;
+    return (float)om;
+}
+
+static int pgm_enqueue_iteration(pmx_ctx* c) {
+    const pmx_pgm_params& p = c->pgm;
+    const float* A = p.accelerated ? c->Xe[0] : c->X[0];
+    const float* St = p.accelerated ? c->Xe[1] : c->X[1];
+    int rc;
+    if (!p.use_fixed_steps) {
+        rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
+        if (rc != PMX_OK) return rc;
+    }
+    rc = enqueue_grad(c, A, St, 1, 1);                                    // algorithms.py:105
+    if (rc != PMX_OK) return rc;
+    PgmArgs u{};
+    for (int j = 0; j < 2; ++j) {
+        u.X[j] = c->X[j];
+        u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
+        u.G[j] = c->G[j];
+        u.slab[j] = slab_ref(c, j);
+        u.rows[j] = c->rows[j];
+        u.prox[j] = to_dev(p.prox[j]);
+    }
+    u.K = (int)c->K;
+    u.status = c->dstatus;
+    u.partials = c->partials;
+    u.accelerated = p.accelerated;
+    u.omega_next = next_omega(c);
+    launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
+    DecideArgs d{};
+    d.status = c->dstatus;
+    d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check = 1;
+    launch_pgm_decide(d, c->stream);                                      // algorithms.py:130-135
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->step[0], s, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
+    if (n_iter < 0) FAIL(PMX_E_INVALID, "n_iter < 0");
+    const int it0 = c->hstatus->it_done;
+    if (c->pgm.use_fixed_steps) {
+        rc = set_fixed_steps(c, c->pgm.fixed_steps);
+        if (rc != PMX_OK) return rc;
+    }
+    int left = n_iter;
+    while (left > 0 && !c->hstatus->stopped) {
+        const int chunk = std::min(left, 32);
+        for (int i = 0; i < chunk; ++i) {
+            rc = pgm_enqueue_iteration(c);
+            if (rc != PMX_OK) return rc;
+        }
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        left -= chunk;
+    }
+    fill_result(c, res, it0);
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaprox                                                 (proxmin/algorithms.py:248-423)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int warm_moments) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!p) FAIL(PMX_E_INVALID, "params is NULL");
+    if (p->scheme < PMX_ADAM || p->scheme > PMX_RADAM) FAIL(PMX_E_INVALID, "unknown scheme %d", p->scheme);
+    if (!(p->b2 >= 0 && p->b2 < 1)) FAIL(PMX_E_INVALID, "b2 out of [0,1)");           // algorithms.py:332
+    if (!(p->eps >= 0)) FAIL(PMX_E_INVALID, "eps < 0");                               // :333
+    if (!(p->p > 0 && p->p <= 0.5)) FAIL(PMX_E_INVALID, "p out of (0,0.5]");           // :334
+    for (int j = 0; j < 2; ++j) {
+        rc = check_prox(p->prox[j], j ? "prox_S" : "prox_A");
+        if (rc != PMX_OK) return rc;
+    }
+    c->ada = *p;
+    c->algo = ALG_ADAPROX;
+    c->it = 0;
+    c->nsub_guess = 2;
+    rc = reset_status(c);
+    if (rc != PMX_OK) return rc;
+    for (int j = 0; j < 2; ++j) {
+        const size_t n = (size_t)c->rows[j] * c->K;
+        const bool fresh_m = c->Mm[j] == nullptr, fresh_v = c->Vv[j] == nullptr;
+        rc = dallocT(c, &c->Mm[j], n);
+        if (rc == PMX_OK) rc = dallocT(c, &c->Vv[j], n);
+        if (rc != PMX_OK) return rc;
+        if (!warm_moments) {   // cold start: zeros (algorithms.py:348-353)
+            if (!fresh_m) HIP_CHECK(hipMemsetAsync(c->Mm[j], 0, n * sizeof(float), c->stream));
+            if (!fresh_v) HIP_CHECK(hipMemsetAsync(c->Vv[j], 0, n * sizeof(float), c->stream));
+        }
+        if (p->warm_vhat && !c->Vh[j]) FAIL(PMX_E_STATE, "warm_vhat set but Vhat buffers were not uploaded");
+        if (p->check_convergence) {
+            rc = dallocT(c, &c->Xp[j], n, false);
+            if (rc != PMX_OK) return rc;
+        }
+        if (p->prox[j].n > 0) {
+            rc = dallocT(c, &c->Psi[j], n, false);
+            if (rc == PMX_OK) rc = dallocT(c, &c->zb[j][0], n, false);
+            if (rc == PMX_OK) rc = dallocT(c, &c->zb[j][1], n, false);
+            if (rc != PMX_OK) return rc;
+        }
+    }
+    // step sizes of the first iteration from the initial factors (algorithms.py:370 -> nmf.py:93)
+    AlphaArgs al = alpha_args(c);
+    al.use_fixed = p->use_fixed_steps;
+    al.fixed[0] = (float)p->fixed_alpha[0];
+    al.fixed[1] = (float)p->fixed_alpha[1];
+    rc = enqueue_alpha_from_factors(c, al);
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+static SubArgs sub_args(pmx_ctx* c, int t) {
+    const pmx_adaprox_params& p = c->ada;
+    SubArgs s{};
+    for (int j = 0; j < 2; ++j) {
+        s.X[j] = c->X[j];
+        s.Psi[j] = c->Psi[j];
+        s.zb[j][0] = c->zb[j][0];
+        s.zb[j][1] = c->zb[j][1];
+        s.rows[j] = c->rows[j];
+        s.prox[j] = to_dev(p.prox[j]);
+        s.e_rel[j] = p.e_rel[j];
+        s.has_prox[j] = p.prox[j].n > 0;
+    }
+    s.K = (int)c->K;
+    s.status = c->dstatus;
+    s.partials = c->partials;
+    s.t = t;
+    s.prox_max_iter = p.prox_max_iter;
+    return s;
+}
+
+// tail of an iteration: finish + decide.  t = number of sub-iteration passes enqueued so far
+static int ada_enqueue_tail(pmx_ctx* c, int t) {
+    const pmx_adaprox_params& p = c->ada;
+    FinishArgs f{};
+    f.s = sub_args(c, t);
+    f.Xp[0] = c->Xp[0]; f.Xp[1] = c->Xp[1];
+    f.colpart = c->colpart;
+    f.check_convergence = p.check_convergence;
+    launch_ada_finish(f, c->stream);
+    AdaDecideArgs d{};
+    d.al = alpha_args(c);
+    d.al.use_fixed = p.use_fixed_steps;
+    d.al.fixed[0] = (float)p.fixed_alpha[0];
+    d.al.fixed[1] = (float)p.fixed_alpha[1];
+    d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check_convergence = p.check_convergence;
+    d.has_prox[0] = p.prox[0].n > 0; d.has_prox[1] = p.prox[1].n > 0;
+    launch_ada_decide(d, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
+    const pmx_adaprox_params& p = c->ada;
+    int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);                     // algorithms.py:369
+    if (rc != PMX_OK) return rc;
+    MomentArgs m{};
+    for (int j = 0; j < 2; ++j) {
+        m.X[j] = c->X[j]; m.Xp[j] = c->Xp[j];
+        m.Mm[j] = c->Mm[j]; m.Vv[j] = c->Vv[j];
+        m.Vh[j] = p.warm_vhat ? c->Vh[j] : nullptr;
+        m.Psi[j] = c->Psi[j];
+        m.slab[j] = slab_ref(c, j);
+        m.rows[j] = c->rows[j];
+        m.has_prox[j] = p.prox[j].n > 0;
+    }
+    m.K = (int)c->K;
+    m.status = c->dstatus;
+    m.partials = c->partials;
+    m.scheme = p.scheme;
+    m.it = it;
+    m.b1t = b1t; m.b1prev = b1prev; m.b2 = p.b2; m.eps = p.eps; m.p = p.p;
+    m.check_convergence = p.check_convergence;
+    launch_ada_moment(m, c->stream);                                      // algorithms.py:375-378
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double b1_prev, pmx_result* res) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
+    if (n_iter < 0 || (n_iter > 0 && !b1)) FAIL(PMX_E_INVALID, "bad n_iter / b1");
+    for (int i = 0; i < n_iter; ++i)
+        if (!(b1[i] >= 0 && b1[i] < 1)) FAIL(PMX_E_INVALID, "b1 out of [0,1)");       // algorithms.py:330
+    const pmx_adaprox_params& p = c->ada;
+    const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
+    const int it0 = c->hstatus->it_done;
+    int done = 0;            // iterations of this call completed
+    while (done < n_iter && !c->hstatus->stopped) {
+        // ---- enqueue a chunk of whole iterations ------------------------------------------------
+        const int chunk = std::min(n_iter - done, 16);
+        const int nsub = any_prox ? std::max(1, std::min(c->nsub_guess, p.prox_max_iter)) : 0;
+        for (int i = 0; i < chunk; ++i) {
+            const int gi = done + i;
+            rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
+            if (rc != PMX_OK) return rc;
+            for (int t = 0; t < nsub; ++t) launch_ada_sub(sub_args(c, t), c->stream);
+            rc = ada_enqueue_tail(c, nsub);
+            if (rc != PMX_OK) return rc;
+        }
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        // ---- a chain stopped inside an iteration's sub-iteration loop: feed it more passes --------
+        int t_enq = nsub;
+        while (c->hstatus->halt && c->hstatus->reason == HALT_NEED_SUB) {
+            rc = clear_halt(c);
+            if (rc != PMX_OK) return rc;
+            const int more = std::min(std::max(4, t_enq), 64);
+            for (int t = t_enq; t < t_enq + more; ++t) launch_ada_sub(sub_args(c, t), c->stream);
+            t_enq += more;
+            rc = ada_enqueue_tail(c, t_enq);
+            if (rc != PMX_OK) return rc;
+            // the iterations that followed in the chunk were skipped: re-enqueue them after this one
+            const int finished_if_ok = c->hstatus->it_done - it0 + 1;
+            for (int gi = finished_if_ok; gi < done + chunk; ++gi) {
+                rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
+                if (rc != PMX_OK) return rc;
+                for (int t = 0; t < nsub; ++t) launch_ada_sub(sub_args(c, t), c->stream);
+                rc = ada_enqueue_tail(c, nsub);
+                if (rc != PMX_OK) return rc;
+            }
+            const int it_before = c->hstatus->it_done;
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (c->hstatus->it_done > it_before) t_enq = nsub;   // moved on to a later iteration
+        }
+        done = c->hstatus->it_done - it0;
+        if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
+        if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+    }
+    fill_result(c, res, it0);
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-SDMM                                              (proxmin/algorithms.py:653-850)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!p) FAIL(PMX_E_INVALID, "params is NULL");
+    for (int j = 0; j < 2; ++j) {
+        rc = check_prox(p->prox_f[j], j ? "prox_S" : "prox_A");
+        if (rc != PMX_OK) return rc;
+        if (p->n_g[j] < 0 || p->n_g[j] > PMX_MAX_G) FAIL(PMX_E_UNSUPPORTED, "at most %d constraints per block", PMX_MAX_G);
+        for (int i = 0; i < p->n_g[j]; ++i) {
+            rc = check_prox(p->prox_g[j][i], "proxs_g");
+            if (rc != PMX_OK) return rc;
+        }
+    }
+    c->bsd = *p;
+    c->algo = ALG_BSDMM;
+    c->it = 0;
+    rc = reset_status(c);
+    if (rc != PMX_OK) return rc;
+    // utils.initZU (utils.py:244-254): Z_i = copy of X, U_i = 0
+    for (int j = 0; j < 2; ++j) {
+        const size_t n = (size_t)c->rows[j] * c->K;
+        for (int i = 0; i < p->n_g[j]; ++i) {
+            rc = dallocT(c, &c->Zg[j][i], n, false);
+            if (rc == PMX_OK) rc = dallocT(c, &c->Ug[j][i], n, false);
+            if (rc != PMX_OK) return rc;
+            HIP_CHECK(hipMemcpyAsync(c->Zg[j][i], c->X[j], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HIP_CHECK(hipMemsetAsync(c->Ug[j][i], 0, n * sizeof(float), c->stream));
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+static int bsdmm_enqueue_iteration(pmx_ctx* c) {
+    const pmx_bsdmm_params& p = c->bsd;
+    for (int j = 0; j < 2; ++j) {                                          // Gauss-Seidel, algorithms.py:805
+        int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
+        if (rc != PMX_OK) return rc;
+        rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1);             // nmf.py:181-185 (only grads[j] is used)
+        if (rc != PMX_OK) return rc;
+        BsdmmArgs u{};
+        u.X = c->X[j];
+        u.slab = slab_ref(c, j);
+        for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
+        u.rows = c->rows[j];
+        u.K = (int)c->K;
+        u.j = j;
+        u.n_g = p.n_g[j];
+        u.prox_f = to_dev(p.prox_f[j]);
+        u.status = c->dstatus;
+        u.partials = c->partials;
+        launch_bsdmm_update(u, c->stream);
+        BsdmmDecideArgs d{};
+        d.status = c->dstatus;
+        d.partials = c->partials;
+        d.j = j;
+        d.n_g = p.n_g[j];
+        d.size = c->rows[j] * c->K;
+        d.e_rel = p.e_rel[j];
+        d.e_abs = p.e_abs[j];
+        d.last_block = j == 1;
+        launch_bsdmm_decide(d, c->stream);
+        HIP_CHECK(hipGetLastError());
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
+    if (n_iter < 0) FAIL(PMX_E_INVALID, "n_iter < 0");
+    const int it0 = c->hstatus->it_done;
+    int left = n_iter;
+    while (left > 0 && !c->hstatus->stopped) {
+        const int chunk = std::min(left, 16);
+        for (int i = 0; i < chunk; ++i) {
+            rc = bsdmm_enqueue_iteration(c);
+            if (rc != PMX_OK) return rc;
+        }
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        left -= chunk;
+    }
+    fill_result(c, res, it0);
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-sharded multi-GPU entry points: declared in pmx.h, implemented in a later milestone
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_set_world(pmx_ctx* c, int rank, int world, int64_t M_global) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (world < 1 || rank < 0 || rank >= world) FAIL(PMX_E_INVALID, "bad rank/world");
+    c->rank = rank; c->world = world; c->M_global = M_global;
+    return PMX_OK;
+}
+extern "C" int pmx_comm_buffer(pmx_ctx* c, void** dptr, int64_t* count_floats) {
+    (void)c; (void)dptr; (void)count_floats;
+    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+}
+extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase) {
+    (void)c; (void)phase;
+    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+}
+extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, double b1_it, double b1_prev) {
+    (void)c; (void)phase; (void)b1_it; (void)b1_prev;
+    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+}
+extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {
+    if (!c || !res) FAIL(PMX_E_INVALID, "NULL argument");
+    int rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    fill_result(c, res, 0);
+    return PMX_OK;
+}

@@ -1,0 +1,87 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI layer of libpmx.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pmx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------
+// elementwise / reduction grid: every factor-sized kernel uses the same fixed geometry so that
+// per-block partial sums written by one kernel can be folded by the next one in a fixed order
+// (deterministic, no float atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int EW_BLOCKS = 256;   // one per CU
+constexpr int EW_THREADS = 256;
+constexpr int LPR = 32;          // lanes per row (half a wavefront): K <= 128 -> <= 4 values per lane
+constexpr int MAXC = 4;          // ceil(128 / LPR)
+constexpr int MAXK = 128;
+
+// reduction slots (double per block), indexed [slot][block(A|S)][EW_BLOCKS]
+enum {
+    SL_DIFF2 = 0,   // sum (X_new - X_old)^2            (algorithms.py:131,406)
+    SL_NORM2 = 1,   // sum X_new^2
+    SL_SUB_D = 2,   // sum (z_new - z)^2, parity 0      (algorithms.py:389)
+    SL_SUB_N = 3,   // sum z^2, parity 0
+    SL_SUB_D1 = 4,  // parity 1
+    SL_SUB_N1 = 5,
+    SL_MAXPSI = 6,  // max Psi                          (algorithms.py:384)
+    SL_G0 = 8,      // bsdmm: 5 sums per constraint i: R^2, Sd^2, Z^2, (U/sg)^2 ; + X^2 in SL_NORM2
+    SL_COUNT = 8 + 4 * PMX_MAX_G
+};
+constexpr int COLSUM_SLOTS = MAXK;   // per-block per-component partial column sums
+
+// device-resident control block.  Every kernel of a chain starts by reading `halt`.
+struct DevStatus {
+    int halt;            // != 0: remaining kernels of the chain are no-ops
+    int reason;          // why (HALT_*)
+    int it_done;         // completed iterations since *_begin
+    int conv[2];         // last outer convergence flags
+    int stopped;         // outer test fired
+    int sub_done[2];     // adaprox: sub-iteration loop finished for block j in this iteration
+    int sub_tau[2];      // adaprox: tau reached in this iteration
+    int need_sub[2];     // adaprox: k_ada_finish found the loop unfinished (more passes must be enqueued)
+    int last_tau[2];     // adaprox: tau of the last completed iteration (host uses it to size the next chain)
+    long long sub_total[2];
+    double step[2];      // pgm/bsdmm: current step sizes
+    double lam[2];       // largest Gram eigenvalues
+    double maxpsi[2];
+    double loss;
+    double norms[2][2];  // [block][diff2,norm2] of the last outer test
+    float alpha[2][MAXK];   // adaprox per-component steps (nmf.py:93)
+    float gamma[2][MAXK];   // alpha / max(Psi)
+    float ratio[2][MAXK];   // gamma / alpha  (NaN when alpha == 0, like the reference)
+    double eigvec[2][MAXK]; // warm start for the power iteration
+    int eig_iters[2];
+    int pad;
+};
+enum { HALT_NONE = 0, HALT_CONVERGED = 1, HALT_NEED_SUB = 2, HALT_ERROR = 3 };
+
+struct ProxSeq {           // device copy of pmx_proxseq
+    int n, repeat;
+    pmx_prox seq[PMX_MAX_SEQ];
+};
+
+__device__ __forceinline__ bool chain_halted(const DevStatus* st) {
+    return __builtin_nontemporal_load(&st->halt) != 0;
+}
+
+// tall factor descriptor: X is rows x K, row-major, K contiguous
+struct Tall {
+    float* p;
+    int64_t rows;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            pmx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PMX_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+void pmx_set_error(const char* fmt, ...);

@@ -1,0 +1,171 @@
+"""Thin object wrapper around one libpmx context: device residency of Y / A / S^T for the
+duration of an `nmf()` call, uploads/downloads with the S <-> S^T transposition, and the solver
+entry points.  Pure plumbing -- every number is produced by the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceNMF:
+    """Device state for one factorisation problem Y (M x N) ~ A (M x K) @ S (K x N)."""
+
+    def __init__(self, M, N, K, device=0, mode="f32", stream=None):
+        self.lib = _lib.require_gpu()
+        self.M, self.N, self.K = int(M), int(N), int(K)
+        self.device = device
+        mode_id = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}[mode]
+        h = C.c_void_p()
+        _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
+                                           C.c_void_p(stream) if stream else None))
+        self.h = h
+        self._keep = []
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pmx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        _lib.check(self.lib.pmx_ctx_sync(self.h))
+
+    # -- data -------------------------------------------------------------------------------
+    def set_Y(self, Y):
+        Y = np.asarray(Y)
+        assert Y.shape == (self.M, self.N), "Y must be M x N"
+        Yf = _f32(Y)
+        _lib.check(self.lib.pmx_set_Y_host(self.h, _vp(Yf), self.N))
+
+    def set_Y_device(self, dptr, ld=None, copy=False, keepalive=None):
+        """Adopt (or copy) a float32 row-major device array, e.g. a torch tensor's data_ptr()."""
+        if keepalive is not None:
+            self._keep.append(keepalive)
+        _lib.check(self.lib.pmx_set_Y_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
+
+    def _upload(self, buf, arr2d):
+        a = _f32(arr2d)
+        _lib.check(self.lib.pmx_upload(self.h, buf, _vp(a), a.size))
+
+    def _download(self, buf, rows):
+        out = np.empty((rows, self.K), dtype=np.float32)
+        _lib.check(self.lib.pmx_download(self.h, buf, _vp(out), out.size))
+        return out
+
+    def set_factors(self, A, S):
+        assert A.shape == (self.M, self.K) and S.shape == (self.K, self.N), "A must be M x K and S K x N"
+        self._upload(_lib.BUF_A, A)
+        self._upload(_lib.BUF_ST, np.asarray(S).T)
+
+    def get_factors(self):
+        return self._download(_lib.BUF_A, self.M), self._download(_lib.BUF_ST, self.N).T
+
+    def put(self, base, j, arr):
+        """upload block j (0: M x K array, 1: K x N array) of a two-block state (moments, Z/U, ...)."""
+        self._upload(base + j, arr if j == 0 else np.asarray(arr).T)
+
+    def get(self, base, j):
+        out = self._download(base + j, self.M if j == 0 else self.N)
+        return out if j == 0 else out.T
+
+    # -- single operations --------------------------------------------------------------------
+    def grad(self):
+        """nmf.grad_likelihood at the current device factors -> (gA (M x K), gS (K x N))."""
+        _lib.check(self.lib.pmx_grad(self.h))
+        return self._download(_lib.BUF_GA, self.M), self._download(_lib.BUF_GST, self.N).T
+
+    def loglike(self):
+        out = C.c_double()
+        _lib.check(self.lib.pmx_loglike(self.h, C.byref(out)))
+        return out.value
+
+    def step_pgm(self):
+        out = (C.c_double * 2)()
+        _lib.check(self.lib.pmx_step_pgm(self.h, out))
+        return out[0], out[1]
+
+    def step_adaprox(self):
+        out = np.empty(2 * self.K, dtype=np.float32)
+        _lib.check(self.lib.pmx_step_adaprox(self.h, _vp(out)))
+        return out[: self.K].copy(), out[self.K:].copy()
+
+    # -- solvers ------------------------------------------------------------------------------
+    def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6)):
+        p = _lib.PgmParams()
+        p.prox[0], p.prox[1] = prox
+        p.accelerated = int(bool(accelerated))
+        p.step_scale = float(step_scale)
+        p.use_fixed_steps = int(fixed_steps is not None)
+        if fixed_steps is not None:
+            p.fixed_steps[0], p.fixed_steps[1] = float(fixed_steps[0]), float(fixed_steps[1])
+        p.e_rel[0], p.e_rel[1] = float(e_rel[0]), float(e_rel[1])
+        _lib.check(self.lib.pmx_pgm_begin(self.h, C.byref(p)))
+
+    def pgm_run(self, n_iter):
+        r = _lib.Result()
+        _lib.check(self.lib.pmx_pgm_run(self.h, int(n_iter), C.byref(r)))
+        return r
+
+    def adaprox_begin(self, prox, scheme="adam", b2=0.999, eps=1e-8, p=0.25, check_convergence=True,
+                      prox_max_iter=1000, warm_moments=False, warm_vhat=False, fixed_alpha=None, e_rel=(1e-6, 1e-6)):
+        q = _lib.AdaproxParams()
+        q.prox[0], q.prox[1] = prox
+        q.scheme = _lib.SCHEME[scheme]
+        q.b2, q.eps, q.p = float(b2), float(eps), float(p)
+        q.check_convergence = int(bool(check_convergence))
+        q.prox_max_iter = int(prox_max_iter)
+        q.warm_vhat = int(bool(warm_vhat))
+        q.use_fixed_steps = int(fixed_alpha is not None)
+        if fixed_alpha is not None:
+            q.fixed_alpha[0], q.fixed_alpha[1] = float(fixed_alpha[0]), float(fixed_alpha[1])
+        q.e_rel[0], q.e_rel[1] = float(e_rel[0]), float(e_rel[1])
+        _lib.check(self.lib.pmx_adaprox_begin(self.h, C.byref(q), int(bool(warm_moments))))
+
+    def adaprox_run(self, b1_slice, b1_prev):
+        b1 = np.ascontiguousarray(b1_slice, dtype=np.float64)
+        r = _lib.Result()
+        _lib.check(self.lib.pmx_adaprox_run(self.h, int(b1.size), b1.ctypes.data_as(C.POINTER(C.c_double)),
+                                            float(b1_prev), C.byref(r)))
+        return r
+
+    def bsdmm_begin(self, prox_f, proxs_g, e_rel=(1e-6, 1e-6), e_abs=(0.0, 0.0)):
+        p = _lib.BsdmmParams()
+        p.prox_f[0], p.prox_f[1] = prox_f
+        for j in range(2):
+            g = proxs_g[j] or []
+            if len(g) > _lib.MAX_G:
+                raise NotImplementedError("at most %d constraints per factor on the device" % _lib.MAX_G)
+            p.n_g[j] = len(g)
+            for i, ps in enumerate(g):
+                p.prox_g[j][i] = ps
+            p.e_rel[j], p.e_abs[j] = float(e_rel[j]), float(e_abs[j])
+        _lib.check(self.lib.pmx_bsdmm_begin(self.h, C.byref(p)))
+
+    def bsdmm_run(self, n_iter):
+        r = _lib.Result()
+        _lib.check(self.lib.pmx_bsdmm_run(self.h, int(n_iter), C.byref(r)))
+        return r

@@ -1,0 +1,153 @@
+"""Constrained matrix factorisation front-end: same call signature and in-place contract as
+`proxmin.nmf.nmf` (proxmin/nmf.py:96-203), executed on the MI355X.
+
+    nmf(Y, A, S, W=1, prox_A=prox_plus, prox_S=prox_plus, algorithm=pgm, step=None,
+        max_iter=1000, e_rel=1e-3, callback=None, **algorithm_args)
+
+Y is uploaded once, A and S live on the device (S as S^T) for the whole call, and are written
+back into the caller's arrays at exit (and before every user callback).  The helper functions
+`log_likelihood`, `grad_likelihood`, `step_pgm`, `step_adaprox` keep the reference's signatures
+and run the same device kernels on the arrays they are given.
+"""
+from __future__ import annotations
+
+import logging
+from functools import partial
+
+import numpy as np
+
+from . import algorithms, operators
+from .engine import DeviceNMF
+
+logger = logging.getLogger("proxmin")
+
+
+def _check_W(W):
+    if not (np.isscalar(W) and W == 1):
+        raise NotImplementedError("weighted likelihood (W != 1) is not implemented on the device "
+                                  "(the reference's own weighted step rule, nmf.py:64-88, is broken on NumPy 2)")
+
+
+def _device_for(A, S, Y):
+    A, S, Y = np.asarray(A), np.asarray(S), np.asarray(Y)
+    dev = DeviceNMF(Y.shape[0], Y.shape[1], A.shape[1])
+    dev.set_Y(Y)
+    dev.set_factors(A, S)
+    return dev
+
+
+def log_likelihood(*X, Y=0, W=1):
+    """1/2 sum (Y - A S)^2 (nmf.py:13-25), reduced inside the fused residual kernel."""
+    _check_W(W)
+    A, S = X
+    with _device_for(A, S, Y) as dev:
+        return dev.loglike()
+
+
+def grad_likelihood(*X, Y=0, W=1):
+    """(R S^T, A^T R) with R = A S - Y (nmf.py:28-41): one launch of the fused residual-gradient
+    kernel.  Returns arrays in the dtype of A."""
+    _check_W(W)
+    A, S = X
+    with _device_for(A, S, Y) as dev:
+        gA, gS = dev.grad()
+    dt = np.asarray(A).dtype
+    return gA.astype(dt), np.ascontiguousarray(gS).astype(dt)
+
+
+def step_A(A, S):
+    """1 / lmax(S S^T) (nmf.py:44-45)."""
+    return step_pgm(A, S)[0]
+
+
+def step_S(A, S):
+    """1 / lmax(A^T A) (nmf.py:48-49)."""
+    return step_pgm(A, S)[1]
+
+
+def step_pgm(*X, it=None, W=1):
+    """Lipschitz step sizes for PGM (nmf.py:52-65, W == 1 branch), Gram matrices and the largest
+    eigenvalues computed on the device."""
+    _check_W(W)
+    A, S = X
+    Yd = np.zeros((A.shape[0], S.shape[1]), dtype=np.float32)
+    with _device_for(A, S, Yd) as dev:
+        return dev.step_pgm()
+
+
+def step_adaprox(*X, it=None):
+    """(mean(A, axis=0) / 10, mean(S, axis=1)[:, None] / 10) (nmf.py:91-93)."""
+    A, S = X
+    Yd = np.zeros((A.shape[0], S.shape[1]), dtype=np.float32)
+    with _device_for(A, S, Yd) as dev:
+        aA, aS = dev.step_adaprox()
+    dt = np.asarray(A).dtype
+    return aA.astype(dt), aS.astype(dt)[:, None]
+
+
+class scaled_step_pgm:
+    """`step=scaled_step_pgm(c)`: the default Lipschitz rule multiplied by a constant, evaluated on
+    the device each iteration.  Equivalent to the reference idiom
+    `step=lambda *X, it=None: tuple(c * s for s in step_pgm(*X))` (needed e.g. for FISTA, which
+    collapses with the undamped rule -- SURVEY.md section 4)."""
+
+    def __init__(self, scale):
+        self.scale = float(scale)
+
+    def __call__(self, *X, it=None):
+        return tuple(self.scale * s for s in step_pgm(*X))
+
+
+class constant_step:
+    """`step=constant_step(a_A, a_S)`: fixed step sizes, e.g. the adaprox learning rates of
+    examples/unmixing.py:139-143 (`lambda *X, it: (alpha, alpha)`)."""
+
+    def __init__(self, step_A, step_S=None):
+        self.steps = (float(step_A), float(step_A if step_S is None else step_S))
+
+    def __call__(self, *X, it=None, grads=None):
+        return self.steps
+
+
+def nmf(
+    Y,
+    A,
+    S,
+    W=1,
+    prox_A=operators.prox_plus,
+    prox_S=operators.prox_plus,
+    algorithm=algorithms.pgm,
+    step=None,
+    max_iter=1000,
+    e_rel=1e-3,
+    callback=None,
+    **algorithm_args
+):
+    """Non-negative / constrained matrix factorisation  minimise || Y - A S ||^2  (nmf.py:96-203).
+
+    Args and returns are those of the reference: A (M x K) and S (K x N) are updated in place; the
+    return value is that of the chosen algorithm (pgm: (converged, grads, steps); adaprox:
+    (converged, M, V, Vhat); bsdmm: converged).  `algorithm` must be one of THIS package's
+    `algorithms.pgm / adaprox / bsdmm` (identity test, nmf.py:141).
+    """
+    assert algorithm in [algorithms.pgm, algorithms.adaprox, algorithms.bsdmm]
+
+    grad = partial(grad_likelihood, Y=Y, W=W)
+    X = [A, S]
+    prox = [prox_A, prox_S]
+
+    if algorithm is algorithms.pgm:
+        if step is None:
+            step = partial(step_pgm, W=W)
+        return algorithm(X, grad, step, prox=prox, max_iter=max_iter, e_rel=e_rel, callback=callback, **algorithm_args)
+
+    if algorithm is algorithms.adaprox:
+        if step is None:
+            step = step_adaprox
+        return algorithm(X, grad, step, prox=prox, max_iter=max_iter, e_rel=e_rel, callback=callback, **algorithm_args)
+
+    if algorithm is algorithms.bsdmm:
+        if step is not None:
+            # the reference raises UnboundLocalError here (nmf.py:187-198 passes the undefined step_f)
+            raise NotImplementedError("a user `step` is not supported with bsdmm (it crashes in the reference too)")
+        return algorithms._bsdmm_nmf(X, grad, prox, max_iter=max_iter, e_rel=e_rel, callback=callback, **algorithm_args)

@@ -1,0 +1,52 @@
+"""Host-side helpers of the nmf() path that are plain Python in the reference and stay plain Python
+here (callback plumbing and the scalar Nesterov sequence); everything array-sized lives on the GPU.
+"""
+from __future__ import annotations
+
+import math
+
+
+def _as_tuple(X):
+    """proxmin/utils.py:8-12."""
+    return X if type(X) in (list, tuple) else (X,)
+
+
+class Traceback(object):
+    """Callback that stores a copy of every iterate it is shown (proxmin/utils.py:104-116)."""
+
+    def __init__(self):
+        self._trace = []
+
+    def __call__(self, *X, it=None):
+        self._trace.append(tuple(x.copy() for x in X))
+
+    @property
+    def trace(self):
+        return self._trace
+
+    def clear(self):
+        self._trace = []
+
+
+class NullCallback(object):
+    """proxmin/utils.py:119-121.  nmf() treats it like callback=None: no per-iteration D2H copies."""
+
+    def __call__(self, *X, it):
+        pass
+
+
+class NesterovAccelerator(object):
+    """FISTA momentum sequence (proxmin/utils.py:193-206); the device keeps its own copy of `t`."""
+
+    def __init__(self, accelerated=False):
+        self.t = 1.0
+        self.accelerated = accelerated
+
+    @property
+    def omega(self):
+        if not self.accelerated:
+            return 0
+        t_ = 0.5 * (1 + math.sqrt(4 * self.t * self.t + 1))
+        om = (self.t - 1) / t_
+        self.t = t_
+        return om

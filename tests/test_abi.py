@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/pmx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from proxmin_amd import _lib
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pmx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmx_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(os.path.join(ROOT, "proxmin_amd", "libpmx.so"))
+    for n in names:
+        assert hasattr(raw, n), "libpmx.so does not export %s" % n
+
+
+def test_binding_covers_header(lib):
+    from proxmin_amd import _lib
+    assert set(_declared_symbols()) == set(_lib.EXPORTED_SYMBOLS)
+    assert lib.pmx_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    """sizes implied by include/pmx.h (checked against the ctypes mirrors)."""
+    from proxmin_amd import _lib
+    assert ctypes.sizeof(_lib.Prox) == 16
+    assert ctypes.sizeof(_lib.ProxSeq) == 8 + 16 * _lib.MAX_SEQ
+    assert ctypes.sizeof(_lib.Result) == 4 * 5 + 4 + 16 + 16   # 5 ints + pad, 2 doubles, 2 int64
+
+
+def test_no_gpu_fails_loudly(lib):
+    """Without a GPU every compute entry must refuse (no silent CPU path)."""
+    import numpy as np
+    from proxmin_amd import _lib, operators
+    if lib.pmx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.PmxError):
+        operators.prox_plus(np.zeros((4, 4)), 1.0)
+    import proxmin_amd as pm
+    with pytest.raises(_lib.PmxError):
+        pm.nmf.nmf(np.ones((8, 8)), np.ones((8, 2)), np.ones((2, 8)), max_iter=1)
+
+
+def test_prox_recognition():
+    from functools import partial
+    from proxmin_amd import operators as ops, _lib
+    s = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0), 1)
+    assert s.n == 1 and s.seq[0].op == _lib.PROX["unity_plus"] and s.seq[0].unit == 0
+    s = ops.device_proxseq(partial(ops.prox_unity_plus, axis=1), 0)
+    assert s.seq[0].unit == 0
+    s = ops.device_proxseq(partial(ops.prox_unity, axis=0), 0)
+    assert s.seq[0].unit == 1
+    s = ops.device_proxseq(partial(ops.prox_soft, thresh=0.5, type="absolute"), 0)
+    assert s.seq[0].op == _lib.PROX["soft"] and s.seq[0].relative == 0 and abs(s.seq[0].thresh - 0.5) < 1e-7
+    assert ops.device_proxseq(None, 0).n == 0
+    ap = ops.AlternatingProjections([partial(ops.prox_unity, axis=1), ops.prox_plus], repeat=3)
+    s = ops.device_proxseq(ap, 0)
+    assert s.n == 2 and s.repeat == 3 and s.seq[0].op == _lib.PROX["plus"] and s.seq[1].op == _lib.PROX["unity"]
+    with pytest.raises(NotImplementedError):
+        ops.device_proxseq(lambda X, step: X, 0)

@@ -1,0 +1,192 @@
+"""GPU: end-to-end parity of proxmin_amd.nmf.nmf() (C ABI -> HIP kernels) with the reference's
+outputs (golden fixtures) and with the oracle on larger seeded problems.
+
+Stated tolerance (fp32 device arithmetic vs fp64 / fp32 NumPy): factors after <= 12 iterations
+from identical inputs agree to rtol 2e-4 / atol 2e-5 for fp32 references; when the reference ran in
+fp64 the same bound applies (the device computes in fp32)."""
+from functools import partial
+
+import numpy as np
+import pytest
+
+from conftest import as_spec, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import __graft_entry__ as g
+    g.build()
+    import proxmin_amd
+    return proxmin_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import nmf_oracle
+    return nmf_oracle
+
+
+def spec_to_prox(pm, spec):
+    if spec is None:
+        return None
+    ops = pm.operators
+    fn = getattr(ops, "prox_" + spec[0])
+    if spec[0] in ("unity", "unity_plus"):
+        return partial(fn, axis=spec[1])
+    if len(spec) > 1:
+        kw = {"thresh": spec[1]}
+        if len(spec) > 2:
+            kw["type"] = spec[2]
+        return partial(fn, **kw)
+    return fn
+
+
+def run_device_case(pm, c, Y, A0, S0, max_iter, e_rel, callback=None):
+    A, S = A0.copy(), S0.copy()
+    kw = dict(c["kw"])
+    alg = {"pgm": pm.pgm, "adaprox": pm.adaprox, "bsdmm": pm.bsdmm}[c["alg"]]
+    if c["half_step"]:
+        kw["step"] = pm.nmf.scaled_step_pgm(0.5)
+    if c["proxs_g"] is not None:
+        kw["proxs_g"] = [None if g is None else [spec_to_prox(pm, as_spec(s)) for s in g] for g in c["proxs_g"]]
+    ret = pm.nmf.nmf(Y, A, S, prox_A=spec_to_prox(pm, as_spec(c["prox_A"])), prox_S=spec_to_prox(pm, as_spec(c["prox_S"])),
+                     algorithm=alg, max_iter=max_iter, e_rel=e_rel, callback=callback, **kw)
+    return A, S, ret
+
+
+@pytest.mark.parametrize("fname", ["nmf_64x96_k8_f32.npz", "nmf_33x47_k3_f64.npz", "nmf_200x1000_k5_f64.npz"])
+def test_nmf_matches_reference_fixtures(pm, fname):
+    z, meta = load_golden(fname)
+    from oracle import nmf_oracle as orc
+    for name, c in meta["cases"].items():
+        tag = "unity" if c["unity_S"] else "plain"
+        if "inputs_%s/Y" % tag in z.files:
+            Y, A0, S0 = z["inputs_%s/Y" % tag], z["inputs_%s/A0" % tag], z["inputs_%s/S0" % tag]
+        else:
+            Y, A0, S0 = orc.synthetic_problem(meta["M"], meta["N"], meta["K"], np.dtype(meta["dtype"]).type, c["unity_S"], meta["seed"])
+        if name == "radam":
+            continue   # diverges (huge iterates) even in the reference; fp32 vs fp64 trajectories are not comparable
+        tb = pm.utils.Traceback()
+        A, S, ret = run_device_case(pm, c, Y, A0, S0, meta["max_iter"], meta["e_rel"], callback=tb)
+        np.testing.assert_allclose(A, z[name + "/A"], rtol=RTOL, atol=ATOL, err_msg="%s %s A" % (fname, name))
+        np.testing.assert_allclose(S, z[name + "/S"], rtol=RTOL, atol=ATOL, err_msg="%s %s S" % (fname, name))
+        assert len(tb.trace) == int(z[name + "/n_callbacks"]), name
+        i = 0
+        while "%s/trace_A_%d" % (name, i) in z.files:
+            np.testing.assert_allclose(tb.trace[i][0], z["%s/trace_A_%d" % (name, i)], rtol=RTOL, atol=ATOL, err_msg=name)
+            np.testing.assert_allclose(tb.trace[i][1], z["%s/trace_S_%d" % (name, i)], rtol=RTOL, atol=ATOL, err_msg=name)
+            i += 1
+        if c["alg"] == "pgm":
+            conv, G, steps = ret
+            gtol = dict(rtol=5e-3, atol=5e-3 * float(np.abs(z[name + "/G_A"]).max()))
+            np.testing.assert_allclose(G[0], z[name + "/G_A"], **gtol)
+            np.testing.assert_allclose(G[1], z[name + "/G_S"], rtol=5e-3, atol=5e-3 * float(np.abs(z[name + "/G_S"]).max()))
+            np.testing.assert_allclose(np.array(steps, dtype=np.float64), z[name + "/steps"], rtol=1e-4)
+            assert list(conv) == list(z[name + "/conv"])
+        elif c["alg"] == "adaprox":
+            conv, Mm, Vv, Vh = ret
+            np.testing.assert_allclose(Mm[0], z[name + "/M_A"], rtol=2e-3, atol=2e-3 * float(np.abs(z[name + "/M_A"]).max()))
+            np.testing.assert_allclose(Vv[1], z[name + "/V_S"], rtol=2e-3, atol=2e-3 * float(np.abs(z[name + "/V_S"]).max()))
+            assert [v is None for v in Vh] == list(z[name + "/vhat_none"])
+            assert [bool(x) for x in conv] == list(z[name + "/conv"])
+        else:
+            assert list(ret) == list(z[name + "/conv"])
+
+
+def test_no_callback_path_equals_callback_path(pm, orc):
+    """chained iterations (no host sync) must give bit-identical factors to one-iteration-per-call"""
+    Y, A0, S0 = orc.synthetic_problem(500, 700, 16, np.float32, unity_S=True, seed=11)
+    for kw in (dict(), dict(algorithm=pm.adaprox, scheme="amsgrad", prox_S=partial(pm.operators.prox_unity_plus, axis=0)),
+               dict(algorithm=pm.bsdmm, proxs_g=[[pm.operators.prox_plus, partial(pm.operators.prox_soft, thresh=0.01)]] * 2)):
+        A1, S1 = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A1, S1, max_iter=9, e_rel=1e-3, **kw)
+        A2, S2 = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A2, S2, max_iter=9, e_rel=1e-3, callback=pm.utils.Traceback(), **kw)
+        np.testing.assert_array_equal(A1, A2)
+        np.testing.assert_array_equal(S1, S2)
+
+
+CONFIGS = [
+    ("pgm", dict(), 1024, 1536, 32, False),
+    ("fista", dict(accelerated=True), 1024, 1536, 32, False),
+    ("amsgrad_unity", dict(scheme="amsgrad"), 1536, 2048, 64, True),
+    ("adam", dict(scheme="adam"), 777, 1290, 64, False),
+    ("bsdmm", dict(), 1024, 1024, 64, False),
+    ("amsgrad_k128", dict(scheme="amsgrad"), 2048, 1024, 128, False),
+]
+
+
+@pytest.mark.parametrize("name,kw,M,N,K,unity", CONFIGS)
+def test_nmf_matches_oracle_medium(pm, orc, name, kw, M, N, K, unity):
+    """BASELINE.json configs at reduced size (same K, same back-end/prox), 6 iterations from identical state."""
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=21)
+    A, S = A0.copy(), S0.copy()
+    Ao, So = A0.copy(), S0.copy()
+    its = 6
+    ops = pm.operators
+    if name in ("pgm", "fista"):
+        step = pm.nmf.scaled_step_pgm(0.5) if name == "fista" else None
+        ostep = (lambda a, s, it, g: tuple(0.5 * x for x in orc.lipschitz_steps(a, s))) if name == "fista" else None
+        pm.nmf.nmf(Y, A, S, step=step, max_iter=its, e_rel=1e-12, **kw)
+        orc.pgm_nmf(Y, Ao, So, step=ostep, max_iter=its, e_rel=1e-12, **kw)
+    elif name == "bsdmm":
+        pg = [[ops.prox_plus, partial(ops.prox_soft, thresh=1e-3)]] * 2
+        pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, proxs_g=pg, max_iter=its, e_rel=1e-12)
+        orc.bsdmm_nmf(Y, Ao, So, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=its, e_rel=1e-12)
+    else:
+        pS = partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus
+        oS = ("unity_plus", 0) if unity else ("plus",)
+        ret = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, prox_S=pS, max_iter=its, e_rel=1e-3, check_convergence=False, **kw)
+        oret = orc.adaprox_nmf(Y, Ao, So, ("plus",), oS, max_iter=its, e_rel=1e-3, check_convergence=False, **kw)
+        assert ret[0] == (None, None)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=ATOL)
+
+
+def test_convergence_stops_chain_at_same_iteration(pm, orc):
+    """loose e_rel: the device-side stopping test must end the run at the oracle's iteration count"""
+    Y, A0, S0 = orc.synthetic_problem(200, 300, 4, np.float32, seed=5)
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv, _, _ = pm.nmf.nmf(Y, A, S, max_iter=400, e_rel=2e-2, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    oconv, _, _, n = orc.pgm_nmf(Y, Ao, So, max_iter=400, e_rel=2e-2)
+    assert all(oconv) and n < 400
+    assert conv == tuple(oconv) and len(tb.trace) == n
+    A2, S2 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A2, S2, max_iter=400, e_rel=2e-2)          # chained path stops at the same place
+    np.testing.assert_allclose(A2, A, rtol=0, atol=0)
+    np.testing.assert_allclose(A, Ao, rtol=5e-3, atol=5e-4)
+
+
+def test_stop_iteration_and_warm_start(pm, orc):
+    Y, A0, S0 = orc.synthetic_problem(96, 130, 6, np.float32, seed=9)
+
+    def stopper(*X, it=None):
+        if it == 3:
+            raise StopIteration
+
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, callback=stopper, max_iter=50, e_rel=1e-9)
+    Ao, So = A0.copy(), S0.copy()
+    orc.pgm_nmf(Y, Ao, So, max_iter=3, e_rel=1e-9)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=ATOL)
+    # adaprox warm start: 3 + 3 iterations with M,V,Vhat carried over == oracle doing the same
+    A, S = A0.copy(), S0.copy()
+    Mm = [np.zeros_like(A), np.zeros_like(S)]
+    Vv = [np.zeros_like(A), np.zeros_like(S)]
+    Vh = [np.zeros_like(A), np.zeros_like(S)]
+    for _ in range(2):
+        pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="amsgrad", max_iter=3, e_rel=1e-9, M=Mm, V=Vv, Vhat=Vh)
+    Ao, So = A0.copy(), S0.copy()
+    oM = [np.zeros_like(A), np.zeros_like(S)]
+    oV = [np.zeros_like(A), np.zeros_like(S)]
+    oVh = [np.zeros_like(A), np.zeros_like(S)]
+    for _ in range(2):
+        orc.adaprox_nmf(Y, Ao, So, scheme="amsgrad", max_iter=3, e_rel=1e-9, M=oM, V=oV, Vhat=oVh)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(Vh[1], oVh[1], rtol=2e-3, atol=1e-6)
