@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- NMF iterations/sec on MI355X for BASELINE.json's headline configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg5] [--no-cpu]
+
+A "step" is ONE solver iteration of proxmin_amd's nmf() hot path on synthetic data already resident
+in HBM: the fused residual-gradient pass over Y (6MNK flop; 8MNK and two passes for bsdmm) plus the
+factor update, proximal operators and stopping-test reductions.  Default workload = BASELINE.json
+configs[2] ("cfg3"): Y 16384 x 16384, K = 64, adaprox/AMSGrad, prox_plus on A, prox_unity_plus on
+the columns of S.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the rows
+of Y and A are sharded over the ranks and gS is all-reduced once per iteration (strong scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (K1, k_grad_f32) from HIP
+events recorded on its launch stream inside the timed region; `cpu_baseline` is the NumPy oracle
+(a validated restatement of the reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: (M, N, K, backend, unity_S, description)
+    "cfg2": (4096, 4096, 32, "pgm", False, "Y 4096x4096, K=32, prox_plus, PGM, fp32"),
+    "cfg3": (16384, 16384, 64, "adaprox", True, "Y 16384x16384, K=64, adaprox/AMSGrad, prox_plus(A) + prox_unity_plus(S columns)"),
+    "cfg5": (16384, 16384, 64, "bsdmm", False, "Y 16384x16384, K=64, bSDMM, proxs_g=[prox_plus, prox_soft(1e-3)] per factor"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_problem_device(M, N, K, unity, seed, device):
+    """Seeded synthetic Y = A_true S_true + 0.01 noise generated on the GPU (fp32), A0/S0 on the host."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    At = torch.rand((M, K), generator=g, device=device, dtype=torch.float32)
+    St = torch.rand((K, N), generator=g, device=device, dtype=torch.float32)
+    if unity:
+        St /= St.sum(0, keepdim=True)
+    Y = At @ St
+    Y += 0.01 * torch.randn((M, N), generator=g, device=device, dtype=torch.float32)
+    rng = np.random.default_rng(seed)
+    A0 = rng.random((M, K), dtype=np.float32)
+    S0 = rng.random((K, N), dtype=np.float32)
+    if unity:
+        S0 /= S0.sum(0, keepdims=True)
+    return Y, A0, S0
+
+
+def begin_solver(dev, backend, unity):
+    from functools import partial
+    from proxmin_amd import operators as ops
+    pA = ops.device_proxseq(ops.prox_plus, 0)
+    pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
+    if backend == "pgm":
+        dev.pgm_begin([pA, pS], accelerated=False, e_rel=(1e-12, 1e-12))
+        return lambda n: dev.pgm_run(n)
+    if backend == "adaprox":
+        # nmf() defaults: e_rel = 1e-3 feeds the proximal sub-iteration test; check_convergence off so
+        # that the outer loop runs a fixed number of iterations
+        dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
+        return lambda n: dev.adaprox_run(np.full(n, 0.9), 0.9)
+    pg = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=1e-3), 0)]
+    dev.bsdmm_begin([pA, pS], [pg, pg], e_rel=(1e-12, 1e-12), e_abs=(0.0, 0.0))
+    return lambda n: dev.bsdmm_run(n)
+
+
+def cpu_baseline(M, N, K, backend, unity, budget_s=20.0):
+    """Oracle (NumPy port of the reference) on this host: a row-subsample of the same workload."""
+    from oracle import nmf_oracle as orc
+    Ms = min(M, 2048)
+    Y, A, S = orc.synthetic_problem(Ms, N, K, np.float32, unity_S=unity, seed=1234)
+    its = 0
+    t_used = 0.0
+    stamps = []
+
+    def cb(*X, it=None):
+        stamps.append(time.perf_counter())
+
+    n_iter = 4
+    if backend == "pgm":
+        orc.pgm_nmf(Y, A, S, max_iter=n_iter, e_rel=1e-12, callback=cb)
+    elif backend == "adaprox":
+        orc.adaprox_nmf(Y, A, S, ("plus",), ("unity_plus", 0) if unity else ("plus",), scheme="amsgrad",
+                        max_iter=n_iter, e_rel=1e-3, check_convergence=False, callback=cb)
+    else:
+        orc.bsdmm_nmf(Y, A, S, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=n_iter, e_rel=1e-12, callback=cb)
+    stamps.append(time.perf_counter())
+    per = np.diff(stamps)[1:]            # exclude iteration 0 (cold caches, 250-pass first prox loop)
+    s_per_it_sample = float(np.median(per))
+    s_per_it_full = s_per_it_sample * (M / Ms)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": 1.0 / s_per_it_full, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": "oracle (NumPy/OpenBLAS, all host threads) on the first %d of %d rows of the same workload, "
+                      "%d iterations, median of iterations 1..%d, scaled by %g to the full row count" % (Ms, M, n_iter, n_iter - 1, M / Ms)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        g.build()
+    M, N, K, backend, unity, desc = CONFIGS[args.config]
+    if args.rows:
+        M = args.rows
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    if world > 1:
+        from proxmin_amd import distributed as pdist
+        out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    from proxmin_amd.engine import DeviceNMF
+    Y, A0, S0 = make_problem_device(M, N, K, unity, 1234, device)
+    torch.cuda.synchronize()
+    dev = DeviceNMF(M, N, K, device=local)
+    dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+    dev.set_factors(A0, S0)
+    run = begin_solver(dev, backend, unity)
+
+    run(args.warmup)                       # untimed (includes adaprox's long first proximal loop)
+    dev.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(args.steps)                  # returns after the stream is idle
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    k1_ms, k1_n = dev.get_timing()
+    dev.set_timing(False)
+    assert res.iterations == args.steps, "chain ended early (%d of %d iterations)" % (res.iterations, args.steps)
+
+    dt = t1 - t0
+    flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
+    its = args.steps / dt
+    k1_avg_ms = k1_ms / max(k1_n, 1)
+    flop_per_launch = flop_per_it / (2 if backend == "bsdmm" else 1)   # bsdmm: two K1 launches of 4MNK each
+    achieved_tflops = flop_per_launch / (k1_avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
+        "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
+                   "mode": "f32 (exact fp32 MFMA, Y fp32 in HBM)", "parallelism": "1 GPU"},
+        "gflops": flop_per_it * its / 1e9,
+        "sub_iterations_per_step": [float(res.sub_iterations[0]) / max(res.total_iterations, 1),
+                                    float(res.sub_iterations[1]) / max(res.total_iterations, 1)],
+        "roofline": {"kernel": "k_grad_f32<%d>" % (32 if K <= 32 else 64 if K <= 64 else 128), "bound": "mfma",
+                     "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "avg_launch_ms": k1_avg_ms, "launches": k1_n,
+                     "hbm_gbs_algorithmic": (M * N * 4) / (k1_avg_ms * 1e-3) / 1e9,
+                     "k1_share_of_step": k1_ms / (1e3 * dt)},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(M, N, K, backend, unity)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

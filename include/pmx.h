@@ -128,6 +128,14 @@ int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
 /* device address of a buffer (for zero-copy interop, e.g. torch.distributed on the comm buffer) */
 int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
 
+/* ---- measurement --------------------------------------------------------------------------
+ * With timing on, every launch of the fused residual-gradient kernel (K1) is bracketed by HIP
+ * events on the context's stream; pmx_get_timing returns their summed duration and count since
+ * the last pmx_set_timing(ctx, 1) (synchronises the stream).  bench.py derives roofline.achieved
+ * from it. */
+int pmx_set_timing(pmx_ctx* ctx, int on);
+int pmx_get_timing(pmx_ctx* ctx, double* total_ms, int* launches);
+
 /* ---- single operations (unit parity tests, and what the reference exposes as functions) --- */
 /* nmf.grad_likelihood, W=1 (nmf.py:28-41): gradients at the current A, St into GA / GST.     */
 int pmx_grad(pmx_ctx* ctx);

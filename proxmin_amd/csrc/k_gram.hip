@@ -100,6 +100,7 @@ struct EigArgs {
     int want[2];
     double scale;          // step = scale / lmax   (user `step = c * step_pgm` support)
     int max_iter;
+    double* Q;             // [2][KP*KP] Lanczos basis scratch (exact fallback)
 };
 // one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
@@ -115,9 +116,15 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     const int t = threadIdx.x;
     for (int e = t; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
     // warm start (all-ones on the first call: the Perron vector of a non-negative Gram matrix is positive)
-    if (t < K) {
-        double v0 = st->eigvec[f][t];
-        vec[t] = v0;
+    {
+        double v0 = (t < K) ? st->eigvec[f][t] : 0.0;
+        double q = v0 * v0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if ((t & 63) == 0) red[t >> 6] = q;
+        __syncthreads();
+        const double n0 = sqrt(red[0] + red[1] + red[2] + red[3]);
+        if (t < K) vec[t] = (n0 > 0.0 && n0 == n0 && n0 < 1e300) ? v0 / n0 : 1.0 / sqrt((double)K);
     }
     __syncthreads();
     double lam_prev = -1.0, lam = 0.0;
@@ -160,13 +167,118 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     __syncthreads();
     if ((t & 63) == 0) { red[t >> 6] = num; red[4 + (t >> 6)] = den; }
     __syncthreads();
+    const double rq_n = red[0] + red[1] + red[2] + red[3], rq_d = red[4] + red[5] + red[6] + red[7];
+    double l = (rq_d > 0.0) ? rq_n / rq_d : lam;
+    if (!(lam == lam)) l = lam;
+    // ---- accept only with a small residual |G v - l v| <= 1e-6 l (an eigenvalue lies that close to l);
+    //      otherwise (clustered top eigenvalues) fall back to the exact tridiagonal solver below --------
+    __syncthreads();
+    double rr = (t < K) ? (wv[t] - l * vec[t]) : 0.0;
+    rr *= rr;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
+    if ((t & 63) == 0) red[t >> 6] = rr;
+    __syncthreads();
+    const double resid = sqrt((red[0] + red[1] + red[2] + red[3]) / (rq_d > 0.0 ? rq_d : 1.0));
+    __syncthreads();
+    int used_exact = 0;
+    if (l > 0.0 && l == l && l < 1e300 && !(resid <= 1e-6 * l)) {
+        // ---- Lanczos tridiagonalisation with full re-orthogonalisation (fp64), K steps = exact ---------
+        __shared__ double al[MAXK], be[MAXK + 1], cdot[MAXK];
+        __shared__ int nT;
+        double* Q = a.Q + (int64_t)f * KP * KP;         // Q[j][*] = j-th Lanczos vector
+        if (t < K) Q[t] = vec[t];                        // q_0 = current iterate (unit norm)
+        if (t == 0) { be[0] = 0.0; nT = K; }
+        __syncthreads();
+        for (int j = 0; j < K; ++j) {
+            __threadfence_block();
+            // w = G q_j   (G symmetric: read column t = row t, coalesced over t)
+            double w = 0.0;
+            if (t < K) {
+                const double* qj = Q + (int64_t)j * KP;
+                for (int k = 0; k < K; ++k) w += G[(int64_t)k * KP + t] * qj[k];
+                wv[t] = w;
+            }
+            __syncthreads();
+            // classical Gram-Schmidt against q_0..q_j, twice ("twice is enough"); alpha_j from the first pass
+            for (int pass = 0; pass < 2; ++pass) {
+                if (t <= j) {
+                    const double* qi = Q + (int64_t)t * KP;
+                    double c = 0.0;
+                    for (int k = 0; k < K; ++k) c += qi[k] * wv[k];
+                    cdot[t] = c;
+                }
+                __syncthreads();
+                if (pass == 0 && t == 0) al[j] = cdot[j];
+                if (t < K) {
+                    double acc = wv[t];
+                    for (int i = 0; i <= j; ++i) acc -= cdot[i] * Q[(int64_t)i * KP + t];
+                    wv[t] = acc;
+                }
+                __syncthreads();
+            }
+            double q2 = (t < K) ? wv[t] * wv[t] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+            if ((t & 63) == 0) red[t >> 6] = q2;
+            __syncthreads();
+            const double beta = sqrt(red[0] + red[1] + red[2] + red[3]);
+            __syncthreads();
+            if (t == 0) be[j + 1] = beta;
+            if (j + 1 == K || !(beta > 1e-13 * l)) {      // invariant subspace reached (uniform)
+                if (t == 0) nT = j + 1;
+                break;
+            }
+            if (t < K) Q[(int64_t)(j + 1) * KP + t] = wv[t] / beta;
+            __syncthreads();
+        }
+        __syncthreads();
+        const int n = nT;
+        // ---- largest eigenvalue of T(al, be) by Sturm-count multisection: 256 shifts per round ---------
+        __shared__ double blo, bhi;
+        __shared__ int firstFull;
+        if (t == 0) {
+            double lo = 1e300, hi = -1e300;
+            for (int i = 0; i < n; ++i) {
+                const double rad = (i > 0 ? fabs(be[i]) : 0.0) + (i + 1 < n ? fabs(be[i + 1]) : 0.0);
+                lo = fmin(lo, al[i] - rad);
+                hi = fmax(hi, al[i] + rad);
+            }
+            blo = lo; bhi = hi;
+        }
+        __syncthreads();
+        for (int round = 0; round < 9; ++round) {
+            const double lo = blo, hi = bhi;
+            const double x = lo + (hi - lo) * (double)(t + 1) / 257.0;
+            // number of eigenvalues of T smaller than x (LDL^T pivots)
+            int cnt = 0;
+            double d = 1.0;
+            for (int i = 0; i < n; ++i) {
+                const double b2 = i > 0 ? be[i] * be[i] : 0.0;
+                d = al[i] - x - (i > 0 ? b2 / d : 0.0);
+                if (d == 0.0) d = -1e-300;
+                cnt += d < 0.0;
+            }
+            if (t == 0) firstFull = 256;
+            __syncthreads();
+            if (cnt == n) atomicMin(&firstFull, t);      // smallest shift that has all n eigenvalues below it
+            __syncthreads();
+            const int ff = firstFull;
+            __syncthreads();
+            if (t == 0) {
+                const double nlo = ff == 0 ? lo : lo + (hi - lo) * (double)ff / 257.0;
+                const double nhi = ff == 256 ? hi : lo + (hi - lo) * (double)(ff + 1) / 257.0;
+                blo = nlo; bhi = nhi;
+            }
+            __syncthreads();
+        }
+        l = 0.5 * (blo + bhi);
+        used_exact = 1;
+    }
     if (t == 0) {
-        const double n = red[0] + red[1] + red[2] + red[3], d = red[4] + red[5] + red[6] + red[7];
-        double l = (d > 0.0) ? n / d : lam;
-        if (!(lam == lam)) l = lam;
         st->lam[f] = l;
         st->step[1 - f] = a.scale / l;     // 1/0 -> inf like the reference
-        st->eig_iters[f] = it;
+        st->eig_iters[f] = used_exact ? -it : it;
     }
     if (t < K) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vec[t] : 1.0;
 }

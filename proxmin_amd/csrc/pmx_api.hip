@@ -73,6 +73,7 @@ struct pmx_ctx {
     double* colpart = nullptr;             // [2][EW_BLOCKS][MAXK]
     float* gramPart = nullptr;             // [2][GRAM_BLOCKS][KP*KP]
     double* gramG = nullptr;               // [2][KP*KP]
+    double* eigQ = nullptr;                // [2][KP*KP] Lanczos scratch
     DevStatus* dstatus = nullptr;
     DevStatus* hstatus = nullptr;          // pinned mirror
 
@@ -86,6 +87,11 @@ struct pmx_ctx {
     float omega_cur = 0.f;
     int nsub_guess = 2;
     std::vector<void*> allocs;
+
+    // K1 timing (HIP events on the launch stream)
+    bool timing = false;
+    std::vector<hipEvent_t> ev;            // pairs
+    size_t ev_used = 0;
 
     // multi-GPU
     int rank = 0, world = 1;
@@ -166,6 +172,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (rc == PMX_OK) rc = dallocT(c, &c->colpart, (size_t)2 * EW_BLOCKS * MAXK);
     if (rc == PMX_OK) rc = dallocT(c, &c->gramPart, (size_t)2 * GRAM_BLOCKS * c->KP * c->KP);
     if (rc == PMX_OK) rc = dallocT(c, &c->gramG, (size_t)2 * c->KP * c->KP);
+    if (rc == PMX_OK) rc = dallocT(c, &c->eigQ, (size_t)2 * c->KP * c->KP);
     if (rc == PMX_OK) rc = dallocT(c, &c->dstatus, 1);
     if (rc == PMX_OK) {
         hipError_t e = hipHostMalloc((void**)&c->hstatus, sizeof(DevStatus), hipHostMallocDefault);
@@ -181,9 +188,38 @@ extern "C" int pmx_ctx_destroy(pmx_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) hipFree(p);
+    for (auto& e : c->ev) hipEventDestroy(e);
     if (c->hstatus) hipHostFree(c->hstatus);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_timing(pmx_ctx* c, int on) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (on && c->ev.empty()) {
+        c->ev.resize(2 * 8192);
+        for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
+    }
+    c->timing = on != 0;
+    c->ev_used = 0;
+    return PMX_OK;
+}
+
+extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
+    if (!c || !total_ms || !launches) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int)(c->ev_used / 2);
     return PMX_OK;
 }
 
@@ -326,7 +362,13 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
     g.RP = c->plan.RP;
     g.doA = doA; g.doS = doS;
+    const bool timed = c->timing && c->ev_used + 2 <= c->ev.size();
+    if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
     HIP_CHECK(grad_launch_f32(c->plan, g, c->stream));
+    if (timed) {
+        HIP_CHECK(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
     return PMX_OK;
 }
 
@@ -356,7 +398,8 @@ static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantS
     e.G = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
     e.want[0] = g.want[0]; e.want[1] = g.want[1];
     e.scale = scale;
-    e.max_iter = 2000;
+    e.max_iter = 200;
+    e.Q = c->eigQ;
     HIP_CHECK(launch_eig(e, c->stream));
     return PMX_OK;
 }

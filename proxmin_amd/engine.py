@@ -92,6 +92,16 @@ class DeviceNMF:
         out = self._download(base + j, self.M if j == 0 else self.N)
         return out if j == 0 else out.T
 
+    # -- measurement --------------------------------------------------------------------------
+    def set_timing(self, on=True):
+        _lib.check(self.lib.pmx_set_timing(self.h, int(bool(on))))
+
+    def get_timing(self):
+        """(summed K1 duration in ms, number of K1 launches) since set_timing(True)."""
+        ms, n = C.c_double(), C.c_int()
+        _lib.check(self.lib.pmx_get_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     # -- single operations --------------------------------------------------------------------
     def grad(self):
         """nmf.grad_likelihood at the current device factors -> (gA (M x K), gS (K x N))."""

@@ -110,7 +110,9 @@ def test_operators_match_reference_fixture():
         step = float(step) if step.ndim == 0 else step
         out = fn(X, step)
         assert out is X                                      # in-place contract
-        np.testing.assert_allclose(out, z[k + "/out"], rtol=2e-6, atol=2e-7, err_msg=str(e))
+        # unity divides by a sum of mixed-sign entries that can cancel: summation order shows up at ~1e-5
+        tol = dict(rtol=3e-5, atol=1e-6) if spec[0].startswith("unity") else dict(rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(out, z[k + "/out"], err_msg=str(e), **tol)
     ap = meta["ap"]
     X = z["ap/X"].copy()
     comp = ops.AlternatingProjections([partial(ops.prox_unity, axis=1), ops.prox_plus], repeat=ap["repeat"])
