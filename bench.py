@@ -129,7 +129,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    if world > 1:
+    if world > 1 or os.environ.get("PMX_FORCE_SHARDED"):
         from proxmin_amd import distributed as pdist
         out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
         if rank == 0:

@@ -207,14 +207,29 @@ int pmx_bsdmm_begin(pmx_ctx* ctx, const pmx_bsdmm_params* p);
 int pmx_bsdmm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
 
 /* ---- row-sharded multi-GPU --------------------------------------------
- * With rows of Y/A split over ranks, an iteration is: phase 0 (local K1 + pack the values that
- * need a cross-rank sum into the comm buffer), one all-reduce(sum) of the comm buffer done by the
- * caller (torch.distributed / RCCL), phase 1 (update).  world > 1 only changes which kernels read
- * the comm buffer; the kernels are the same ones the *_run entry points launch. */
+ * Rows of Y and A are split over `world` ranks (this context holds M local rows of M_global); S is
+ * replicated.  One iteration = phase 0 (local K1 + packing of everything that needs a cross-rank SUM
+ * into the comm buffer), ONE all-reduce(sum) of the comm buffer issued by the caller on the same
+ * stream (torch.distributed / RCCL over xGMI), phase 1 (update).  The kernels are the ones the
+ * single-GPU *_run entry points launch; only the source of gS, of A's column sums and of A's
+ * stopping-test sums changes.  The outer stopping test of iteration i is evaluated right after the
+ * all-reduce of iteration i+1, before that iteration's update is applied (exact stop semantics).
+ *
+ * comm layout (float32): [ gSt: N*K | Gram(A): KP*KP | colsum(A): 128 | scalars: 32 ];
+ * pmx_comm_layout reports the total count and the three offsets after gSt.  The buffer itself is
+ * supplied by the caller (pmx_set_comm_buffer), e.g. a torch tensor, so that the collective library
+ * can work on memory it knows. */
 int pmx_set_world(pmx_ctx* ctx, int rank, int world, int64_t M_global);
-int pmx_comm_buffer(pmx_ctx* ctx, void** dptr, int64_t* count_floats);
-int pmx_pgm_phase(pmx_ctx* ctx, int phase);
-int pmx_adaprox_phase(pmx_ctx* ctx, int phase, double b1_it, double b1_prev);
+int pmx_comm_layout(pmx_ctx* ctx, int64_t* count, int64_t offsets[3]);
+int pmx_set_comm_buffer(pmx_ctx* ctx, float* dptr, int64_t count);
+/* phase 0: K1 + pack.  phase 1: consume + update (+ `nsub` proximal sub-iteration passes).
+ * phase 2: pack only (final stopping-test flush).  phase 3: consume only.  No synchronisation. */
+int pmx_adaprox_phase(pmx_ctx* ctx, int phase, int it, double b1_it, double b1_prev, int nsub);
+/* synchronise and report where the chain stands: halted (0/1), reason (1 converged, 2 needs more
+ * sub-iteration passes), completed iterations, last tau per block. */
+int pmx_chain_status(pmx_ctx* ctx, int* halted, int* reason, int* it_done, int last_tau[2]);
+/* resume an iteration that ran out of sub-iteration passes: passes t0 .. t0+n-1, then finish+decide */
+int pmx_adaprox_more_subs(pmx_ctx* ctx, int t0, int n);
 int pmx_iter_result(pmx_ctx* ctx, pmx_result* res);
 
 #ifdef __cplusplus

@@ -83,9 +83,11 @@ _SIGNATURES = {
     "pmx_bsdmm_begin": (C.c_int, [C.c_void_p, C.POINTER(BsdmmParams)]),
     "pmx_bsdmm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
     "pmx_set_world": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64]),
-    "pmx_comm_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
-    "pmx_pgm_phase": (C.c_int, [C.c_void_p, C.c_int]),
-    "pmx_adaprox_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "pmx_comm_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pmx_set_comm_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_adaprox_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "pmx_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pmx_adaprox_more_subs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pmx_iter_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
 }
 

@@ -368,6 +368,7 @@ struct AlphaArgs {
     int K;
     int use_fixed;
     float fixed[2];
+    const float* comm_colsum;  // row-sharded runs: all-reduced column sums of A (K floats), else nullptr
 };
 __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
     const int t = threadIdx.x;
@@ -377,8 +378,11 @@ __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
             if (a.use_fixed) al = a.fixed[j];
             else {
                 double s = 0.0;
-                const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + t;
-                for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
+                if (j == 0 && a.comm_colsum != nullptr) s = (double)a.comm_colsum[t];
+                else {
+                    const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + t;
+                    for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
+                }
                 al = (float)(s / (double)a.rows_global[j]) / 10.f;
             }
             a.status->alpha[j][t] = al;
@@ -861,6 +865,97 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-sharded multi-GPU: pack what needs a cross-rank sum into the comm buffer, and consume it
+//   comm = [ gSt (N*K) | Gram(A) (KP*KP) | colsum(A) (MAXK) | scalars (32) ]      (float32)
+//   scalars: [0] = sum (A_new - A_old)^2, [1] = sum A_new^2 of the PREVIOUS iteration (outer test)
+// ------------------------------------------------------------------------------------------------
+struct PackArgs {
+    SlabRef slabS;           // local gSt slabs
+    float* comm;
+    int64_t N;
+    int K, KP;
+    const double* colpart;   // block 0 partial column sums of the local A rows
+    const double* partials;  // SL_DIFF2 / SL_NORM2 of block 0 (local rows)
+    const double* gramA;     // local A^T A (KP*KP doubles) or nullptr
+    const DevStatus* status;
+    int fold_grad;           // 0: only the extras (final convergence flush)
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
+    __shared__ double scratch[8];
+    if (chain_halted(a.status)) return;
+    const int K = a.K;
+    if (a.fold_grad) {
+        ROW_LOOP_BEGIN(a.N)
+            bool ok[NC];
+            float g[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+            load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) a.comm[r * K + l32 + 32 * c] = g[c];
+        ROW_LOOP_END
+    }
+    if (blockIdx.x == 0) {
+        float* ex = a.comm + a.N * K;
+        const int t = threadIdx.x;
+        if (a.gramA != nullptr)
+            for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = (float)a.gramA[e];
+        else
+            for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
+        float* cs = ex + a.KP * a.KP;
+        if (t < MAXK) {
+            double s = 0.0;
+            if (t < K) {
+                const double* p = a.colpart + t;   // block 0
+                for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
+            }
+            cs[t] = (float)s;
+        }
+        float* sc = cs + MAXK;
+        const double d = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, scratch);
+        const double n = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS, scratch);
+        if (t < 32) sc[t] = t == 0 ? (float)d : (t == 1 ? (float)n : 0.f);
+    }
+}
+
+// after the all-reduce: global step sizes for A and the deferred outer test of the previous iteration
+struct ShardPostArgs {
+    AlphaArgs al;            // comm_colsum set
+    const float* scalars;    // comm scalars
+    double* partials;        // local S-block sums
+    double e_rel[2];
+    int check_convergence;
+    int have_prev;           // 0 on the first iteration (nothing to test yet)
+};
+__global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
+    __shared__ double scratch[8];
+    DevStatus* st = a.al.status;
+    if (chain_halted(st)) return;
+    compute_alpha(a.al);
+    if (a.check_convergence && a.have_prev) {
+        const double dS = fold_partials(part_ptr(a.partials, SL_DIFF2, 1), scratch);
+        const double nS = fold_partials(part_ptr(a.partials, SL_NORM2, 1), scratch);
+        if (threadIdx.x == 0) {
+            const double dA = (double)a.scalars[0], nA = (double)a.scalars[1];
+            const int cA = dA <= a.e_rel[0] * a.e_rel[0] * nA;
+            const int cS = dS <= a.e_rel[1] * a.e_rel[1] * nS;
+            st->conv[0] = cA;
+            st->conv[1] = cS;
+            st->norms[0][0] = dA; st->norms[0][1] = nA;
+            st->norms[1][0] = dS; st->norms[1][1] = nS;
+            if (cA && cS) {
+                st->stopped = 1;
+                st->reason = HALT_CONVERGED;
+                __threadfence();
+                st->halt = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side launch wrappers (NC dispatch)
 // ------------------------------------------------------------------------------------------------
 #define DISPATCH_NC(K, KERNEL, grid, stream, args)                                               \
@@ -881,4 +976,6 @@ void launch_ada_sub(const SubArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_su
 void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, k_ada_finish, dim3(EW_BLOCKS, 2), s, a); }
 void launch_ada_decide(const AdaDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ada_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }
+void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS), s, a); }
+void launch_shard_post(const ShardPostArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_decide(const BsdmmDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bsdmm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }

@@ -96,6 +96,8 @@ struct pmx_ctx {
     // multi-GPU
     int rank = 0, world = 1;
     int64_t M_global = 0;
+    float* comm = nullptr;                 // caller-owned all-reduce buffer
+    bool shard_grad_from_comm = false;
 };
 
 static int dalloc(pmx_ctx* c, void** p, size_t bytes, bool zero = true) {
@@ -755,17 +757,16 @@ static int ada_enqueue_tail(pmx_ctx* c, int t) {
     d.al.fixed[1] = (float)p.fixed_alpha[1];
     d.partials = c->partials;
     d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
-    d.check_convergence = p.check_convergence;
+    // row-sharded: A's sums are only local here; the test is made after the next all-reduce (k_shard_post)
+    d.check_convergence = c->comm ? 0 : p.check_convergence;
     d.has_prox[0] = p.prox[0].n > 0; d.has_prox[1] = p.prox[1].n > 0;
     launch_ada_decide(d, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
 }
 
-static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
+static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     const pmx_adaprox_params& p = c->ada;
-    int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);                     // algorithms.py:369
-    if (rc != PMX_OK) return rc;
     MomentArgs m{};
     for (int j = 0; j < 2; ++j) {
         m.X[j] = c->X[j]; m.Xp[j] = c->Xp[j];
@@ -775,6 +776,10 @@ static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
         m.slab[j] = slab_ref(c, j);
         m.rows[j] = c->rows[j];
         m.has_prox[j] = p.prox[j].n > 0;
+    }
+    if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer
+        m.slab[1].base = c->comm;
+        m.slab[1].n = 1;
     }
     m.K = (int)c->K;
     m.status = c->dstatus;
@@ -786,6 +791,12 @@ static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
     launch_ada_moment(m, c->stream);                                      // algorithms.py:375-378
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
+}
+
+static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
+    int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);                     // algorithms.py:369
+    if (rc != PMX_OK) return rc;
+    return ada_enqueue_moment(c, it, b1t, b1prev);
 }
 
 extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double b1_prev, pmx_result* res) {
@@ -937,26 +948,132 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// row-sharded multi-GPU entry points: declared in pmx.h, implemented in a later milestone
+// row-sharded multi-GPU; see include/pmx.h for the protocol
 // ------------------------------------------------------------------------------------------------
+static int64_t comm_count(const pmx_ctx* c) { return c->N * c->K + (int64_t)c->KP * c->KP + MAXK + 32; }
+
 extern "C" int pmx_set_world(pmx_ctx* c, int rank, int world, int64_t M_global) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (world < 1 || rank < 0 || rank >= world) FAIL(PMX_E_INVALID, "bad rank/world");
+    if (M_global < c->M) FAIL(PMX_E_INVALID, "M_global < local M");
     c->rank = rank; c->world = world; c->M_global = M_global;
     return PMX_OK;
 }
-extern "C" int pmx_comm_buffer(pmx_ctx* c, void** dptr, int64_t* count_floats) {
-    (void)c; (void)dptr; (void)count_floats;
-    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+
+extern "C" int pmx_comm_layout(pmx_ctx* c, int64_t* count, int64_t offsets[3]) {
+    if (!c || !count || !offsets) FAIL(PMX_E_INVALID, "NULL argument");
+    *count = comm_count(c);
+    offsets[0] = c->N * c->K;                               // Gram(A)
+    offsets[1] = offsets[0] + (int64_t)c->KP * c->KP;       // colsum(A)
+    offsets[2] = offsets[1] + MAXK;                         // scalars
+    return PMX_OK;
 }
-extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase) {
-    (void)c; (void)phase;
-    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+
+extern "C" int pmx_set_comm_buffer(pmx_ctx* c, float* dptr, int64_t count) {
+    if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
+    if (count < comm_count(c)) FAIL(PMX_E_INVALID, "comm buffer too small: %lld < %lld", (long long)count, (long long)comm_count(c));
+    c->comm = dptr;
+    return PMX_OK;
 }
-extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, double b1_it, double b1_prev) {
-    (void)c; (void)phase; (void)b1_it; (void)b1_prev;
-    FAIL(PMX_E_UNSUPPORTED, "row-sharded mode is not implemented yet");
+
+static AlphaArgs alpha_args_sharded(pmx_ctx* c) {
+    AlphaArgs a = alpha_args(c);
+    a.use_fixed = c->ada.use_fixed_steps;
+    a.fixed[0] = (float)c->ada.fixed_alpha[0];
+    a.fixed[1] = (float)c->ada.fixed_alpha[1];
+    a.comm_colsum = c->comm + c->N * c->K + (int64_t)c->KP * c->KP;
+    return a;
 }
+
+static int shard_pack(pmx_ctx* c, int fold_grad) {
+    PackArgs p{};
+    p.slabS = slab_ref(c, 1);
+    p.comm = c->comm;
+    p.N = c->N;
+    p.K = (int)c->K; p.KP = c->KP;
+    p.colpart = c->colpart;
+    p.partials = c->partials;
+    p.gramA = nullptr;
+    p.status = c->dstatus;
+    p.fold_grad = fold_grad;
+    launch_shard_pack(p, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+static int shard_post(pmx_ctx* c, int have_prev) {
+    ShardPostArgs q{};
+    q.al = alpha_args_sharded(c);
+    q.scalars = c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK;
+    q.partials = c->partials;
+    q.e_rel[0] = c->ada.e_rel[0]; q.e_rel[1] = c->ada.e_rel[1];
+    q.check_convergence = c->ada.check_convergence;
+    q.have_prev = have_prev;
+    launch_shard_post(q, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, double b1_prev, int nsub) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
+    if (!c->comm) FAIL(PMX_E_STATE, "pmx_set_comm_buffer has not been called");
+    const pmx_adaprox_params& p = c->ada;
+    for (int i = 0; i < p.prox[0].n; ++i) {
+        // A's proximal loop would need cross-rank sums per pass unless the operator is a coordinate-wise
+        // projection whose fixed point is reached in one pass (result independent of gamma)
+        const pmx_prox& q = p.prox[0].seq[i];
+        const bool box = q.op == PMX_PROX_ID || q.op == PMX_PROX_ZERO || q.op == PMX_PROX_PLUS ||
+                         ((q.op == PMX_PROX_MIN || q.op == PMX_PROX_MAX || q.op == PMX_PROX_HARD || q.op == PMX_PROX_HARD_PLUS) && !q.relative);
+        if (!box) FAIL(PMX_E_UNSUPPORTED, "row-sharded adaprox supports only projection-type prox_A (plus/id/zero/absolute min,max,hard)");
+    }
+    switch (phase) {
+        case 0:
+            rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
+            if (rc != PMX_OK) return rc;
+            return shard_pack(c, 1);
+        case 1: {
+            rc = shard_post(c, it > 0);
+            if (rc != PMX_OK) return rc;
+            c->shard_grad_from_comm = true;
+            rc = ada_enqueue_moment(c, it, b1_it, b1_prev);
+            c->shard_grad_from_comm = false;
+            if (rc != PMX_OK) return rc;
+            const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
+            const int ns = any_prox ? std::max(1, std::min(nsub, p.prox_max_iter)) : 0;
+            for (int t = 0; t < ns; ++t) launch_ada_sub(sub_args(c, t), c->stream);
+            return ada_enqueue_tail(c, ns);
+        }
+        case 2: return shard_pack(c, 0);
+        case 3: return shard_post(c, 1);
+        default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    }
+}
+
+extern "C" int pmx_chain_status(pmx_ctx* c, int* halted, int* reason, int* it_done, int last_tau[2]) {
+    if (!c || !halted || !reason || !it_done || !last_tau) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    int rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    *halted = c->hstatus->halt;
+    *reason = c->hstatus->reason;
+    *it_done = c->hstatus->it_done;
+    last_tau[0] = c->hstatus->last_tau[0];
+    last_tau[1] = c->hstatus->last_tau[1];
+    return PMX_OK;
+}
+
+extern "C" int pmx_adaprox_more_subs(pmx_ctx* c, int t0, int n) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
+    rc = clear_halt(c);
+    if (rc != PMX_OK) return rc;
+    for (int t = t0; t < t0 + n; ++t) launch_ada_sub(sub_args(c, t), c->stream);
+    return ada_enqueue_tail(c, t0 + n);
+}
+
 extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {
     if (!c || !res) FAIL(PMX_E_INVALID, "NULL argument");
     int rc = read_status(c);

@@ -1,0 +1,269 @@
+"""Row-sharded multi-GPU NMF (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI).
+
+The K-factor NMF shards naturally by rows: rank r owns rows [r0, r1) of Y and A
+and their optimiser state; S and its state are replicated.  Everything is local except
+    gS = sum_r A_r^T R_r          (nmf.py:41 decomposed by rows)
+and three small sums (column sums of A for the adaprox step rule, and A's two stopping-test sums).
+They travel in ONE float32 buffer that is all-reduced once per iteration:
+
+    comm = [ gSt (N*K) | Gram(A) (KP*KP) | colsum(A) (128) | scalars (32) ]
+
+The driver below is written against a small engine interface (phase / chain_status / more_subs /
+comm) so that the protocol can be exercised on CPU with the gloo backend and a NumPy stand-in engine
+(tests/test_distributed_cpu.py); the product engine is `ShardEngine`, a thin wrapper over the
+libpmx phase entry points (HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+
+HALT_CONVERGED, HALT_NEED_SUB = 1, 2
+MAXK = 128
+N_SCALARS = 32
+
+
+def shard_rows(M, world):
+    """Contiguous, nearly equal row ranges: returns list of (r0, r1)."""
+    base, rem = divmod(M, world)
+    out, r0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((r0, r0 + n))
+        r0 += n
+    return out
+
+
+class CommLayout:
+    """Offsets (in floats) inside the all-reduce buffer; mirrors pmx_comm_layout."""
+
+    def __init__(self, N, K):
+        self.N, self.K = int(N), int(K)
+        self.KP = 32 if K <= 32 else (64 if K <= 64 else 128)
+        self.gram = self.N * self.K
+        self.colsum = self.gram + self.KP * self.KP
+        self.scalars = self.colsum + MAXK
+        self.count = self.scalars + N_SCALARS
+
+
+class ShardedAdaproxDriver:
+    """Iteration loop of the row-sharded adaprox back-end (algorithms.py:365-413 with one all-reduce
+    per iteration).  `engine` provides phase(), chain_status(), more_subs() and the `comm` tensor."""
+
+    def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=16):
+        import torch.distributed as dist
+        self.dist = dist
+        self.eng = engine
+        self.group = group
+        self.check = bool(check_convergence)
+        self.any_prox = bool(any_prox)
+        self.prox_max_iter = int(prox_max_iter)
+        self.chunk = int(chunk)
+        self.nsub = 2
+        self.it = 0              # completed iterations
+        self.stopped = False
+
+    def _allreduce(self):
+        self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _iteration(self, it, b1):
+        b1_prev = b1[it - 1]    # b1[-1] at it = 0, like the reference (algorithms.py:213)
+        self.eng.phase(0, it, b1[it], b1_prev, 0)
+        self._allreduce()
+        self.eng.phase(1, it, b1[it], b1_prev, self.nsub)
+
+    def run(self, n_iter, b1):
+        """Advance up to n_iter iterations; b1 is the full per-iteration array (len >= it + n_iter)."""
+        target = self.it + int(n_iter)
+        while self.it < target and not self.stopped:
+            hi = min(target, self.it + self.chunk)
+            first = self.it
+            for it in range(first, hi):
+                self._iteration(it, b1)
+            halted, reason, it_done, tau = self.eng.chain_status()
+            t_enq = self.nsub
+            while halted and reason == HALT_NEED_SUB:
+                # iteration `it_done` ran out of proximal sub-iteration passes (same on every rank: the
+                # S block is replicated and A's projection-type prox never needs more than two passes)
+                more = min(max(4, t_enq), 64)
+                self.eng.more_subs(t_enq, more)
+                t_enq += more
+                for it in range(it_done + 1, hi):
+                    self._iteration(it, b1)
+                before = it_done
+                halted, reason, it_done, tau = self.eng.chain_status()
+                if it_done > before:
+                    t_enq = self.nsub
+            self.it = it_done
+            if self.any_prox:
+                self.nsub = max(2, min(max(tau), self.prox_max_iter))
+            if halted and reason == HALT_CONVERGED:
+                self.stopped = True
+        if self.check and not self.stopped and n_iter > 0:
+            # the stopping test of the last iteration has not been evaluated yet (it needs A's global sums)
+            self.eng.phase(2, self.it, 0.0, 0.0, 0)
+            self._allreduce()
+            self.eng.phase(3, self.it, 0.0, 0.0, 0)
+            halted, reason, it_done, tau = self.eng.chain_status()
+            if halted and reason == HALT_CONVERGED:
+                self.stopped = True
+        return self.it
+
+
+class ShardEngine:
+    """libpmx-backed engine for one rank (HIP kernels; comm buffer is a torch CUDA tensor)."""
+
+    def __init__(self, dev, world, rank, M_global):
+        import torch
+        self.dev = dev
+        lib = dev.lib
+        _lib.check(lib.pmx_set_world(dev.h, rank, world, int(M_global)))
+        cnt = C.c_int64()
+        offs = (C.c_int64 * 3)()
+        _lib.check(lib.pmx_comm_layout(dev.h, C.byref(cnt), offs))
+        self.layout = CommLayout(dev.N, dev.K)
+        assert (cnt.value, offs[0], offs[1], offs[2]) == (self.layout.count, self.layout.gram, self.layout.colsum, self.layout.scalars)
+        self.comm = torch.zeros(cnt.value, dtype=torch.float32, device=torch.device("cuda", dev.device))
+        _lib.check(lib.pmx_set_comm_buffer(dev.h, C.c_void_p(self.comm.data_ptr()), cnt.value))
+
+    def phase(self, phase, it, b1_it, b1_prev, nsub):
+        _lib.check(self.dev.lib.pmx_adaprox_phase(self.dev.h, int(phase), int(it), float(b1_it), float(b1_prev), int(nsub)))
+
+    def chain_status(self):
+        h, r, i = C.c_int(), C.c_int(), C.c_int()
+        tau = (C.c_int * 2)()
+        _lib.check(self.dev.lib.pmx_chain_status(self.dev.h, C.byref(h), C.byref(r), C.byref(i), tau))
+        return h.value, r.value, i.value, (tau[0], tau[1])
+
+    def more_subs(self, t0, n):
+        _lib.check(self.dev.lib.pmx_adaprox_more_subs(self.dev.h, int(t0), int(n)))
+
+
+def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, scheme="adam", b1=0.9, b2=0.999,
+                        eps=1e-8, p=0.25, check_convergence=True, e_rel=1e-3, max_iter=1000, prox_max_iter=1000,
+                        group=None, device=None, Y_is_device_ptr=None):
+    """Row-sharded counterpart of `nmf(Y, A, S, algorithm=adaprox, ...)` for one rank.
+
+    Y_local: this rank's rows of Y (ndarray, M_local x N); A_local: the matching rows of A (updated in
+    place); S: full K x N (replicated, updated in place, identical on every rank).
+    Requires an initialised torch.distributed process group whose backend can reduce CUDA tensors
+    (nccl = RCCL).  Returns (converged, iterations)."""
+    import torch
+    import torch.distributed as dist
+    from . import operators
+    from .engine import DeviceNMF
+
+    if prox_A is None:
+        prox_A = operators.prox_plus
+    if prox_S is None:
+        prox_S = operators.prox_plus
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if device is None:
+        device = torch.cuda.current_device()
+    seqs = [operators.device_proxseq(prox_A, 0), operators.device_proxseq(prox_S, 1)]
+    if not hasattr(b1, "__iter__"):
+        b1 = np.array((b1,) * max_iter)
+    b1 = np.asarray(b1, dtype=np.float64)
+    e = (e_rel, e_rel) if np.isscalar(e_rel) else tuple(e_rel)
+    # kernels and collectives must share a (non-default) stream: torch's collectives order themselves
+    # against the CURRENT stream, so make ours current for the duration of the solve
+    tstream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(tstream), DeviceNMF(A_local.shape[0], S.shape[1], A_local.shape[1], device=device,
+                                               stream=tstream.cuda_stream) as dev:
+        dev.set_Y(Y_local)
+        dev.set_factors(A_local, S)
+        eng = ShardEngine(dev, world, rank, M_global)
+        dev.adaprox_begin(seqs, scheme=scheme, b2=b2, eps=eps, p=p, check_convergence=check_convergence,
+                          prox_max_iter=prox_max_iter, e_rel=e)
+        drv = ShardedAdaproxDriver(eng, group, check_convergence, seqs[0].n > 0 or seqs[1].n > 0, prox_max_iter)
+        its = drv.run(max_iter, b1)
+        dA, dS = dev.get_factors()
+        A_local[...] = dA
+        S[...] = dS
+        r = _lib.Result()
+        _lib.check(dev.lib.pmx_iter_result(dev.h, C.byref(r)))
+    conv = (bool(r.converged[0]), bool(r.converged[1])) if check_convergence else (None, None)
+    return conv, its
+
+
+def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
+    """bench.py leg for --gpus N > 1: rows of Y / A sharded over the ranks (strong scaling)."""
+    import torch
+    import torch.distributed as dist
+    from functools import partial
+    from . import operators as ops
+    from .engine import DeviceNMF
+
+    if backend != "adaprox":
+        raise NotImplementedError("multi-GPU bench is implemented for the adaprox back-end (BASELINE cfg3/cfg4)")
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    device = torch.device("cuda", local)
+    r0, r1 = shard_rows(M, world)[rank]
+    Ml = r1 - r0
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    At = torch.rand((M, K), generator=g, device=device, dtype=torch.float32)
+    St = torch.rand((K, N), generator=g, device=device, dtype=torch.float32)
+    if unity:
+        St /= St.sum(0, keepdim=True)
+    g.manual_seed(1234 + 7919 * (rank + 1))
+    Y = At[r0:r1] @ St
+    Y += 0.01 * torch.randn((Ml, N), generator=g, device=device, dtype=torch.float32)
+    del At, St
+    rng = np.random.default_rng(1234)
+    A0 = rng.random((M, K), dtype=np.float32)[r0:r1].copy()
+    S0 = rng.random((K, N), dtype=np.float32)
+    if unity:
+        S0 /= S0.sum(0, keepdims=True)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)          # collectives order against the current stream
+    dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream)
+    dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+    dev.set_factors(A0, S0)
+    eng = ShardEngine(dev, world, rank, M)
+    pA = ops.device_proxseq(ops.prox_plus, 0)
+    pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
+    dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
+    drv = ShardedAdaproxDriver(eng, None, False, True, 1000)
+    total = args.warmup + args.steps
+    b1 = np.full(total, 0.9)
+    drv.run(args.warmup, b1)
+    dev.set_timing(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.run(args.steps, b1)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    k1_ms, k1_n = dev.get_timing()
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    k1 = torch.tensor([k1_ms / max(k1_n, 1)], dtype=torch.float64, device=device)
+    dist.all_reduce(k1, op=dist.ReduceOp.MAX)
+    k1_avg_ms = float(k1.item())
+    flop_per_it = 6.0 * M * N * K
+    its = args.steps / dt
+    ach = (6.0 * Ml * N * K) / (k1_avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
+        "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
+                   "mode": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
+                   "parallelism": "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration" % (world, eng.layout.count)},
+        "gflops": flop_per_it * its / 1e9,
+        "roofline": {"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
+                     "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)},
+    }
+    dev.close()
+    dist.destroy_process_group()
+    return out
