@@ -33,7 +33,29 @@ CONFIGS = {
     "cfg5": (16384, 16384, 64, "bsdmm", False, "Y 16384x16384, K=64, bSDMM, proxs_g=[prox_plus, prox_soft(1e-3)] per factor"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s is what a float4 copy achieves)
+MODE_DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32-class accuracy)"}
+MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
+             "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)"}
+
+
+def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
+    """Dominant kernel = K1 (fused residual-gradient).  f32: matrix-core bound (exact-fp32 MFMA peak).
+    bf16x3: at K=64 the algorithmic intensity 6K/4 = 96 flop/B puts the kernel under the HBM roof
+    (96 x 8 TB/s = 768 TFLOP/s < bf16 MFMA peak), so the bound is the single pass over Y."""
+    t = k1_avg_ms * 1e-3
+    tflops = flop_per_launch / t / 1e12
+    gbs = (M * N * 4) / t / 1e9
+    kp = 32 if K <= 32 else 64 if K <= 64 else 128
+    if mode == "f32":
+        return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
+                "launches": k1_n, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share}
+    return {"kernel": "k_grad_bf16<%d>" % kp, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
+            "algorithmic_tflops": tflops, "mfma_issued_tflops": 4.0 * tflops,
+            "mfma_issued_frac_of_bf16_peak": 4.0 * tflops / PEAK_BF16_MFMA_TFLOPS, "k1_share_of_step": share}
 
 
 def make_problem_device(M, N, K, unity, seed, device):
@@ -114,6 +136,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
+    ap.add_argument("--mode", default=None, choices=["f32", "bf16x3"], help="contraction arithmetic (default: package default)")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +162,7 @@ def main():
     from proxmin_amd.engine import DeviceNMF
     Y, A0, S0 = make_problem_device(M, N, K, unity, 1234, device)
     torch.cuda.synchronize()
-    dev = DeviceNMF(M, N, K, device=local)
+    dev = DeviceNMF(M, N, K, device=local, mode=args.mode)
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
     run = begin_solver(dev, backend, unity)
@@ -165,18 +188,13 @@ def main():
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": MODE_DTYPE[dev.mode if K <= 64 else "f32"], "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": "f32 (exact fp32 MFMA, Y fp32 in HBM)", "parallelism": "1 GPU"},
+                   "mode": MODE_DESC[dev.mode if K <= 64 else "f32"], "parallelism": "1 GPU"},
         "gflops": flop_per_it * its / 1e9,
         "sub_iterations_per_step": [float(res.sub_iterations[0]) / max(res.total_iterations, 1),
                                     float(res.sub_iterations[1]) / max(res.total_iterations, 1)],
-        "roofline": {"kernel": "k_grad_f32<%d>" % (32 if K <= 32 else 64 if K <= 64 else 128), "bound": "mfma",
-                     "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                     "hbm_gbs_algorithmic": (M * N * 4) / (k1_avg_ms * 1e-3) / 1e9,
-                     "k1_share_of_step": k1_ms / (1e3 * dt)},
+        "roofline": roofline_entry(dev.mode if K <= 64 else "f32", M, N, K, flop_per_launch, k1_avg_ms, k1_n, k1_ms / (1e3 * dt)),
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(M, N, K, backend, unity)

@@ -1,0 +1,390 @@
+// K1, split-bf16 variant: the same fused residual-gradient pass as k_grad.hip
+//     R = A S - Y ;  gA = R S^T ;  gS = A^T R ;  loss = 1/2 sum R^2        (proxmin/nmf.py:25,39-41)
+// but on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) with fp32-class
+// accuracy: every fp32 operand x is split into bf16 terms x = x0 + x1 (+ x2) and the products that
+// matter are accumulated in fp32:
+//     A S      : 3-term split of A and S, 6 products  a0s0 a0s1 a1s0 a0s2 a1s1 a2s0   (error ~2^-24)
+//     R S^T    : 2-term split of R and S, 3 products  r0s0 r0s1 r1s0                   (error ~2^-17,
+//     A^T R    : 2-term split of A and R, 3 products                                    no cancellation)
+// The residual is where cancellation happens (|R| << |A S| near a solution), hence the third term
+// there; measured gradient error vs fp64 equals the pure-fp32 path's ("split-bf16").
+// 12 bf16 MFMA passes replace 3 fp32 passes = 4x fewer matrix-core cycles.
+//
+// k_presplit writes, once per gradient evaluation, the bf16 terms of both factors in the two
+// orientations the contractions need (row-major with K contiguous, and transposed with the long
+// dimension contiguous), zero-padded to KP columns and to a multiple of 128 rows, so the hot kernel
+// stages them into LDS with unguarded 16-byte copies.
+//
+// Workgroup = 8 wavefronts, step = 128 x 64 block of Y (KP = 64 or 32):
+//   GEMM1  wave w: P tile (mt = w>>1, nt = w&1); A terms live in registers for the whole row panel,
+//          S terms from LDS (Sl, ds_read_b128); P accumulates on top of -Y (prefetched into the acc).
+//   R      parked once in LDS as fp32 (Rl, stride 68: rows as ds_read_b128, columns as ds_read_b32,
+//          both conflict-free); split into bf16 terms by whichever wave consumes it.
+//   GEMM2  wave w: gA tile (mt = w>>1, kt = w&1), contraction over the block's 64 columns.
+//   GEMM3  wave w: gSt tile (nt = w&1, kt = (w>>1)&1), half (w>>2) of the block's 128 rows.
+// Accumulators: gA persists over the CB column blocks of a region, gSt over its RP row panels
+// (same slab scheme as k_grad.hip; gSt gets two slabs per row region, one per row half).
+#include "pmx_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BG_BM = 128, BG_BN = 64, BG_CB = 4, BG_THREADS = 512;
+
+// ------------------------------------------------------------------------------------------------
+// presplit: X (rows x K fp32) -> Xp[3][rowsPad][KP] and Xt[2][KP][rowsPad]  (bf16)
+// ------------------------------------------------------------------------------------------------
+struct PresplitArgs {
+    const float* X[2];
+    __bf16* Xp[2];     // [3][rowsPad][KP]
+    __bf16* Xt[2];     // [2][KP][rowsPad]
+    int64_t rows[2], rowsPad[2];
+    int K, KP;
+    const DevStatus* status;
+};
+__global__ __launch_bounds__(256) void k_presplit(PresplitArgs a) {
+    __shared__ __bf16 tile[2][64][66];   // [term][row in tile][k]  (+2 pad)
+    if (chain_halted(a.status)) return;
+    const int f = blockIdx.y;
+    const int64_t rows = a.rows[f], rowsPad = a.rowsPad[f];
+    const int K = a.K, KP = a.KP;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    if (r0 >= rowsPad) return;
+    const float* X = a.X[f];
+    __bf16* Xp = a.Xp[f];
+    __bf16* Xt = a.Xt[f];
+    for (int k0 = 0; k0 < KP; k0 += 64) {
+        __syncthreads();
+        // 64 rows x 64 k tile: thread handles (row = e / 64, k = e % 64), coalesced over k
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int rr = e >> 6, kk = e & 63;
+            const int64_t r = r0 + rr;
+            const int k = k0 + kk;
+            float x = 0.f;
+            if (r < rows && k < K) x = X[r * K + k];
+            const __bf16 t0 = (__bf16)x;
+            const float e1 = x - (float)t0;
+            const __bf16 t1 = (__bf16)e1;
+            const __bf16 t2 = (__bf16)(e1 - (float)t1);
+            if (k < KP) {
+                Xp[((int64_t)0 * rowsPad + r) * KP + k] = t0;
+                Xp[((int64_t)1 * rowsPad + r) * KP + k] = t1;
+                Xp[((int64_t)2 * rowsPad + r) * KP + k] = t2;
+            }
+            tile[0][rr][kk] = t0;
+            tile[1][rr][kk] = t1;
+        }
+        __syncthreads();
+        // transposed store: thread handles (k = e / 64, row = e % 64), coalesced over rows
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int kk = e >> 6, rr = e & 63;
+            if (k0 + kk < KP) {
+                Xt[((int64_t)0 * KP + k0 + kk) * rowsPad + r0 + rr] = tile[0][rr][kk];
+                Xt[((int64_t)1 * KP + k0 + kk) * rowsPad + r0 + rr] = tile[1][rr][kk];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GradBfArgs {
+    const float* Y;
+    int64_t ldY;
+    const __bf16* Ap;    // [3][MPad][KP]
+    const __bf16* At;    // [2][KP][MPad]
+    const __bf16* Sp;    // [3][NPad][KP]   (terms of St = S^T)
+    const __bf16* Stt;   // [2][KP][NPad]   (= terms of S, N contiguous)
+    int64_t MPad, NPad;
+    float* slabA;        // [nSlabA][M][K]
+    float* slabS;        // [nSlabS][N][K]
+    double* lossPart;
+    const DevStatus* status;
+    int M, N, K;
+    int RP;
+    int doA, doS;
+};
+
+__device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(x[i] - (float)h);
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
+    constexpr int KS1 = KP / 16;             // k-steps of GEMM1
+    constexpr int LDS_S = KP + 8;            // Sl row stride (bf16 elements): 16-byte multiple, conflict-free b128
+    constexpr int LDT_S = BG_BN + 8;         // Stl row stride
+    constexpr int LDT_A = BG_BM + 8;         // Atl row stride
+    constexpr int LDR = BG_BN + 4;           // Rl row stride (floats)
+    // work split of the two gradient contractions over the 8 waves
+    constexpr int G2SPLIT = KP == 64 ? 1 : 2;   // KP=32: 4 output tiles x 2 column halves
+    constexpr int G3SPLIT = KP == 64 ? 2 : 4;   // row halves / quarters
+    constexpr int G2_INNER = BG_BN / G2SPLIT, G3_INNER = BG_BM / G3SPLIT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* Sl = reinterpret_cast<__bf16*>(smem);                       // [3][64][LDS_S]
+    __bf16* Stl = Sl + 3 * BG_BN * LDS_S;                               // [2][KP][LDT_S]
+    __bf16* Atl = Stl + 2 * KP * LDT_S;                                 // [2][KP][LDT_A]
+    float* Rl = reinterpret_cast<float*>(Atl + 2 * KP * LDT_A);         // [128][LDR]
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int M = a.M, N = a.N, K = a.K;
+    const int rowRegion = blockIdx.x, colRegion = blockIdx.y;
+    const int row0 = rowRegion * a.RP * BG_BM;
+    const int col0 = colRegion * BG_CB * BG_BN;
+
+    const int g1_mt = w >> 1, g1_nt = w & 1;
+    const int g2_mt = w >> 1;
+    const int g2_kt = KP == 64 ? (w & 1) : 0;
+    const int g2_half = KP == 64 ? 0 : (w & 1);
+    const int g3_nt = w & 1;
+    const int g3_kt = KP == 64 ? ((w >> 1) & 1) : 0;
+    const int g3_part = KP == 64 ? (w >> 2) : (w >> 1);
+
+    f32x16 accS[BG_CB];
+#pragma unroll
+    for (int cb = 0; cb < BG_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
+    f32x16 accA;
+    f32x16 p;
+    bf16x8 afr[KS1][3];
+    float lossAcc = 0.f;
+
+    int nrp = (M - row0 + BG_BM - 1) / BG_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    int ncb = (N - col0 + BG_BN - 1) / BG_BN;
+    if (ncb > BG_CB) ncb = BG_CB;
+    const int nsteps = nrp * ncb;
+
+    const int laneRow = g1_mt * 32 + 4 * hi;
+    const int laneCol = g1_nt * 32 + l31;
+    const int laneOff = laneRow * (int)a.ldY + laneCol;
+    auto request_Y = [&](int prow0, int bcol0) {
+        const float* blk = a.Y + (int64_t)prow0 * a.ldY + bcol0;
+        if (prow0 + BG_BM <= M && bcol0 + BG_BN <= N) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float* rowp = blk + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY;
+                p[i] = rowp[laneOff];
+            }
+        } else {
+            const int rmax = M - 1 - prow0, cmax = N - 1 - bcol0;
+            const int cc = laneCol < cmax ? laneCol : cmax;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int lr = laneRow + (i & 3) + 8 * (i >> 2);
+                const int rr = lr < rmax ? lr : rmax;
+                const float v = blk[(int64_t)rr * a.ldY + cc];
+                p[i] = (lr <= rmax && laneCol <= cmax) ? v : 0.f;
+            }
+        }
+    };
+    auto flush_gA = [&](int prow0) {
+        const int slab = colRegion * G2SPLIT + g2_half;
+        float* dst = a.slabA + (int64_t)slab * M * K;
+        const int kk = g2_kt * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = prow0 + g2_mt * 32 + tile_row(i, lane);
+            if (gr < M && kk < K) dst[(int64_t)gr * K + kk] = accA[i];
+        }
+    };
+    // staging helpers: 16-byte unguarded copies from the zero-padded presplit arrays
+    auto stage_S = [&](int bcol0) {
+        // Sl[t][n][k]: rows of KP bf16 (KP/8 chunks of 16 B)
+        constexpr int CH = KP / 8;
+        for (int e = tid; e < 3 * BG_BN * CH; e += BG_THREADS) {
+            const int t = e / (BG_BN * CH), r = (e / CH) % BG_BN, c = e % CH;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.Sp + ((int64_t)t * a.NPad + bcol0 + r) * KP + c * 8);
+            *reinterpret_cast<uint4*>(Sl + (t * BG_BN + r) * LDS_S + c * 8) = v;
+        }
+        // Stl[t][kk][n]: rows of 64 bf16 (8 chunks)
+        for (int e = tid; e < 2 * KP * 8; e += BG_THREADS) {
+            const int t = e / (KP * 8), r = (e / 8) % KP, c = e % 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.Stt + ((int64_t)t * KP + r) * a.NPad + bcol0 + c * 8);
+            *reinterpret_cast<uint4*>(Stl + (t * KP + r) * LDT_S + c * 8) = v;
+        }
+    };
+    auto stage_A = [&](int prow0) {
+        // Atl[t][kk][m]: rows of 128 bf16 (16 chunks)
+        for (int e = tid; e < 2 * KP * 16; e += BG_THREADS) {
+            const int t = e / (KP * 16), r = (e / 16) % KP, c = e % 16;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.At + ((int64_t)t * KP + r) * a.MPad + prow0 + c * 8);
+            *reinterpret_cast<uint4*>(Atl + (t * KP + r) * LDT_A + c * 8) = v;
+        }
+        // this wave's GEMM1 A fragments, straight from global into registers
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + g1_mt * 32 + l31) * KP + ks * 16 + hi * 8);
+    };
+
+    if (nsteps > 0) request_Y(row0, col0);
+    int rp = 0, cb = 0;
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const int prow0 = row0 + rp * BG_BM;
+        const int bcol0 = col0 + cb * BG_BN;
+        __syncthreads();                       // B0: previous step's LDS readers are done
+        if (cb == 0) {
+            stage_A(prow0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+        }
+        stage_S(bcol0);
+        __syncthreads();                       // B1: staged operands visible
+        // ---- GEMM1: P = A S on top of -Y, 6 products per k-step ------------------------------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = -p[i];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const __bf16* sb = Sl + (g1_nt * 32 + l31) * LDS_S + ks * 16 + hi * 8;
+            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + BG_BN * LDS_S);
+            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(sb + 2 * BG_BN * LDS_S);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
+        }
+        // ---- loss, park R (fp32) in LDS ---------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = g1_mt * 32 + tile_row(i, lane);
+            const float r = p[i];
+            lossAcc += r * r;
+            Rl[lr * LDR + g1_nt * 32 + l31] = r;
+        }
+        __syncthreads();                       // B2: R visible
+        // ---- next step's Y tile flies during GEMM2/GEMM3 --------------------------------------------------
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        if (step + 1 < nsteps) request_Y(row0 + nrp_ * BG_BM, col0 + ncb_ * BG_BN);
+        // ---- GEMM2: gA tile += R . St_blk  (contraction over this wave's share of the 64 columns) --------
+        if (a.doA) {
+#pragma unroll
+            for (int ks = 0; ks < G2_INNER / 16; ++ks) {
+                const int n0 = g2_half * G2_INNER + ks * 16 + hi * 8;
+                const float* rrow = Rl + (g2_mt * 32 + l31) * LDR + n0;
+                float x[8];
+                *reinterpret_cast<float4*>(&x[0]) = *reinterpret_cast<const float4*>(rrow);
+                *reinterpret_cast<float4*>(&x[4]) = *reinterpret_cast<const float4*>(rrow + 4);
+                bf16x8 r0, r1;
+                split2(x, r0, r1);
+                const __bf16* sb = Stl + (g2_kt * 32 + l31) * LDT_S + n0;
+                const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);
+                const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + KP * LDT_S);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
+            }
+        }
+        // ---- GEMM3: gSt tile += R^T . A_panel  (contraction over this wave's share of the 128 rows) ---------
+        if (a.doS) {
+#define BG_GEMM3_INTO(ACC)                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < G3_INNER / 16; ++ks) {                                     \
+        const int m0 = g3_part * G3_INNER + ks * 16 + hi * 8;                                           \
+        const float* rcol = Rl + m0 * LDR + g3_nt * 32 + l31;                                           \
+        float x[8];                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) x[q] = rcol[q * LDR];                              \
+        bf16x8 r0, r1;                                                                                  \
+        split2(x, r0, r1);                                                                              \
+        const __bf16* ab = Atl + (g3_kt * 32 + l31) * LDT_A + m0;                                       \
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab);                                         \
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + KP * LDT_A);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
+    }
+            switch (cb) {
+                case 0: BG_GEMM3_INTO(accS[0]) break;
+                case 1: BG_GEMM3_INTO(accS[1]) break;
+                case 2: BG_GEMM3_INTO(accS[2]) break;
+                default: BG_GEMM3_INTO(accS[3]) break;
+            }
+#undef BG_GEMM3_INTO
+        }
+        if (cb + 1 == ncb && a.doA) flush_gA(prow0);
+        cb = ncb_;
+        rp = nrp_;
+    }
+    // ---- flush gSt: slab = rowRegion * G3SPLIT + part ---------------------------------------------------
+    if (a.doS) {
+        const int slab = rowRegion * G3SPLIT + g3_part;
+        float* dst = a.slabS + (int64_t)slab * N * K;
+        const int kk = g3_kt * 32 + l31;
+#pragma unroll
+        for (int cbi = 0; cbi < BG_CB; ++cbi) {
+            const int bcol0 = col0 + cbi * BG_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gn = bcol0 + g3_nt * 32 + tile_row(i, lane);
+                if (gn < N && kk < K) dst[(int64_t)gn * K + kk] = accS[cbi][i];
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < BG_THREADS / 64; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.y * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// host side -----------------------------------------------------------------------------------------
+GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
+    GradPlan p{};
+    p.KP = K <= 32 ? 32 : 64;
+    p.BN = BG_BN;
+    const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
+    const int64_t panels = (M + BG_BM - 1) / BG_BM;
+    p.gridY = (int)((N + (int64_t)BG_CB * BG_BN - 1) / ((int64_t)BG_CB * BG_BN));
+    int64_t wantX = (512 + p.gridY - 1) / p.gridY;
+    if (wantX < 1) wantX = 1;
+    if (wantX > panels) wantX = panels;
+    p.RP = (int)((panels + wantX - 1) / wantX);
+    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    p.nSlabA = p.gridY * splitA;
+    p.nSlabS = p.gridX * splitS;
+    p.ldsBytes = 2 * ((size_t)3 * BG_BN * (p.KP + 8) + (size_t)2 * p.KP * (BG_BN + 8) + (size_t)2 * p.KP * (BG_BM + 8)) +
+                 sizeof(float) * (size_t)BG_BM * (BG_BN + 4);
+    return p;
+}
+
+hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
+    dim3 grid(p.gridX, p.gridY), block(BG_THREADS);
+    hipError_t e;
+    if (p.KP == 32) {
+        e = hipFuncSetAttribute((const void*)k_grad_bf16<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_grad_bf16<32>, grid, block, p.ldsBytes, stream, a);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_grad_bf16<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_grad_bf16<64>, grid, block, p.ldsBytes, stream, a);
+    }
+    return hipGetLastError();
+}
+
+void launch_presplit(const PresplitArgs& a, hipStream_t s) {
+    const int64_t mx = a.rowsPad[0] > a.rowsPad[1] ? a.rowsPad[0] : a.rowsPad[1];
+    hipLaunchKernelGGL(k_presplit, dim3((unsigned)(mx / 64), 2), dim3(256), 0, s, a);
+}

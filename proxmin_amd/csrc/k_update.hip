@@ -39,38 +39,37 @@ __device__ __forceinline__ double wave_max(double v) {
 
 // block-wide sum of NV doubles; thread 0 writes dst[i * stride]
 template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* dst, int64_t stride, double* scratch /* >= NV*4 */) {
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* dst, int64_t stride, double* scratch /* >= NV*EW_WAVES */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
     __syncthreads();
     if (lane == 0)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) scratch[i * 4 + w] = v[i];
+        for (int i = 0; i < NV; ++i) scratch[i * EW_WAVES + w] = v[i];
     __syncthreads();
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) dst[i * stride] = scratch[i * 4 + 0] + scratch[i * 4 + 1] + scratch[i * 4 + 2] + scratch[i * 4 + 3];
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) s += scratch[threadIdx.x * EW_WAVES + q];
+        dst[threadIdx.x * stride] = s;
+    }
 }
 
-// fold one slot's EW_BLOCKS partials (every thread returns the same value; fixed order)
-__device__ __forceinline__ double fold_partials(const double* part, double* scratch) {
+// fold one slot's EW_BLOCKS partials: every WAVE does it on its own (EW_BLOCKS/64 coalesced loads per
+// lane + shuffles, no LDS, no barrier), in a fixed order, so every thread of the grid gets the same value.
+__device__ __forceinline__ double fold_partials(const double* part, double* /*scratch*/) {
+    const int lane = threadIdx.x & 63;
     double v = 0.0;
-    for (int i = threadIdx.x; i < EW_BLOCKS; i += EW_THREADS) v += part[i];
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v += part[i * 64 + lane];
+    return wave_sum(v);
 }
-__device__ __forceinline__ double fold_partials_max(const double* part, double* scratch) {
+__device__ __forceinline__ double fold_partials_max(const double* part, double* /*scratch*/) {
+    const int lane = threadIdx.x & 63;
     double v = -1.0;
-    for (int i = threadIdx.x; i < EW_BLOCKS; i += EW_THREADS) v = fmax(v, part[i]);
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v = fmax(v, part[i * 64 + lane]);
+    return wave_max(v);
 }
 
 __device__ __forceinline__ double* part_ptr(double* partials, int slot, int blk) {
@@ -155,11 +154,26 @@ struct SlabRef {
 
 template <int NC>
 __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], const SlabRef& s, int64_t rows, int K, int64_t r, int l32) {
+    // fixed summation order (slab 0, 1, 2, ...), but 4 slabs' loads are issued before the first add so that
+    // the fold is bandwidth- rather than latency-bound
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
     const int64_t stride = rows * K;
     const float* p = s.base + r * K + l32;
-    for (int i = 0; i < s.n; ++i) {
+    int i = 0;
+    for (; i + 4 <= s.n; i += 4) {
+        float v[4][NC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? p[u * stride + c * 32] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] += v[u][c];
+        p += 4 * stride;
+    }
+    for (; i < s.n; ++i) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             if (ok[c]) g[c] += p[c * 32];
@@ -242,7 +256,7 @@ struct PgmArgs {
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
-    __shared__ double scratch[16];
+    __shared__ double scratch[2 * EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
     const int64_t rows = a.rows[j];
@@ -293,7 +307,7 @@ struct DecideArgs {
     int check;          // evaluate the convergence test
 };
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_decide(DecideArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     if (chain_halted(a.status)) return;
     double d[2], n[2];
     for (int j = 0; j < 2; ++j) {
@@ -371,19 +385,28 @@ struct AlphaArgs {
     const float* comm_colsum;  // row-sharded runs: all-reduced column sums of A (K floats), else nullptr
 };
 __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
-    const int t = threadIdx.x;
+    // thread t: component t & 127, block group t >> 7; fixed-order two-level sum of the per-workgroup partials
+    __shared__ double asum[EW_THREADS / MAXK][MAXK];
+    const int t = threadIdx.x, k = t & (MAXK - 1), grp = t >> 7;
+    constexpr int NG = EW_THREADS / MAXK;
     for (int j = 0; j < 2; ++j) {
+        double s = 0.0;
+        if (k < a.K && !a.use_fixed && !(j == 0 && a.comm_colsum != nullptr)) {
+            const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + k;
+            for (int b = grp; b < EW_BLOCKS; b += NG) s += p[(int64_t)b * MAXK];
+        }
+        __syncthreads();
+        asum[grp][k] = s;
+        __syncthreads();
         if (t < a.K) {
             float al;
             if (a.use_fixed) al = a.fixed[j];
             else {
-                double s = 0.0;
-                if (j == 0 && a.comm_colsum != nullptr) s = (double)a.comm_colsum[t];
-                else {
-                    const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + t;
-                    for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
-                }
-                al = (float)(s / (double)a.rows_global[j]) / 10.f;
+                double tot = 0.0;
+                if (j == 0 && a.comm_colsum != nullptr) tot = (double)a.comm_colsum[t];
+                else
+                    for (int q = 0; q < NG; ++q) tot += asum[q][t];
+                al = (float)(tot / (double)a.rows_global[j]) / 10.f;
             }
             a.status->alpha[j][t] = al;
         }
@@ -417,7 +440,7 @@ struct MomentArgs {
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
     const int64_t rows = a.rows[j];
@@ -501,8 +524,11 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mv;
     __syncthreads();
-    if (threadIdx.x == 0)
-        part_ptr(a.partials, SL_MAXPSI, j)[blockIdx.x] = fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+    if (threadIdx.x == 0) {
+        double m = scratch[0];
+        for (int q = 1; q < EW_WAVES; ++q) m = fmax(m, scratch[q]);
+        part_ptr(a.partials, SL_MAXPSI, j)[blockIdx.x] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,7 +576,7 @@ __device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, doub
 
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_sub(SubArgs a) {
-    __shared__ double scratch[16];
+    __shared__ double scratch[2 * EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
     if (!a.has_prox[j]) return;
@@ -612,7 +638,7 @@ struct FinishArgs {
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
-    __shared__ double scratch[16];
+    __shared__ double scratch[2 * EW_WAVES];
     __shared__ float sm[(EW_THREADS / 32) * MAXK];
     if (chain_halted(a.s.status)) return;
     const int j = blockIdx.y;
@@ -664,7 +690,7 @@ struct AdaDecideArgs {
     int has_prox[2];
 };
 __global__ __launch_bounds__(EW_THREADS) void k_ada_decide(AdaDecideArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     DevStatus* st = a.al.status;
     if (chain_halted(st)) return;
     __shared__ int need;
@@ -728,7 +754,7 @@ struct BsdmmArgs {
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
-    __shared__ double scratch[4 * (2 + 4 * PMX_MAX_G)];
+    __shared__ double scratch[EW_WAVES * (2 + 4 * PMX_MAX_G)];
     if (chain_halted(a.status)) return;
     const int j = a.j;
     const int K = a.K;
@@ -825,7 +851,7 @@ struct BsdmmDecideArgs {
     int last_block;      // 1 for the second block: closes the iteration (algorithms.py:841-844)
 };
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = a.j;
     const double d2 = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
@@ -882,7 +908,7 @@ struct PackArgs {
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     if (chain_halted(a.status)) return;
     const int K = a.K;
     if (a.fold_grad) {
@@ -930,7 +956,7 @@ struct ShardPostArgs {
     int have_prev;           // 0 on the first iteration (nothing to test yet)
 };
 __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
-    __shared__ double scratch[8];
+    __shared__ double scratch[EW_WAVES];
     DevStatus* st = a.al.status;
     if (chain_halted(st)) return;
     compute_alpha(a.al);

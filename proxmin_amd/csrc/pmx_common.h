@@ -14,8 +14,9 @@ constexpr int WAVE = 64;
 // per-block partial sums written by one kernel can be folded by the next one in a fixed order
 // (deterministic, no float atomics).
 // ------------------------------------------------------------------------------------------
-constexpr int EW_BLOCKS = 256;   // one per CU
-constexpr int EW_THREADS = 256;
+constexpr int EW_BLOCKS = 256;   // one per CU, 16 wavefronts each: factor-sized kernels are latency-bound
+constexpr int EW_THREADS = 1024;
+constexpr int EW_WAVES = EW_THREADS / 64;
 constexpr int LPR = 32;          // lanes per row (half a wavefront): K <= 128 -> <= 4 values per lane
 constexpr int MAXC = 4;          // ceil(128 / LPR)
 constexpr int MAXK = 128;

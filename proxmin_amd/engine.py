@@ -5,10 +5,29 @@ entry points.  Pure plumbing -- every number is produced by the HIP kernels behi
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib
+
+
+# Arithmetic of the three contractions inside the fused residual-gradient kernel:
+#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+#   "bf16x3" split-bf16 MFMA with fp32-class accuracy (3-term split for A@S, 2-term for the gradients);
+#            K <= 64, larger K runs the fp32 kernel
+_DEFAULT_MODE = os.environ.get("PMX_MODE", "bf16x3")
+
+
+def set_default_mode(mode):
+    """Select the contraction arithmetic used by nmf() and friends ("f32" or "bf16x3")."""
+    global _DEFAULT_MODE
+    assert mode in ("f32", "bf16x3")
+    _DEFAULT_MODE = mode
+
+
+def get_default_mode():
+    return _DEFAULT_MODE
 
 
 def _f32(a):
@@ -22,10 +41,12 @@ def _vp(a):
 class DeviceNMF:
     """Device state for one factorisation problem Y (M x N) ~ A (M x K) @ S (K x N)."""
 
-    def __init__(self, M, N, K, device=0, mode="f32", stream=None):
+    def __init__(self, M, N, K, device=0, mode=None, stream=None):
         self.lib = _lib.require_gpu()
         self.M, self.N, self.K = int(M), int(N), int(K)
         self.device = device
+        mode = mode or _DEFAULT_MODE
+        self.mode = mode
         mode_id = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,

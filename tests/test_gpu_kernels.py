@@ -26,12 +26,13 @@ SHAPES = [(33, 47, 3), (64, 96, 8), (128, 128, 32), (200, 1000, 5), (257, 513, 3
           (1024, 640, 64), (384, 1100, 100), (512, 512, 128), (4096, 4096, 32)]
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("M,N,K", SHAPES)
-def test_fused_gradient_matches_oracle(eng, orc, M, N, K):
+def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     """K1 (nmf.grad_likelihood + log_likelihood) vs NumPy, fp32 tolerance: the contraction runs on
     exact-fp32 MFMA, so the difference is summation order only."""
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N + K)
-    with eng.DeviceNMF(M, N, K) as dev:
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         dev.set_Y(Y)
         dev.set_factors(A, S)
         gA, gS = dev.grad()
@@ -44,7 +45,8 @@ def test_fused_gradient_matches_oracle(eng, orc, M, N, K):
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
 
 
-def test_gradient_is_transpose_sensitive(eng, orc):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_gradient_is_transpose_sensitive(eng, orc, mode):
     """asymmetric inputs: a swapped tile mapping cannot pass (guide rule: A=I with asymmetric B)."""
     M, N, K = 96, 160, 32
     A = np.zeros((M, K), np.float32)
@@ -52,7 +54,7 @@ def test_gradient_is_transpose_sensitive(eng, orc):
     S = (np.arange(K * N, dtype=np.float32).reshape(K, N) % 97) / 97.0
     Y = np.zeros((M, N), np.float32)
     Y[5, 7] = 3.0
-    with eng.DeviceNMF(M, N, K) as dev:
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         dev.set_Y(Y)
         dev.set_factors(A, S)
         gA, gS = dev.grad()
@@ -131,3 +133,22 @@ def test_operator_edge_cases():
     Z = np.zeros((3, 4), np.float32)
     with np.errstate(all="ignore"):
         assert np.isnan(ops.prox_unity(Z, 1.0, axis=1)).all()
+
+
+def test_split_bf16_gradient_near_solution_is_fp32_class(eng, orc):
+    """Where cancellation bites (|R| << |A S|): the split-bf16 kernel must be as close to the fp64
+    gradient as the exact-fp32 kernel is (within 3x), and both ~1e-5 of the gradient norm."""
+    M, N, K = 1536, 2048, 64
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=31)
+    orc.adaprox_nmf(Y, A, S, scheme="amsgrad", max_iter=60, e_rel=1e-3, check_convergence=False)
+    g64 = orc.residual_gradients(A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64))
+    err = {}
+    for mode in ("f32", "bf16x3"):
+        with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+            dev.set_Y(Y)
+            dev.set_factors(A, S)
+            g = dev.grad()
+        err[mode] = [np.linalg.norm(g[j] - g64[j]) / np.linalg.norm(g64[j]) for j in range(2)]
+    for j in range(2):
+        assert err["f32"][j] < 5e-5
+        assert err["bf16x3"][j] < max(3 * err["f32"][j], 2e-5), err
