@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
-    ap.add_argument("--mode", default=None, choices=["f32", "bf16x3"], help="contraction arithmetic (default: package default)")
+    ap.add_argument("--mode", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="contraction arithmetic: bf16x3 = split-bf16 MFMA (headline), f32 = exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch

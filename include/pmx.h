@@ -135,6 +135,9 @@ int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
  * from it. */
 int pmx_set_timing(pmx_ctx* ctx, int on);
 int pmx_get_timing(pmx_ctx* ctx, double* total_ms, int* launches);
+/* average duration (ms, HIP events) of `reps` back-to-back launches of K1 at the current factors with
+ * only the requested outputs (do_A / do_S; 0,0 = residual + loss only): kernel ablation for tuning. */
+int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
 
 /* ---- single operations (unit parity tests, and what the reference exposes as functions) --- */
 /* nmf.grad_likelihood, W=1 (nmf.py:28-41): gradients at the current A, St into GA / GST.     */

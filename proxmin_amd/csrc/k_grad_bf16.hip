@@ -101,7 +101,8 @@ struct GradBfArgs {
     const DevStatus* status;
     int M, N, K;
     int RP;
-    int doA, doS;
+    int doA, doS;        // doA bit 1: ablation switch "no Y traffic" (tuning only)
+    int gridX, gridY;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& 
     }
 }
 
-template <int KP>
+template <int KP, bool EDGE>
 __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
     constexpr int KS1 = KP / 16;             // k-steps of GEMM1
     constexpr int LDS_S = KP + 8;            // Sl row stride (bf16 elements): 16-byte multiple, conflict-free b128
@@ -130,12 +131,28 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
     __bf16* Stl = Sl + 3 * BG_BN * LDS_S;                               // [2][KP][LDT_S]
     __bf16* Atl = Stl + 2 * KP * LDT_S;                                 // [2][KP][LDT_A]
     float* Rl = reinterpret_cast<float*>(Atl + 2 * KP * LDT_A);         // [128][LDR]
+    float* Yl = Rl + BG_BM * LDR;                                       // [8 waves][32][32]  private Y landing tiles
 
     if (chain_halted(a.status)) return;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int M = a.M, N = a.N, K = a.K;
-    const int rowRegion = blockIdx.x, colRegion = blockIdx.y;
+    // Workgroup -> region map.  Consecutive workgroup ids land on consecutive XCDs (id % 8), each with its own
+    // 4 MiB L2.  The S terms a region streams (46 KB per step) are shared by all row regions of the same column
+    // region, so every XCD is given a contiguous eighth of the column regions: its share of the S terms then
+    // stays L2-resident instead of being re-fetched across the fabric.  (Speed only; any placement is correct.)
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
     const int row0 = rowRegion * a.RP * BG_BM;
     const int col0 = colRegion * BG_CB * BG_BN;
 
@@ -166,6 +183,28 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
     const int laneRow = g1_mt * 32 + 4 * hi;
     const int laneCol = g1_nt * 32 + l31;
     const int laneOff = laneRow * (int)a.ldY + laneCol;
+    // Y tile of this wave (32 x 32 fp32).  !EDGE: fetched by LDS-DMA (global_load_lds, 16 B per lane, 8 rows per
+    // instruction) into a wave-private 4 KiB landing tile -- no registers are tied up while it is in flight, so
+    // the request for step s+1 is issued before GEMM1 of step s and has a whole step to arrive.  The tile is
+    // produced and consumed by the same wave: its own vmcnt wait is the only synchronisation needed.
+    // EDGE (partial blocks): guarded register loads issued after the residual has been parked.
+    float* Ytile = Yl + w * 1024;
+    const int dmaRow = lane >> 3, dmaCol = (lane & 7) * 4;     // lane -> (row within 8, first of 4 columns)
+    // The DMA is issued from inline asm so that the compiler does not know LDS is being written behind its back:
+    // with the builtin it conservatively drains vmcnt before the next ds_read and before every barrier, which
+    // serialises the transfer.  Completion is guaranteed by program order instead (see the wait at its consumer).
+    const unsigned ytile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Ytile;
+    auto request_Y_dma = [&](int prow0, int bcol0) {
+        const float* src = a.Y + (int64_t)(prow0 + g1_mt * 32 + dmaRow) * a.ldY + bcol0 + g1_nt * 32 + dmaCol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* g = src + (int64_t)q * 8 * a.ldY;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    };
     auto request_Y = [&](int prow0, int bcol0) {
         const float* blk = a.Y + (int64_t)prow0 * a.ldY + bcol0;
         if (prow0 + BG_BM <= M && bcol0 + BG_BN <= N) {
@@ -196,22 +235,43 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
             if (gr < M && kk < K) dst[(int64_t)gr * K + kk] = accA[i];
         }
     };
-    // staging helpers: 16-byte unguarded copies from the zero-padded presplit arrays
-    auto stage_S = [&](int bcol0) {
-        // Sl[t][n][k]: rows of KP bf16 (KP/8 chunks of 16 B)
-        constexpr int CH = KP / 8;
-        for (int e = tid; e < 3 * BG_BN * CH; e += BG_THREADS) {
-            const int t = e / (BG_BN * CH), r = (e / CH) % BG_BN, c = e % CH;
-            const uint4 v = *reinterpret_cast<const uint4*>(a.Sp + ((int64_t)t * a.NPad + bcol0 + r) * KP + c * 8);
-            *reinterpret_cast<uint4*>(Sl + (t * BG_BN + r) * LDS_S + c * 8) = v;
-        }
-        // Stl[t][kk][n]: rows of 64 bf16 (8 chunks)
-        for (int e = tid; e < 2 * KP * 8; e += BG_THREADS) {
-            const int t = e / (KP * 8), r = (e / 8) % KP, c = e % 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(a.Stt + ((int64_t)t * KP + r) * a.NPad + bcol0 + c * 8);
-            *reinterpret_cast<uint4*>(Stl + (t * KP + r) * LDT_S + c * 8) = v;
-        }
-    };
+    // S terms: 16-byte unguarded copies from the zero-padded presplit arrays.  They are requested into registers
+    // one step ahead (right after this step's operands became visible) and written to LDS at the top of the next
+    // step, so the L2 round trip overlaps the three contractions.
+    constexpr int CH = KP / 8;                                   // 16-byte chunks per Sl row
+    constexpr int T_SL = 3 * BG_BN * CH, T_STL = 2 * KP * 8;      // chunk counts
+    constexpr int N_SL = (T_SL + BG_THREADS - 1) / BG_THREADS, N_STL = (T_STL + BG_THREADS - 1) / BG_THREADS;
+    uint4 pre_sl[N_SL], pre_stl[N_STL];
+#define BG_LOAD_S(BCOL0)                                                                                         \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < N_SL; ++u) {                                                       \
+            const int e = tid + u * BG_THREADS;                                                                  \
+            const int t = e / (BG_BN * CH), r = (e / CH) % BG_BN, c = e % CH;                                    \
+            if (T_SL % BG_THREADS == 0 || e < T_SL)                                                              \
+                pre_sl[u] = *reinterpret_cast<const uint4*>(a.Sp + ((int64_t)t * a.NPad + (BCOL0) + r) * KP + c * 8); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < N_STL; ++u) {                                                      \
+            const int e = tid + u * BG_THREADS;                                                                  \
+            const int t = e / (KP * 8), r = (e / 8) % KP, c = e % 8;                                             \
+            if (T_STL % BG_THREADS == 0 || e < T_STL)                                                            \
+                pre_stl[u] = *reinterpret_cast<const uint4*>(a.Stt + ((int64_t)t * KP + r) * a.NPad + (BCOL0) + c * 8); \
+        }                                                                                                        \
+    } while (0)
+#define BG_STORE_S()                                                                                             \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < N_SL; ++u) {                                                       \
+            const int e = tid + u * BG_THREADS;                                                                  \
+            const int t = e / (BG_BN * CH), r = (e / CH) % BG_BN, c = e % CH;                                    \
+            if (T_SL % BG_THREADS == 0 || e < T_SL)                                                              \
+                *reinterpret_cast<uint4*>(Sl + (t * BG_BN + r) * LDS_S + c * 8) = pre_sl[u];                     \
+        }                                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < N_STL; ++u) {                                                      \
+            const int e = tid + u * BG_THREADS;                                                                  \
+            const int t = e / (KP * 8), r = (e / 8) % KP, c = e % 8;                                             \
+            if (T_STL % BG_THREADS == 0 || e < T_STL)                                                            \
+                *reinterpret_cast<uint4*>(Stl + (t * KP + r) * LDT_S + c * 8) = pre_stl[u];                      \
+        }                                                                                                        \
+    } while (0)
     auto stage_A = [&](int prow0) {
         // Atl[t][kk][m]: rows of 128 bf16 (16 chunks)
         for (int e = tid; e < 2 * KP * 16; e += BG_THREADS) {
@@ -227,23 +287,51 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
                 afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + g1_mt * 32 + l31) * KP + ks * 16 + hi * 8);
     };
 
-    if (nsteps > 0) request_Y(row0, col0);
+    const bool noY = (a.doA & 2) != 0;
+    if (nsteps > 0) {
+        if (!noY) {
+            if (EDGE) request_Y(row0, col0);
+            else request_Y_dma(row0, col0);
+        }
+    }
     int rp = 0, cb = 0;
 #pragma nounroll
     for (int step = 0; step < nsteps; ++step) {
         const int prow0 = row0 + rp * BG_BM;
-        const int bcol0 = col0 + cb * BG_BN;
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        const bool more = step + 1 < nsteps;
         __syncthreads();                       // B0: previous step's LDS readers are done
         if (cb == 0) {
             stage_A(prow0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) accA[i] = 0.f;
         }
-        stage_S(bcol0);
+        BG_LOAD_S(col0 + cb * BG_BN);          // (holding these 20 registers across a step costs scratch spills:
+        BG_STORE_S();                          //  the S terms are staged synchronously, the Y tile asynchronously)
         __syncthreads();                       // B1: staged operands visible
-        // ---- GEMM1: P = A S on top of -Y, 6 products per k-step ------------------------------------
+        // ---- P accumulator starts at -Y -----------------------------------------------------------------
+        if (!EDGE) {
+            if (noY) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) p[i] = -p[i];
+                for (int i = 0; i < 16; ++i) p[i] = 0.f;
+            } else {
+                // the landing tile was requested a step ago; the S-term loads consumed above were issued after it
+                // and memory operations retire in order, so it has landed (the explicit wait costs nothing)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
+                if (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile has been read: it may be overwritten
+                    request_Y_dma(row0 + nrp_ * BG_BM, col0 + ncb_ * BG_BN);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = -p[i];
+        }
+        // ---- GEMM1: P = A S on top of -Y, 6 products per k-step ------------------------------------
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             const __bf16* sb = Sl + (g1_nt * 32 + l31) * LDS_S + ks * 16 + hi * 8;
@@ -265,35 +353,34 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
             lossAcc += r * r;
             Rl[lr * LDR + g1_nt * 32 + l31] = r;
         }
-        __syncthreads();                       // B2: R visible
-        // ---- next step's Y tile flies during GEMM2/GEMM3 --------------------------------------------------
-        int nrp_ = rp, ncb_ = cb + 1;
-        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
-        if (step + 1 < nsteps) request_Y(row0 + nrp_ * BG_BM, col0 + ncb_ * BG_BN);
-        // ---- GEMM2: gA tile += R . St_blk  (contraction over this wave's share of the 64 columns) --------
-        if (a.doA) {
-#pragma unroll
-            for (int ks = 0; ks < G2_INNER / 16; ++ks) {
-                const int n0 = g2_half * G2_INNER + ks * 16 + hi * 8;
-                const float* rrow = Rl + (g2_mt * 32 + l31) * LDR + n0;
-                float x[8];
-                *reinterpret_cast<float4*>(&x[0]) = *reinterpret_cast<const float4*>(rrow);
-                *reinterpret_cast<float4*>(&x[4]) = *reinterpret_cast<const float4*>(rrow + 4);
-                bf16x8 r0, r1;
-                split2(x, r0, r1);
-                const __bf16* sb = Stl + (g2_kt * 32 + l31) * LDT_S + n0;
-                const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);
-                const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + KP * LDT_S);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
-            }
-        }
-        // ---- GEMM3: gSt tile += R^T . A_panel  (contraction over this wave's share of the 128 rows) ---------
-        if (a.doS) {
-#define BG_GEMM3_INTO(ACC)                                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < G3_INNER / 16; ++ks) {                                     \
-        const int m0 = g3_part * G3_INNER + ks * 16 + hi * 8;                                           \
+        // B2: R visible.  Raw barrier: the LDS-DMA of the next Y tile is in flight and must stay in flight
+        // (a __syncthreads() here would make the compiler drain vmcnt first)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (EDGE && more && !noY) request_Y(row0 + nrp_ * BG_BM, col0 + ncb_ * BG_BN);
+        // ---- GEMM2: gA tile += R . St_blk   (contraction over this wave's share of the 64 columns)
+        //      GEMM3: gSt tile += R^T . A_panel (contraction over this wave's share of the 128 rows)
+        // The two have independent accumulators; their k-steps are interleaved in one basic block so that each
+        // MFMA chain's dependency latency and the other's LDS reads / bf16 splits overlap.
+#define BG_G2_STEP(KS)                                                                                  \
+    {                                                                                                   \
+        const int n0 = g2_half * G2_INNER + (KS) * 16 + hi * 8;                                         \
+        const float* rrow = Rl + (g2_mt * 32 + l31) * LDR + n0;                                         \
+        float x[8];                                                                                     \
+        *reinterpret_cast<float4*>(&x[0]) = *reinterpret_cast<const float4*>(rrow);                     \
+        *reinterpret_cast<float4*>(&x[4]) = *reinterpret_cast<const float4*>(rrow + 4);                 \
+        bf16x8 r0, r1;                                                                                  \
+        split2(x, r0, r1);                                                                              \
+        const __bf16* sb = Stl + (g2_kt * 32 + l31) * LDT_S + n0;                                       \
+        const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);                                         \
+        const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + KP * LDT_S);                            \
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);                          \
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);                          \
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);                          \
+    }
+#define BG_G3_STEP(ACC, KS)                                                                             \
+    {                                                                                                   \
+        const int m0 = g3_part * G3_INNER + (KS) * 16 + hi * 8;                                         \
         const float* rcol = Rl + m0 * LDR + g3_nt * 32 + l31;                                           \
         float x[8];                                                                                     \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) x[q] = rcol[q * LDR];                              \
@@ -306,15 +393,24 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
     }
-            switch (cb) {
-                case 0: BG_GEMM3_INTO(accS[0]) break;
-                case 1: BG_GEMM3_INTO(accS[1]) break;
-                case 2: BG_GEMM3_INTO(accS[2]) break;
-                default: BG_GEMM3_INTO(accS[3]) break;
-            }
-#undef BG_GEMM3_INTO
+        static_assert(G2_INNER / 16 == G3_INNER / 16 || true, "");
+        constexpr int NK2 = G2_INNER / 16, NK3 = G3_INNER / 16, NKM = NK2 > NK3 ? NK2 : NK3;
+        const bool wantA = (a.doA & 1) != 0, wantS = a.doS != 0;
+#define BG_BOTH_INTO(ACC)                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < NKM; ++ks) {                                                \
+        if (wantA && ks < NK2) BG_G2_STEP(ks)                                                           \
+        if (wantS && ks < NK3) BG_G3_STEP(ACC, ks)                                                      \
+    }
+        switch (cb) {
+            case 0: BG_BOTH_INTO(accS[0]) break;
+            case 1: BG_BOTH_INTO(accS[1]) break;
+            case 2: BG_BOTH_INTO(accS[2]) break;
+            default: BG_BOTH_INTO(accS[3]) break;
         }
-        if (cb + 1 == ncb && a.doA) flush_gA(prow0);
+#undef BG_BOTH_INTO
+#undef BG_G2_STEP
+#undef BG_G3_STEP
+        if (cb + 1 == ncb && (a.doA & 1)) flush_gA(prow0);
         cb = ncb_;
         rp = nrp_;
     }
@@ -344,7 +440,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
         if (tid == 0) {
             double s = 0.0;
             for (int i = 0; i < BG_THREADS / 64; ++i) s += (double)red[i];
-            a.lossPart[blockIdx.y * gridDim.x + blockIdx.x] = s;
+            a.lossPart[blockIdx.x] = s;
         }
     }
 }
@@ -365,23 +461,26 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     p.nSlabA = p.gridY * splitA;
     p.nSlabS = p.gridX * splitS;
     p.ldsBytes = 2 * ((size_t)3 * BG_BN * (p.KP + 8) + (size_t)2 * p.KP * (BG_BN + 8) + (size_t)2 * p.KP * (BG_BM + 8)) +
-                 sizeof(float) * (size_t)BG_BM * (BG_BN + 4);
+                 sizeof(float) * ((size_t)BG_BM * (BG_BN + 4) + (size_t)(BG_THREADS / 64) * 1024);
     return p;
 }
 
-hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
-    dim3 grid(p.gridX, p.gridY), block(BG_THREADS);
-    hipError_t e;
-    if (p.KP == 32) {
-        e = hipFuncSetAttribute((const void*)k_grad_bf16<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_grad_bf16<32>, grid, block, p.ldsBytes, stream, a);
-    } else {
-        e = hipFuncSetAttribute((const void*)k_grad_bf16<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_grad_bf16<64>, grid, block, p.ldsBytes, stream, a);
-    }
+template <int KP, bool EDGE>
+static hipError_t grad_launch_bf16_t(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16<KP, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_bf16<KP, EDGE>), dim3(p.gridX * p.gridY), dim3(BG_THREADS), p.ldsBytes, stream, a);
     return hipGetLastError();
+}
+
+hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, hipStream_t stream) {
+    GradBfArgs a = a_;
+    a.gridX = p.gridX;
+    a.gridY = p.gridY;
+    // Whole 128 x 64 blocks with 16-byte-aligned rows take the LDS-DMA variant; anything else the guarded one.
+    const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || (a.ldY % 4) != 0 || (((uintptr_t)a.Y) & 15) != 0;
+    if (p.KP == 32) return edge ? grad_launch_bf16_t<32, true>(p, a, stream) : grad_launch_bf16_t<32, false>(p, a, stream);
+    return edge ? grad_launch_bf16_t<64, true>(p, a, stream) : grad_launch_bf16_t<64, false>(p, a, stream);
 }
 
 void launch_presplit(const PresplitArgs& a, hipStream_t s) {

@@ -486,6 +486,30 @@ extern "C" int pmx_grad(pmx_ctx* c) {
     return PMX_OK;
 }
 
+extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* avg_ms) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!avg_ms || reps < 1) FAIL(PMX_E_INVALID, "bad argument");
+    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+    const bool was = c->timing;
+    c->timing = false;
+    rc = enqueue_grad(c, c->X[0], c->X[1], do_A, do_S);   // warm-up
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps && rc == PMX_OK; ++i) rc = enqueue_grad(c, c->X[0], c->X[1], do_A, do_S);
+    HIP_CHECK(hipEventRecord(e1, c->stream));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->timing = was;
+    *avg_ms = ms / reps;
+    return rc;
+}
+
 extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;

@@ -222,7 +222,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)          # collectives order against the current stream
-    dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream)
+    dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream, mode=getattr(args, "mode", None))
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
     eng = ShardEngine(dev, world, rank, M)
@@ -255,14 +255,18 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": dev.mode, "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
+                   "mode": dev.mode,
                    "parallelism": "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration" % (world, eng.layout.count)},
         "gflops": flop_per_it * its / 1e9,
-        "roofline": {"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                     "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)},
+        "roofline": ({"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+                      "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
+                      "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)} if dev.mode == "f32" or K > 64 else
+                     {"kernel": "k_grad_bf16", "bound": "hbm", "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,
+                      "unit": "GB/s", "frac": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                      "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
+                      "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)}),
     }
     dev.close()
     dist.destroy_process_group()

@@ -16,7 +16,7 @@ from . import _lib
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
 #   "bf16x3" split-bf16 MFMA with fp32-class accuracy (3-term split for A@S, 2-term for the gradients);
 #            K <= 64, larger K runs the fp32 kernel
-_DEFAULT_MODE = os.environ.get("PMX_MODE", "bf16x3")
+_DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
 def set_default_mode(mode):
@@ -122,6 +122,12 @@ class DeviceNMF:
         ms, n = C.c_double(), C.c_int()
         _lib.check(self.lib.pmx_get_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def time_grad(self, do_A=True, do_S=True, reps=10):
+        """average K1 duration in ms (kernel ablation helper, includes the presplit kernel in bf16x3 mode)"""
+        ms = C.c_double()
+        _lib.check(self.lib.pmx_time_grad(self.h, int(do_A), int(do_S), int(reps), C.byref(ms)))
+        return ms.value
 
     # -- single operations --------------------------------------------------------------------
     def grad(self):
