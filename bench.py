@@ -40,6 +40,12 @@ MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
              "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)"}
 
 
+# HBM bytes per K1 launch from the PMC passes committed in profiles/r01_c_pmc_traffic_cfg3.json
+# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command; FETCH_SIZE doubled per the gfx950 correction).
+# Only known for the configuration that was profiled; null otherwise.
+PMC_TRAFFIC_BYTES = {("cfg3", "bf16x3"): 2 * 687215 * 1024 + 327696 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
+
+
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
     """Dominant kernel = K1 (fused residual-gradient).  f32: matrix-core bound (exact-fp32 MFMA peak).
     bf16x3: at K=64 the algorithmic intensity 6K/4 = 96 flop/B puts the kernel under the HBM roof
@@ -197,6 +203,9 @@ def main():
                                     float(res.sub_iterations[1]) / max(res.total_iterations, 1)],
         "roofline": roofline_entry(dev.mode if K <= 64 else "f32", M, N, K, flop_per_launch, k1_avg_ms, k1_n, k1_ms / (1e3 * dt)),
     }
+    if not args.rows:
+        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get((args.config, dev.mode if K <= 64 else "f32"))
+        out["roofline"]["traffic_unit"] = "bytes per K1 launch (algorithmic: %d)" % (M * N * 4)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(M, N, K, backend, unity)
     print(json.dumps(out))
