@@ -168,6 +168,8 @@ typedef struct pmx_pgm_params { /* algorithms.pgm arguments, algorithms.py:12-23
     int32_t use_fixed_steps; /* 1: use fixed_steps[] instead of the Lipschitz rule (user `step`) */
     double fixed_steps[2];
     double e_rel[2];      /* algorithms.py:66-68 */
+    int32_t bb_type;      /* 0: off; 1 / 2: utils.BarzilaiBorweinStepper(type) as the step rule (utils.py:209-241) */
+    double bb_init_r;     /* its init_r */
 } pmx_pgm_params;
 
 typedef struct pmx_result {

@@ -81,8 +81,11 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     assert backtracking is False or f is not None
     if backtracking:
         raise NotImplementedError("backtracking line search is not implemented on the device yet")
-    scale, fixed = 1.0, None
-    if isinstance(step, _nmf.scaled_step_pgm):
+    scale, fixed, bb = 1.0, None, None
+    bb_owner = getattr(step, "__self__", step)
+    if isinstance(bb_owner, utils.BarzilaiBorweinStepper):
+        bb = bb_owner
+    elif isinstance(step, _nmf.scaled_step_pgm):
         scale = step.scale
     elif isinstance(step, _nmf.constant_step):
         fixed = step.steps
@@ -95,7 +98,8 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     with DeviceNMF(A.shape[0], S.shape[1], A.shape[1]) as dev:
         dev.set_Y(Y)
         dev.set_factors(A, S)
-        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=fixed, e_rel=e_rel)
+        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=fixed, e_rel=e_rel,
+                      bb=(bb.type, bb.r) if bb is not None else None)
         res = None
         it_done = 0
         if _wants_iterates(callback):

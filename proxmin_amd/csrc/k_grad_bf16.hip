@@ -24,6 +24,7 @@
 //   GEMM3  wave w: gSt tile (nt = w&1, kt = (w>>1)&1), half (w>>2) of the block's 128 rows.
 // Accumulators: gA persists over the CB column blocks of a region, gSt over its RP row panels
 // (same slab scheme as k_grad.hip; gSt gets two slabs per row region, one per row half).
+#include <stdlib.h>
 #include "pmx_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -103,6 +104,7 @@ struct GradBfArgs {
     int RP;
     int doA, doS;        // doA bit 1: ablation switch "no Y traffic" (tuning only)
     int gridX, gridY;
+    unsigned long long* prof;   // tuning only: per-phase cycle sums of wave 0 of every workgroup (nullptr = off)
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -445,6 +447,332 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16(GradBfArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_grad_bf16_pipe: the same computation for whole-block shapes (M % 128 == 0, N % 64 == 0, 16-byte aligned Y
+// rows), software-pipelined with LDS-DMA so that no global-memory round trip is exposed inside a step:
+//   * the Y tile of step s+1 lands in a wave-private tile, requested right after the tile of step s was read;
+//   * the S terms of step s+1 are DMA'd into the SAME single LDS images as soon as all waves are done reading
+//     them: Sl (read only by GEMM1) right after barrier B2, Stl (read only by GEMM2) right after barrier B3.
+//     Padded row strides are kept (bank-conflict-free ds_read_b128): the images are transferred as linear
+//     1 KiB chunks, one per wave instruction, and the lanes that fall on a pad slot fetch a dummy address.
+//   * all DMA is issued from inline asm (invisible to the compiler's wait-count model, which would otherwise
+//     drain it before every LDS read and barrier); completion is enforced with hand-counted s_waitcnt vmcnt(N)
+//     in front of the raw s_barrier that publishes the data.  Per wave and step, in issue order:
+//         Y(s+1): 4 instructions   Sl(s+1): NI_SL   Stl(s+1): NI_STL
+//     top of step s+1:  vmcnt(NI_STL)  -> Y, Sl landed, Stl may still fly;   B2:  vmcnt(4) -> Stl landed.
+// Registers hold no in-flight data, so nothing spills.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+template <int KP>
+__global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) {
+    constexpr int KS1 = KP / 16;
+    constexpr int LDS_S = KP + 8, LDT_S = BG_BN + 8, LDT_A = BG_BM + 8, LDR = BG_BN + 4;
+    constexpr int G2SPLIT = KP == 64 ? 1 : 2, G3SPLIT = KP == 64 ? 2 : 4;
+    constexpr int G2_INNER = BG_BN / G2SPLIT, G3_INNER = BG_BM / G3SPLIT;
+    constexpr int NW = BG_THREADS / 64;
+    // linear DMA images
+    constexpr int SL_ROWB = LDS_S * 2, SL_TERMB = BG_BN * SL_ROWB, SL_BYTES = 3 * SL_TERMB, SL_DATA = KP / 8;
+    constexpr int STL_ROWB = LDT_S * 2, STL_TERMB = KP * STL_ROWB, STL_BYTES = 2 * STL_TERMB, STL_DATA = BG_BN / 8;
+    constexpr int NI_SL = (SL_BYTES + 1024 * NW - 1) / (1024 * NW);      // DMA instructions per wave
+    constexpr int NI_STL = (STL_BYTES + 1024 * NW - 1) / (1024 * NW);
+    constexpr int SL_REGION = NI_SL * NW * 1024, STL_REGION = NI_STL * NW * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* Sl = reinterpret_cast<__bf16*>(smem);
+    __bf16* Stl = reinterpret_cast<__bf16*>(smem + SL_REGION);
+    __bf16* Atl = reinterpret_cast<__bf16*>(smem + SL_REGION + STL_REGION);      // [2][KP][LDT_A]
+    float* Rl = reinterpret_cast<float*>(Atl + 2 * KP * LDT_A);                  // [128][LDR]
+    float* Yl = Rl + BG_BM * LDR;                                                // [8 waves][32][32]
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int M = a.M, N = a.N, K = a.K;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * BG_BM;
+    const int col0 = colRegion * BG_CB * BG_BN;
+
+    const int g1_mt = w >> 1, g1_nt = w & 1;
+    const int g2_mt = w >> 1;
+    const int g2_kt = KP == 64 ? (w & 1) : 0;
+    const int g2_half = KP == 64 ? 0 : (w & 1);
+    const int g3_nt = w & 1;
+    const int g3_kt = KP == 64 ? ((w >> 1) & 1) : 0;
+    const int g3_part = KP == 64 ? (w >> 2) : (w >> 1);
+
+    f32x16 accS[BG_CB];
+#pragma unroll
+    for (int cb = 0; cb < BG_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
+    f32x16 accA;
+    f32x16 p;
+    bf16x8 afr[KS1][3];
+    float lossAcc = 0.f;
+
+    int nrp = (M - row0 + BG_BM - 1) / BG_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    int ncb = (N - col0 + BG_BN - 1) / BG_BN;
+    if (ncb > BG_CB) ncb = BG_CB;
+    const int nsteps = nrp * ncb;
+    const bool noY = (a.doA & 2) != 0;
+
+    // ---- DMA address tables (step-invariant per-lane element offsets) ------------------------------------
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    int goff_sl[NI_SL], goff_stl[NI_STL];
+#pragma unroll
+    for (int i = 0; i < NI_SL; ++i) {
+        const int o = 1024 * (i * NW + w) + 16 * lane;
+        const int t = o / SL_TERMB, wi = o % SL_TERMB, r = wi / SL_ROWB, sl = (wi % SL_ROWB) / 16;
+        goff_sl[i] = (o < SL_BYTES && sl < SL_DATA) ? (int)(((int64_t)t * a.NPad + r) * KP + sl * 8) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NI_STL; ++i) {
+        const int o = 1024 * (i * NW + w) + 16 * lane;
+        const int t = o / STL_TERMB, wi = o % STL_TERMB, r = wi / STL_ROWB, sl = (wi % STL_ROWB) / 16;
+        goff_stl[i] = (o < STL_BYTES && sl < STL_DATA) ? (int)(((int64_t)t * KP + r) * a.NPad + sl * 8) : 0;
+    }
+    auto dma_Sl = [&](int bcol0) {
+        const __bf16* base = a.Sp + (int64_t)bcol0 * KP;
+#pragma unroll
+        for (int i = 0; i < NI_SL; ++i)
+            lds_dma16(base + goff_sl[i], __builtin_amdgcn_readfirstlane(lds_base + 1024 * (i * NW + w)));
+    };
+    auto dma_Stl = [&](int bcol0) {
+        const __bf16* base = a.Stt + bcol0;
+#pragma unroll
+        for (int i = 0; i < NI_STL; ++i)
+            lds_dma16(base + goff_stl[i], __builtin_amdgcn_readfirstlane(lds_base + SL_REGION + 1024 * (i * NW + w)));
+    };
+    float* Ytile = Yl + w * 1024;
+    const unsigned ytile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Ytile;
+    const int dmaRow = lane >> 3, dmaCol = (lane & 7) * 4;
+    auto dma_Y = [&](int prow0, int bcol0) {
+        const float* src = a.Y + (int64_t)(prow0 + g1_mt * 32 + dmaRow) * a.ldY + bcol0 + g1_nt * 32 + dmaCol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024));
+    };
+    auto flush_gA = [&](int prow0) {
+        const int slab = colRegion * G2SPLIT + g2_half;
+        float* dst = a.slabA + (int64_t)slab * M * K;
+        const int kk = g2_kt * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = prow0 + g2_mt * 32 + tile_row(i, lane);
+            if (kk < K) dst[(int64_t)gr * K + kk] = accA[i];
+        }
+    };
+    auto stage_A = [&](int prow0) {
+        constexpr int CA = BG_BM / 8;
+        for (int e = tid; e < 2 * KP * CA; e += BG_THREADS) {
+            const int t = e / (KP * CA), r = (e / CA) % KP, c = e % CA;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.At + ((int64_t)t * KP + r) * a.MPad + prow0 + c * 8);
+            *reinterpret_cast<uint4*>(Atl + (t * KP + r) * LDT_A + c * 8) = v;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + g1_mt * 32 + l31) * KP + ks * 16 + hi * 8);
+    };
+
+    if (nsteps > 0) {   // prologue: same issue order as inside the loop
+        if (!noY) dma_Y(row0, col0);
+        else { lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds)); lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds));
+               lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds)); lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds)); }
+        dma_Sl(col0);
+        dma_Stl(col0);
+    }
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool prof = a.prof != nullptr && w == 0;
+#define PH(i) if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+    int rp = 0, cb = 0;
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const int prow0 = row0 + rp * BG_BM;
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        const bool more = step + 1 < nsteps;
+        const int nprow0 = row0 + nrp_ * BG_BM, nbcol0 = col0 + ncb_ * BG_BN;
+        // ---- B0: previous step done everywhere; Y(s) and Sl(s) landed (Stl(s) may still be in flight) ---------
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NI_STL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(0)
+        if (cb == 0) {
+            stage_A(prow0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+        }
+        PH(1)
+        // ---- P accumulator starts at -Y; then request the next Y tile into the same private tile ---------------
+        if (noY) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !noY) dma_Y(nprow0, nbcol0);
+        else {   // keep the per-step instruction count fixed so the hand-counted waits stay valid
+            lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds)); lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds));
+            lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds)); lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(ytile_lds));
+        }
+        PH(2)
+        // ---- GEMM1 ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const __bf16* sb = Sl + (g1_nt * 32 + l31) * LDS_S + ks * 16 + hi * 8;
+            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + BG_BN * LDS_S);
+            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(sb + 2 * BG_BN * LDS_S);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = g1_mt * 32 + tile_row(i, lane);
+            const float r = p[i];
+            lossAcc += r * r;
+            Rl[lr * LDR + g1_nt * 32 + l31] = r;
+        }
+        PH(3)
+        // ---- B2: R visible, Stl(s) landed (the 4 Y instructions issued above may still fly) -----------------
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(4)
+        dma_Sl(more ? nbcol0 : col0);          // every wave is done with GEMM1's reads of Sl
+        // ---- GEMM2 ------------------------------------------------------------------------------------------
+        if (a.doA & 1) {
+#pragma unroll
+            for (int ks = 0; ks < G2_INNER / 16; ++ks) {
+                const int n0 = g2_half * G2_INNER + ks * 16 + hi * 8;
+                const float* rrow = Rl + (g2_mt * 32 + l31) * LDR + n0;
+                float x[8];
+                *reinterpret_cast<float4*>(&x[0]) = *reinterpret_cast<const float4*>(rrow);
+                *reinterpret_cast<float4*>(&x[4]) = *reinterpret_cast<const float4*>(rrow + 4);
+                bf16x8 r0, r1;
+                split2(x, r0, r1);
+                const __bf16* sb = Stl + (g2_kt * 32 + l31) * LDT_S + n0;
+                const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sb);
+                const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sb + KP * LDT_S);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
+            }
+        }
+        PH(5)
+        // ---- B3: every wave is done with GEMM2's reads of Stl ---------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(6)
+        dma_Stl(more ? nbcol0 : col0);
+        // ---- GEMM3 ------------------------------------------------------------------------------------------
+        if (a.doS) {
+#define BG_GEMM3_INTO(ACC)                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < G3_INNER / 16; ++ks) {                                     \
+        const int m0 = g3_part * G3_INNER + ks * 16 + hi * 8;                                           \
+        const float* rcol = Rl + m0 * LDR + g3_nt * 32 + l31;                                           \
+        float x[8];                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) x[q] = rcol[q * LDR];                              \
+        bf16x8 r0, r1;                                                                                  \
+        split2(x, r0, r1);                                                                              \
+        const __bf16* ab = Atl + (g3_kt * 32 + l31) * LDT_A + m0;                                       \
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab);                                         \
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + KP * LDT_A);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
+    }
+            switch (cb) {
+                case 0: BG_GEMM3_INTO(accS[0]) break;
+                case 1: BG_GEMM3_INTO(accS[1]) break;
+                case 2: BG_GEMM3_INTO(accS[2]) break;
+                default: BG_GEMM3_INTO(accS[3]) break;
+            }
+#undef BG_GEMM3_INTO
+        }
+        PH(7)
+        if (cb + 1 == ncb && (a.doA & 1)) flush_gA(prow0);
+        PH(8)
+        cb = ncb_;
+        rp = nrp_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the DMAs of the (non-existent) step after the last
+    if (a.doS) {
+        const int slab = rowRegion * G3SPLIT + g3_part;
+        float* dst = a.slabS + (int64_t)slab * N * K;
+        const int kk = g3_kt * 32 + l31;
+#pragma unroll
+        for (int cbi = 0; cbi < BG_CB; ++cbi) {
+            const int bcol0 = col0 + cbi * BG_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gn = bcol0 + g3_nt * 32 + tile_row(i, lane);
+                if (gn < N && kk < K) dst[(int64_t)gn * K + kk] = accS[cbi][i];
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < BG_THREADS / 64; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    PH(9)
+    if (prof && lane == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+#undef PH
+}
+
+template <int KP>
+static size_t pipe_lds_bytes() {
+    constexpr int NW = BG_THREADS / 64;
+    constexpr int SL_BYTES = 3 * BG_BN * (KP + 8) * 2, STL_BYTES = 2 * KP * (BG_BN + 8) * 2;
+    constexpr int NI_SL = (SL_BYTES + 1024 * NW - 1) / (1024 * NW), NI_STL = (STL_BYTES + 1024 * NW - 1) / (1024 * NW);
+    return (size_t)(NI_SL + NI_STL) * NW * 1024 + (size_t)2 * KP * (BG_BM + 8) * 2 + sizeof(float) * ((size_t)BG_BM * (BG_BN + 4) + NW * 1024);
+}
+template <int KP>
+static hipError_t grad_launch_bf16_pipe(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
+    const size_t lds = pipe_lds_bytes<KP>();
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_pipe<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_bf16_pipe<KP>), dim3(p.gridX * p.gridY), dim3(BG_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
+
 // host side -----------------------------------------------------------------------------------------
 GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     GradPlan p{};
@@ -479,6 +807,8 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, hipStream_t
     a.gridY = p.gridY;
     // Whole 128 x 64 blocks with 16-byte-aligned rows take the LDS-DMA variant; anything else the guarded one.
     const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || (a.ldY % 4) != 0 || (((uintptr_t)a.Y) & 15) != 0;
+    static const int variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 1;   // 0: un-pipelined (tuning A/B)
+    if (!edge && variant == 1) return p.KP == 32 ? grad_launch_bf16_pipe<32>(p, a, stream) : grad_launch_bf16_pipe<64>(p, a, stream);
     if (p.KP == 32) return edge ? grad_launch_bf16_t<32, true>(p, a, stream) : grad_launch_bf16_t<32, false>(p, a, stream);
     return edge ? grad_launch_bf16_t<64, true>(p, a, stream) : grad_launch_bf16_t<64, false>(p, a, stream);
 }

@@ -299,6 +299,105 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Barzilai-Borwein step rule (utils.BarzilaiBorweinStepper, proxmin/utils.py:209-241), evaluated like the
+// reference at the point the gradient was taken (the extrapolated point when accelerated).
+//   k_bb_reduce: folds the gradient slabs into G (so the update kernel reads one array), forms
+//                s = X - X_prev, y = G - G_prev, stores the new X_prev / G_prev, and reduces
+//                sum s^2, sum s.y, sum y^2, sum G^2, max|X|, max|G| per workgroup;
+//   k_bb_step  : it == 0 -> r * max|X| / max|G|; else min(|BB1 or BB2|, Delta / |G|) with Delta the
+//                running minimum of |s| over it <= 3 (Burdakov et al. stabilisation).
+// ------------------------------------------------------------------------------------------------
+struct BBArgs {
+    const float* X[2];      // point of evaluation
+    SlabRef slab[2];
+    float* G[2];            // folded gradient (output)
+    float* Xprev[2];
+    float* Gprev[2];
+    int64_t rows[2];
+    int K;
+    const DevStatus* status;
+    double* partials;
+    int first;              // it == 0: nothing to difference against
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_bb_reduce(BBArgs a) {
+    __shared__ double scratch[6 * EW_WAVES];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    float ss = 0.f, sy = 0.f, yy = 0.f, gg = 0.f, mx = 0.f, mg = 0.f;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float g[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        load_grad<NC>(g, ok, a.slab[j], rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) {
+                const int64_t e = r * K + l32 + 32 * c;
+                const float x = a.X[j][e];
+                if (!a.first) {
+                    const float sv = x - a.Xprev[j][e], yv = g[c] - a.Gprev[j][e];
+                    ss += sv * sv;
+                    sy += sv * yv;
+                    yy += yv * yv;
+                }
+                gg += g[c] * g[c];
+                mx = fmaxf(mx, fabsf(x));
+                mg = fmaxf(mg, fabsf(g[c]));
+                a.Xprev[j][e] = x;
+                a.Gprev[j][e] = g[c];
+                a.G[j][e] = g[c];
+            }
+    ROW_LOOP_END
+    double red[4] = {(double)ss, (double)sy, (double)yy, (double)gg};
+    block_sum_store<4>(red, part_ptr(a.partials, SL_BB0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    double m0 = wave_max((double)mx), m1 = wave_max((double)mg);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { scratch[threadIdx.x >> 6] = m0; scratch[EW_WAVES + (threadIdx.x >> 6)] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) { a0 = fmax(a0, scratch[q]); a1 = fmax(a1, scratch[EW_WAVES + q]); }
+        part_ptr(a.partials, SL_BB0 + 4, j)[blockIdx.x] = a0;
+        part_ptr(a.partials, SL_BB0 + 5, j)[blockIdx.x] = a1;
+    }
+}
+struct BBStepArgs {
+    DevStatus* status;
+    double* partials;
+    int it, type;
+    double init_r;
+};
+__global__ __launch_bounds__(EW_THREADS) void k_bb_step(BBStepArgs a) {
+    __shared__ double scratch[EW_WAVES];
+    if (chain_halted(a.status)) return;
+    for (int j = 0; j < 2; ++j) {
+        const double ss = fold_partials(part_ptr(a.partials, SL_BB0 + 0, j), scratch);
+        const double sy = fold_partials(part_ptr(a.partials, SL_BB0 + 1, j), scratch);
+        const double yy = fold_partials(part_ptr(a.partials, SL_BB0 + 2, j), scratch);
+        const double gg = fold_partials(part_ptr(a.partials, SL_BB0 + 3, j), scratch);
+        const double mx = fold_partials_max(part_ptr(a.partials, SL_BB0 + 4, j), scratch);
+        const double mg = fold_partials_max(part_ptr(a.partials, SL_BB0 + 5, j), scratch);
+        if (threadIdx.x == 0) {
+            DevStatus* st = a.status;
+            double step;
+            if (a.it == 0) {
+                st->bb_delta[j] = 1e300 * 1e300;              // inf (utils.py:219)
+                step = a.init_r * mx / mg;                    // utils.py:222
+            } else {
+                const double bb = a.type == 1 ? ss / sy : sy / yy;              // utils.py:231-234
+                if (a.it <= 3) st->bb_delta[j] = fmin(st->bb_delta[j], sqrt(ss));   // utils.py:237-238
+                step = fmin(fabs(bb), st->bb_delta[j] / sqrt(gg));              // utils.py:239-241
+            }
+            st->step[j] = step;
+        }
+    }
+}
+
 // single-block decision kernel shared by pgm and adaprox outer tests (algorithms.py:130-135,403-410)
 struct DecideArgs {
     DevStatus* status;
@@ -994,6 +1093,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
 void launch_fold(const FoldArgs& a, int nblocks_y, hipStream_t s) { DISPATCH_NC(a.K, k_fold, dim3(EW_BLOCKS, nblocks_y), s, a); }
 void launch_prox_apply(const ProxArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_prox_apply, dim3(EW_BLOCKS), s, a); }
 void launch_pgm_update(const PgmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pgm_update, dim3(EW_BLOCKS, 2), s, a); }
+void launch_bb_reduce(const BBArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bb_reduce, dim3(EW_BLOCKS, 2), s, a); }
+void launch_bb_step(const BBStepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bb_step, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_pgm_decide(const DecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pgm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_colsum(const ColsumArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colsum, dim3(EW_BLOCKS, 2), s, a); }
 void launch_alpha_init(const AlphaArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_alpha_init, dim3(1), dim3(EW_THREADS), 0, s, a); }

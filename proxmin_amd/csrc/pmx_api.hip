@@ -62,9 +62,11 @@ struct pmx_ctx {
     float* zb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* Zg[2][PMX_MAX_G] = {};
     float* Ug[2][PMX_MAX_G] = {};
-    float* tmp[2] = {nullptr, nullptr};    // scratch for pmx_prox_apply on arbitrary rows
+    float* bbX[2] = {nullptr, nullptr};    // Barzilai-Borwein X_prev
+    float* bbG[2] = {nullptr, nullptr};    // Barzilai-Borwein G_prev
 
     // K1
+    unsigned long long* k1prof = nullptr;  // tuning: phase cycle sums (PMX_K1_PROF=1)
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 and K <= 64), else exact fp32 MFMA
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
@@ -393,6 +395,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
+        g.prof = c->k1prof;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_bf16(c->plan, g, c->stream));
     } else {
@@ -490,6 +493,11 @@ extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* a
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!avg_ms || reps < 1) FAIL(PMX_E_INVALID, "bad argument");
+    if (getenv("PMX_K1_PROF") && !c->k1prof) {
+        rc = dallocT(c, &c->k1prof, 16);
+        if (rc != PMX_OK) return rc;
+    }
+    if (c->k1prof) HIP_CHECK(hipMemsetAsync(c->k1prof, 0, 16 * sizeof(unsigned long long), c->stream));
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
     const bool was = c->timing;
     c->timing = false;
@@ -507,6 +515,15 @@ extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* a
     (void)hipEventDestroy(e1);
     c->timing = was;
     *avg_ms = ms / reps;
+    if (c->k1prof) {
+        unsigned long long h[16];
+        HIP_CHECK(hipMemcpy(h, c->k1prof, sizeof(h), hipMemcpyDeviceToHost));
+        const double nwg = (double)c->plan.gridX * c->plan.gridY * (reps + 1);
+        static const char* nm[10] = {"B0 wait", "stage_A", "Y read+dma", "GEMM1+R", "B2 wait", "dmaSl+GEMM2", "B3 wait", "dmaStl+GEMM3", "flush gA", "tail"};
+        fprintf(stderr, "[k1prof] doA=%d doS=%d cycles per workgroup (wave 0):", do_A, do_S);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.0f", nm[i], (double)h[i] / nwg);
+        fprintf(stderr, "\n");
+    }
     return rc;
 }
 
@@ -641,6 +658,13 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     c->omega_cur = 0.f;
     rc = reset_status(c);
     if (rc != PMX_OK) return rc;
+    if (p->bb_type != 0 && p->bb_type != 1 && p->bb_type != 2) FAIL(PMX_E_INVALID, "bb_type must be 0, 1 or 2");   // utils.py:212
+    if (p->bb_type)
+        for (int j = 0; j < 2; ++j) {
+            rc = dallocT(c, &c->bbX[j], (size_t)c->rows[j] * c->K, false);
+            if (rc == PMX_OK) rc = dallocT(c, &c->bbG[j], (size_t)c->rows[j] * c->K, false);
+            if (rc != PMX_OK) return rc;
+        }
     if (p->accelerated) {
         for (int j = 0; j < 2; ++j) {
             rc = dallocT(c, &c->Xe[j], (size_t)c->rows[j] * c->K, false);
@@ -670,18 +694,34 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     const float* A = p.accelerated ? c->Xe[0] : c->X[0];
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     int rc;
-    if (!p.use_fixed_steps) {
+    if (!p.use_fixed_steps && !p.bb_type) {
         rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
         if (rc != PMX_OK) return rc;
     }
     rc = enqueue_grad(c, A, St, 1, 1);                                    // algorithms.py:105
     if (rc != PMX_OK) return rc;
+    if (p.bb_type) {                                                      // step(*_X, it, grads=G): utils.py:216-241
+        BBArgs b{};
+        b.X[0] = A; b.X[1] = St;
+        for (int j = 0; j < 2; ++j) {
+            b.slab[j] = slab_ref(c, j);
+            b.G[j] = c->G[j]; b.Xprev[j] = c->bbX[j]; b.Gprev[j] = c->bbG[j];
+            b.rows[j] = c->rows[j];
+        }
+        b.K = (int)c->K; b.status = c->dstatus; b.partials = c->partials;
+        b.first = c->it == 0;
+        launch_bb_reduce(b, c->stream);
+        BBStepArgs bs{};
+        bs.status = c->dstatus; bs.partials = c->partials; bs.it = c->it; bs.type = p.bb_type; bs.init_r = p.bb_init_r;
+        launch_bb_step(bs, c->stream);
+    }
     PgmArgs u{};
     for (int j = 0; j < 2; ++j) {
         u.X[j] = c->X[j];
         u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
         u.G[j] = c->G[j];
         u.slab[j] = slab_ref(c, j);
+        if (p.bb_type) { u.slab[j].base = c->G[j]; u.slab[j].n = 1; }    // already folded by k_bb_reduce
         u.rows[j] = c->rows[j];
         u.prox[j] = to_dev(p.prox[j]);
     }
@@ -698,6 +738,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     d.check = 1;
     launch_pgm_decide(d, c->stream);                                      // algorithms.py:130-135
     HIP_CHECK(hipGetLastError());
+    c->it += 1;
     return PMX_OK;
 }
 

@@ -50,3 +50,22 @@ class NesterovAccelerator(object):
         om = (self.t - 1) / t_
         self.t = t_
         return om
+
+
+class BarzilaiBorweinStepper:
+    """Barzilai-Borwein step sizes with Burdakov stabilisation (proxmin/utils.py:209-241).
+
+    Pass the object (or its bound `.step`) as `step=` to `nmf(..., algorithm=pgm)`: the reductions
+    (sum s^2, s.y, y^2, |G|^2, max|X|, max|G| with s = X - X_prev, y = G - G_prev) and the step formula run
+    on the device each iteration, evaluated -- like the reference -- at the point the gradient was taken.
+    It has no host implementation: calling `.step` directly on ndarrays is not supported."""
+
+    def __init__(self, type=1, init_r=0.1):
+        assert type in [1, 2]
+        self.r = init_r
+        self.type = type
+
+    def step(self, *X, it=None, grads=None):
+        raise NotImplementedError("BarzilaiBorweinStepper runs inside the device solver: pass it as step= to nmf(..., algorithm=pgm)")
+
+    __call__ = step

@@ -227,3 +227,19 @@ def test_stop_iteration_and_warm_start(pm, orc):
         orc.adaprox_nmf(Y, Ao, So, scheme="amsgrad", max_iter=3, e_rel=1e-9, M=oM, V=oV, Vhat=oVh)
     assert_factors_close(A, Ao, np.float32, "warm start A")
     np.testing.assert_allclose(Vh[1], oVh[1], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("bbtype,accel", [(1, False), (2, False), (1, True)])
+def test_barzilai_borwein_step_rule(pm, orc, bbtype, accel):
+    """utils.BarzilaiBorweinStepper as the PGM step rule: device reductions vs the oracle's restatement
+    (itself pinned to the reference's stepper in tests/golden/helpers.npz)."""
+    Y, A0, S0 = orc.synthetic_problem(220, 310, 7, np.float32, seed=13)
+    A, S = A0.copy(), S0.copy()
+    bb = pm.utils.BarzilaiBorweinStepper(type=bbtype, init_r=0.1)
+    _, _, steps = pm.nmf.nmf(Y, A, S, step=bb.step, accelerated=accel, max_iter=8, e_rel=1e-12)
+    Ao, So = A0.copy(), S0.copy()
+    obb = orc.BBStepper(kind=bbtype, init_r=0.1)
+    _, _, osteps, _ = orc.pgm_nmf(Y, Ao, So, step=lambda a, s, it, g: obb.step((a, s), it, g), accelerated=accel, max_iter=8, e_rel=1e-12)
+    np.testing.assert_allclose(np.array(steps, dtype=np.float64), np.array(osteps, dtype=np.float64), rtol=2e-3)
+    assert_factors_close(A, Ao, np.float32, "bb A")
+    assert_factors_close(S, So, np.float32, "bb S")
