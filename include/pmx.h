@@ -170,6 +170,7 @@ typedef struct pmx_pgm_params { /* algorithms.pgm arguments, algorithms.py:12-23
     double e_rel[2];      /* algorithms.py:66-68 */
     int32_t bb_type;      /* 0: off; 1 / 2: utils.BarzilaiBorweinStepper(type) as the step rule (utils.py:209-241) */
     double bb_init_r;     /* its init_r */
+    int32_t backtracking; /* 1: Beck-Teboulle line search with f = nmf.log_likelihood (algorithms.py:110-127) */
 } pmx_pgm_params;
 
 typedef struct pmx_result {

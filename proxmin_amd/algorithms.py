@@ -80,7 +80,12 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     e_rel = _e_rel_pair(e_rel)
     assert backtracking is False or f is not None
     if backtracking:
-        raise NotImplementedError("backtracking line search is not implemented on the device yet")
+        # the smooth function must be the NMF likelihood of the same Y (it is evaluated by the fused residual kernel)
+        ok = isinstance(f, partial) and f.func is _nmf.log_likelihood and not f.args and f.keywords.get("Y") is grad.keywords["Y"]
+        if not ok:
+            raise NotImplementedError("backtracking on the device needs f=functools.partial(proxmin_amd.nmf.log_likelihood, Y=Y) "
+                                      "with the same Y as the gradient")
+        _nmf._check_W(f.keywords.get("W", 1))
     scale, fixed, bb = 1.0, None, None
     bb_owner = getattr(step, "__self__", step)
     if isinstance(bb_owner, utils.BarzilaiBorweinStepper):
@@ -99,7 +104,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         dev.set_Y(Y)
         dev.set_factors(A, S)
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=fixed, e_rel=e_rel,
-                      bb=(bb.type, bb.r) if bb is not None else None)
+                      bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking)
         res = None
         it_done = 0
         if _wants_iterates(callback):

@@ -300,6 +300,125 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PGM with backtracking line search (Beck & Teboulle eq. 3.2; proxmin/algorithms.py:110-127).
+// k_bt_update (re)applies  X_j = prox(Xe_j - T_j s_j G_j, T_j s_j)  for the selected blocks, keeps X_ (the
+// iterate before the step) in Xp, and reduces what the sufficient-decrease test needs:
+//     sum (X - X_).G,  sum (X - X_)^2,  max|G|,  max|X_|   (+ sum X^2 for the stopping test).
+// The first call of an iteration folds the gradient slabs into G; halvings re-read G.
+// k_bt_collect folds the partials into DevStatus::bt for the host, which owns the while loop (each trial
+// needs a fresh pass over Y for f(X), so a host round trip per trial is noise).
+// ------------------------------------------------------------------------------------------------
+struct BtArgs {
+    float* X[2];
+    const float* Xe[2];
+    float* Xp[2];
+    float* G[2];
+    SlabRef slab[2];
+    int64_t rows[2];
+    int K;
+    ProxSeq prox[2];
+    DevStatus* status;
+    double* partials;
+    float T[2];
+    int do_block[2];
+    int first;           // first application in this iteration: X still holds X_, fold slabs, store Xp and G
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_bt_update(BtArgs a) {
+    __shared__ double scratch[3 * EW_WAVES];
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    if (!a.do_block[j]) return;
+    const int64_t rows = a.rows[j];
+    const int K = a.K;
+    const float s = a.T[j] * (float)a.status->step[j];      // T[j] * S[j]   (algorithms.py:108,125)
+    float d1 = 0.f, d2 = 0.f, n2 = 0.f, mg = 0.f, mx = 0.f;
+    ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float g[NC], xo[NC], v[NC], sk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+        if (a.first) load_grad<NC>(g, ok, a.slab[j], rows, K, r, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t e = r * K + l32 + 32 * c;
+            if (!a.first) g[c] = ok[c] ? a.G[j][e] : 0.f;
+            xo[c] = ok[c] ? (a.first ? a.X[j][e] : a.Xp[j][e]) : 0.f;
+            const float xe = ok[c] ? a.Xe[j][e] : 0.f;
+            v[c] = xe - s * g[c];
+            sk[c] = s;
+        }
+        prox_row<NC>(v, ok, a.prox[j], sk);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) {
+                const int64_t e = r * K + l32 + 32 * c;
+                a.X[j][e] = v[c];
+                if (a.first) { a.Xp[j][e] = xo[c]; a.G[j][e] = g[c]; }
+                const float d = v[c] - xo[c];
+                d1 += d * g[c];
+                d2 += d * d;
+                n2 += v[c] * v[c];
+                mg = fmaxf(mg, fabsf(g[c]));
+                mx = fmaxf(mx, fabsf(xo[c]));
+            }
+    ROW_LOOP_END
+    double red[2] = {(double)d2, (double)n2};
+    block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    double r1[1] = {(double)d1};
+    block_sum_store<1>(r1, part_ptr(a.partials, SL_BT0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    double m0 = wave_max((double)mg), m1 = wave_max((double)mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { scratch[threadIdx.x >> 6] = m0; scratch[EW_WAVES + (threadIdx.x >> 6)] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) { a0 = fmax(a0, scratch[q]); a1 = fmax(a1, scratch[EW_WAVES + q]); }
+        part_ptr(a.partials, SL_BT0 + 1, j)[blockIdx.x] = a0;
+        part_ptr(a.partials, SL_BT0 + 2, j)[blockIdx.x] = a1;
+    }
+}
+struct BtCollectArgs {
+    DevStatus* status;
+    double* partials;
+    int do_block[2];
+};
+__global__ __launch_bounds__(EW_THREADS) void k_bt_collect(BtCollectArgs a) {
+    __shared__ double scratch[EW_WAVES];
+    if (chain_halted(a.status)) return;
+    for (int j = 0; j < 2; ++j) {
+        if (!a.do_block[j]) continue;
+        const double d1 = fold_partials(part_ptr(a.partials, SL_BT0, j), scratch);
+        const double d2 = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
+        const double n2 = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+        const double mg = fold_partials_max(part_ptr(a.partials, SL_BT0 + 1, j), scratch);
+        const double mx = fold_partials_max(part_ptr(a.partials, SL_BT0 + 2, j), scratch);
+        if (threadIdx.x == 0) {
+            a.status->bt[j][0] = d1; a.status->bt[j][1] = d2; a.status->bt[j][2] = mg; a.status->bt[j][3] = mx; a.status->bt[j][4] = n2;
+        }
+    }
+}
+// after the line search settled: FISTA extrapolation for the next iteration (algorithms.py:95) or plain copy
+struct BtFinishArgs {
+    const float* X[2];
+    const float* Xp[2];
+    float* Xe[2];
+    int64_t rows[2];
+    int K;
+    const DevStatus* status;
+    float omega_next;
+};
+__global__ __launch_bounds__(EW_THREADS) void k_bt_finish(BtFinishArgs a) {
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t n = a.rows[j] * a.K;
+    for (int64_t e = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (int64_t)EW_BLOCKS * EW_THREADS) {
+        const float x = a.X[j][e];
+        a.Xe[j][e] = x + a.omega_next * (x - a.Xp[j][e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Barzilai-Borwein step rule (utils.BarzilaiBorweinStepper, proxmin/utils.py:209-241), evaluated like the
 // reference at the point the gradient was taken (the extrapolated point when accelerated).
 //   k_bb_reduce: folds the gradient slabs into G (so the update kernel reads one array), forms
@@ -1095,6 +1214,9 @@ void launch_prox_apply(const ProxArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pr
 void launch_pgm_update(const PgmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pgm_update, dim3(EW_BLOCKS, 2), s, a); }
 void launch_bb_reduce(const BBArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bb_reduce, dim3(EW_BLOCKS, 2), s, a); }
 void launch_bb_step(const BBStepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bb_step, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_bt_update(const BtArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bt_update, dim3(EW_BLOCKS, 2), s, a); }
+void launch_bt_collect(const BtCollectArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bt_collect, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_bt_finish(const BtFinishArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bt_finish, dim3(EW_BLOCKS, 2), dim3(EW_THREADS), 0, s, a); }
 void launch_pgm_decide(const DecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pgm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_colsum(const ColsumArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colsum, dim3(EW_BLOCKS, 2), s, a); }
 void launch_alpha_init(const AlphaArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_alpha_init, dim3(1), dim3(EW_THREADS), 0, s, a); }

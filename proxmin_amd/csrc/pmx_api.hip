@@ -91,6 +91,8 @@ struct pmx_ctx {
     pmx_bsdmm_params bsd{};
     int it = 0;                            // iterations enqueued AND completed (host view)
     double nest_t = 1.0;                   // NesterovAccelerator.t (utils.py:195)
+    double btT[2] = {1.0, 1.0};            // backtracking step multipliers T (algorithms.py:85), never reset inside a run
+    double bt_fprev = 0.0;
     float omega_cur = 0.f;
     int nsub_guess = 2;
     std::vector<void*> allocs;
@@ -659,11 +661,20 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     rc = reset_status(c);
     if (rc != PMX_OK) return rc;
     if (p->bb_type != 0 && p->bb_type != 1 && p->bb_type != 2) FAIL(PMX_E_INVALID, "bb_type must be 0, 1 or 2");   // utils.py:212
+    if (p->bb_type && p->backtracking) FAIL(PMX_E_UNSUPPORTED, "Barzilai-Borwein steps together with backtracking are not implemented");
     if (p->bb_type)
         for (int j = 0; j < 2; ++j) {
             rc = dallocT(c, &c->bbX[j], (size_t)c->rows[j] * c->K, false);
             if (rc == PMX_OK) rc = dallocT(c, &c->bbG[j], (size_t)c->rows[j] * c->K, false);
             if (rc != PMX_OK) return rc;
+        }
+    c->btT[0] = c->btT[1] = 1.0;
+    if (p->backtracking)
+        for (int j = 0; j < 2; ++j) {
+            rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
+            if (rc == PMX_OK) rc = dallocT(c, &c->Xe[j], (size_t)c->rows[j] * c->K, false);
+            if (rc != PMX_OK) return rc;
+            HIP_CHECK(hipMemcpyAsync(c->Xe[j], c->X[j], c->rows[j] * c->K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         }
     if (p->accelerated) {
         for (int j = 0; j < 2; ++j) {
@@ -742,6 +753,90 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     return PMX_OK;
 }
 
+static int loss_now(pmx_ctx* c, const float* A, const float* St, double* out) {
+    int rc = enqueue_grad(c, A, St, 0, 0);
+    if (rc != PMX_OK) return rc;
+    const int n = c->plan.gridX * c->plan.gridY;
+    std::vector<double> h(n);
+    HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += h[i];
+    *out = 0.5 * s;
+    return PMX_OK;
+}
+
+// one PGM iteration with the Beck-Teboulle line search (algorithms.py:93-135); host-driven, synchronous
+static int pgm_bt_iteration(pmx_ctx* c) {
+    const pmx_pgm_params& p = c->pgm;
+    int rc;
+    // _X is a separate buffer in this mode (algorithms.py:96-97): Xe already holds it (copy of X, or the
+    // extrapolated point written by k_bt_finish at the end of the previous iteration)
+    if (c->it == 0) {                                        // f_prev = f(*X_) on the first iteration (:113-114)
+        rc = loss_now(c, c->X[0], c->X[1], &c->bt_fprev);
+        if (rc != PMX_OK) return rc;
+    }
+    if (!p.use_fixed_steps && !p.bb_type) {
+        rc = enqueue_steps(c, c->Xe[0], c->Xe[1], true, true, (double)p.step_scale);
+        if (rc != PMX_OK) return rc;
+    }
+    rc = enqueue_grad(c, c->Xe[0], c->Xe[1], 1, 1);
+    if (rc != PMX_OK) return rc;
+    BtArgs u{};
+    for (int j = 0; j < 2; ++j) {
+        u.X[j] = c->X[j]; u.Xe[j] = c->Xe[j]; u.Xp[j] = c->Xp[j]; u.G[j] = c->G[j];
+        u.slab[j] = slab_ref(c, j);
+        u.rows[j] = c->rows[j];
+        u.prox[j] = to_dev(p.prox[j]);
+        u.T[j] = (float)c->btT[j];
+        u.do_block[j] = 1;
+    }
+    u.K = (int)c->K; u.status = c->dstatus; u.partials = c->partials; u.first = 1;
+    launch_bt_update(u, c->stream);
+    BtCollectArgs col{};
+    col.status = c->dstatus; col.partials = c->partials; col.do_block[0] = col.do_block[1] = 1;
+    launch_bt_collect(col, c->stream);
+    double f_now;
+    rc = loss_now(c, c->X[0], c->X[1], &f_now);
+    if (rc != PMX_OK) return rc;
+    rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    for (int guard = 0; guard < 200; ++guard) {
+        const DevStatus* s = c->hstatus;
+        double q = 0.0;
+        for (int j = 0; j < 2; ++j) q += s->bt[j][0] + 0.5 / (c->btT[j] * s->step[j]) * s->bt[j][1];
+        if (!(f_now > c->bt_fprev + q)) break;               // algorithms.py:117-118
+        // block with the largest relative update direction (algorithms.py:121)
+        const double r0 = s->step[0] * s->bt[0][2] / s->bt[0][3], r1 = s->step[1] * s->bt[1][2] / s->bt[1][3];
+        const int jm = r1 > r0 ? 1 : 0;                      // np.argmax: first maximum
+        c->btT[jm] *= 0.5;
+        u.first = 0;
+        u.do_block[0] = jm == 0; u.do_block[1] = jm == 1;
+        u.T[jm] = (float)c->btT[jm];
+        launch_bt_update(u, c->stream);
+        col.do_block[0] = u.do_block[0]; col.do_block[1] = u.do_block[1];
+        launch_bt_collect(col, c->stream);
+        rc = loss_now(c, c->X[0], c->X[1], &f_now);
+        if (rc != PMX_OK) return rc;
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+    }
+    c->bt_fprev = f_now;                                      // :127
+    BtFinishArgs fin{};
+    for (int j = 0; j < 2; ++j) { fin.X[j] = c->X[j]; fin.Xp[j] = c->Xp[j]; fin.Xe[j] = c->Xe[j]; fin.rows[j] = c->rows[j]; }
+    fin.K = (int)c->K; fin.status = c->dstatus;
+    fin.omega_next = next_omega(c);
+    launch_bt_finish(fin, c->stream);
+    DecideArgs d{};
+    d.status = c->dstatus; d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check = 1;
+    launch_pgm_decide(d, c->stream);
+    HIP_CHECK(hipGetLastError());
+    c->it += 1;
+    return PMX_OK;
+}
+
 static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
     HIP_CHECK(hipMemcpyAsync(&c->dstatus->step[0], s, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return PMX_OK;
@@ -759,9 +854,9 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     }
     int left = n_iter;
     while (left > 0 && !c->hstatus->stopped) {
-        const int chunk = std::min(left, 32);
+        const int chunk = c->pgm.backtracking ? 1 : std::min(left, 32);
         for (int i = 0; i < chunk; ++i) {
-            rc = pgm_enqueue_iteration(c);
+            rc = c->pgm.backtracking ? pgm_bt_iteration(c) : pgm_enqueue_iteration(c);
             if (rc != PMX_OK) return rc;
         }
         rc = read_status(c);

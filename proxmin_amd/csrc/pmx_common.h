@@ -32,7 +32,8 @@ enum {
     SL_MAXPSI = 6,  // max Psi                          (algorithms.py:384)
     SL_G0 = 8,      // bsdmm: 5 sums per constraint i: R^2, Sd^2, Z^2, (U/sg)^2 ; + X^2 in SL_NORM2
     SL_BB0 = 8 + 4 * PMX_MAX_G,   // Barzilai-Borwein: sum s^2, sum s.y, sum y^2, sum g^2, max|x|, max|g|  (utils.py:216-241)
-    SL_COUNT = 8 + 4 * PMX_MAX_G + 6
+    SL_BT0 = 8 + 4 * PMX_MAX_G + 6,   // backtracking: sum (X-X_).G, max|G|, max|X_|        (algorithms.py:117-121)
+    SL_COUNT = 8 + 4 * PMX_MAX_G + 6 + 3
 };
 constexpr int COLSUM_SLOTS = MAXK;   // per-block per-component partial column sums
 
@@ -57,6 +58,7 @@ struct DevStatus {
     float gamma[2][MAXK];   // alpha / max(Psi)
     float ratio[2][MAXK];   // gamma / alpha  (NaN when alpha == 0, like the reference)
     double bb_delta[2];     // Barzilai-Borwein stabilisation radius (utils.py:237-239)
+    double bt[2][5];        // backtracking sums per block: (X-X_).G, (X-X_)^2, max|G|, max|X_|, X^2
     double eigvec[2][MAXK]; // warm start for the power iteration
     int eig_iters[2];
     int pad;

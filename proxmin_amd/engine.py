@@ -151,7 +151,7 @@ class DeviceNMF:
         return out[: self.K].copy(), out[self.K:].copy()
 
     # -- solvers ------------------------------------------------------------------------------
-    def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6), bb=None):
+    def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6), bb=None, backtracking=False):
         p = _lib.PgmParams()
         p.prox[0], p.prox[1] = prox
         p.accelerated = int(bool(accelerated))
@@ -162,6 +162,7 @@ class DeviceNMF:
         p.e_rel[0], p.e_rel[1] = float(e_rel[0]), float(e_rel[1])
         if bb is not None:
             p.bb_type, p.bb_init_r = int(bb[0]), float(bb[1])
+        p.backtracking = int(bool(backtracking))
         _lib.check(self.lib.pmx_pgm_begin(self.h, C.byref(p)))
 
     def pgm_run(self, n_iter):

@@ -243,3 +243,41 @@ def test_barzilai_borwein_step_rule(pm, orc, bbtype, accel):
     np.testing.assert_allclose(np.array(steps, dtype=np.float64), np.array(osteps, dtype=np.float64), rtol=2e-3)
     assert_factors_close(A, Ao, np.float32, "bb A")
     assert_factors_close(S, So, np.float32, "bb S")
+
+
+@pytest.mark.parametrize("accel", [False, True])
+def test_backtracking_line_search(pm, orc, accel):
+    """algorithms.py:110-127 on the device (f = log_likelihood from the fused residual kernel) vs the oracle;
+    a 4x too long fixed step forces halvings in the first iterations."""
+    Y, A0, S0 = orc.synthetic_problem(150, 210, 5, np.float32, seed=17)
+    sA, sS = orc.lipschitz_steps(A0.astype(np.float64), S0.astype(np.float64))
+    fixed = (4 * sA, 4 * sS)
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    pm.nmf.nmf(Y, A, S, step=pm.nmf.constant_step(*fixed), accelerated=accel, backtracking=True,
+               f=partial(pm.nmf.log_likelihood, Y=Y), max_iter=10, e_rel=1e-9, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    trace = []
+    orc.pgm_nmf(Y, Ao, So, step=lambda a, s, it, g: fixed, accelerated=accel, backtracking=True, max_iter=10, e_rel=1e-9, trace=trace)
+    assert len(tb.trace) == len(trace)
+    assert_factors_close(A, Ao, np.float32, "backtracking A")
+    assert_factors_close(S, So, np.float32, "backtracking S")
+    assert abs(pm.nmf.log_likelihood(A, S, Y=Y) / orc.half_sq_residual(Ao, So, Y) - 1) < 1e-3
+
+
+def test_unmixing_example_pgm_backtracking(pm):
+    """examples/unmixing.py (the reference's only NMF example): PGM with backtracking to convergence; the
+    reference's final loss and iteration count are in tests/golden/unmixing.npz."""
+    z, meta = load_golden("unmixing.npz")
+    Y, A0, S0 = z["Y"], z["A0"], z["S0"]
+    for r in meta["runs"]:
+        if r["cfg"] is not None or r["mode"] != "nmf":
+            continue
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A, S, prox_A=spec_to_prox(pm, tuple(r["prox_A"])), prox_S=spec_to_prox(pm, tuple(r["prox_S"])),
+                   backtracking=True, f=partial(pm.nmf.log_likelihood, Y=Y), e_rel=1e-4, max_iter=1000, callback=tb)
+        loss = pm.nmf.log_likelihood(A, S, Y=Y)
+        # a converged non-convex run in fp32 vs fp64: same basin, loss within 0.5 %, iteration count within 15 %
+        assert abs(loss / r["loss"] - 1) < 5e-3, (loss, r["loss"])
+        assert abs(len(tb.trace) - r["iters"]) <= 0.15 * r["iters"], (len(tb.trace), r["iters"])
