@@ -231,6 +231,13 @@ int pmx_set_comm_buffer(pmx_ctx* ctx, float* dptr, int64_t count);
 /* phase 0: K1 + pack.  phase 1: consume + update (+ `nsub` proximal sub-iteration passes).
  * phase 2: pack only (final stopping-test flush).  phase 3: consume only.  No synchronisation. */
 int pmx_adaprox_phase(pmx_ctx* ctx, int phase, int it, double b1_it, double b1_prev, int nsub);
+/* pgm: phase 0 = Gram matrices + K1 + pack (gSt, local A^T A, A's stopping sums); phase 1 = global lmax(A^T A),
+ * update; phases 2/3 = final stopping-test flush.  Lipschitz or fixed steps (no Barzilai-Borwein, no backtracking). */
+int pmx_pgm_phase(pmx_ctx* ctx, int phase, int it);
+/* bsdmm: phase 0 = the whole (row-local) A step, then Gram(A_new) + K1 for gS + pack (incl. A's residual norms);
+ * phase 1 = global step_S, A's convergence test on the all-reduced norms, S step, close of the iteration.  The
+ * single all-reduce sits between the A step and the S step; stop semantics are exact. */
+int pmx_bsdmm_phase(pmx_ctx* ctx, int phase);
 /* synchronise and report where the chain stands: halted (0/1), reason (1 converged, 2 needs more
  * sub-iteration passes), completed iterations, last tau per block. */
 int pmx_chain_status(pmx_ctx* ctx, int* halted, int* reason, int* it_done, int last_tau[2]);

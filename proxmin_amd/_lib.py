@@ -88,6 +88,8 @@ _SIGNATURES = {
     "pmx_comm_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmx_set_comm_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pmx_adaprox_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "pmx_pgm_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pmx_bsdmm_phase": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pmx_adaprox_more_subs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pmx_iter_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),

@@ -1067,15 +1067,22 @@ struct BsdmmDecideArgs {
     int64_t size;        // X.size == Z.size (identity L)
     double e_rel, e_abs;
     int last_block;      // 1 for the second block: closes the iteration (algorithms.py:841-844)
+    const float* comm_scalars;   // row-sharded block A: all-reduced sums [d2, x2, q0..] instead of the local partials
 };
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) {
     __shared__ double scratch[EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = a.j;
-    const double d2 = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
-    const double x2 = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
-    double q[4 * PMX_MAX_G];
-    for (int i = 0; i < 4 * a.n_g; ++i) q[i] = fold_partials(part_ptr(a.partials, SL_G0 + i, j), scratch);
+    double d2, x2, q[4 * PMX_MAX_G];
+    if (a.comm_scalars != nullptr) {
+        d2 = (double)a.comm_scalars[0];
+        x2 = (double)a.comm_scalars[1];
+        for (int i = 0; i < 4 * a.n_g; ++i) q[i] = (double)a.comm_scalars[2 + i];
+    } else {
+        d2 = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
+        x2 = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+        for (int i = 0; i < 4 * a.n_g; ++i) q[i] = fold_partials(part_ptr(a.partials, SL_G0 + i, j), scratch);
+    }
     if (threadIdx.x == 0) {
         DevStatus* st = a.status;
         const double sq = sqrt((double)a.size);
@@ -1123,6 +1130,7 @@ struct PackArgs {
     const double* gramA;     // local A^T A (KP*KP doubles) or nullptr
     const DevStatus* status;
     int fold_grad;           // 0: only the extras (final convergence flush)
+    int n_extra;             // bsdmm: additional block-0 slots SL_G0 .. SL_G0+n_extra-1 -> scalars[2..]
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
@@ -1161,7 +1169,24 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
         const double d = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, scratch);
         const double n = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS, scratch);
         if (t < 32) sc[t] = t == 0 ? (float)d : (t == 1 ? (float)n : 0.f);
+        for (int i = 0; i < a.n_extra; ++i) {
+            const double q = fold_partials(a.partials + ((int64_t)(SL_G0 + i) * 2 + 0) * EW_BLOCKS, scratch);
+            if (t == 0) sc[2 + i] = (float)q;
+        }
     }
+}
+
+// all-reduced Gram(A) (float32 in the comm buffer) -> the fp64 matrix k_eig reads (factor 0)
+struct GramInArgs {
+    const float* comm_gram;
+    double* G;               // gramG[0]
+    int n;
+    const DevStatus* status;
+};
+__global__ __launch_bounds__(256) void k_shard_gram_in(GramInArgs a) {
+    if (chain_halted(a.status)) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < a.n) a.G[e] = (double)a.comm_gram[e];
 }
 
 // after the all-reduce: global step sizes for A and the deferred outer test of the previous iteration
@@ -1172,12 +1197,13 @@ struct ShardPostArgs {
     double e_rel[2];
     int check_convergence;
     int have_prev;           // 0 on the first iteration (nothing to test yet)
+    int do_alpha;            // adaprox only
 };
 __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
     __shared__ double scratch[EW_WAVES];
     DevStatus* st = a.al.status;
     if (chain_halted(st)) return;
-    compute_alpha(a.al);
+    if (a.do_alpha) compute_alpha(a.al);
     if (a.check_convergence && a.have_prev) {
         const double dS = fold_partials(part_ptr(a.partials, SL_DIFF2, 1), scratch);
         const double nS = fold_partials(part_ptr(a.partials, SL_NORM2, 1), scratch);
@@ -1226,5 +1252,6 @@ void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, 
 void launch_ada_decide(const AdaDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ada_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }
 void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS), s, a); }
+void launch_shard_gram_in(const GramInArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_gram_in, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 void launch_shard_post(const ShardPostArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_decide(const BsdmmDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bsdmm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }

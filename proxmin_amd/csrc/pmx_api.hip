@@ -452,6 +452,43 @@ static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantS
     return PMX_OK;
 }
 
+static int enqueue_gram_only(pmx_ctx* c, const float* A, const float* St, bool wantA_factor, bool wantS_factor) {
+    GramArgs g{};
+    g.X[0] = A; g.X[1] = St;
+    g.rows[0] = c->M; g.rows[1] = c->N;
+    g.K = (int)c->K;
+    g.part = c->gramPart;
+    g.status = c->dstatus;
+    g.want[0] = wantA_factor; g.want[1] = wantS_factor;
+    launch_gram(g, c->KP, c->stream);
+    GramReduceArgs r{};
+    r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
+    r.want[0] = g.want[0]; r.want[1] = g.want[1];
+    launch_gram_reduce(r, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+static int enqueue_eig_only(pmx_ctx* c, bool wantA_factor, bool wantS_factor, double scale) {
+    EigArgs e{};
+    e.G = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+    e.want[0] = wantA_factor; e.want[1] = wantS_factor;
+    e.scale = scale;
+    e.max_iter = 200;
+    e.Q = c->eigQ;
+    HIP_CHECK(launch_eig(e, c->stream));
+    return PMX_OK;
+}
+static int shard_gram_in(pmx_ctx* c) {
+    GramInArgs g{};
+    g.comm_gram = c->comm + c->N * c->K;
+    g.G = c->gramG;
+    g.n = c->KP * c->KP;
+    g.status = c->dstatus;
+    launch_shard_gram_in(g, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
 static int require_ready(pmx_ctx* c) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!c->haveY) FAIL(PMX_E_STATE, "Y has not been set");
@@ -1186,7 +1223,7 @@ static AlphaArgs alpha_args_sharded(pmx_ctx* c) {
     return a;
 }
 
-static int shard_pack(pmx_ctx* c, int fold_grad) {
+static int shard_pack(pmx_ctx* c, int fold_grad, bool with_gram = false, int n_extra = 0) {
     PackArgs p{};
     p.slabS = slab_ref(c, 1);
     p.comm = c->comm;
@@ -1194,9 +1231,10 @@ static int shard_pack(pmx_ctx* c, int fold_grad) {
     p.K = (int)c->K; p.KP = c->KP;
     p.colpart = c->colpart;
     p.partials = c->partials;
-    p.gramA = nullptr;
+    p.gramA = with_gram ? c->gramG : nullptr;   // factor 0 = A
     p.status = c->dstatus;
     p.fold_grad = fold_grad;
+    p.n_extra = n_extra;
     launch_shard_pack(p, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1204,11 +1242,14 @@ static int shard_pack(pmx_ctx* c, int fold_grad) {
 
 static int shard_post(pmx_ctx* c, int have_prev) {
     ShardPostArgs q{};
-    q.al = alpha_args_sharded(c);
+    const bool ada = c->algo == ALG_ADAPROX;
+    q.al = ada ? alpha_args_sharded(c) : alpha_args(c);
     q.scalars = c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK;
     q.partials = c->partials;
-    q.e_rel[0] = c->ada.e_rel[0]; q.e_rel[1] = c->ada.e_rel[1];
-    q.check_convergence = c->ada.check_convergence;
+    q.e_rel[0] = ada ? c->ada.e_rel[0] : c->pgm.e_rel[0];
+    q.e_rel[1] = ada ? c->ada.e_rel[1] : c->pgm.e_rel[1];
+    q.check_convergence = ada ? c->ada.check_convergence : 1;
+    q.do_alpha = ada;
     q.have_prev = have_prev;
     launch_shard_post(q, c->stream);
     HIP_CHECK(hipGetLastError());
@@ -1250,6 +1291,134 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
         case 3: return shard_post(c, 1);
         default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
     }
+}
+
+static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
+    const pmx_pgm_params& p = c->pgm;
+    PgmArgs u{};
+    for (int j = 0; j < 2; ++j) {
+        u.X[j] = c->X[j];
+        u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
+        u.G[j] = c->G[j];
+        u.slab[j] = slab_ref(c, j);
+        u.rows[j] = c->rows[j];
+        u.prox[j] = to_dev(p.prox[j]);
+    }
+    if (gS_from_comm) { u.slab[1].base = c->comm; u.slab[1].n = 1; }
+    u.K = (int)c->K;
+    u.status = c->dstatus;
+    u.partials = c->partials;
+    u.accelerated = p.accelerated;
+    u.omega_next = next_omega(c);
+    launch_pgm_update(u, c->stream);
+    DecideArgs d{};
+    d.status = c->dstatus;
+    d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check = check;
+    launch_pgm_decide(d, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
+    if (!c->comm) FAIL(PMX_E_STATE, "pmx_set_comm_buffer has not been called");
+    const pmx_pgm_params& p = c->pgm;
+    if (p.bb_type || p.backtracking) FAIL(PMX_E_UNSUPPORTED, "row-sharded pgm supports the Lipschitz rule or fixed steps only");
+    const float* A = p.accelerated ? c->Xe[0] : c->X[0];
+    const float* St = p.accelerated ? c->Xe[1] : c->X[1];
+    switch (phase) {
+        case 0:
+            if (!p.use_fixed_steps) {
+                rc = enqueue_gram_only(c, A, St, true, true);
+                if (rc != PMX_OK) return rc;
+            }
+            rc = enqueue_grad(c, A, St, 1, 1);
+            if (rc != PMX_OK) return rc;
+            return shard_pack(c, 1, !p.use_fixed_steps, 0);
+        case 1:
+            rc = shard_post(c, it > 0);
+            if (rc != PMX_OK) return rc;
+            if (p.use_fixed_steps) rc = set_fixed_steps(c, p.fixed_steps);
+            else {
+                rc = shard_gram_in(c);
+                if (rc == PMX_OK) rc = enqueue_eig_only(c, true, true, (double)p.step_scale);
+            }
+            if (rc != PMX_OK) return rc;
+            c->it += 1;
+            return pgm_enqueue_update(c, true, 0);
+        case 2: return shard_pack(c, 0, false, 0);
+        case 3: return shard_post(c, 1);
+        default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    }
+}
+
+static int bsdmm_enqueue_block(pmx_ctx* c, int j, bool gS_from_comm, const float* comm_scalars, int64_t size_global) {
+    const pmx_bsdmm_params& p = c->bsd;
+    BsdmmArgs u{};
+    u.X = c->X[j];
+    u.slab = slab_ref(c, j);
+    if (gS_from_comm) { u.slab.base = c->comm; u.slab.n = 1; }
+    for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
+    u.rows = c->rows[j];
+    u.K = (int)c->K;
+    u.j = j;
+    u.n_g = p.n_g[j];
+    u.prox_f = to_dev(p.prox_f[j]);
+    u.status = c->dstatus;
+    u.partials = c->partials;
+    launch_bsdmm_update(u, c->stream);
+    (void)comm_scalars; (void)size_global;
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+static int bsdmm_enqueue_decide(pmx_ctx* c, int j, const float* comm_scalars, int64_t size) {
+    const pmx_bsdmm_params& p = c->bsd;
+    BsdmmDecideArgs d{};
+    d.status = c->dstatus;
+    d.partials = c->partials;
+    d.j = j;
+    d.n_g = p.n_g[j];
+    d.size = size;
+    d.e_rel = p.e_rel[j];
+    d.e_abs = p.e_abs[j];
+    d.last_block = j == 1;
+    d.comm_scalars = comm_scalars;
+    launch_bsdmm_decide(d, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
+extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
+    if (!c->comm) FAIL(PMX_E_STATE, "pmx_set_comm_buffer has not been called");
+    const pmx_bsdmm_params& p = c->bsd;
+    const float* scal = c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK;
+    if (phase == 0) {
+        // A step: everything is local (step_A comes from the replicated S)
+        rc = enqueue_steps(c, c->X[0], c->X[1], true, false, 1.0);
+        if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], 1, 0);
+        if (rc == PMX_OK) rc = bsdmm_enqueue_block(c, 0, false, nullptr, 0);
+        // S step, local part: Gram of the UPDATED A, gS with the updated A, pack
+        if (rc == PMX_OK) rc = enqueue_gram_only(c, c->X[0], c->X[1], true, false);
+        if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], 0, 1);
+        if (rc == PMX_OK) rc = shard_pack(c, 1, true, 4 * p.n_g[0]);
+        return rc;
+    }
+    if (phase == 1) {
+        rc = shard_gram_in(c);
+        if (rc == PMX_OK) rc = enqueue_eig_only(c, true, false, 1.0);                   // lmax(A^T A) -> step_S
+        if (rc == PMX_OK) rc = bsdmm_enqueue_decide(c, 0, scal, c->M_global * c->K);    // block A on the global norms
+        if (rc == PMX_OK) rc = bsdmm_enqueue_block(c, 1, true, nullptr, 0);
+        if (rc == PMX_OK) rc = bsdmm_enqueue_decide(c, 1, nullptr, c->N * c->K);
+        return rc;
+    }
+    FAIL(PMX_E_INVALID, "bad phase %d", phase);
 }
 
 extern "C" int pmx_chain_status(pmx_ctx* c, int* halted, int* reason, int* it_done, int last_tau[2]) {

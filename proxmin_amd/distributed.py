@@ -114,10 +114,49 @@ class ShardedAdaproxDriver:
         return self.it
 
 
+class ShardedLoop:
+    """Iteration loop of the row-sharded pgm and bsdmm back-ends: phase 0, ONE all-reduce, phase 1.
+    pgm evaluates its stopping test one iteration late (A's sums are global only after the next all-reduce)
+    and flushes it after the last iteration; bsdmm's all-reduce sits between its A step and its S step, so its
+    test is exact without deferral."""
+
+    def __init__(self, engine, group=None, deferred_test=True, chunk=16):
+        import torch.distributed as dist
+        self.dist, self.eng, self.group = dist, engine, group
+        self.deferred = bool(deferred_test)
+        self.chunk = int(chunk)
+        self.it = 0
+        self.stopped = False
+
+    def _allreduce(self):
+        self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def run(self, n_iter):
+        target = self.it + int(n_iter)
+        while self.it < target and not self.stopped:
+            hi = min(target, self.it + self.chunk)
+            for it in range(self.it, hi):
+                self.eng.phase(0, it)
+                self._allreduce()
+                self.eng.phase(1, it)
+            halted, reason, it_done, _ = self.eng.chain_status()
+            self.it = it_done
+            if halted and reason == HALT_CONVERGED:
+                self.stopped = True
+        if self.deferred and not self.stopped and n_iter > 0:
+            self.eng.phase(2, self.it)
+            self._allreduce()
+            self.eng.phase(3, self.it)
+            halted, reason, _, _ = self.eng.chain_status()
+            self.stopped = bool(halted and reason == HALT_CONVERGED)
+        return self.it
+
+
 class ShardEngine:
     """libpmx-backed engine for one rank (HIP kernels; comm buffer is a torch CUDA tensor)."""
 
-    def __init__(self, dev, world, rank, M_global):
+    def __init__(self, dev, world, rank, M_global, algorithm="adaprox"):
+        self.algorithm = algorithm
         import torch
         self.dev = dev
         lib = dev.lib
@@ -130,8 +169,14 @@ class ShardEngine:
         self.comm = torch.zeros(cnt.value, dtype=torch.float32, device=torch.device("cuda", dev.device))
         _lib.check(lib.pmx_set_comm_buffer(dev.h, C.c_void_p(self.comm.data_ptr()), cnt.value))
 
-    def phase(self, phase, it, b1_it, b1_prev, nsub):
-        _lib.check(self.dev.lib.pmx_adaprox_phase(self.dev.h, int(phase), int(it), float(b1_it), float(b1_prev), int(nsub)))
+    def phase(self, phase, it, b1_it=0.0, b1_prev=0.0, nsub=0):
+        lib, h = self.dev.lib, self.dev.h
+        if self.algorithm == "adaprox":
+            _lib.check(lib.pmx_adaprox_phase(h, int(phase), int(it), float(b1_it), float(b1_prev), int(nsub)))
+        elif self.algorithm == "pgm":
+            _lib.check(lib.pmx_pgm_phase(h, int(phase), int(it)))
+        else:
+            _lib.check(lib.pmx_bsdmm_phase(h, int(phase)))
 
     def chain_status(self):
         h, r, i = C.c_int(), C.c_int(), C.c_int()
@@ -188,6 +233,70 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
         _lib.check(dev.lib.pmx_iter_result(dev.h, C.byref(r)))
     conv = (bool(r.converged[0]), bool(r.converged[1])) if check_convergence else (None, None)
     return conv, its
+
+
+def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, accelerated=False, step_scale=1.0,
+                    fixed_steps=None, e_rel=1e-3, max_iter=1000, group=None, device=None):
+    """Row-sharded `nmf(Y, A, S, algorithm=pgm, ...)` for one rank (Lipschitz steps x step_scale, or fixed steps).
+    Returns (converged, iterations)."""
+    import torch
+    import torch.distributed as dist
+    from . import operators
+    from .engine import DeviceNMF
+    prox_A = operators.prox_plus if prox_A is None else prox_A
+    prox_S = operators.prox_plus if prox_S is None else prox_S
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = torch.cuda.current_device() if device is None else device
+    seqs = [operators.device_proxseq(prox_A, 0), operators.device_proxseq(prox_S, 1)]
+    e = (e_rel, e_rel) if np.isscalar(e_rel) else tuple(e_rel)
+    tstream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(tstream), DeviceNMF(A_local.shape[0], S.shape[1], A_local.shape[1], device=device,
+                                               stream=tstream.cuda_stream) as dev:
+        dev.set_Y(Y_local)
+        dev.set_factors(A_local, S)
+        eng = ShardEngine(dev, world, rank, M_global, "pgm")
+        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=step_scale, fixed_steps=fixed_steps, e_rel=e)
+        loop = ShardedLoop(eng, group, deferred_test=True)
+        its = loop.run(max_iter)
+        dA, dS = dev.get_factors()
+        A_local[...] = dA
+        S[...] = dS
+        r = _lib.Result()
+        _lib.check(dev.lib.pmx_iter_result(dev.h, C.byref(r)))
+    return (bool(r.converged[0]), bool(r.converged[1])), its
+
+
+def nmf_bsdmm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, proxs_g=None, e_rel=1e-3, e_abs=0.0,
+                      max_iter=1000, group=None, device=None):
+    """Row-sharded `nmf(Y, A, S, algorithm=bsdmm, proxs_g=...)` for one rank.  Returns (converged, iterations)."""
+    import torch
+    import torch.distributed as dist
+    from . import operators
+    from .engine import DeviceNMF
+    prox_A = operators.prox_plus if prox_A is None else prox_A
+    prox_S = operators.prox_plus if prox_S is None else prox_S
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = torch.cuda.current_device() if device is None else device
+    seq_f = [operators.device_proxseq(prox_A, 0), operators.device_proxseq(prox_S, 1)]
+    proxs_g = proxs_g or [None, None]
+    seq_g = [None if g is None else [operators.device_proxseq(q, j) for q in g] for j, g in enumerate(proxs_g)]
+    er = (e_rel, e_rel) if np.isscalar(e_rel) else tuple(e_rel)
+    ea = (e_abs, e_abs) if np.isscalar(e_abs) else tuple(e_abs)
+    tstream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(tstream), DeviceNMF(A_local.shape[0], S.shape[1], A_local.shape[1], device=device,
+                                               stream=tstream.cuda_stream) as dev:
+        dev.set_Y(Y_local)
+        dev.set_factors(A_local, S)
+        eng = ShardEngine(dev, world, rank, M_global, "bsdmm")
+        dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea)
+        loop = ShardedLoop(eng, group, deferred_test=False)
+        its = loop.run(max_iter)
+        dA, dS = dev.get_factors()
+        A_local[...] = dA
+        S[...] = dS
+        r = _lib.Result()
+        _lib.check(dev.lib.pmx_iter_result(dev.h, C.byref(r)))
+    return [bool(r.converged[0]), bool(r.converged[1])], its
 
 
 def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):

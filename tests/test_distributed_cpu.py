@@ -14,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import nmf_oracle as orc
-from proxmin_amd.distributed import CommLayout, ShardedAdaproxDriver, shard_rows, HALT_CONVERGED
+from proxmin_amd.distributed import CommLayout, ShardedAdaproxDriver, ShardedLoop, shard_rows, HALT_CONVERGED
 
 
 class NumpyShardEngine:
@@ -95,6 +95,139 @@ class NumpyShardEngine:
         raise AssertionError("the stand-in engine never runs out of sub-iteration passes")
 
 
+class NumpyPgmShardEngine:
+    """pgm phases (FISTA optional), same protocol as pmx_pgm_phase."""
+
+    def __init__(self, Y_l, A_l, S, M_global, accelerated, e_rel):
+        self.Y, self.A, self.S, self.Mg = Y_l, A_l, S, M_global
+        self.K, self.N = S.shape
+        self.lay = CommLayout(self.N, self.K)
+        self.comm = torch.zeros(self.lay.count, dtype=torch.float64)
+        self.acc, self.e = accelerated, e_rel
+        self.omegas = orc.nesterov_omegas(10000, accelerated)
+        self.prev = None
+        self.halted, self.reason, self.it_done = 0, 0, 0
+        self.sums = [(0.0, 0.0), (0.0, 0.0)]
+
+    def _extras(self):
+        L, c = self.lay, self.comm.numpy()
+        c[L.scalars:L.scalars + 2] = self.sums[0]
+
+    def _test(self):
+        L, c = self.lay, self.comm.numpy()
+        dA, nA = c[L.scalars], c[L.scalars + 1]
+        dS, nS = self.sums[1]
+        if dA <= self.e ** 2 * nA and dS <= self.e ** 2 * nS:
+            self.halted, self.reason = 1, HALT_CONVERGED
+
+    def phase(self, phase, it, *unused):
+        if self.halted:
+            return
+        L, c = self.lay, self.comm.numpy()
+        K, KP = self.K, self.lay.KP
+        if phase == 0:
+            om = self.omegas[it]
+            X = [self.A, self.S]
+            self.E = [X[j] + om * (X[j] - self.prev[j]) for j in range(2)] if om > 0 else [x.copy() for x in X]
+            self.gA, gS = orc.residual_gradients(self.E[0], self.E[1], self.Y)
+            c[:L.gram] = gS.T.ravel()
+            G = np.zeros((KP, KP))
+            G[:K, :K] = self.E[0].T @ self.E[0]
+            c[L.gram:L.colsum] = G.ravel()
+            self._extras()
+        elif phase == 1:
+            if it > 0:
+                self._test()
+                if self.halted:
+                    return
+            G = c[L.gram:L.colsum].reshape(KP, KP)[:K, :K]
+            sS = 1 / np.linalg.eigvalsh(G)[-1]
+            sA = 1 / orc.gram_lambda_max(self.E[1].T)
+            X = [self.A, self.S]
+            self.prev = [x.copy() for x in X]
+            Gs = [self.gA, c[:L.gram].reshape(self.N, K).T.copy()]
+            for j, st in enumerate((sA, sS)):
+                X[j][:] = orc.apply_prox(self.E[j] - st * Gs[j], st, ("plus",))
+                self.sums[j] = (float(((X[j] - self.prev[j]) ** 2).sum()), float((X[j] ** 2).sum()))
+            self.it_done += 1
+        elif phase == 2:
+            self._extras()
+        elif phase == 3:
+            self._test()
+
+    def chain_status(self):
+        return self.halted, self.reason, self.it_done, (0, 0)
+
+
+class NumpyBsdmmShardEngine:
+    """bsdmm phases with proxs_g = [plus, soft(thresh)] on both blocks, same protocol as pmx_bsdmm_phase."""
+
+    def __init__(self, Y_l, A_l, S, M_global, thresh, e_rel):
+        self.Y, self.A, self.S, self.Mg = Y_l, A_l, S, M_global
+        self.K, self.N = S.shape
+        self.lay = CommLayout(self.N, self.K)
+        self.comm = torch.zeros(self.lay.count, dtype=torch.float64)
+        self.pg = [("plus",), ("soft", thresh, "relative")]
+        self.e = e_rel
+        self.Z = [[A_l.copy(), A_l.copy()], [S.copy(), S.copy()]]
+        self.U = [[np.zeros_like(A_l), np.zeros_like(A_l)], [np.zeros_like(S), np.zeros_like(S)]]
+        self.halted, self.reason, self.it_done = 0, 0, 0
+
+    def _block(self, j, sf, G):
+        X, Z, U = (self.A, self.S)[j], self.Z[j], self.U[j]
+        sg = sf * 2 * 2
+        dX = sum(sf / sg * (X - Z[i] + U[i]) for i in range(2))
+        old = X.copy()
+        X[:] = orc.apply_prox((X - dX) - sf * G, sf, ("plus",))
+        sums = [float(((X - old) ** 2).sum()), float((X ** 2).sum())]
+        for i in range(2):
+            Zn = orc.apply_prox(X + U[i], sg, self.pg[i])
+            R = X - Zn
+            Sd = -1 / sg * (Zn - Z[i])
+            Z[i][:] = Zn
+            U[i][:] += R
+            sums += [float((R ** 2).sum()), float((Sd ** 2).sum()), float((Zn ** 2).sum()), float(((U[i] / sg) ** 2).sum())]
+        return sums
+
+    def _conv(self, sums, size):
+        x2 = sums[1]
+        ok = True
+        for i in range(2):
+            r2, s2, z2, u2 = sums[2 + 4 * i: 6 + 4 * i]
+            e_pri = self.e * max(np.sqrt(x2), np.sqrt(z2))
+            e_dual = self.e * np.sqrt(u2)
+            ok &= (np.sqrt(r2) <= e_pri) and (np.sqrt(s2) <= e_dual)
+        return bool(ok)
+
+    def phase(self, phase, it, *unused):
+        if self.halted:
+            return
+        L, c = self.lay, self.comm.numpy()
+        K, KP = self.K, self.lay.KP
+        if phase == 0:
+            sA = 1 / orc.gram_lambda_max(self.S.T)
+            gA, _ = orc.residual_gradients(self.A, self.S, self.Y)
+            sums = self._block(0, sA, gA)
+            _, gS = orc.residual_gradients(self.A, self.S, self.Y)
+            c[:L.gram] = gS.T.ravel()
+            G = np.zeros((KP, KP))
+            G[:K, :K] = self.A.T @ self.A
+            c[L.gram:L.colsum] = G.ravel()
+            c[L.scalars:L.scalars + len(sums)] = sums
+        else:
+            G = c[L.gram:L.colsum].reshape(KP, KP)[:K, :K]
+            sS = 1 / np.linalg.eigvalsh(G)[-1]
+            convA = self._conv(list(c[L.scalars:L.scalars + 10]), self.Mg * K)
+            sumsS = self._block(1, sS, c[:L.gram].reshape(self.N, K).T.copy())
+            convS = self._conv(sumsS, self.N * K)
+            self.it_done += 1
+            if convA and convS:
+                self.halted, self.reason = 1, HALT_CONVERGED
+
+    def chain_status(self):
+        return self.halted, self.reason, self.it_done, (0, 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -108,6 +241,17 @@ def _worker(rank, world, port, case, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if case[0] in ("pgm", "bsdmm"):
+            alg, M, N, K, opt, e_rel, its = case
+            Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, seed=3)
+            r0, r1 = shard_rows(M, world)[rank]
+            A_l, S = A0[r0:r1].copy(), S0.copy()
+            eng = (NumpyPgmShardEngine(Y[r0:r1], A_l, S, M, opt, e_rel) if alg == "pgm"
+                   else NumpyBsdmmShardEngine(Y[r0:r1], A_l, S, M, opt, e_rel))
+            loop = ShardedLoop(eng, None, deferred_test=(alg == "pgm"), chunk=3)
+            n = loop.run(its)
+            ret[rank] = (r0, r1, A_l, S, n, loop.stopped)
+            return
         M, N, K, unity, scheme, pS, check, e_rel, its = case
         Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=unity, seed=3)
         r0, r1 = shard_rows(M, world)[rank]
@@ -154,3 +298,36 @@ def test_shard_rows_and_layout():
     assert shard_rows(16384, 8)[-1] == (14336, 16384)
     L = CommLayout(1000, 5)
     assert (L.gram, L.colsum, L.scalars, L.count) == (5000, 5000 + 32 * 32, 5000 + 1024 + 128, 5000 + 1024 + 128 + 32)
+
+
+PB_CASES = [
+    ("pgm", 57, 80, 4, False, 1e-9, 7),
+    ("pgm", 48, 66, 3, True, 1e-9, 6),          # FISTA (undamped steps; first iterations only)
+    ("pgm", 40, 60, 3, False, 6e-2, 200),       # converges early: deferred test stops at the same iterate
+    ("bsdmm", 52, 70, 4, 0.01, 1e-9, 6),
+    ("bsdmm", 44, 50, 3, 0.01, 0.5, 50),        # converges early (loose e_rel)
+]
+
+
+@pytest.mark.parametrize("case", PB_CASES)
+def test_sharded_pgm_bsdmm_match_unsharded_oracle(case):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    alg, M, N, K, opt, e_rel, its = case
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, seed=3)
+    Ao, So = A0.copy(), S0.copy()
+    if alg == "pgm":
+        conv, _, _, n_ref = orc.pgm_nmf(Y, Ao, So, accelerated=opt, max_iter=its, e_rel=e_rel)
+    else:
+        pg = [[("plus",), ("soft", opt, "relative")]] * 2
+        conv, n_ref = orc.bsdmm_nmf(Y, Ao, So, proxs_g=pg, max_iter=its, e_rel=e_rel)
+    A = np.zeros_like(A0)
+    for rank in range(world):
+        r0, r1, A_l, S, n, stopped = ret[rank]
+        A[r0:r1] = A_l
+        np.testing.assert_allclose(S, So, rtol=1e-8, atol=1e-11)
+        assert n == n_ref, (n, n_ref)
+        assert stopped == all(conv)
+    np.testing.assert_allclose(A, Ao, rtol=1e-8, atol=1e-11)

@@ -51,3 +51,40 @@ def test_world1_sharded_equals_single_gpu(pg, unity, scheme, check, e_rel, its):
     np.testing.assert_allclose(S2, S1, rtol=2e-5, atol=2e-6)
     if check:
         assert conv == ret[0]
+
+
+@pytest.mark.parametrize("accel,e_rel,its", [(False, 1e-9, 7), (True, 1e-9, 6), (False, 3e-2, 300)])
+def test_world1_sharded_pgm_equals_single_gpu(pg, accel, e_rel, its):
+    import proxmin_amd as pm
+    from proxmin_amd import distributed as pdist
+    from oracle import nmf_oracle as orc
+    M, N, K = 520, 700, 12
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, seed=6)
+    scale = 0.5 if accel else 1.0
+    A1, S1 = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv1, _, _ = pm.nmf.nmf(Y, A1, S1, step=pm.nmf.scaled_step_pgm(scale), accelerated=accel, max_iter=its, e_rel=e_rel, callback=tb)
+    A2, S2 = A0.copy(), S0.copy()
+    conv2, n = pdist.nmf_pgm_sharded(Y, A2, S2, M, accelerated=accel, step_scale=scale, e_rel=e_rel, max_iter=its)
+    assert n == len(tb.trace) and conv2 == conv1
+    np.testing.assert_allclose(A2, A1, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(S2, S1, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("e_rel,its", [(1e-9, 6), (0.5, 60)])
+def test_world1_sharded_bsdmm_equals_single_gpu(pg, e_rel, its):
+    import proxmin_amd as pm
+    from proxmin_amd import distributed as pdist
+    from oracle import nmf_oracle as orc
+    ops = pm.operators
+    M, N, K = 480, 640, 10
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, seed=8)
+    pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)], [ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]]
+    A1, S1 = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv1 = pm.nmf.nmf(Y, A1, S1, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=its, e_rel=e_rel, callback=tb)
+    A2, S2 = A0.copy(), S0.copy()
+    conv2, n = pdist.nmf_bsdmm_sharded(Y, A2, S2, M, proxs_g=pgl, e_rel=e_rel, max_iter=its)
+    assert n == len(tb.trace) and conv2 == conv1
+    np.testing.assert_allclose(A2, A1, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(S2, S1, rtol=2e-5, atol=2e-6)
