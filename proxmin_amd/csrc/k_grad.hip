@@ -292,6 +292,7 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
 struct GradPlan {
     int KP, BN, RP, gridX, gridY, nSlabA, nSlabS;
     size_t ldsBytes;
+    int variant;   // split-bf16 kernels only: which K1 implementation whole-block shapes take (PMX_K1_VARIANT, tuning A/B)
 };
 
 GradPlan grad_plan_f32(int64_t M, int64_t N, int64_t K) {

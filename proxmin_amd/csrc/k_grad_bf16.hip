@@ -469,7 +469,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
-template <int KP>
+template <int KP, bool PROF>
 __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) {
     constexpr int KS1 = KP / 16;
     constexpr int LDS_S = KP + 8, LDT_S = BG_BN + 8, LDT_A = BG_BM + 8, LDR = BG_BN + 4;
@@ -592,6 +592,12 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) 
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + g1_mt * 32 + l31) * KP + ks * 16 + hi * 8);
+        // Consume the loads HERE: otherwise the compiler's wait for them lands in front of GEMM1 on every step
+        // (it cannot see that the panel switch is rare) and, blind to the asm DMAs, drains the Y prefetch with it.
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(afr[ks][t]));
     };
 
     if (nsteps > 0) {   // prologue: same issue order as inside the loop
@@ -601,9 +607,10 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) 
         dma_Sl(col0);
         dma_Stl(col0);
     }
-    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool prof = a.prof != nullptr && w == 0;
-#define PH(i) if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; }
+    // phase profiler (PROF instantiation only: its counters cost ~20 VGPRs, which the production kernel needs)
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && w == 0;
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
     unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
     int rp = 0, cb = 0;
 #pragma nounroll
@@ -752,9 +759,720 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) 
         }
     }
     PH(9)
-    if (prof && lane == 0)
-        for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
 #undef PH
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_grad_bf16_v3 (KP = 64, whole 64 x 64 blocks): 4 wavefronts per workgroup, TWO workgroups per CU.
+//
+// Why: inside one workgroup every wave is in the same phase at the same time (LDS reads, then a dependent
+// MFMA chain, then a barrier), so the matrix pipe idles while operands are fetched and the LDS idles while
+// the MFMAs run.  Two independent workgroups per CU drift against each other and fill those gaps.  To fit
+// two of them (<= 80 KiB LDS, <= 256 VGPRs each) the step shrinks to 64 x 64 and the LDS images shrink:
+//   * R is parked ONCE, already split into its two bf16 terms, as [n][m] images (128-byte rows, 16-byte chunks
+//     XOR-swizzled by the row so that all three access patterns below are bank-conflict-free):
+//         producer      ds_write_b64        (lane = column n of the accumulator tile, 4 consecutive rows m)
+//         GEMM3 (A^T R) ds_read_b128        (lane = n, 8 consecutive m = the contraction index)
+//         GEMM2 (R S^T) ds_read_b64_tr_b16  (lane = m, 4 consecutive n: the transposing LDS read)
+//     so no consumer converts anything, and the fp32 R image and its strided column reads are gone;
+//   * S^T for GEMM2 comes from the SAME Sl image GEMM1 reads, through the transposing read (no Stl image, no
+//     second orientation of S in flight);
+//   * all operand images arrive by LDS-DMA (Y tile of step s+1, Sl of step s+1, Atl of the next row panel).
+// Wave w: GEMM1 tile (mt, nt) = (w>>1, w&1); GEMM2 tile gA (mt, kt) = (w>>1, w&1) over the block's 64
+// columns; GEMM3 tile gSt (nt, kt) = (w&1, w>>1) over the block's 64 rows (no row split: one gSt slab per
+// row region).  Per step and wave: 24 + 12 + 12 MFMAs, 3 barriers.
+// Waits: every DMA is inline asm; s_waitcnt vmcnt(0) at the top-of-step barrier (everything for this step has
+// landed), vmcnt(4) in front of the barrier that publishes a new Atl (only the 4 Y(s+1) requests are younger).
+// ------------------------------------------------------------------------------------------------
+constexpr int V3_BM = 64, V3_BN = 64, V3_THREADS = 256, V3_NW = 4;
+constexpr int V3_SL_BYTES = 3 * 64 * 144, V3_ATL_BYTES = 2 * 64 * 144, V3_R_BYTES = 2 * 64 * 128, V3_Y_BYTES = V3_NW * 4096;
+constexpr int V3_OFF_ATL = V3_SL_BYTES, V3_OFF_R = V3_OFF_ATL + V3_ATL_BYTES, V3_OFF_Y = V3_OFF_R + V3_R_BYTES,
+              V3_OFF_DUMP = V3_OFF_Y + V3_Y_BYTES, V3_LDS_BYTES = V3_OFF_DUMP + 1024;
+static_assert(V3_OFF_R % 256 == 0, "R images must start on a bank row");
+static_assert(2 * V3_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+// chunk permutation of the R images: 16-byte chunk c of row n lives at chunk c ^ v3_swz(n)
+__device__ __forceinline__ int v3_swz(int n) {
+    const int x = (n >> 1) & 7;
+    return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1);
+}
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x8 v3_tr_pair(const unsigned char* base, int off0, int off1) {
+    // two transposing reads = the 8 contraction slots of one 32x32x16 operand
+    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off0));
+    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off1));
+    bf16x8 r;
+    r[0] = a0[0]; r[1] = a0[1]; r[2] = a0[2]; r[3] = a0[3];
+    r[4] = a1[0]; r[5] = a1[1]; r[6] = a1[2]; r[7] = a1[3];
+    return r;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(V3_THREADS, 2) void k_grad_bf16_v3(GradBfArgs a) {
+    constexpr int KP = 64, KS = 4, NW = V3_NW;
+    constexpr int ROWB = 144, TERMB = 64 * ROWB;            // Sl and Atl: 64 rows of 64 bf16 + 16 bytes of pad
+    constexpr int N_SL = V3_SL_BYTES / 1024, N_ATL = V3_ATL_BYTES / 1024;      // 27 and 18 chunks of 1 KiB
+    constexpr int NI_SL = (N_SL + NW - 1) / NW, NI_ATL = (N_ATL + NW - 1) / NW;
+    static_assert(V3_SL_BYTES % 1024 == 0 && V3_ATL_BYTES % 1024 == 0, "");
+
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    unsigned char* Slb = smem;
+    unsigned char* Atlb = smem + V3_OFF_ATL;
+    unsigned char* Rb = smem + V3_OFF_R;
+    float* Yl = reinterpret_cast<float*>(smem + V3_OFF_Y);
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int M = a.M, N = a.N, K = a.K;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V3_BM;
+    const int col0 = colRegion * BG_CB * V3_BN;
+    const int mt = w >> 1, nt = w & 1;       // GEMM1 tile; GEMM2 uses (mt, kt = nt); GEMM3 uses (nt3 = nt, kt3 = mt)
+
+    f32x16 accS[BG_CB];
+#pragma unroll
+    for (int cb = 0; cb < BG_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
+    f32x16 accA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    f32x16 p;
+    bf16x8 afr[KS][3];
+    float lossAcc = 0.f;
+
+    int nrp = (M - row0 + V3_BM - 1) / V3_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    int ncb = (N - col0 + V3_BN - 1) / V3_BN;
+    if (ncb > BG_CB) ncb = BG_CB;
+    if (ncb < 0) ncb = 0;
+    const int nsteps = nrp * ncb;
+    const bool noY = (a.doA & 2) != 0;
+
+    // ---- step-invariant per-lane addresses --------------------------------------------------------------
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    int goff_sl[NI_SL];                       // element offsets into a.Sp for the Sl image chunks of this wave
+#pragma unroll
+    for (int i = 0; i < NI_SL; ++i) {
+        const int o = 1024 * (i * NW + w) + 16 * lane;
+        const int t = o / TERMB, wi = o % TERMB, r = wi / ROWB, sl = (wi % ROWB) / 16;
+        goff_sl[i] = (o < V3_SL_BYTES && sl < 8) ? (int)(((int64_t)t * a.NPad + r) * KP + sl * 8) : 0;
+    }
+    auto dma_Sl = [&](int bcol0) {
+        const __bf16* base = a.Sp + (int64_t)bcol0 * KP;
+#pragma unroll
+        for (int i = 0; i < NI_SL; ++i) {
+            const int ci = i * NW + w;
+            lds_dma16(base + goff_sl[i], __builtin_amdgcn_readfirstlane(lds_base + (ci < N_SL ? 1024 * ci : V3_OFF_DUMP)));
+        }
+    };
+    auto dma_Atl = [&](int prow0) {
+#pragma unroll
+        for (int i = 0; i < NI_ATL; ++i) {
+            const int ci = i * NW + w;
+            const int o = 1024 * ci + 16 * lane;
+            const int t = o / TERMB, wi = o % TERMB, r = wi / ROWB, sl = (wi % ROWB) / 16;
+            const int64_t off = (ci < N_ATL && sl < 8) ? ((int64_t)t * KP + r) * a.MPad + prow0 + sl * 8 : 0;
+            lds_dma16(a.At + off, __builtin_amdgcn_readfirstlane(lds_base + (ci < N_ATL ? V3_OFF_ATL + 1024 * ci : V3_OFF_DUMP)));
+        }
+    };
+    float* Ytile = Yl + w * 1024;
+    const unsigned ytile_lds = lds_base + V3_OFF_Y + w * 4096;
+    const int dmaRow = lane >> 3, dmaCol = (lane & 7) * 4;
+    auto dma_Y = [&](int prow0, int bcol0) {
+        const float* src = a.Y + (int64_t)(prow0 + mt * 32 + dmaRow) * a.ldY + bcol0 + nt * 32 + dmaCol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024));
+    };
+    auto dma_Y_dummy = [&]() {   // keeps "4 requests younger than Atl" true on every step
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(lds_base + V3_OFF_DUMP));
+    };
+    auto load_afr = [&](int prow0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + mt * 32 + l31) * KP + ks * 16 + hi * 8);
+        // consume here: the compiler must not carry a pending-load state into the loop body (it would put its
+        // wait in front of GEMM1 on every step and, blind to the asm DMAs, drain the Y prefetch with it)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(afr[ks][t]));
+    };
+    auto flush_gA = [&](int prow0) {
+        float* dst = a.slabA + (int64_t)colRegion * M * K;
+        const int kk = nt * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = prow0 + mt * 32 + tile_row(i, lane);
+            if (kk < K) dst[(int64_t)gr * K + kk] = accA[i];
+        }
+    };
+    // GEMM1 B operand: Sl[t][nt*32 + l31][ks*16 + hi*8]
+    const unsigned char* sl_g1 = Slb + (nt * 32 + l31) * ROWB + hi * 16;
+    // R producer: row n = nt*32 + l31, chunk (4*mt + g) ^ swz(n), half hi
+    const int n_w = nt * 32 + l31;
+    const int r_wbase = n_w * 128 + (((4 * mt) ^ v3_swz(n_w)) << 4) + 8 * hi;
+    // GEMM2 A operand (R, transposing read): source lane i of a 16-lane group q
+    const int li = lane & 15, lq = lane >> 4;
+    int r_t0, r_t1;
+    {
+        const int m = mt * 32 + 16 * (lq & 1) + 4 * (li & 3);
+        const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+        r_t0 = n0 * 128 + ((((m >> 3) ^ v3_swz(n0)) & 7) << 4) + 8 * ((m >> 2) & 1);
+        r_t1 = n1 * 128 + ((((m >> 3) ^ v3_swz(n1)) & 7) << 4) + 8 * ((m >> 2) & 1);
+    }
+    // GEMM2 B operand (S^T from Sl, transposing read): row n = ks*16 + 8*hi + 4*u + (li>>2), col kk
+    const int s_t = (8 * hi + (li >> 2)) * ROWB + (nt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;
+    // GEMM3 A operand (R^T): row n = nt*32 + l31, chunk (2*ks + hi) ^ swz(n)
+    const int r_g3 = n_w * 128 + ((hi ^ v3_swz(n_w)) << 4);
+    // GEMM3 B operand: Atl[t][kt3*32 + l31][ks*16 + hi*8]
+    const unsigned char* atl_g3 = Atlb + (mt * 32 + l31) * ROWB + hi * 16;
+
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && w == 0;
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+
+    if (nsteps > 0) {
+        load_afr(row0);
+        if (!noY) dma_Y(row0, col0); else dma_Y_dummy();
+        dma_Sl(col0);
+    }
+    int rp = 0, cb = 0;
+    int flush_row = -1;                       // panel whose gA still sits in accA (flushed at the next panel's start)
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const int prow0 = row0 + rp * V3_BM;
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        const bool more = step + 1 < nsteps;
+        const int nprow0 = row0 + nrp_ * V3_BM, nbcol0 = col0 + ncb_ * V3_BN;
+        // ---- TOP: previous step done everywhere; Y(s), Sl(s) landed --------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(0)
+        if (cb == 0) {
+            if (step > 0) load_afr(prow0);
+            dma_Atl(prow0);                  // every wave is past GEMM3 of the previous panel
+            if (flush_row >= 0) {
+                flush_gA(flush_row);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+            }
+        }
+        PH(1)
+        if (noY) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !noY) dma_Y(nprow0, nbcol0); else dma_Y_dummy();
+        PH(2)
+        // ---- GEMM1: P = A S - Y -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32 + TERMB);
+            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32 + 2 * TERMB);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
+        }
+        // ---- R: loss, split into two bf16 terms, park as [n][m] images ---------------------------------------------
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = p[4 * g + j];
+                lossAcc += r * r;
+                const __bf16 hh = (__bf16)r;
+                h[j] = hh;
+                l[j] = (__bf16)(r - (float)hh);
+            }
+            const int o = r_wbase ^ (g << 4);
+            *reinterpret_cast<bf16x4*>(Rb + o) = h;
+            *reinterpret_cast<bf16x4*>(Rb + 8192 + o) = l;
+        }
+        PH(3)
+        // ---- B_R: R visible; every wave is done with GEMM1's reads of Sl -------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(4)
+        // ---- GEMM2: gA += R S^T  (both operands through the transposing read) --------------------------------------
+        if (a.doA & 1) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 2048, r_t1 + ks * 2048);
+                const bf16x8 r1 = v3_tr_pair(Rb + 8192, r_t0 + ks * 2048, r_t1 + ks * 2048);
+                const bf16x8 s0 = v3_tr_pair(Slb, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
+                const bf16x8 s1 = v3_tr_pair(Slb + TERMB, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
+            }
+        }
+        PH(5)
+        // ---- B_S: every wave is done with Sl; a new Atl (requested at TOP) has landed ------------------------------
+        if (cb == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PH(6)
+        if (more) dma_Sl(nbcol0);
+        // ---- GEMM3: gSt += R^T A -----------------------------------------------------------------------------------
+        if (a.doS) {
+#define V3_GEMM3_INTO(ACC)                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                 \
+        const int ro = r_g3 ^ (ks << 5);                                                                \
+        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);                                    \
+        const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + 8192 + ro);                             \
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(atl_g3 + ks * 32);                           \
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(atl_g3 + ks * 32 + TERMB);                   \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
+    }
+            switch (cb) {
+                case 0: V3_GEMM3_INTO(accS[0]) break;
+                case 1: V3_GEMM3_INTO(accS[1]) break;
+                case 2: V3_GEMM3_INTO(accS[2]) break;
+                default: V3_GEMM3_INTO(accS[3]) break;
+            }
+#undef V3_GEMM3_INTO
+        }
+        PH(7)
+        if (cb + 1 == ncb && (a.doA & 1)) flush_row = prow0;
+        cb = ncb_;
+        rp = nrp_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (flush_row >= 0) flush_gA(flush_row);
+    PH(8)
+    if (a.doS) {
+        float* dst = a.slabS + (int64_t)rowRegion * N * K;
+        const int kk = mt * 32 + l31;
+#pragma unroll
+        for (int cbi = 0; cbi < BG_CB; ++cbi) {
+            const int bcol0 = col0 + cbi * V3_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gn = bcol0 + nt * 32 + tile_row(i, lane);
+                if (gn < N && kk < K) dst[(int64_t)gn * K + kk] = accS[cbi][i];
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < NW; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    PH(9)
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
+#undef PH
+}
+
+template <bool PROF>
+static hipError_t grad_launch_bf16_v3_t(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v3<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_bf16_v3<PROF>), dim3(a.gridX * a.gridY), dim3(V3_THREADS), V3_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_grad_bf16_v4 (K = 64, whole 128 x 64 blocks): the minimum-traffic variant.
+//
+// In the LDS-DMA variants above most of the bytes a CU pulls per step are OPERANDS, not Y: the bf16 terms of S
+// (6-10 bytes per fp32 element, re-fetched for every row panel) and of A, and the waves stall at the DMA issue.
+// This variant fetches every operand as the fp32 it is (4 bytes per element) and splits it into bf16 terms
+// inside the kernel, so per 128 x 64 step a CU pulls 32 KiB of Y + 16 KiB of S (+ 32 KiB of A per 4 steps)
+// instead of ~100 KiB; no presplit pass, no second orientation of anything:
+//   * S block (64 x 64 fp32, one contiguous 16 KiB run of St) and A panel (128 x 64 fp32, 32 KiB) are loaded
+//     one step ahead into registers (8 / 16 VGPRs per thread), split into 3 bf16 terms and written to the
+//     [row][k] images Sl (double-buffered) and Aimg; the transposed operands GEMM2/GEMM3 need are produced
+//     by the transposing LDS read (ds_read_b64_tr_b16) from those same images;
+//   * Y is loaded straight into the accumulator layout, one step ahead (16 VGPRs), no LDS round trip;
+//   * R is parked once as two bf16 [n][m] images (see v3) and never converted again.
+// All global loads are ordinary loads, so the compiler's wait counts are exact; no inline-asm DMA here.
+// Two barriers per step: TOP (publishes Sl(s), retires R(s-1)) and B_R (publishes R(s)).
+// ------------------------------------------------------------------------------------------------
+constexpr int V4_BM = 128, V4_BN = 64, V4_THREADS = 512, V4_NW = 8;
+constexpr int V4_SL_BYTES = 3 * 64 * 144, V4_A_BYTES = 3 * 128 * 144, V4_R_TERM = 64 * 256;
+constexpr int V4_OFF_A = 2 * V4_SL_BYTES, V4_OFF_R = V4_OFF_A + V4_A_BYTES, V4_LDS_BYTES = V4_OFF_R + 2 * V4_R_TERM;
+static_assert(V4_OFF_R % 256 == 0, "R images must start on a bank row");
+static_assert(V4_LDS_BYTES <= 160 * 1024, "");
+
+// chunk permutation of the 256-byte-row R images: 16-byte chunk c of row n lives at chunk c ^ v4_swz(n)
+__device__ __forceinline__ int v4_swz(int n) { return ((n & 3) << 2) | ((n >> 2) & 3); }
+
+__device__ __forceinline__ void v4_split3(const float4& x, bf16x4& t0, bf16x4& t1, bf16x4& t2) {
+    const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float e1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)e1;
+        t0[j] = a;
+        t1[j] = b;
+        t2[j] = (__bf16)(e1 - (float)b);
+    }
+}
+
+struct GradV4Args {
+    const float* Y;
+    int64_t ldY;
+    const float* A;      // [M][64]
+    const float* St;     // [N][64]
+    float* slabA;
+    float* slabS;
+    double* lossPart;
+    const DevStatus* status;
+    int M, N;
+    int RP;
+    int doA, doS;
+    int gridX, gridY;
+    unsigned long long* prof;
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(V4_THREADS, 2) void k_grad_bf16_v4(GradV4Args a) {
+    constexpr int K = 64, KS = 4, ROWB = 144, S_TERM = 64 * ROWB, A_TERM = 128 * ROWB;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    unsigned char* Aimg = smem + V4_OFF_A;
+    unsigned char* Rb = smem + V4_OFF_R;
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int M = a.M, N = a.N;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V4_BM;
+    const int col0 = colRegion * BG_CB * V4_BN;
+    const int mt = w >> 1, nt = w & 1;                       // GEMM1 tile; GEMM2 tile (mt, kt = nt)
+    const int kt3 = (w >> 1) & 1, part = w >> 2;             // GEMM3 tile (nt, kt3), row half `part`
+
+    f32x16 accS[BG_CB];
+#pragma unroll
+    for (int cb = 0; cb < BG_CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
+    f32x16 accA;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+    f32x16 p;
+    float lossAcc = 0.f;
+
+    int nrp = (M - row0 + V4_BM - 1) / V4_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    int ncb = (N - col0 + V4_BN - 1) / V4_BN;
+    if (ncb > BG_CB) ncb = BG_CB;
+    if (ncb < 0) ncb = 0;
+    const int nsteps = nrp * ncb;
+    const bool noY = (a.doA & 2) != 0;
+
+    // ---- prefetch registers and their loaders -----------------------------------------------------------
+    float4 sreg[2], areg[4];
+    float yreg[16];
+    auto load_S = [&](int bcol0) {
+        const float4* src = reinterpret_cast<const float4*>(a.St + (int64_t)bcol0 * K);
+        sreg[0] = src[tid];
+        sreg[1] = src[tid + V4_THREADS];
+    };
+    auto load_A = [&](int prow0) {
+        const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)prow0 * K);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) areg[i] = src[tid + i * V4_THREADS];
+    };
+    // Y is requested a full step ahead, in the accumulator layout (lane = column, 16 rows)
+    auto load_Y = [&](int prow0, int bcol0) {
+        const float* src = a.Y + (int64_t)(prow0 + mt * 32 + 4 * hi) * a.ldY + bcol0 + nt * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yreg[i] = src[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY];
+    };
+    // element (row = f >> 4, k = (f & 15) * 4) of a [rows][64] fp32 block lands at row * 144 + k * 2 of each term image
+    const int st_off = (tid >> 4) * ROWB + (tid & 15) * 8;
+    auto store_S = [&](int buf) {
+        unsigned char* dst = smem + buf * V4_SL_BYTES + st_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x4 t0, t1, t2;
+            v4_split3(sreg[i], t0, t1, t2);
+            unsigned char* d = dst + i * 32 * ROWB;
+            *reinterpret_cast<bf16x4*>(d) = t0;
+            *reinterpret_cast<bf16x4*>(d + S_TERM) = t1;
+            *reinterpret_cast<bf16x4*>(d + 2 * S_TERM) = t2;
+        }
+    };
+    auto store_A = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 t0, t1, t2;
+            v4_split3(areg[i], t0, t1, t2);
+            unsigned char* d = Aimg + st_off + i * 32 * ROWB;
+            *reinterpret_cast<bf16x4*>(d) = t0;
+            *reinterpret_cast<bf16x4*>(d + A_TERM) = t1;
+            *reinterpret_cast<bf16x4*>(d + 2 * A_TERM) = t2;
+        }
+    };
+    auto flush_gA = [&](int prow0) {
+        float* dst = a.slabA + (int64_t)colRegion * M * K;
+        const int kk = nt * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gr = prow0 + mt * 32 + tile_row(i, lane);
+            dst[(int64_t)gr * K + kk] = accA[i];
+        }
+    };
+
+    // ---- step-invariant LDS addresses ---------------------------------------------------------------------
+    const int li = lane & 15, lq = lane >> 4;
+    const int a_g1 = (mt * 32 + l31) * ROWB + hi * 16;                        // GEMM1 A operand (b128), + ks*32 + t*A_TERM
+    const int s_g1 = (nt * 32 + l31) * ROWB + hi * 16;                        // GEMM1 B operand (b128), + ks*32 + t*S_TERM
+    const int n_w = nt * 32 + l31;
+    const int r_w = n_w * 256 + (((4 * mt) ^ v4_swz(n_w)) << 4) + 8 * hi;    // R producer, ^ (g << 4)
+    int r_t0, r_t1;                                                           // GEMM2 A operand (R, transposing read)
+    {
+        const int m = mt * 32 + 16 * (lq & 1) + 4 * (li & 3);
+        const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+        r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+        r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+    }
+    const int s_t = (8 * hi + (li >> 2)) * ROWB + (nt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM2 B operand (tr)
+    const int r_g3 = n_w * 256 + (((8 * part + hi) ^ v4_swz(n_w)) << 4);      // GEMM3 A operand (b128), ^ (ks << 5)
+    const int a_t = (64 * part + 8 * hi + (li >> 2)) * ROWB + (kt3 * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM3 B operand (tr)
+
+    if (nsteps > 0) {   // prologue: first panel, first S block, first Y tile
+        load_A(row0);
+        load_S(col0);
+        if (!noY) load_Y(row0, col0);
+        store_A();
+        store_S(0);
+    }
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && w == 0;
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+    int rp = 0, cb = 0;
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const int prow0 = row0 + rp * V4_BM;
+        int nrp_ = rp, ncb_ = cb + 1;
+        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
+        const bool more = step + 1 < nsteps;
+        const int nprow0 = row0 + nrp_ * V4_BM, nbcol0 = col0 + ncb_ * V4_BN;
+        const unsigned char* Slb = smem + (step & 1) * V4_SL_BYTES;
+        // ---- TOP: Sl(step) published, everyone done with step - 1 ------------------------------------------
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own LDS writes retired before the barrier
+        __builtin_amdgcn_s_barrier();
+        PH(0)
+        if (cb == 0 && step > 0) {            // new row panel: Aimg may be overwritten only now
+            store_A();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        PH(1)
+        if (noY) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = -yreg[i];
+        }
+        // keep the new loads BELOW the uses of the old ones: hoisted above, the compiler's wait for Y would have to
+        // cover them too (vmcnt(0)) and the S/A latency would be exposed on every step
+        asm volatile("" : "+v"(p));
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {                           // next step's Y tile and S block (stored into the other Sl buffer at the end of this step)
+            if (!noY) load_Y(nprow0, nbcol0);
+            load_S(nbcol0);
+        }
+        PH(2)
+        // ---- GEMM1: P = A S - Y ---------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32 + A_TERM);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32 + 2 * A_TERM);
+            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32 + S_TERM);
+            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32 + 2 * S_TERM);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s2, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, s0, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s1, p, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s0, p, 0, 0, 0);
+        }
+        PH(3)
+        // ---- R: loss, split into two bf16 terms, park as [n][m] images -------------------------------------------
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = p[4 * g + j];
+                lossAcc += r * r;
+                const __bf16 hh = (__bf16)r;
+                h[j] = hh;
+                l[j] = (__bf16)(r - (float)hh);
+            }
+            const int o = r_w ^ (g << 4);
+            *reinterpret_cast<bf16x4*>(Rb + o) = h;
+            *reinterpret_cast<bf16x4*>(Rb + V4_R_TERM + o) = l;
+        }
+        PH(4)
+        // ---- B_R: R visible ----------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        PH(5)
+        // ---- GEMM2: gA += R S^T (both operands through the transposing read) --------------------------------------
+        if (a.doA & 1) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                const bf16x8 r1 = v3_tr_pair(Rb + V4_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                const bf16x8 s0 = v3_tr_pair(Slb, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
+                const bf16x8 s1 = v3_tr_pair(Slb + S_TERM, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
+            }
+            if (cb + 1 == ncb) {
+                flush_gA(prow0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+            }
+        }
+        PH(6)
+        // ---- GEMM3: gSt += R^T A ----------------------------------------------------------------------------------
+        if (a.doS) {
+#define V4_GEMM3_INTO(ACC)                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                 \
+        const int ro = r_g3 ^ (ks << 5);                                                                \
+        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);                                    \
+        const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V4_R_TERM + ro);                        \
+        const bf16x8 a0 = v3_tr_pair(Aimg, a_t + ks * 16 * ROWB, a_t + ks * 16 * ROWB + 4 * ROWB);      \
+        const bf16x8 a1 = v3_tr_pair(Aimg + A_TERM, a_t + ks * 16 * ROWB, a_t + ks * 16 * ROWB + 4 * ROWB); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
+    }
+            switch (cb) {
+                case 0: V4_GEMM3_INTO(accS[0]) break;
+                case 1: V4_GEMM3_INTO(accS[1]) break;
+                case 2: V4_GEMM3_INTO(accS[2]) break;
+                default: V4_GEMM3_INTO(accS[3]) break;
+            }
+#undef V4_GEMM3_INTO
+        }
+        PH(7)
+        // ---- next S block into the other Sl buffer (its last readers finished before this step's TOP) -------------
+        if (more) store_S((step + 1) & 1);
+        // next panel's A rows: requested here, where nothing but the accumulators is live (held any longer, the
+        // register allocator splits the tuples and waits on them mid-step), split and stored after the next TOP
+        if (more && ncb_ == 0) load_A(nprow0);
+        PH(8)
+        cb = ncb_;
+        rp = nrp_;
+    }
+    if (a.doS) {
+        float* dst = a.slabS + (int64_t)(rowRegion * 2 + part) * N * K;
+        const int kk = kt3 * 32 + l31;
+#pragma unroll
+        for (int cbi = 0; cbi < BG_CB; ++cbi) {
+            const int bcol0 = col0 + cbi * V4_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gn = bcol0 + nt * 32 + tile_row(i, lane);
+                if (gn < N) dst[(int64_t)gn * K + kk] = accS[cbi][i];
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < V4_NW; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    PH(9)
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
+#undef PH
+}
+
+template <bool PROF>
+static hipError_t grad_launch_bf16_v4_t(const GradV4Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v4<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_grad_bf16_v4<PROF>, dim3(a.gridX * a.gridY), dim3(V4_THREADS), V4_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+static hipError_t grad_launch_bf16_v4(const GradV4Args& a, hipStream_t stream) {
+    return a.prof ? grad_launch_bf16_v4_t<true>(a, stream) : grad_launch_bf16_v4_t<false>(a, stream);
 }
 
 template <int KP>
@@ -764,13 +1482,17 @@ static size_t pipe_lds_bytes() {
     constexpr int NI_SL = (SL_BYTES + 1024 * NW - 1) / (1024 * NW), NI_STL = (STL_BYTES + 1024 * NW - 1) / (1024 * NW);
     return (size_t)(NI_SL + NI_STL) * NW * 1024 + (size_t)2 * KP * (BG_BM + 8) * 2 + sizeof(float) * ((size_t)BG_BM * (BG_BN + 4) + NW * 1024);
 }
+template <int KP, bool PROF>
+static hipError_t grad_launch_bf16_pipe_t(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
+    const size_t lds = pipe_lds_bytes<KP>();
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_pipe<KP, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_bf16_pipe<KP, PROF>), dim3(p.gridX * p.gridY), dim3(BG_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
 template <int KP>
 static hipError_t grad_launch_bf16_pipe(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
-    const size_t lds = pipe_lds_bytes<KP>();
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_pipe<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_bf16_pipe<KP>), dim3(p.gridX * p.gridY), dim3(BG_THREADS), lds, stream, a);
-    return hipGetLastError();
+    return a.prof ? grad_launch_bf16_pipe_t<KP, true>(p, a, stream) : grad_launch_bf16_pipe_t<KP, false>(p, a, stream);
 }
 
 // host side -----------------------------------------------------------------------------------------
@@ -778,6 +1500,9 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     GradPlan p{};
     p.KP = K <= 32 ? 32 : 64;
     p.BN = BG_BN;
+    // PMX_K1_VARIANT (read per context; tuning A/B and the variant tests): 0 guarded kernel only, 1 LDS-DMA pipeline
+    // 128 x 64 / 8 waves, 3 LDS-DMA 64 x 64 / 4 waves x 2 per CU, 4 (default) fp32 operands split in-kernel
+    p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 4;
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
     p.gridY = (int)((N + (int64_t)BG_CB * BG_BN - 1) / ((int64_t)BG_CB * BG_BN));
@@ -801,14 +1526,34 @@ static hipError_t grad_launch_bf16_t(const GradPlan& p, const GradBfArgs& a, hip
     return hipGetLastError();
 }
 
-hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, hipStream_t stream) {
+// true when the launch below will take the variant that reads A and St as fp32 (no presplit pass needed)
+bool grad_bf16_reads_fp32(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
+    return p.variant >= 4 && p.KP == 64 && K == 64 && (M % V4_BM) == 0 && (N % V4_BN) == 0;
+}
+hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float* A, const float* St, hipStream_t stream, int* nloss) {
     GradBfArgs a = a_;
     a.gridX = p.gridX;
     a.gridY = p.gridY;
-    // Whole 128 x 64 blocks with 16-byte-aligned rows take the LDS-DMA variant; anything else the guarded one.
-    const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || (a.ldY % 4) != 0 || (((uintptr_t)a.Y) & 15) != 0;
-    static const int variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 1;   // 0: un-pipelined (tuning A/B)
-    if (!edge && variant == 1) return p.KP == 32 ? grad_launch_bf16_pipe<32>(p, a, stream) : grad_launch_bf16_pipe<64>(p, a, stream);
+    *nloss = p.gridX * p.gridY;
+    const int variant = p.variant;
+    if (grad_bf16_reads_fp32(p, a.M, a.N, a.K)) {
+        GradV4Args g{};
+        g.Y = a.Y; g.ldY = a.ldY; g.A = A; g.St = St;
+        g.slabA = a.slabA; g.slabS = a.slabS; g.lossPart = a.lossPart; g.status = a.status;
+        g.M = a.M; g.N = a.N; g.RP = a.RP; g.doA = a.doA; g.doS = a.doS;
+        g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
+        return grad_launch_bf16_v4(g, stream);
+    }
+    // Whole blocks with 16-byte-aligned rows take an LDS-DMA variant; anything else the guarded kernel.
+    const bool aligned = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
+    const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || !aligned;
+    if (variant == 3 && p.KP == 64 && aligned && (a.M % V3_BM) == 0 && (a.N % V3_BN) == 0) {
+        // same regions, each split into two row halves: 2 * gridX row regions of RP 64-row panels (= nSlabS slabs)
+        a.gridX = 2 * p.gridX;
+        *nloss = a.gridX * a.gridY;
+        return a.prof ? grad_launch_bf16_v3_t<true>(p, a, stream) : grad_launch_bf16_v3_t<false>(p, a, stream);
+    }
+    if (!edge && variant >= 1) return p.KP == 32 ? grad_launch_bf16_pipe<32>(p, a, stream) : grad_launch_bf16_pipe<64>(p, a, stream);
     if (p.KP == 32) return edge ? grad_launch_bf16_t<32, true>(p, a, stream) : grad_launch_bf16_t<32, false>(p, a, stream);
     return edge ? grad_launch_bf16_t<64, true>(p, a, stream) : grad_launch_bf16_t<64, false>(p, a, stream);
 }

@@ -74,6 +74,7 @@ struct pmx_ctx {
     GradPlan plan{};
     float* slab[2] = {nullptr, nullptr};
     double* lossPart = nullptr;
+    int nloss = 0;                         // loss partials written by the last gradient launch
 
     // reductions / control
     double* partials = nullptr;            // [SL_COUNT][2][EW_BLOCKS]
@@ -186,7 +187,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     }
     if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->plan.nSlabA * M * K, false);
     if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * N * K, false);
-    if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)c->plan.gridX * c->plan.gridY);
+    if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)2 * c->plan.gridX * c->plan.gridY);
     if (rc == PMX_OK) rc = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
     if (rc == PMX_OK) rc = dallocT(c, &c->colpart, (size_t)2 * EW_BLOCKS * MAXK);
     if (rc == PMX_OK) rc = dallocT(c, &c->gramPart, (size_t)2 * GRAM_BLOCKS * c->KP * c->KP);
@@ -386,7 +387,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         for (int j = 0; j < 2; ++j) { ps.Xp[j] = c->Bp[j]; ps.Xt[j] = c->Bt[j]; ps.rows[j] = c->rows[j]; ps.rowsPad[j] = c->rowsPad[j]; }
         ps.K = (int)c->K; ps.KP = c->KP;
         ps.status = c->dstatus;
-        launch_presplit(ps, c->stream);
+        if (!grad_bf16_reads_fp32(c->plan, c->M, c->N, c->K)) launch_presplit(ps, c->stream);
         GradBfArgs g{};
         g.Y = c->Y; g.ldY = c->ldY;
         g.Ap = c->Bp[0]; g.At = c->Bt[0]; g.Sp = c->Bp[1]; g.Stt = c->Bt[1];
@@ -399,7 +400,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.doA = doA; g.doS = doS;
         g.prof = c->k1prof;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
-        HIP_CHECK(grad_launch_bf16(c->plan, g, c->stream));
+        HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
     } else {
         GradArgs g{};
         g.Y = c->Y; g.ldY = c->ldY;
@@ -412,6 +413,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.doA = doA; g.doS = doS;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f32(c->plan, g, c->stream));
+        c->nloss = c->plan.gridX * c->plan.gridY;
     }
     if (timed) {
         HIP_CHECK(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
@@ -558,7 +560,7 @@ extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* a
         unsigned long long h[16];
         HIP_CHECK(hipMemcpy(h, c->k1prof, sizeof(h), hipMemcpyDeviceToHost));
         const double nwg = (double)c->plan.gridX * c->plan.gridY * (reps + 1);
-        static const char* nm[10] = {"B0 wait", "stage_A", "Y read+dma", "GEMM1+R", "B2 wait", "dmaSl+GEMM2", "B3 wait", "dmaStl+GEMM3", "flush gA", "tail"};
+        static const char* nm[10] = {"p0", "p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p9"};   // phase meaning: see the PH(i) marks of the kernel variant in use
         fprintf(stderr, "[k1prof] doA=%d doS=%d cycles per workgroup (wave 0):", do_A, do_S);
         for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.0f", nm[i], (double)h[i] / nwg);
         fprintf(stderr, "\n");
@@ -573,7 +575,7 @@ extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
     rc = enqueue_grad(c, c->X[0], c->X[1], 0, 0);
     if (rc != PMX_OK) return rc;
-    const int n = c->plan.gridX * c->plan.gridY;
+    const int n = c->nloss;
     std::vector<double> h(n);
     HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -793,7 +795,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
 static int loss_now(pmx_ctx* c, const float* A, const float* St, double* out) {
     int rc = enqueue_grad(c, A, St, 0, 0);
     if (rc != PMX_OK) return rc;
-    const int n = c->plan.gridX * c->plan.gridY;
+    const int n = c->nloss;
     std::vector<double> h(n);
     HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -45,6 +45,28 @@ def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1024, 640, 64), (640, 1536, 64), (256, 320, 40), (384, 256, 32)])
+def test_split_bf16_kernel_variants_agree_with_oracle(eng, orc, monkeypatch, M, N, K, variant):
+    """Every implementation of the split-bf16 K1 (guarded, LDS-DMA pipelines, fp32-operand variant; selected per
+    context by PMX_K1_VARIANT, shapes that a variant does not take fall through to the next) gives the oracle's
+    gradients and loss; asymmetric data, so a swapped tile or operand orientation cannot pass."""
+    monkeypatch.setenv("PMX_K1_VARIANT", str(variant))
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=11 * M + N + K)
+    A[:, 0] += np.linspace(0.0, 1.0, M, dtype=np.float32)
+    S[K - 1, :] += np.linspace(1.0, 0.0, N, dtype=np.float32)
+    with eng.DeviceNMF(M, N, K, mode="bf16x3") as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+    A64, S64, Y64 = A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64)
+    rA, rS = orc.residual_gradients(A64, S64, Y64)
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_gradient_is_transpose_sensitive(eng, orc, mode):
     """asymmetric inputs: a swapped tile mapping cannot pass (guide rule: A=I with asymmetric B)."""
