@@ -29,6 +29,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BG_BM = 128, BG_BN = 64, BG_CB = 4, BG_THREADS = 512;
 
@@ -1475,6 +1476,388 @@ static hipError_t grad_launch_bf16_v4(const GradV4Args& a, hipStream_t stream) {
     return a.prof ? grad_launch_bf16_v4_t<true>(a, stream) : grad_launch_bf16_v4_t<false>(a, stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_grad_bf16_v5 (K = 64, M % 128 == 0, N % 32 == 0): producer / consumer wavefronts.
+//
+// In every variant above all waves of a workgroup walk through the same phases together (operand reads, a
+// dependent MFMA chain, a barrier), so the matrix pipe idles while the LDS works and vice versa.  Here the 8 waves
+// of a workgroup split into two roles that are busy with DIFFERENT things at the same time, one of each per SIMD:
+//   producers (waves 0-3)  slot t: P = A S - Y for the 128 x 32 block t (wave j: rows 32j..32j+31; its A terms
+//                          live in registers for the whole row panel), split R into two bf16 terms, park it in
+//                          R[t & 1]
+//   consumers (waves 4-7)  slot t: the two gradient contractions of block t-1 from R[(t-1) & 1]:
+//                          gA (wave c: rows 32c.., both 32-wide k tiles) and gSt (wave c: k tile c & 1, row half c >> 1)
+// One barrier per slot.  24 + 24 MFMAs per SIMD-pair of waves per slot, operands: S terms (Sl, triple-buffered:
+// written in slot t-1 by all waves from fp32 St, read by the producers in slot t and by the consumers, through the
+// transposing read, in slot t+1), A terms for gSt (Aimg, double-buffered per row panel, written by the producers
+// from their register fragments), R (see v4: swizzled [n][m] bf16 images).  The consumers carry no A/S fragments
+// between slots, so they hold 8 column blocks of gSt accumulators: regions are 256 columns wide with 32-column
+// steps.  Everything is plain loads (exact compiler wait counts); Y and St/A are requested one slot ahead.
+// ------------------------------------------------------------------------------------------------
+constexpr int V5_BM = 128, V5_BN = 32, V5_NB = 8, V5_THREADS = 512;
+constexpr int V5_S_TERM = 32 * 144, V5_SL_BYTES = 3 * V5_S_TERM, V5_A_TERM = 128 * 144, V5_AIMG_BYTES = 2 * V5_A_TERM,
+              V5_R_TERM = 32 * 256, V5_R_BYTES = 2 * V5_R_TERM;
+constexpr int V5_OFF_A = 3 * V5_SL_BYTES, V5_OFF_R = V5_OFF_A + V5_AIMG_BYTES, V5_OFF_Y = V5_OFF_R + 2 * V5_R_BYTES,
+              V5_LDS_BYTES = V5_OFF_Y + 4 * 4096;
+static_assert(V5_OFF_R % 256 == 0, "R images must start on a bank row");
+static_assert(V5_LDS_BYTES <= 160 * 1024, "");
+static_assert(V5_NB * V5_BN == BG_CB * BG_BN, "same region width as the other variants (shared plan)");
+
+template <bool PROF>
+__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
+    constexpr int K = 64, ROWB = 144;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lq = lane >> 4;
+    const int M = a.M, N = a.N;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V5_BM;
+    const int col0 = colRegion * V5_NB * V5_BN;
+    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    int ncb = (N - col0 + V5_BN - 1) / V5_BN;
+    if (ncb > V5_NB) ncb = V5_NB;
+    if (ncb < 0) ncb = 0;
+    const int T = nrp * ncb;                 // blocks of this region; slots = T + 1
+    const bool noY = (a.doA & 2) != 0;
+    const bool producer = w < 4;
+    const int j = w & 3;                     // index within the role
+    float lossAcc = 0.f;
+    // phase profiler: wave 0 (producer) fills slots 0-5, wave 4 (consumer) slots 6-9
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+
+    // ---- S staging (all 512 threads): one float4 of the 32 x 64 fp32 block per thread ------------------------
+    // Loads are issued on EVERY slot (block index clamped at the end of the region), all of them right after the
+    // slot's uses of the previous ones: whatever the compiler's wait for an old load also covers was requested a
+    // whole slot ago.  (Hand-counted waits on inline-asm loads were tried and dropped: the register allocator
+    // copies in-flight destination registers around the asm statements.)
+    float4 sreg;
+    const int st_off = (tid >> 4) * ROWB + (tid & 15) * 8;
+    int s_cb = 0;                            // column block of the next S request (wraps at ncb; no integer division in the loop)
+    auto load_S = [&]() {
+        sreg = reinterpret_cast<const float4*>(a.St + (int64_t)(col0 + s_cb * V5_BN) * K)[tid];
+        if (++s_cb == ncb) s_cb = 0;
+    };
+    auto store_S = [&](int t) {
+        bf16x4 t0, t1, t2;
+        v4_split3(sreg, t0, t1, t2);
+        unsigned char* d = smem + (t % 3) * V5_SL_BYTES + st_off;
+        *reinterpret_cast<bf16x4*>(d) = t0;
+        *reinterpret_cast<bf16x4*>(d + V5_S_TERM) = t1;
+        *reinterpret_cast<bf16x4*>(d + 2 * V5_S_TERM) = t2;
+    };
+    if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
+        if (!producer) {
+            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            for (int c = 0; c < V5_NB; ++c)
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                    if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
+                }
+        }
+        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
+        return;
+    }
+    load_S();
+    store_S(0);
+    load_S();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();              // Sl(0) published
+
+    if (producer) {
+        // ================================ producers: GEMM1 and R =================================================
+        f32x16 p;
+        float4 areg[4][2];
+        bf16x8 afr[4][3];
+        // Y tile of the next block: LDS-DMA into a private 32 x 32 landing tile, requested one slot ahead (4 requests
+        // of 1 KiB per wave instead of 16 dword loads: the request count, not the bytes, is what the CU's address unit charges)
+        float* Ytile = reinterpret_cast<float*>(smem + V5_OFF_Y) + j * 1024;
+        const unsigned ytile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Ytile;
+        int y_rp = 0, y_cb = 0;              // block of the next Y request
+        auto dma_Y = [&]() {
+            const float* src = a.Y + (int64_t)(row0 + y_rp * V5_BM + j * 32 + (lane >> 3)) * a.ldY + col0 + y_cb * V5_BN + (lane & 7) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024));
+            if (++y_cb == ncb) { y_cb = 0; if (y_rp + 1 < nrp) ++y_rp; }
+        };
+        auto load_A = [&](int prow) {
+            const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                areg[ks][0] = src[ks * 4];
+                areg[ks][1] = src[ks * 4 + 1];
+            }
+        };
+        auto make_afr = [&]() {              // split the panel rows into bf16 terms (register fragments of GEMM1's A operand)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
+                                    areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const __bf16 t0 = (__bf16)x[q];
+                    const float e1 = x[q] - (float)t0;
+                    const __bf16 t1 = (__bf16)e1;
+                    afr[ks][0][q] = t0;
+                    afr[ks][1][q] = t1;
+                    afr[ks][2][q] = (__bf16)(e1 - (float)t1);
+                }
+            }
+        };
+        auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
+            unsigned char* dst = smem + V5_OFF_A + (j * 32 + l31) * ROWB + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                *reinterpret_cast<bf16x8*>(dst + ks * 32) = afr[ks][0];
+                *reinterpret_cast<bf16x8*>(dst + ks * 32 + V5_A_TERM) = afr[ks][1];
+            }
+        };
+        const int s_g1 = l31 * ROWB + hi * 16;                                   // GEMM1 B operand: Sl[t][l31][ks*16 + hi*8]
+        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
+        load_A(row0);
+        dma_Y();
+        int rp = 0, cb = 0;
+        bool new_panel = false;              // the previous block opened a row panel: its A terms go to Aimg now
+        // One slot: stage S(t+1), then block t: P = A S - Y, R -> R[t & 1].
+        auto slot = [&](int t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last slot's requests (Y tile by DMA, S, A) have landed
+            store_S(t + 1);                  // Sl[(t+1) % 3]: its last readers (consumers, block t-2) finished in slot t-1
+            if (new_panel) {                 // consumers are past the old panel (block t-2); they read the new one from this slot on
+                publish_A();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
+            PH(5)
+            if (t < T) {
+                new_panel = cb == 0;
+                if (cb == 0) make_afr();
+                PH(1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p));
+                __builtin_amdgcn_sched_barrier(0);
+                // next slot's requests: S block, next panel's rows (on the panel's last block), Y tile
+                load_S();
+                if (cb + 1 == ncb && rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
+                dma_Y();
+                PH(2)
+                const unsigned char* Slb = smem + (t % 3) * V5_SL_BYTES + s_g1;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32);
+                    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32 + V5_S_TERM);
+                    const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32 + 2 * V5_S_TERM);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
+                }
+                PH(3)
+                unsigned char* Rb = smem + V5_OFF_R + (t & 1) * V5_R_BYTES;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float r = p[4 * g + q];
+                        lossAcc += r * r;
+                        const __bf16 hh = (__bf16)r;
+                        h[q] = hh;
+                        l[q] = (__bf16)(r - (float)hh);
+                    }
+                    const int o = r_w ^ (g << 4);
+                    *reinterpret_cast<bf16x4*>(Rb + o) = h;
+                    *reinterpret_cast<bf16x4*>(Rb + V5_R_TERM + o) = l;
+                }
+                if (++cb == ncb) { cb = 0; ++rp; }
+                PH(4)
+            } else {
+                new_panel = false;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
+            __builtin_amdgcn_s_barrier();
+            PH(0)
+        };
+#pragma nounroll
+        for (int t = 0; t <= T; ++t) slot(t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ================================ consumers: GEMM2 and GEMM3 of the previous block ======================
+        f32x16 accS[V5_NB];
+#pragma unroll
+        for (int c = 0; c < V5_NB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
+        f32x16 accA0, accA1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+        const int kt = j & 1, mh = j >> 1;   // GEMM3 tile; GEMM2: rows 32j.., both k tiles
+        int r_t0, r_t1;                      // GEMM2 A operand (R, transposing read)
+        {
+            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
+            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+        }
+        const int s_t = (8 * hi + (li >> 2)) * ROWB + (16 * (lq & 1) + 4 * (li & 3)) * 2;     // GEMM2 B operand (tr), + kt*64
+        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
+        const int a_t = (64 * mh + 8 * hi + (li >> 2)) * ROWB + (kt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM3 B operand (tr)
+        auto flush_gA = [&](int prow) {
+            float* dst = a.slabA + (int64_t)colRegion * M * K;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t o = (int64_t)(prow + j * 32 + tile_row(i, lane)) * K + l31;
+                dst[o] = accA0[i];
+                dst[o + 32] = accA1[i];
+            }
+        };
+        // slot t works on block t - 1; the column-block loop is unrolled so that each gSt accumulator is a fixed
+        // register tuple (a switch over 8 accumulators makes the compiler shuffle them through scratch)
+        auto stage = [&](int t) {            // top of slot t (see the producers)
+            store_S(t + 1);
+            load_S();
+            PH(8)
+        };
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            PH(9)
+        };
+        auto consume = [&](int t, int rp, int cb, f32x16& accSc) {
+            const int prow = row0 + rp * V5_BM;
+            const unsigned char* Rb = smem + V5_OFF_R + ((t - 1) & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + ((t - 1) % 3) * V5_SL_BYTES;
+            const unsigned char* Ab = smem + V5_OFF_A;
+            if (a.doA & 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const bf16x8 r1 = v3_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const int so = s_t + ks * 16 * ROWB;
+                    const bf16x8 s00 = v3_tr_pair(Slb, so, so + 4 * ROWB);
+                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so, so + 4 * ROWB);
+                    const bf16x8 s10 = v3_tr_pair(Slb, so + 64, so + 64 + 4 * ROWB);
+                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so + 64, so + 64 + 4 * ROWB);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s10, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s01, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s11, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s10, accA1, 0, 0, 0);
+                }
+            }
+            PH(6)
+            if (a.doS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ro = r_g3 ^ (ks << 5);
+                    const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);
+                    const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V5_R_TERM + ro);
+                    const int ao = a_t + ks * 16 * ROWB;
+                    const bf16x8 a0 = v3_tr_pair(Ab, ao, ao + 4 * ROWB);
+                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao, ao + 4 * ROWB);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);
+                }
+            }
+            // the panel's gA goes out AFTER the gSt contraction: a branch between the two contractions would keep the
+            // scheduler from starting the second one's LDS reads under the first one's MFMAs
+            if ((a.doA & 1) && cb + 1 == ncb) {
+                flush_gA(prow);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+            }
+        };
+        stage(0);
+        sync();
+        int t = 1;
+#pragma nounroll
+        for (int rp = 0; rp < nrp; ++rp) {
+#pragma unroll
+            for (int cb = 0; cb < V5_NB; ++cb) {
+                if (cb < ncb) {
+                    stage(t);
+                    if (cb == 0) {           // this block opens a row panel: the producers publish its A terms now
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    consume(t, rp, cb, accS[cb]);
+                    PH(7)
+                    sync();
+                    ++t;
+                }
+            }
+        }
+        if (a.doS) {
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            const int kk = kt * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < V5_NB; ++c) {
+                const int bcol = col0 + c * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = bcol + tile_row(i, lane);
+                    if (gn < N) dst[(int64_t)gn * K + kk] = accS[c][i];
+                }
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 4; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
+#undef PH
+}
+
+template <bool PROF>
+static hipError_t grad_launch_bf16_v5_t(const GradV4Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v5<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_grad_bf16_v5<PROF>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V5_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+static hipError_t grad_launch_bf16_v5(const GradV4Args& a, hipStream_t stream) {
+    return a.prof ? grad_launch_bf16_v5_t<true>(a, stream) : grad_launch_bf16_v5_t<false>(a, stream);
+}
+
 template <int KP>
 static size_t pipe_lds_bytes() {
     constexpr int NW = BG_THREADS / 64;
@@ -1501,8 +1884,9 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     p.KP = K <= 32 ? 32 : 64;
     p.BN = BG_BN;
     // PMX_K1_VARIANT (read per context; tuning A/B and the variant tests): 0 guarded kernel only, 1 LDS-DMA pipeline
-    // 128 x 64 / 8 waves, 3 LDS-DMA 64 x 64 / 4 waves x 2 per CU, 4 (default) fp32 operands split in-kernel
-    p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 4;
+    // 128 x 64 / 8 waves, 3 LDS-DMA 64 x 64 / 4 waves x 2 per CU, 4 fp32 operands split in-kernel, 5 (default) the same
+    // with producer / consumer wavefronts
+    p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 5;
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
     p.gridY = (int)((N + (int64_t)BG_CB * BG_BN - 1) / ((int64_t)BG_CB * BG_BN));
@@ -1542,7 +1926,9 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.slabA = a.slabA; g.slabS = a.slabS; g.lossPart = a.lossPart; g.status = a.status;
         g.M = a.M; g.N = a.N; g.RP = a.RP; g.doA = a.doA; g.doS = a.doS;
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
-        return grad_launch_bf16_v4(g, stream);
+        // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
+        const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
+        return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }
     // Whole blocks with 16-byte-aligned rows take an LDS-DMA variant; anything else the guarded kernel.
     const bool aligned = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
