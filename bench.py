@@ -54,11 +54,13 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
     tflops = flop_per_launch / t / 1e12
     gbs = (M * N * 4) / t / 1e9
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
+    # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
+    bf16_kernel = "k_grad_bf16_v5" if (K == 64 and M % 128 == 0 and N % 64 == 0) else "k_grad_bf16<%d>" % kp
     if mode == "f32":
         return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
                 "launches": k1_n, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share}
-    return {"kernel": "k_grad_bf16<%d>" % kp, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+    return {"kernel": bf16_kernel, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
             "algorithmic_tflops": tflops, "mfma_issued_tflops": 4.0 * tflops,
             "mfma_issued_frac_of_bf16_peak": 4.0 * tflops / PEAK_BF16_MFMA_TFLOPS, "k1_share_of_step": share}

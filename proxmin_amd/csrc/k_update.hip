@@ -20,20 +20,57 @@
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+// Cross-lane sums use DPP moves (ALU latency) where the hardware has the pattern and one LDS-crossbar swizzle /
+// permute where it does not: five dependent ds_bpermute (what __shfl_xor compiles to) per row sum made the
+// proximal sub-iteration passes latency-bound.  All lanes of the group end up with bit-identical totals.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int SWZ_XOR16 = (0x10 << 10) | 0x1f;                                                  // ds_swizzle bit mode
+
+// Row sums keep the butterfly order 16, 8, 4, 2, 1 (the association the parity fixtures were pinned with): the
+// three long strides as swizzles, the two short ones as DPP quad permutes.
+constexpr int SWZ_XOR8 = (0x08 << 10) | 0x1f, SWZ_XOR4 = (0x04 << 10) | 0x1f;
 __device__ __forceinline__ float row_sum32(float v) {   // sum over the 32 lanes that share a row
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), SWZ_XOR16));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), SWZ_XOR8));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), SWZ_XOR4));
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_XOR1>(v);
     return v;
 }
 
+__device__ __forceinline__ double swz16_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, SWZ_XOR16);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), SWZ_XOR16);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    v += swz16_d(v);
+    v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    v = fmax(v, dpp_d<DPP_XOR1>(v));
+    v = fmax(v, dpp_d<DPP_XOR2>(v));
+    v = fmax(v, dpp_d<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_d<DPP_MIRROR>(v));
+    v = fmax(v, swz16_d(v));
+    v = fmax(v, __shfl_xor(v, 32));
     return v;
 }
 
@@ -766,82 +803,116 @@ struct SubArgs {
     DevStatus* status;
     double* partials;
     double e_rel[2];
-    int t;               // pass index within this iteration
+    int t;               // index of the first pass of this launch (finish: number of passes enqueued)
+    int nt;              // passes per launch (1 or SUB_NT_MAX), the same for every launch of an iteration
     int prox_max_iter;
     int has_prox[2];
 };
 
-// If the loop of block j finished BEFORE pass t, returns the number of passes it took (tau >= 1);
-// otherwise returns 0.  Uniform across the workgroup (and across workgroups).
-__device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, double* scratch) {
+// If the loop of block j finished BEFORE pass a.t, returns the number of passes it took (tau >= 1); otherwise 0.
+// Uniform across the workgroup (and across workgroups).  The passes to judge are those of the previous launch,
+// [a.t - a.nt, a.t): wave w folds the sum (pass w >> 1, kind w & 1) in the usual fixed order, then every thread
+// scans the passes in order.  Earlier launches were judged by their successors (verdict published in DevStatus).
+__device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, double* scratch /* >= 2 * SUB_NT_MAX */) {
     if (a.t == 0) return 0;
     __shared__ int pub;
     if (threadIdx.x == 0) pub = a.status->sub_done[j] ? a.status->sub_tau[j] : 0;   // published by an earlier kernel
     __syncthreads();
     const int tau_pub = pub;
     if (tau_pub > 0) return tau_pub;
-    const int par = (a.t - 1) & 1;
-    const double d = fold_partials(part_ptr(a.partials, par ? SL_SUB_D1 : SL_SUB_D, j), scratch);
-    const double n = fold_partials(part_ptr(a.partials, par ? SL_SUB_N1 : SL_SUB_N, j), scratch);
-    const bool done = (d <= a.e_rel[j] * a.e_rel[j] * n) || (a.t >= a.prox_max_iter);
-    if (done && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.status->sub_tau[j] = a.t;
+    const int t0 = a.t - a.nt;
+    const int w = threadIdx.x >> 6;
+    if (w < 2 * a.nt) {
+        const int pass = t0 + (w >> 1);
+        const double v = fold_partials(part_ptr(a.partials, SL_SUBR0 + 2 * (pass % SUB_RING) + (w & 1), j), scratch);
+        if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    }
+    __syncthreads();
+    int tau = 0;
+    for (int q = 0; q < a.nt && tau == 0; ++q) {
+        const double d = scratch[2 * q], n = scratch[2 * q + 1];
+        if ((d <= a.e_rel[j] * a.e_rel[j] * n) || (t0 + q + 1 >= a.prox_max_iter)) tau = t0 + q + 1;
+    }
+    __syncthreads();   // scratch is reused by the caller
+    if (tau > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.status->sub_tau[j] = tau;
         __threadfence();
         a.status->sub_done[j] = 1;
     }
-    return done ? a.t : 0;
+    return tau;
 }
 
+// step size data of the sub-iteration of block j (algorithms.py:384): gamma = Alpha / max(Psi), ratio = gamma / Alpha
 template <int NC>
+__device__ __forceinline__ void sub_steps(const SubArgs& a, int j, double* scratch, float (&gam)[NC], float (&rat)[NC]) {
+    const double maxpsi = fold_partials_max(part_ptr(a.partials, SL_MAXPSI, j), scratch);
+    const int l32_ = threadIdx.x & 31;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int kk = l32_ + 32 * c;
+        const float al = kk < a.K ? a.status->alpha[j][kk] : 0.f;
+        gam[c] = al / (float)maxpsi;
+        rat[c] = gam[c] / al;                     // NaN if alpha == 0, as in the reference
+    }
+}
+
+// NT passes per launch, z kept in registers between them (every supported prox acts within a row, and a row lives
+// in one 32-lane group); per pass the two sums of the stopping test go to that pass's ring slot.  The launch writes
+// only the state after its LAST pass: if the loop turns out to have ended inside the launch, k_ada_finish replays
+// the few passes from the launch's (untouched) input.  Launch b reads X (b = 0) or zb[(b-1) & 1] and writes zb[b & 1].
+template <int NC, int NT>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_sub(SubArgs a) {
-    __shared__ double scratch[2 * EW_WAVES];
+    __shared__ double scratch[2 * NT * EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
     if (!a.has_prox[j]) return;
     if (sub_finished_before(a, j, scratch) > 0) return;
     const int64_t rows = a.rows[j];
     const int K = a.K;
-    const double maxpsi = fold_partials_max(part_ptr(a.partials, SL_MAXPSI, j), scratch);
-    const float* zc = a.t == 0 ? a.X[j] : a.zb[j][(a.t - 1) & 1];
-    float* zn = a.zb[j][a.t & 1];
+    const int b = a.t / NT;
+    const float* zc = b == 0 ? a.X[j] : a.zb[j][(b - 1) & 1];
+    float* zn = a.zb[j][b & 1];
     float gam[NC], rat[NC];
-    {
-        const int l32_ = threadIdx.x & 31;
+    sub_steps<NC>(a, j, scratch, gam, rat);
+    float d2[NT], n2[NT];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int kk = l32_ + 32 * c;
-            const float al = kk < K ? a.status->alpha[j][kk] : 0.f;
-            gam[c] = al / (float)maxpsi;          // gamma = Alpha / max(Psi)      algorithms.py:384
-            rat[c] = gam[c] / al;                 // gamma / Alpha (NaN if alpha == 0, as in the reference)
-        }
-    }
-    float d2 = 0.f, n2 = 0.f;
+    for (int q = 0; q < NT; ++q) { d2[q] = 0.f; n2[q] = 0.f; }
     ROW_LOOP_BEGIN(rows)
         bool ok[NC];
-        float z[NC], v[NC];
+        float z[NC], x[NC], ps[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int64_t e = r * K + l32 + 32 * c;
             ok[c] = l32 + 32 * c < K;
             z[c] = ok[c] ? zc[e] : 0.f;
-            const float x = ok[c] ? a.X[j][e] : 0.f;
-            const float psi = ok[c] ? a.Psi[j][e] : 0.f;
-            v[c] = z[c] - rat[c] * psi * (z[c] - x);
+            x[c] = ok[c] ? a.X[j][e] : 0.f;
+            ps[c] = ok[c] ? a.Psi[j][e] : 0.f;
         }
-        prox_row<NC>(v, ok, a.prox[j], gam);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (ok[c]) {
-                zn[r * K + l32 + 32 * c] = v[c];
-                const float d = v[c] - z[c];
-                d2 += d * d;
-                n2 += z[c] * z[c];
+        for (int q = 0; q < NT; ++q) {
+            float v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = z[c] - rat[c] * ps[c] * (z[c] - x[c]);
+            prox_row<NC>(v, ok, a.prox[j], gam);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (ok[c]) {
+                    const float d = v[c] - z[c];
+                    d2[q] += d * d;
+                    n2[q] += z[c] * z[c];
+                }
+                z[c] = v[c];
             }
         }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) zn[r * K + l32 + 32 * c] = z[c];
     ROW_LOOP_END
-    double red[2] = {(double)d2, (double)n2};
-    const int par = a.t & 1;
-    block_sum_store<2>(red, part_ptr(a.partials, par ? SL_SUB_D1 : SL_SUB_D, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    double red[2 * NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { red[2 * q] = (double)d2[q]; red[2 * q + 1] = (double)n2[q]; }
+    // a.t is a multiple of NT and SUB_RING of SUB_NT_MAX: the NT ring slots of this launch are consecutive
+    block_sum_store<2 * NT>(red, part_ptr(a.partials, SL_SUBR0 + 2 * (a.t % SUB_RING), j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,14 +935,34 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
     const int K = a.s.K;
     DevStatus* st = a.s.status;
     const float* src = a.s.X[j];
-    if (a.s.has_prox[j]) {
-        const int tau = sub_finished_before(a.s, j, scratch);
-        if (tau == 0) {
+    int replay = 0;                      // passes to redo from `src` (the loop ended inside a launch)
+    float gam[NC], rat[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { gam[c] = 0.f; rat[c] = 0.f; }
+    // Nothing is written until BOTH blocks' loops have ended: a replay below starts from X itself, so finishing
+    // one block now and coming back for the other (after the host fed it more passes) would apply it twice.
+    int tau_of[2] = {0, 0};
+    bool need_more = false;
+    for (int jj = 0; jj < 2; ++jj) {
+        if (!a.s.has_prox[jj]) continue;
+        tau_of[jj] = sub_finished_before(a.s, jj, scratch);
+        if (tau_of[jj] == 0) {
             // more passes are needed than were enqueued: leave everything untouched; k_ada_decide halts
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->need_sub[j] = 1;
-            return;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) st->need_sub[jj] = 1;
+            need_more = true;
         }
-        src = a.s.zb[j][(tau - 1) & 1];
+    }
+    if (need_more) return;
+    if (a.s.has_prox[j]) {
+        const int tau = tau_of[j];
+        const int b = (tau - 1) / a.s.nt, q = (tau - 1) % a.s.nt;
+        if (q == a.s.nt - 1) {
+            src = a.s.zb[j][b & 1];                              // the launch's own output
+        } else {
+            src = b == 0 ? a.s.X[j] : a.s.zb[j][(b - 1) & 1];    // its input, q + 1 passes to redo
+            replay = q + 1;
+            sub_steps<NC>(a.s, j, scratch, gam, rat);
+        }
     }
     float* X = a.s.X[j];
     float d2 = 0.f, n2 = 0.f;
@@ -879,11 +970,35 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) cs[c] = 0.f;
     ROW_LOOP_BEGIN(rows)
+        bool ok[NC];
+        float z[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (l32 + 32 * c < K) {
+            ok[c] = l32 + 32 * c < K;
+            z[c] = ok[c] ? src[r * K + l32 + 32 * c] : 0.f;
+        }
+        if (replay > 0) {
+            float x[NC], ps[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
                 const int64_t e = r * K + l32 + 32 * c;
-                const float x = src[e];
+                x[c] = ok[c] ? X[e] : 0.f;
+                ps[c] = ok[c] ? a.s.Psi[j][e] : 0.f;
+            }
+            for (int q = 0; q < replay; ++q) {
+                float v[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) v[c] = z[c] - rat[c] * ps[c] * (z[c] - x[c]);
+                prox_row<NC>(v, ok, a.s.prox[j], gam);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) z[c] = v[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (ok[c]) {
+                const int64_t e = r * K + l32 + 32 * c;
+                const float x = z[c];
                 X[e] = x;
                 if (a.check_convergence) {
                     const float d = x - a.Xp[j][e];
@@ -1247,7 +1362,16 @@ void launch_pgm_decide(const DecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(
 void launch_colsum(const ColsumArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colsum, dim3(EW_BLOCKS, 2), s, a); }
 void launch_alpha_init(const AlphaArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_alpha_init, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_ada_moment(const MomentArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_moment, dim3(EW_BLOCKS, 2), s, a); }
-void launch_ada_sub(const SubArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_sub, dim3(EW_BLOCKS, 2), s, a); }
+#define DISPATCH_NC_NT(K, NT, KERNEL, grid, stream, args)                                                          \
+    do {                                                                                                           \
+        if ((K) <= 32) hipLaunchKernelGGL((KERNEL<1, NT>), grid, dim3(EW_THREADS), 0, stream, args);                \
+        else if ((K) <= 64) hipLaunchKernelGGL((KERNEL<2, NT>), grid, dim3(EW_THREADS), 0, stream, args);           \
+        else hipLaunchKernelGGL((KERNEL<4, NT>), grid, dim3(EW_THREADS), 0, stream, args);                          \
+    } while (0)
+void launch_ada_sub(const SubArgs& a, hipStream_t s) {
+    if (a.nt == 1) DISPATCH_NC_NT(a.K, 1, k_ada_sub, dim3(EW_BLOCKS, 2), s, a);
+    else DISPATCH_NC_NT(a.K, SUB_NT_MAX, k_ada_sub, dim3(EW_BLOCKS, 2), s, a);
+}
 void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, k_ada_finish, dim3(EW_BLOCKS, 2), s, a); }
 void launch_ada_decide(const AdaDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ada_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }

@@ -96,6 +96,8 @@ struct pmx_ctx {
     double bt_fprev = 0.0;
     float omega_cur = 0.f;
     int nsub_guess = 2;
+    int sub_nt = SUB_NT_MAX;               // proximal sub-iteration passes per launch (PMX_SUB_BATCH=1: one launch per pass)
+    int sub_enq = 0;                       // passes enqueued for the iteration in flight (row-sharded protocol)
     std::vector<void*> allocs;
 
     // K1 timing (HIP events on the launch stream)
@@ -925,6 +927,7 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
     c->algo = ALG_ADAPROX;
     c->it = 0;
     c->nsub_guess = 2;
+    c->sub_nt = (getenv("PMX_SUB_BATCH") && atoi(getenv("PMX_SUB_BATCH")) == 1) ? 1 : SUB_NT_MAX;
     rc = reset_status(c);
     if (rc != PMX_OK) return rc;
     for (int j = 0; j < 2; ++j) {
@@ -977,8 +980,18 @@ static SubArgs sub_args(pmx_ctx* c, int t) {
     s.status = c->dstatus;
     s.partials = c->partials;
     s.t = t;
+    s.nt = c->sub_nt;
     s.prox_max_iter = p.prox_max_iter;
     return s;
+}
+
+// enqueue sub-iteration launches covering at least passes [t0, t0 + n); t0 is a multiple of the launch size.
+// Returns the number of passes enqueued so far (a multiple of the launch size).
+static int ada_enqueue_subs(pmx_ctx* c, int t0, int n) {
+    const int nt = c->sub_nt;
+    int t = t0;
+    for (; t < t0 + n; t += nt) launch_ada_sub(sub_args(c, t), c->stream);
+    return t;
 }
 
 // tail of an iteration: finish + decide.  t = number of sub-iteration passes enqueued so far
@@ -1058,20 +1071,19 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             const int gi = done + i;
             rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
             if (rc != PMX_OK) return rc;
-            for (int t = 0; t < nsub; ++t) launch_ada_sub(sub_args(c, t), c->stream);
-            rc = ada_enqueue_tail(c, nsub);
+            rc = ada_enqueue_tail(c, ada_enqueue_subs(c, 0, nsub));
             if (rc != PMX_OK) return rc;
         }
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
         // ---- a chain stopped inside an iteration's sub-iteration loop: feed it more passes --------
-        int t_enq = nsub;
+        const int nsub_enq = nsub > 0 ? ((nsub + c->sub_nt - 1) / c->sub_nt) * c->sub_nt : 0;
+        int t_enq = nsub_enq;
         while (c->hstatus->halt && c->hstatus->reason == HALT_NEED_SUB) {
             rc = clear_halt(c);
             if (rc != PMX_OK) return rc;
             const int more = std::min(std::max(4, t_enq), 64);
-            for (int t = t_enq; t < t_enq + more; ++t) launch_ada_sub(sub_args(c, t), c->stream);
-            t_enq += more;
+            t_enq = ada_enqueue_subs(c, t_enq, more);
             rc = ada_enqueue_tail(c, t_enq);
             if (rc != PMX_OK) return rc;
             // the iterations that followed in the chunk were skipped: re-enqueue them after this one
@@ -1079,14 +1091,13 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             for (int gi = finished_if_ok; gi < done + chunk; ++gi) {
                 rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
                 if (rc != PMX_OK) return rc;
-                for (int t = 0; t < nsub; ++t) launch_ada_sub(sub_args(c, t), c->stream);
-                rc = ada_enqueue_tail(c, nsub);
+                rc = ada_enqueue_tail(c, ada_enqueue_subs(c, 0, nsub));
                 if (rc != PMX_OK) return rc;
             }
             const int it_before = c->hstatus->it_done;
             rc = read_status(c);
             if (rc != PMX_OK) return rc;
-            if (c->hstatus->it_done > it_before) t_enq = nsub;   // moved on to a later iteration
+            if (c->hstatus->it_done > it_before) t_enq = nsub_enq;   // moved on to a later iteration
         }
         done = c->hstatus->it_done - it0;
         if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
@@ -1286,8 +1297,8 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             if (rc != PMX_OK) return rc;
             const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
             const int ns = any_prox ? std::max(1, std::min(nsub, p.prox_max_iter)) : 0;
-            for (int t = 0; t < ns; ++t) launch_ada_sub(sub_args(c, t), c->stream);
-            return ada_enqueue_tail(c, ns);
+            c->sub_enq = ada_enqueue_subs(c, 0, ns);
+            return ada_enqueue_tail(c, c->sub_enq);
         }
         case 2: return shard_pack(c, 0);
         case 3: return shard_post(c, 1);
@@ -1442,8 +1453,10 @@ extern "C" int pmx_adaprox_more_subs(pmx_ctx* c, int t0, int n) {
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
     rc = clear_halt(c);
     if (rc != PMX_OK) return rc;
-    for (int t = t0; t < t0 + n; ++t) launch_ada_sub(sub_args(c, t), c->stream);
-    return ada_enqueue_tail(c, t0 + n);
+    // launches cover whole groups of sub_nt passes: continue from what was really enqueued (>= the caller's t0)
+    (void)t0;
+    c->sub_enq = ada_enqueue_subs(c, c->sub_enq, n);
+    return ada_enqueue_tail(c, c->sub_enq);
 }
 
 extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {

@@ -21,19 +21,20 @@ constexpr int LPR = 32;          // lanes per row (half a wavefront): K <= 128 -
 constexpr int MAXC = 4;          // ceil(128 / LPR)
 constexpr int MAXK = 128;
 
+constexpr int SUB_RING = 16;     // passes whose stopping-test sums are kept (two launches of SUB_NT_MAX passes)
+constexpr int SUB_NT_MAX = 8;    // passes of the proximal sub-iteration one launch runs back to back
 // reduction slots (double per block), indexed [slot][block(A|S)][EW_BLOCKS]
 enum {
     SL_DIFF2 = 0,   // sum (X_new - X_old)^2            (algorithms.py:131,406)
     SL_NORM2 = 1,   // sum X_new^2
-    SL_SUB_D = 2,   // sum (z_new - z)^2, parity 0      (algorithms.py:389)
-    SL_SUB_N = 3,   // sum z^2, parity 0
-    SL_SUB_D1 = 4,  // parity 1
-    SL_SUB_N1 = 5,
     SL_MAXPSI = 6,  // max Psi                          (algorithms.py:384)
     SL_G0 = 8,      // bsdmm: 5 sums per constraint i: R^2, Sd^2, Z^2, (U/sg)^2 ; + X^2 in SL_NORM2
     SL_BB0 = 8 + 4 * PMX_MAX_G,   // Barzilai-Borwein: sum s^2, sum s.y, sum y^2, sum g^2, max|x|, max|g|  (utils.py:216-241)
     SL_BT0 = 8 + 4 * PMX_MAX_G + 6,   // backtracking: sum (X-X_).G, max|G|, max|X_|        (algorithms.py:117-121)
-    SL_COUNT = 8 + 4 * PMX_MAX_G + 6 + 3
+    // adaprox proximal sub-iterations: per pass t the two sums of the stopping test (algorithms.py:389),
+    // slot SL_SUBR0 + 2 * (t % SUB_RING) = sum (z_new - z)^2, + 1 = sum z^2
+    SL_SUBR0 = 8 + 4 * PMX_MAX_G + 6 + 3,
+    SL_COUNT = SL_SUBR0 + 2 * 16
 };
 constexpr int COLSUM_SLOTS = MAXK;   // per-block per-component partial column sums
 

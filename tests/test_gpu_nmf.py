@@ -147,6 +147,28 @@ def test_no_callback_path_equals_callback_path(pm, orc):
         np.testing.assert_array_equal(S1, S2)
 
 
+@pytest.mark.parametrize("K,unity", [(16, True), (64, True), (40, False)])
+def test_batched_sub_iterations_equal_one_pass_per_launch(pm, orc, monkeypatch, K, unity):
+    """adaprox's proximal sub-iteration loop (algorithms.py:383-400) runs 8 passes per kernel launch with the
+    iterate kept in registers and, when the loop ends inside a launch, replays the passes up to the stopping one.
+    It must take the same number of passes and give bit-identical factors as one launch per pass."""
+    Y, A0, S0 = orc.synthetic_problem(384, 640, K, np.float32, unity_S=unity, seed=5)
+    prox_S = partial(pm.operators.prox_unity_plus, axis=0) if unity else partial(pm.operators.prox_soft_plus, thresh=1e-3)
+    out = []
+    for batch in ("1", "8"):
+        monkeypatch.setenv("PMX_SUB_BATCH", batch)
+        A, S = A0.copy(), S0.copy()
+        tr = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A, S, max_iter=12, e_rel=1e-3, algorithm=pm.adaprox, scheme="amsgrad", prox_S=prox_S, callback=tr)
+        A2, S2 = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A2, S2, max_iter=12, e_rel=1e-3, algorithm=pm.adaprox, scheme="amsgrad", prox_S=prox_S)   # chained
+        np.testing.assert_array_equal(A, A2)
+        np.testing.assert_array_equal(S, S2)
+        out.append((A, S))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 CONFIGS = [
     ("pgm", dict(), 1024, 1536, 32, False),
     ("fista", dict(accelerated=True), 1024, 1536, 32, False),
