@@ -1496,7 +1496,7 @@ static hipError_t grad_launch_bf16_v4(const GradV4Args& a, hipStream_t stream) {
 // steps.  Everything is plain loads (exact compiler wait counts); Y and St/A are requested one slot ahead.
 // ------------------------------------------------------------------------------------------------
 constexpr int V5_BM = 128, V5_BN = 32, V5_NB = 8, V5_THREADS = 512;
-constexpr int V5_S_TERM = 32 * 144, V5_SL_BYTES = 3 * V5_S_TERM, V5_A_TERM = 128 * 144, V5_AIMG_BYTES = 2 * V5_A_TERM,
+constexpr int V5_S_TERM = 32 * 128, V5_SL_BYTES = 3 * V5_S_TERM, V5_A_TERM = 128 * 128, V5_AIMG_BYTES = 2 * V5_A_TERM,
               V5_R_TERM = 32 * 256, V5_R_BYTES = 2 * V5_R_TERM;
 constexpr int V5_OFF_A = 3 * V5_SL_BYTES, V5_OFF_R = V5_OFF_A + V5_AIMG_BYTES, V5_OFF_Y = V5_OFF_R + 2 * V5_R_BYTES,
               V5_LDS_BYTES = V5_OFF_Y + 4 * 4096;
@@ -1506,7 +1506,11 @@ static_assert(V5_NB * V5_BN == BG_CB * BG_BN, "same region width as the other va
 
 template <bool PROF>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
-    constexpr int K = 64, ROWB = 144;
+    // Sl and Aimg: [row][64 bf16] images with 128-byte rows whose 16-byte chunks are XOR-swizzled by the row
+    // (v3_swz), which makes the b128 reads (lane = row), the transposing reads (4 rows x 64 bytes per 32 lanes) and
+    // the staging writes all bank-conflict-free (a padded 144-byte row left the transposing reads 2-way conflicted:
+    // SQ_LDS_BANK_CONFLICT was 84 % of SQ_ACTIVE_INST_LDS)
+    constexpr int K = 64, ROWB = 128;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     if (chain_halted(a.status)) return;
@@ -1551,7 +1555,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
     // whole slot ago.  (Hand-counted waits on inline-asm loads were tried and dropped: the register allocator
     // copies in-flight destination registers around the asm statements.)
     float4 sreg;
-    const int st_off = (tid >> 4) * ROWB + (tid & 15) * 8;
+    const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
     int s_cb = 0;                            // column block of the next S request (wraps at ncb; no integer division in the loop)
     auto load_S = [&]() {
         sreg = reinterpret_cast<const float4*>(a.St + (int64_t)(col0 + s_cb * V5_BN) * K)[tid];
@@ -1626,14 +1630,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
             }
         };
         auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
-            unsigned char* dst = smem + V5_OFF_A + (j * 32 + l31) * ROWB + hi * 16;
+            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<bf16x8*>(dst + ks * 32) = afr[ks][0];
-                *reinterpret_cast<bf16x8*>(dst + ks * 32 + V5_A_TERM) = afr[ks][1];
+                *reinterpret_cast<bf16x8*>(smem + V5_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<bf16x8*>(smem + V5_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
             }
         };
-        const int s_g1 = l31 * ROWB + hi * 16;                                   // GEMM1 B operand: Sl[t][l31][ks*16 + hi*8]
+        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
         const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
         load_A(row0);
         dma_Y();
@@ -1662,12 +1666,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
                 if (cb + 1 == ncb && rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
                 dma_Y();
                 PH(2)
-                const unsigned char* Slb = smem + (t % 3) * V5_SL_BYTES + s_g1;
+                const unsigned char* Slb = smem + (t % 3) * V5_SL_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32);
-                    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32 + V5_S_TERM);
-                    const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + ks * 32 + 2 * V5_S_TERM);
+                    const int so = s_g1 ^ (ks << 5);
+                    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + so);
+                    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + so + V5_S_TERM);
+                    const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + so + 2 * V5_S_TERM);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
@@ -1722,9 +1727,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
             r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
             r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
         }
-        const int s_t = (8 * hi + (li >> 2)) * ROWB + (16 * (lq & 1) + 4 * (li & 3)) * 2;     // GEMM2 B operand (tr), + kt*64
+        // transposing reads of a swizzled [row][k] image: source lane (li, lq) supplies row r0 + 4 u + (li >> 2), 4 k's from
+        // k0 + 16 (lq & 1) + 4 (li & 3); + 16 rows per ks leaves the swizzle unchanged
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
         const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
-        const int a_t = (64 * mh + 8 * hi + (li >> 2)) * ROWB + (kt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM3 B operand (tr)
+        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
         auto flush_gA = [&](int prow) {
             float* dst = a.slabA + (int64_t)colRegion * M * K;
 #pragma unroll
@@ -1756,11 +1767,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
                     const bf16x8 r1 = v3_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                    const int so = s_t + ks * 16 * ROWB;
-                    const bf16x8 s00 = v3_tr_pair(Slb, so, so + 4 * ROWB);
-                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so, so + 4 * ROWB);
-                    const bf16x8 s10 = v3_tr_pair(Slb, so + 64, so + 64 + 4 * ROWB);
-                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so + 64, so + 64 + 4 * ROWB);
+                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+                    const bf16x8 s00 = v3_tr_pair(Slb, so0, so1);
+                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so0, so1);
+                    const bf16x8 s10 = v3_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
+                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
                     accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s00, accA0, 0, 0, 0);
                     accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s10, accA1, 0, 0, 0);
                     accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s01, accA0, 0, 0, 0);
@@ -1776,9 +1787,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
                     const int ro = r_g3 ^ (ks << 5);
                     const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);
                     const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V5_R_TERM + ro);
-                    const int ao = a_t + ks * 16 * ROWB;
-                    const bf16x8 a0 = v3_tr_pair(Ab, ao, ao + 4 * ROWB);
-                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao, ao + 4 * ROWB);
+                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
+                    const bf16x8 a0 = v3_tr_pair(Ab, ao0, ao1);
+                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao0, ao1);
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, accSc, 0, 0, 0);
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, accSc, 0, 0, 0);
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);

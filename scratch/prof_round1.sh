@@ -12,3 +12,8 @@ python profiles/summarize_pmc.py $O/r1d_pmc_summary.json fetch=$(ls $O/r1d_bf16x
 find $O/r1d_bf16x3_fetch $O/r1d_bf16x3_write $O/r1d_bf16x3_sq -name "*counter_collection.csv" -delete
 find $O -name "*kernel_trace.csv" -path "*r1d*" -delete
 tail -1 $O/r1d_bf16x3.json | cut -c1-300
+python bench.py > $O/r1d_bench_default.json 2> $O/r1d_bench_default.err
+python bench.py --mode f32 --no-cpu > $O/r1d_bench_f32.json 2>/dev/null
+python bench.py --config cfg2 --mode f32 --steps 200 --warmup 20 --no-cpu > $O/r1d_bench_cfg2.json 2>/dev/null
+python bench.py --config cfg5 --steps 20 --warmup 5 --no-cpu > $O/r1d_bench_cfg5.json 2>/dev/null
+tail -c 600 $O/r1d_bench_default.json
