@@ -1901,7 +1901,10 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
     p.gridY = (int)((N + (int64_t)BG_CB * BG_BN - 1) / ((int64_t)BG_CB * BG_BN));
-    int64_t wantX = (512 + p.gridY - 1) / p.gridY;
+    // one resident workgroup per CU for the 8-wave variants: a single round of 256 measured 1-12 % faster than two of
+    // 512 (fewer prologues / accumulator flushes, half the gSt slabs); PMX_K1_WGS overrides (tuning)
+    const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : (p.variant >= 4 && K == 64 ? 256 : 512);
+    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
     if (wantX < 1) wantX = 1;
     if (wantX > panels) wantX = panels;
     p.RP = (int)((panels + wantX - 1) / wantX);

@@ -4,11 +4,12 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 for r in rows:
     m = re.search(r"\b(k_[A-Za-z0-9_]+)", r["Kernel_Name"])
-    if m:
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1)))
+    name = m.group(1) if m else ("nccl" if "ccl" in r["Kernel_Name"].lower() else None)
+    if name:
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 ev.sort()
 # find K1 launches that really ran (> 100 us) and print the timeline of the last few iterations
-k1 = [i for i, e in enumerate(ev) if e[2].startswith("k_grad") and e[1] - e[0] > 100000]
+k1 = [i for i, e in enumerate(ev) if e[2].startswith("k_grad") and e[1] - e[0] > (int(sys.argv[2]) if len(sys.argv) > 2 else 100000)]
 for a, b in zip(k1[-4:-1], k1[-3:]):
     print("--- iteration: %.1f us from K1 start to next K1 start" % ((ev[b][0] - ev[a][0]) / 1e3))
     prev_end = None
