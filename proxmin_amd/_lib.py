@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmx.so")
@@ -112,6 +113,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PmxError("libpmx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). proxmin_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If it is loaded AFTER this library
+    # (which resolves the system one), the process ends up with two runtimes and the second sees no device; loaded
+    # first, libpmx binds to the copy already in the process.  So bring torch in first when it is installed.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol

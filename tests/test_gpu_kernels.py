@@ -174,3 +174,57 @@ def test_split_bf16_gradient_near_solution_is_fp32_class(eng, orc):
     for j in range(2):
         assert err["f32"][j] < 5e-5
         assert err["bf16x3"][j] < max(3 * err["f32"][j], 2e-5), err
+
+
+def test_full_size_gradient_properties(eng):
+    """BASELINE's headline shape (Y 16384 x 16384, K = 64), where the oracle would take minutes: size-independent
+    properties instead.  (1) the two independent K1 implementations (exact-fp32 MFMA and split-bf16 producer/consumer)
+    agree to fp32 rounding; (2) the gradient is affine in Y, gA(Y + E) - gA(Y) = -E S^T and gS(Y + E) - gS(Y) = -A^T E,
+    checked exactly for a sparse E; (3) at an exact factorisation Y = A S the loss and the gradients vanish to
+    rounding (the residual is pure cancellation: the third bf16 term earns its keep here)."""
+    import torch
+    M = N = 16384
+    K = 64
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    Y = torch.rand((M, N), generator=gen, device="cuda", dtype=torch.float32)
+    rng = np.random.default_rng(7)
+    A = rng.random((M, K), dtype=np.float32)
+    S = rng.random((K, N), dtype=np.float32)
+    # sparse perturbation: 64 entries, values exactly representable
+    ii = rng.integers(0, M, 64)
+    jj = rng.integers(0, N, 64)
+    vv = (rng.integers(1, 9, 64) * 0.25).astype(np.float32)
+    Y2 = Y.clone()
+    Y2[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()] += torch.from_numpy(vv).cuda()
+    Yx = torch.from_numpy(A).cuda() @ torch.from_numpy(S).cuda()   # fp32 product: Y - A S is at rounding level
+    out = {}
+    for mode in ("f32", "bf16x3"):
+        with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+            dev.set_factors(A, S)
+            dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+            gA, gS = dev.grad()
+            loss = dev.loglike()
+            dev.set_Y_device(Y2.data_ptr(), ld=N, copy=False, keepalive=Y2)
+            gA2, gS2 = dev.grad()
+            dev.set_Y_device(Yx.data_ptr(), ld=N, copy=False, keepalive=Yx)
+            gAx, gSx = dev.grad()
+            lossx = dev.loglike()
+        out[mode] = (gA, gS, loss)
+        # (2) affine in Y: only the touched rows / columns change, by -E S^T and -A^T E
+        dA = np.zeros((M, K), np.float64)
+        dS = np.zeros((K, N), np.float64)
+        for i, j, v in zip(ii, jj, vv):
+            dA[i] -= float(v) * S[:, j].astype(np.float64)
+            dS[:, j] -= float(v) * A[i].astype(np.float64)
+        scaleA, scaleS = np.abs(gA).max(), np.abs(gS).max()
+        np.testing.assert_allclose(gA2.astype(np.float64) - gA, dA, atol=4e-6 * scaleA)
+        np.testing.assert_allclose(gS2.astype(np.float64) - gS, dS, atol=4e-6 * scaleS)
+        # (3) exact factorisation: residual entries are fp32 rounding of a K-term dot product (<= ~K eps |A||S|)
+        assert lossx < 1e-9 * loss
+        assert np.abs(gAx).max() < 2e-5 * scaleA and np.abs(gSx).max() < 2e-5 * scaleS
+    # (1) two implementations, one answer
+    for a, b in zip(out["f32"][:2], out["bf16x3"][:2]):
+        assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max())
+    assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)

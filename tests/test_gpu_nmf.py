@@ -303,3 +303,44 @@ def test_unmixing_example_pgm_backtracking(pm):
         # a converged non-convex run in fp32 vs fp64: same basin, loss within 0.5 %, iteration count within 15 %
         assert abs(loss / r["loss"] - 1) < 5e-3, (loss, r["loss"])
         assert abs(len(tb.trace) - r["iters"]) <= 0.15 * r["iters"], (len(tb.trace), r["iters"])
+
+
+def test_full_size_modes_agree_and_loss_decreases():
+    """cfg3's shape (Y 16384 x 16384, K = 64, adaprox/AMSGrad, prox_plus + prox_unity_plus on the columns of S), which
+    the oracle cannot reach in test time: the exact-fp32 and the split-bf16 arithmetic modes run the same 6 iterations
+    from the same start and must land on the same factors within the stated trajectory tolerance; constraints hold;
+    after the initial transient of the adaptive steps (loss x4 at iteration 3) 40 iterations cut the loss below half."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    import bench
+    from proxmin_amd.engine import DeviceNMF
+    M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
+    Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 99, torch.device("cuda", 0))
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        with DeviceNMF(M, N, K, mode=mode) as dev:
+            dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+            dev.set_factors(A0, S0)
+            l0 = dev.loglike()
+            run = bench.begin_solver(dev, backend, unity)
+            r = run(6)
+            assert r.iterations == 6
+            A, S = dev.get_factors()
+            l1 = dev.loglike()
+            if mode == "bf16x3":
+                assert run(34).iterations == 34
+                assert dev.loglike() < 0.5 * l0
+        assert np.isfinite(A).all() and np.isfinite(S).all()
+        np.testing.assert_allclose(S.sum(0), 1.0, rtol=1e-5)          # prox_unity_plus on the columns of S
+        assert (A >= 0).all() and (S >= 0).all()
+        res[mode] = (A, S, l1)
+    for a, b in zip(res["f32"][:2], res["bf16x3"][:2]):
+        ok = np.abs(a - b) <= 2e-5 + 2e-4 * np.abs(a)
+        assert ok.mean() >= 0.999, ok.mean()
+        # the tail is AMSGrad's eps clamp amplifying a rounding difference on near-zero gradient entries (DESIGN.md section 2);
+        # measured here: A worst entry 1.3 x the bound, S 3.4e-5 of the entries beyond 25 x, worst 182 x
+        ratio = np.abs(a - b) / (2e-5 + 2e-4 * np.abs(a))
+        assert (ratio > 25).mean() <= 1e-4, (ratio > 25).mean()
+        assert ratio.max() <= 1000, ratio.max()
+    assert res["bf16x3"][2] == pytest.approx(res["f32"][2], rel=1e-4)
