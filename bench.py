@@ -141,7 +141,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")

@@ -11,7 +11,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpmx.so")
+LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "libpmx.so")   # PMX_LIB: A/B a second build (tuning)
 
 MAX_SEQ = 4
 MAX_G = 4

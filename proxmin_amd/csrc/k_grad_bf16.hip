@@ -1736,13 +1736,21 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
         const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
         const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
         const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
+        // two base pointers per lane and compile-time row offsets (immediates): sixteen separate 64-bit addresses kept
+        // live across the slot loop cost the consumers 32 VGPRs they need for operand prefetch
         auto flush_gA = [&](int prow) {
-            float* dst = a.slabA + (int64_t)colRegion * M * K;
+            float* p0 = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t o = (int64_t)(prow + j * 32 + tile_row(i, lane)) * K + l31;
-                dst[o] = accA0[i];
-                dst[o + 32] = accA1[i];
+            for (int half = 0; half < 2; ++half) {
+                float* ph_ = p0 + half * 16 * K;
+                asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
+                    const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                    ph_[ro] = accA0[i];
+                    ph_[ro + 32] = accA1[i];
+                }
             }
         };
         // slot t works on block t - 1; the column-block loop is unrolled so that each gSt accumulator is a fixed

@@ -1370,6 +1370,7 @@ void launch_ada_moment(const MomentArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_
     } while (0)
 void launch_ada_sub(const SubArgs& a, hipStream_t s) {
     if (a.nt == 1) DISPATCH_NC_NT(a.K, 1, k_ada_sub, dim3(EW_BLOCKS, 2), s, a);
+    else if (a.nt == 4) DISPATCH_NC_NT(a.K, 4, k_ada_sub, dim3(EW_BLOCKS, 2), s, a);
     else DISPATCH_NC_NT(a.K, SUB_NT_MAX, k_ada_sub, dim3(EW_BLOCKS, 2), s, a);
 }
 void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, k_ada_finish, dim3(EW_BLOCKS, 2), s, a); }

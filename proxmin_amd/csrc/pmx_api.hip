@@ -1067,6 +1067,9 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
         // ---- enqueue a chunk of whole iterations ------------------------------------------------
         const int chunk = std::min(n_iter - done, 16);
         const int nsub = any_prox ? std::max(1, std::min(c->nsub_guess, p.prox_max_iter)) : 0;
+        // passes per launch for this chunk: 4 when the loops have been ending within 4 passes (the usual steady state:
+        // 1 pass for a projection, 2-3 for prox_unity_plus), else 8; PMX_SUB_BATCH=1 keeps one pass per launch
+        if (c->sub_nt != 1) c->sub_nt = nsub <= 4 ? 4 : SUB_NT_MAX;
         for (int i = 0; i < chunk; ++i) {
             const int gi = done + i;
             rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
@@ -1297,6 +1300,7 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             if (rc != PMX_OK) return rc;
             const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
             const int ns = any_prox ? std::max(1, std::min(nsub, p.prox_max_iter)) : 0;
+            if (c->sub_nt != 1) c->sub_nt = ns <= 4 ? 4 : SUB_NT_MAX;   // fixed for this iteration (pmx_adaprox_more_subs continues with it)
             c->sub_enq = ada_enqueue_subs(c, 0, ns);
             return ada_enqueue_tail(c, c->sub_enq);
         }
