@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r1d_bf16x3 -o s -- python bench.py --steps 20 --warmup 5 --no-cpu > $O/r1d_bf16x3.json 2> $O/r1d_bf16x3.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r1d_f32 -o s -- python bench.py --steps 20 --warmup 5 --no-cpu --mode f32 > $O/r1d_f32.json 2> $O/r1d_f32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r1d_bf16x3 -o s -- python bench.py --steps 100 --warmup 20 --no-cpu > $O/r1d_bf16x3.json 2> $O/r1d_bf16x3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r1d_f32 -o s -- python bench.py --steps 100 --warmup 20 --no-cpu --mode f32 > $O/r1d_f32.json 2> $O/r1d_f32.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r1d_bf16x3_fetch -o f -- python bench.py --steps 6 --warmup 2 --no-cpu > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r1d_bf16x3_write -o f -- python bench.py --steps 6 --warmup 2 --no-cpu > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/r1d_bf16x3_sq -o f -- python bench.py --steps 6 --warmup 2 --no-cpu > /dev/null 2>&1
