@@ -22,6 +22,7 @@
 //
 // LDS images are row-major with an odd leading dimension (KP+1 / BN+1) so that every ds_read_b32 /
 // ds_write_b32 pattern used below (lanes walk rows, or lanes walk columns) is bank-conflict free.
+#include <type_traits>
 #include "pmx_common.h"
 
 struct GradArgs {
@@ -154,6 +155,25 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
         }
     };
 
+    // whole blocks with K == KP are one contiguous run of rows * KP floats: all 16-byte loads issued back to back,
+    // then scattered into the odd-stride LDS image.  (The guarded element loop below compiles to one dependent
+    // 4-byte load + full wait per element: 16 serial L2 round trips per thread and step.)
+    auto stage_rows_whole = [&](float* img, const float* src, auto rows_tag) {
+        constexpr int ROWS = decltype(rows_tag)::value;
+        constexpr int NV = ROWS * (KP / 4) / GRAD_THREADS;        // float4 per thread
+        static_assert(ROWS * (KP / 4) % GRAD_THREADS == 0, "");
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = s4[tid + i * GRAD_THREADS];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * GRAD_THREADS;
+            const int r = f / (KP / 4), k = (f - r * (KP / 4)) * 4;
+            float* d = img + r * LDK + k;
+            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        }
+    };
     if (nsteps > 0) request_Y(row0, col0);
     int rp = 0, cb = 0;
 #pragma nounroll
@@ -163,26 +183,30 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
         __syncthreads();   // previous step's readers of Al / Sl / Rl are done
         if (cb == 0) {     // new row panel (uniform)
             // ---- stage the A panel: Al[m][k] = A[prow0+m][k], zero padded -----------------------
+            if (K == KP && prow0 + GRAD_BM <= M) stage_rows_whole(Al, a.A + (int64_t)prow0 * K, std::integral_constant<int, GRAD_BM>{});
+            else
 #pragma unroll 4
-            for (int e = tid; e < GRAD_BM * KP; e += GRAD_THREADS) {
-                const int m = e / KP, k = e - m * KP;
-                float v = 0.f;
-                if (prow0 + m < M && k < K) v = a.A[(int64_t)(prow0 + m) * K + k];
-                Al[m * LDK + k] = v;
-            }
+                for (int e = tid; e < GRAD_BM * KP; e += GRAD_THREADS) {
+                    const int m = e / KP, k = e - m * KP;
+                    float v = 0.f;
+                    if (prow0 + m < M && k < K) v = a.A[(int64_t)(prow0 + m) * K + k];
+                    Al[m * LDK + k] = v;
+                }
 #pragma unroll
             for (int t = 0; t < C::G2T; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) accA[t][i] = 0.f;
         }
         // ---- stage the St block: Sl[n][k] = St[bcol0+n][k] --------------------------------------
+        if (K == KP && bcol0 + BN <= N) stage_rows_whole(Sl, a.St + (int64_t)bcol0 * K, std::integral_constant<int, BN>{});
+        else
 #pragma unroll 4
-        for (int e = tid; e < BN * KP; e += GRAD_THREADS) {
-            const int n = e / KP, k = e - n * KP;
-            float v = 0.f;
-            if (bcol0 + n < N && k < K) v = a.St[(int64_t)(bcol0 + n) * K + k];
-            Sl[n * LDK + k] = v;
-        }
+            for (int e = tid; e < BN * KP; e += GRAD_THREADS) {
+                const int n = e / KP, k = e - n * KP;
+                float v = 0.f;
+                if (bcol0 + n < N && k < K) v = a.St[(int64_t)(bcol0 + n) * K + k];
+                Sl[n * LDK + k] = v;
+            }
         __syncthreads();
         // ---- GEMM1: P = A S accumulated on top of -Y ---------------------------------------------
 #pragma unroll
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
         int nrp_ = rp, ncb_ = cb + 1;
         if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
         if (step + 1 < nsteps) request_Y(row0 + nrp_ * GRAD_BM, col0 + ncb_ * BN);
+
         // ---- GEMM2: gA(rows of this panel) += R . St_blk ----------------------------------------
         if (a.doA) {
             const float* rq = Rl + (g2_mt * 32 + l31) * LDR + g2_half * G2_INNER + hi * (G2_INNER / 2);
