@@ -44,7 +44,7 @@ MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
 # and profiles/r01_c_pmc_traffic_cfg3.json (f32)
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command; FETCH_SIZE doubled per the gfx950 correction).
 # Only known for the configuration that was profiled; null otherwise.
-PMC_TRAFFIC_BYTES = {("cfg3", "bf16x3"): 2 * 608912 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
+PMC_TRAFFIC_BYTES = {("cfg3", "bf16x3"): 2 * 608824 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):

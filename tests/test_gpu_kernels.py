@@ -228,3 +228,30 @@ def test_full_size_gradient_properties(eng):
         assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
         np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max())
     assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)
+
+
+@pytest.mark.parametrize("pitch_extra,offset", [(0, 0), (64, 0), (3, 0), (64, 1)])
+def test_zero_copy_Y_with_row_pitch_and_alignment(eng, orc, pitch_extra, offset):
+    """Y adopted zero-copy from a device pointer (pmx_set_Y_device, copy=0) with a row pitch larger than N and with /
+    without 16-byte alignment: aligned pitches take the LDS-DMA producer/consumer kernel, the others fall back to
+    the plain-load variant -- same gradients either way."""
+    import torch
+    M, N, K = 512, 768, 64
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=77)
+    ld = N + pitch_extra
+    buf = torch.zeros(M * ld + 8, dtype=torch.float32, device="cuda")
+    view = buf[offset:offset + M * ld].view(M, ld)
+    view[:, :N] = torch.from_numpy(Y).cuda()
+    if pitch_extra:
+        view[:, N:] = 1e30            # must never be read as data
+    A64, S64, Y64 = A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64)
+    rA, rS = orc.residual_gradients(A64, S64, Y64)
+    for mode in ("f32", "bf16x3"):
+        with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+            dev.set_Y_device(view.data_ptr(), ld=ld, copy=False, keepalive=buf)
+            dev.set_factors(A, S)
+            gA, gS = dev.grad()
+            loss = dev.loglike()
+        np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+        np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+        assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
