@@ -255,3 +255,26 @@ def test_zero_copy_Y_with_row_pitch_and_alignment(eng, orc, pitch_extra, offset)
         np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
         np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
         assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
+
+
+def test_split_bf16_default_kernel_on_many_region_shapes(eng):
+    """Whole-block shapes with every kind of region raggedness (row panels that do not divide evenly over the row
+    regions, a last column region of 1..7 blocks, tiny and tall-thin problems): the default split-bf16 K1 against the
+    exact-fp32 K1 (independent implementations), gradients and loss."""
+    rng = np.random.default_rng(2024)
+    shapes = [(128, 64), (128, 2048), (3712, 64), (1152, 1984), (2944, 4160), (640, 16448), (8320, 320), (4224, 2368)]
+    for M, N in shapes:
+        K = 64
+        Y = rng.random((M, N), dtype=np.float32)
+        A = rng.random((M, K), dtype=np.float32)
+        S = rng.random((K, N), dtype=np.float32)
+        out = {}
+        for mode in ("f32", "bf16x3"):
+            with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+                dev.set_Y(Y)
+                dev.set_factors(A, S)
+                gA, gS = dev.grad()
+                out[mode] = (gA, gS, dev.loglike())
+        for a, b in zip(out["f32"][:2], out["bf16x3"][:2]):
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max(), err_msg="shape %dx%d" % (M, N))
+        assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)
