@@ -102,16 +102,20 @@ def apply_prox_sequence(X, step, specs, repeat=1):
 # likelihood, gradient, step rules                          (proxmin/nmf.py:13-93)
 # --------------------------------------------------------------------------------------
 
-def half_sq_residual(A, S, Y):
-    """nmf.log_likelihood with W=1 (nmf.py:13-25): 1/2 * sum (Y - A S)^2."""
+def half_sq_residual(A, S, Y, W=None):
+    """nmf.log_likelihood (nmf.py:13-25): 1/2 * sum W (Y - A S)^2; W=None is the reference's W=1."""
     D = Y - A @ S
+    if W is not None:
+        return np.sum(W * D * D) / 2
     return np.sum(D * D) / 2
 
 
-def residual_gradients(A, S, Y):
-    """nmf.grad_likelihood with W=1 (nmf.py:28-41): R = A S - Y; (R S^T, A^T R)."""
+def residual_gradients(A, S, Y, W=None):
+    """nmf.grad_likelihood (nmf.py:28-41): D = W (A S - Y); (D S^T, A^T D).  W=None is the reference's W=1."""
     R = A @ S
     R -= Y
+    if W is not None:
+        R = W * R
     return R @ S.T, A.T @ R
 
 
@@ -186,7 +190,7 @@ def _sumsq(x):
 
 
 def pgm_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, accelerated=False,
-            backtracking=False, max_iter=1000, e_rel=1e-3, callback=None, trace=None):
+            backtracking=False, max_iter=1000, e_rel=1e-3, callback=None, trace=None, W=None):
     """`nmf(Y, A, S, algorithm=pgm, ...)` (nmf.py:150-162 -> algorithms.py:12-144).
 
     A and S are updated in place.  `step`: None -> lipschitz_steps evaluated at the
@@ -221,14 +225,17 @@ def pgm_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, accelerated=
         else:
             E = [X[j].copy() for j in range(2)]                        # :96-99 (alias/copy)
         prev = [x.copy() for x in X]                                   # :102
-        G = residual_gradients(E[0], E[1], Y)                          # :105
+        G = residual_gradients(E[0], E[1], Y, W)                       # :105
+        if step is None and W is not None:
+            # nmf.step_pgm tests `W == 1` on the array (nmf.py:63): NumPy raises, and so does the reference
+            raise ValueError("The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()")
         St = lipschitz_steps(E[0], E[1]) if step is None else tuple(step(E[0], E[1], it, G))  # :106
         for j in range(2):                                             # :107-108
             X[j][:] = apply_prox(E[j] - T[j] * St[j] * G[j], T[j] * St[j], specs[j])
         if backtracking:                                               # :110-127
-            f_now = half_sq_residual(A, S, Y)
+            f_now = half_sq_residual(A, S, Y, W)
             if it == 0:
-                f_prev = half_sq_residual(prev[0], prev[1], Y)
+                f_prev = half_sq_residual(prev[0], prev[1], Y, W)
 
             def quad():
                 return sum(np.sum((X[j] - prev[j]) * G[j]) + 0.5 / (T[j] * St[j]) * np.sum((X[j] - prev[j]) ** 2)
@@ -237,7 +244,7 @@ def pgm_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, accelerated=
                 jmax = int(np.argmax([np.max(np.abs(St[j] * G[j])) / np.max(np.abs(prev[j])) for j in range(2)]))
                 T[jmax] /= 2
                 X[jmax][:] = apply_prox(E[jmax] - T[jmax] * St[jmax] * G[jmax], T[jmax] * St[jmax], specs[jmax])
-                f_now = half_sq_residual(A, S, Y)
+                f_now = half_sq_residual(A, S, Y, W)
             f_prev = f_now
         conv = tuple(bool(_sumsq(X[j] - prev[j]) <= e[j] ** 2 * _sumsq(X[j])) for j in range(2))  # :130-133
         if all(conv):
@@ -298,7 +305,7 @@ def moment_update(scheme, it, G, M, V, Vhat, b1, b2, eps, p):
 def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="adam",
                 b1=0.9, b2=0.999, eps=1e-8, check_convergence=True, p=0.25, max_iter=1000,
                 e_rel=1e-3, prox_max_iter=1000, M=None, V=None, Vhat=None, callback=None,
-                trace=None):
+                trace=None, W=None):
     """`nmf(Y, A, S, algorithm=adaprox, ...)` (nmf.py:164-176 -> algorithms.py:248-423).
 
     Returns (converged, M, V, Vhat, n_iter, sub_iters) -- the reference returns the first
@@ -330,7 +337,7 @@ def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="
                 callback(A, S, it=it)
             except StopIteration:
                 break
-        G = residual_gradients(A, S, Y)                                # :369 (Jacobi: both at old X)
+        G = residual_gradients(A, S, Y, W)                             # :369 (Jacobi: both at old X)
         alpha = adaprox_steps(A, S) if step is None else tuple(step(A, S, it))   # :370
         prev = [x.copy() for x in X] if check_convergence else None   # :371-372
         for j in range(2):

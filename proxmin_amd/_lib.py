@@ -67,6 +67,8 @@ _SIGNATURES = {
     "pmx_ctx_sync": (C.c_int, [C.c_void_p]),
     "pmx_set_Y_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pmx_set_Y_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "pmx_set_W_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_set_W_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pmx_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

@@ -28,6 +28,8 @@
 struct GradArgs {
     const float* Y;      // M x N (ldY)
     int64_t ldY;
+    const float* W;      // M x N weights (ldW) or nullptr for W == 1 (nmf.py:13-41)
+    int64_t ldW;
     const float* A;      // M x K
     const float* St;     // N x K
     float* slabA;        // [nSlabA][M][K]
@@ -233,8 +235,15 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int lr = g1_mt * 32 + tile_row(i, lane);
-                const float r = p[t][i];
-                lossAcc += r * r;
+                float r = p[t][i];
+                if (a.W != nullptr) {        // weighted likelihood: loss 1/2 sum W d^2, D = W d  (uniform branch)
+                    const int gr = prow0 + lr, gc = bcol0 + lc;
+                    const float wv = (gr < M && gc < N) ? a.W[(int64_t)gr * a.ldW + gc] : 0.f;
+                    lossAcc += wv * (r * r);
+                    r *= wv;
+                } else {
+                    lossAcc += r * r;
+                }
                 Rl[lr * LDR + lc] = r;
             }
         }

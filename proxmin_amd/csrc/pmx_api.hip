@@ -73,6 +73,9 @@ struct pmx_ctx {
     int64_t rowsPad[2] = {0, 0};
     GradPlan plan{};
     float* slab[2] = {nullptr, nullptr};
+    const float* W = nullptr;              // weights of the likelihood (nullptr: W == 1), nmf.py:13-41
+    int64_t ldW = 0;
+    float* Wown = nullptr;
     double* lossPart = nullptr;
     int nloss = 0;                         // loss partials written by the last gradient launch
 
@@ -290,6 +293,32 @@ extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int cop
     return PMX_OK;
 }
 
+static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, int copy) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (!W) { c->W = nullptr; c->ldW = 0; return PMX_OK; }
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    if (c->use_bf16) FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood needs a context created with PMX_MODE_F32");
+    if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (from_host || copy) {
+        if (!c->Wown) {
+            int rc = dallocT(c, &c->Wown, (size_t)c->M * c->N, false);
+            if (rc != PMX_OK) return rc;
+        }
+        HIP_CHECK(hipMemcpy2DAsync(c->Wown, c->N * sizeof(float), W, ld * sizeof(float), c->N * sizeof(float), c->M,
+                                   from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->W = c->Wown;
+        c->ldW = c->N;
+    } else {
+        c->W = W;
+        c->ldW = ld;
+    }
+    return PMX_OK;
+}
+extern "C" int pmx_set_W_host(pmx_ctx* c, const float* W, int64_t ld) { return set_W_common(c, W, ld, 1, 1); }
+extern "C" int pmx_set_W_device(pmx_ctx* c, const float* dW, int64_t ld, int copy) { return set_W_common(c, dW, ld, 0, copy); }
+
 static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool create) {
     int j;
     float** p = nullptr;
@@ -406,6 +435,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     } else {
         GradArgs g{};
         g.Y = c->Y; g.ldY = c->ldY;
+        g.W = c->W; g.ldW = c->ldW;
         g.A = A; g.St = St;
         g.slabA = c->slab[0]; g.slabS = c->slab[1];
         g.lossPart = c->lossPart;
@@ -694,6 +724,8 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
         rc = check_prox(p->prox[j], j ? "prox_S" : "prox_A");
         if (rc != PMX_OK) return rc;
     }
+    if (c->W && !p->use_fixed_steps && !p->bb_type)   // nmf.step_pgm with an array W raises (nmf.py:63)
+        FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
     c->pgm = *p;
     c->algo = ALG_PGM;
     c->it = 0;
@@ -1117,6 +1149,8 @@ extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
+    if (c->W)                                          // bsdmm's steps come from nmf.step_pgm (nmf.py:187-193)
+        FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
     for (int j = 0; j < 2; ++j) {
         rc = check_prox(p->prox_f[j], j ? "prox_S" : "prox_A");
         if (rc != PMX_OK) return rc;
@@ -1226,6 +1260,7 @@ extern "C" int pmx_comm_layout(pmx_ctx* c, int64_t* count, int64_t offsets[3]) {
 extern "C" int pmx_set_comm_buffer(pmx_ctx* c, float* dptr, int64_t count) {
     if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
     if (count < comm_count(c)) FAIL(PMX_E_INVALID, "comm buffer too small: %lld < %lld", (long long)count, (long long)comm_count(c));
+    if (c->W) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     c->comm = dptr;
     return PMX_OK;
 }

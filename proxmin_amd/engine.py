@@ -88,6 +88,21 @@ class DeviceNMF:
             self._keep.append(keepalive)
         _lib.check(self.lib.pmx_set_Y_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
 
+    def set_W(self, W):
+        """Weights of the likelihood (nmf.py:13-41), an M x N array; None goes back to W == 1.  Needs mode "f32"."""
+        if W is None:
+            _lib.check(self.lib.pmx_set_W_host(self.h, None, 0))
+            return
+        W = np.asarray(W)
+        assert W.shape == (self.M, self.N), "W must be M x N"
+        Wf = _f32(W)
+        _lib.check(self.lib.pmx_set_W_host(self.h, _vp(Wf), self.N))
+
+    def set_W_device(self, dptr, ld=None, copy=False, keepalive=None):
+        if keepalive is not None:
+            self._keep.append(keepalive)
+        _lib.check(self.lib.pmx_set_W_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
+
     def _upload(self, buf, arr2d):
         a = _f32(arr2d)
         _lib.check(self.lib.pmx_upload(self.h, buf, _vp(a), a.size))

@@ -22,34 +22,43 @@ from .engine import DeviceNMF
 logger = logging.getLogger("proxmin")
 
 
-def _check_W(W):
-    if not (np.isscalar(W) and W == 1):
-        raise NotImplementedError("weighted likelihood (W != 1) is not implemented on the device "
-                                  "(the reference's own weighted step rule, nmf.py:64-88, is broken on NumPy 2)")
+_AMBIGUOUS = "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()"
 
 
-def _device_for(A, S, Y):
+def _weights(W, shape):
+    """None for the reference's default W == 1, else the M x N float32 weight array (a scalar is broadcast)."""
+    if np.isscalar(W):
+        if W == 1:
+            return None
+        return np.full(shape, W, dtype=np.float32)
+    W = np.asarray(W)
+    assert W.shape == tuple(shape), "W must be M x N"
+    return W
+
+
+def _device_for(A, S, Y, W=None):
+    """Context with Y (and W) and the factors on the device.  A weighted likelihood runs the exact-fp32 kernel."""
     A, S, Y = np.asarray(A), np.asarray(S), np.asarray(Y)
-    dev = DeviceNMF(Y.shape[0], Y.shape[1], A.shape[1])
+    dev = DeviceNMF(Y.shape[0], Y.shape[1], A.shape[1], mode="f32" if W is not None else None)
     dev.set_Y(Y)
+    if W is not None:
+        dev.set_W(W)
     dev.set_factors(A, S)
     return dev
 
 
 def log_likelihood(*X, Y=0, W=1):
-    """1/2 sum (Y - A S)^2 (nmf.py:13-25), reduced inside the fused residual kernel."""
-    _check_W(W)
+    """1/2 sum W (Y - A S)^2 (nmf.py:13-25), reduced inside the fused residual kernel."""
     A, S = X
-    with _device_for(A, S, Y) as dev:
+    with _device_for(A, S, Y, _weights(W, np.shape(Y))) as dev:
         return dev.loglike()
 
 
 def grad_likelihood(*X, Y=0, W=1):
-    """(R S^T, A^T R) with R = A S - Y (nmf.py:28-41): one launch of the fused residual-gradient
+    """(D S^T, A^T D) with D = W (A S - Y) (nmf.py:28-41): one launch of the fused residual-gradient
     kernel.  Returns arrays in the dtype of A."""
-    _check_W(W)
     A, S = X
-    with _device_for(A, S, Y) as dev:
+    with _device_for(A, S, Y, _weights(W, np.shape(Y))) as dev:
         gA, gS = dev.grad()
     dt = np.asarray(A).dtype
     return gA.astype(dt), np.ascontiguousarray(gS).astype(dt)
@@ -67,8 +76,12 @@ def step_S(A, S):
 
 def step_pgm(*X, it=None, W=1):
     """Lipschitz step sizes for PGM (nmf.py:52-65, W == 1 branch), Gram matrices and the largest
-    eigenvalues computed on the device."""
-    _check_W(W)
+    eigenvalues computed on the device.  With an array W the reference's `if W == 1` raises ValueError (nmf.py:63); a
+    scalar W != 1 reaches its sparse weighted rule, which is not implemented here."""
+    if not np.isscalar(W):
+        raise ValueError(_AMBIGUOUS)
+    if W != 1:
+        raise NotImplementedError("the weighted step rule of nmf.step_pgm (nmf.py:64-88) is not implemented; pass `step`")
     A, S = X
     Yd = np.zeros((A.shape[0], S.shape[1]), dtype=np.float32)
     with _device_for(A, S, Yd) as dev:

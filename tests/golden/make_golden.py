@@ -304,6 +304,46 @@ def write_unmixing_fixture():
     print("wrote unmixing.npz")
 
 
+def write_weighted_fixture():
+    """Weighted likelihood W (M x N array; nmf.py:13-41) through nmf(): adaprox (its step rule ignores W) and pgm with a
+    user step.  pgm's default step rule tests `W == 1` on the array (nmf.py:63) and raises: the exception type is recorded."""
+    blob, meta = {}, {"cases": {}, "numpy": np.__version__, "reference": "proxmin 0.6.12"}
+    for tag, (M, N, K, dtype) in {"f64": (40, 56, 4, np.float64), "f32": (64, 96, 8, np.float32)}.items():
+        rng = np.random.default_rng(4321)
+        Y, A0, S0 = problem(M, N, K, dtype, False, 4321)
+        W = (0.2 + 1.8 * rng.random((M, N))).astype(dtype)
+        W[rng.random((M, N)) < 0.1] = 0                      # masked entries
+        blob[tag + "/Y"], blob[tag + "/A0"], blob[tag + "/S0"], blob[tag + "/W"] = Y, A0, S0, W
+        blob[tag + "/loss0"] = rnmf.log_likelihood(A0, S0, Y=Y, W=W)
+        gA, gS = rnmf.grad_likelihood(A0, S0, Y=Y, W=W)
+        blob[tag + "/gA0"], blob[tag + "/gS0"] = gA, gS
+        s_const = float(0.5 / max(np.linalg.eigvalsh(S0 @ S0.T)[-1], np.linalg.eigvalsh(A0.T @ A0)[-1]) / max(W.max(), 1.0))
+        runs = {
+            "amsgrad": dict(algorithm=ralg.adaprox, scheme="amsgrad", check_convergence=False),
+            "adam_unityS": dict(algorithm=ralg.adaprox, scheme="adam", check_convergence=False,
+                                prox_S=partial(rops.prox_unity_plus, axis=0)),
+            "pgm_const_step": dict(algorithm=ralg.pgm, step=lambda *X, it=None: (s_const, s_const)),
+        }
+        for name, kw in runs.items():
+            A, S = A0.copy(), S0.copy()
+            tb = rutils.Traceback()
+            rnmf.nmf(Y, A, S, W=W, max_iter=10, e_rel=1e-6, callback=tb, **kw)
+            key = "%s/%s" % (tag, name)
+            blob[key + "/A"], blob[key + "/S"] = A, S
+            blob[key + "/loss"] = rnmf.log_likelihood(A, S, Y=Y, W=W)
+            blob[key + "/n_callbacks"] = len(tb.trace)
+            print("  weighted %-4s %-16s loss=%.9g its=%d" % (tag, name, blob[key + "/loss"], len(tb.trace)))
+        meta["cases"][tag] = {"M": M, "N": N, "K": K, "s_const": s_const}
+        try:
+            rnmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
+            meta["cases"][tag]["default_step_error"] = None
+        except Exception as e:   # noqa: BLE001
+            meta["cases"][tag]["default_step_error"] = type(e).__name__
+    blob["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "weighted.npz"), **blob)
+    print("wrote weighted.npz", meta["cases"])
+
+
 if __name__ == "__main__":
     all_names = list(CASES)
     print("nmf 200x1000 K=5 fp64 (SURVEY section 4 table; inputs regenerated from seed by the tests)")
@@ -317,3 +357,4 @@ if __name__ == "__main__":
     write_operator_fixture()
     write_helper_fixture()
     write_unmixing_fixture()
+    write_weighted_fixture()

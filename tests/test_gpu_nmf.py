@@ -344,3 +344,37 @@ def test_full_size_modes_agree_and_loss_decreases():
         assert (ratio > 25).mean() <= 1e-4, (ratio > 25).mean()
         assert ratio.max() <= 1000, ratio.max()
     assert res["bf16x3"][2] == pytest.approx(res["f32"][2], rel=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_weighted_likelihood_matches_reference(pm, tag):
+    """W as an M x N array (nmf.py:13-41): loss, gradients, adaprox and pgm with a user step against the reference's
+    outputs (tests/golden/weighted.npz); the default pgm / bsdmm step rule raises ValueError like the reference."""
+    z, meta = load_golden("weighted.npz")
+    meta = meta["cases"][tag]
+    Y, A0, S0, W = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"], z[tag + "/W"]
+    assert pm.nmf.log_likelihood(A0, S0, Y=Y, W=W) == pytest.approx(float(z[tag + "/loss0"]), rel=2e-5)
+    gA, gS = pm.nmf.grad_likelihood(A0, S0, Y=Y, W=W)
+    np.testing.assert_allclose(gA, z[tag + "/gA0"], rtol=2e-5, atol=2e-5 * np.abs(z[tag + "/gA0"]).max())
+    np.testing.assert_allclose(gS, z[tag + "/gS0"], rtol=2e-5, atol=2e-5 * np.abs(z[tag + "/gS0"]).max())
+    sc = meta["s_const"]
+    runs = {
+        "amsgrad": dict(algorithm=pm.adaprox, scheme="amsgrad", check_convergence=False),
+        "adam_unityS": dict(algorithm=pm.adaprox, scheme="adam", check_convergence=False,
+                            prox_S=partial(pm.operators.prox_unity_plus, axis=0)),
+        "pgm_const_step": dict(algorithm=pm.pgm, step=pm.nmf.constant_step(sc, sc)),
+    }
+    for name, kw in runs.items():
+        A, S = A0.copy(), S0.copy()
+        tr = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A, S, W=W, max_iter=10, e_rel=1e-6, callback=tr, **kw)
+        key = "%s/%s" % (tag, name)
+        assert len(tr.trace) == int(z[key + "/n_callbacks"])
+        assert_factors_close(A, z[key + "/A"], Y.dtype, "%s A" % key)
+        assert_factors_close(S, z[key + "/S"], Y.dtype, "%s S" % key)
+        assert pm.nmf.log_likelihood(A, S, Y=Y, W=W) == pytest.approx(float(z[key + "/loss"]), rel=2e-3)
+    assert meta["default_step_error"] == "ValueError"
+    with pytest.raises(ValueError):
+        pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
+    with pytest.raises(ValueError):
+        pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2, algorithm=pm.bsdmm)

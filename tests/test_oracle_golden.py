@@ -168,3 +168,35 @@ def test_unmixing_known_answers():
         assert n == r["iters"], r["key"]
         assert orc.half_sq_residual(A, S, Y) == pytest.approx(r["loss"], rel=1e-8), r["key"]
         np.testing.assert_allclose(A, z[r["key"] + "/A"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_weighted_likelihood_matches_reference(tag):
+    """W as an M x N array (nmf.py:13-41): loss, gradients, adaprox (whose step rule ignores W) and pgm with a user
+    step reproduce the reference; pgm's default step rule raises like the reference does (`W == 1` on an array)."""
+    z, meta = load_golden("weighted.npz")
+    meta = meta["cases"][tag]
+    Y, A0, S0, W = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"], z[tag + "/W"]
+    tol = TOL[str(Y.dtype)]
+    assert orc.half_sq_residual(A0, S0, Y, W) == pytest.approx(float(z[tag + "/loss0"]), rel=tol["rtol"])
+    gA, gS = orc.residual_gradients(A0, S0, Y, W)
+    np.testing.assert_allclose(gA, z[tag + "/gA0"], **tol)
+    np.testing.assert_allclose(gS, z[tag + "/gS0"], **tol)
+    sc = meta["s_const"]
+    runs = {
+        "amsgrad": lambda A, S: orc.adaprox_nmf(Y, A, S, scheme="amsgrad", check_convergence=False, max_iter=10, e_rel=1e-6, W=W),
+        "adam_unityS": lambda A, S: orc.adaprox_nmf(Y, A, S, ("plus",), ("unity_plus", 0), scheme="adam", check_convergence=False,
+                                                    max_iter=10, e_rel=1e-6, W=W),
+        "pgm_const_step": lambda A, S: orc.pgm_nmf(Y, A, S, step=lambda a, s, it, g: (sc, sc), max_iter=10, e_rel=1e-6, W=W),
+    }
+    loose = dict(rtol=5e-3, atol=5e-4) if tag == "f32" else tol     # fp32 trajectories: see DESIGN.md section 2
+    for name, run in runs.items():
+        A, S = A0.copy(), S0.copy()
+        run(A, S)
+        key = "%s/%s" % (tag, name)
+        np.testing.assert_allclose(A, z[key + "/A"], err_msg=key, **loose)
+        np.testing.assert_allclose(S, z[key + "/S"], err_msg=key, **loose)
+        assert orc.half_sq_residual(A, S, Y, W) == pytest.approx(float(z[key + "/loss"]), rel=1e-3 if tag == "f32" else 1e-9)
+    assert meta["default_step_error"] == "ValueError"
+    with pytest.raises(ValueError):
+        orc.pgm_nmf(Y, A0.copy(), S0.copy(), max_iter=2, W=W)
