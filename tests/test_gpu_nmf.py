@@ -378,3 +378,25 @@ def test_weighted_likelihood_matches_reference(pm, tag):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
     with pytest.raises(ValueError):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2, algorithm=pm.bsdmm)
+
+
+@pytest.mark.parametrize("scheme", ["adamx", "adam"])
+def test_array_valued_b1_schedule(pm, orc, scheme):
+    """b1 given per iteration (algorithms.py:327-330); adamx also reads b1[it-1] (b1[-1] at it = 0, :213), which the
+    chained runner must feed across its chunk boundaries exactly like the one-iteration-per-call path."""
+    Y, A0, S0 = orc.synthetic_problem(300, 420, 8, np.float32, seed=21)
+    its = 20
+    # a slow decay: a fast one (0.97 ** it) makes the adaptive iteration itself unstable after ~14 iterations, and the fp32
+    # oracle and the device then part ways exponentially (1e-6 -> 1e-4 in five iterations) without either being wrong
+    b1 = 0.9 * 0.995 ** np.arange(its)
+    kw = dict(scheme=scheme, b1=b1, check_convergence=False)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, max_iter=its, e_rel=1e-3, **kw)
+    A2, S2 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A2, S2, algorithm=pm.adaprox, max_iter=its, e_rel=1e-3, callback=pm.utils.Traceback(), **kw)
+    np.testing.assert_array_equal(A, A2)
+    np.testing.assert_array_equal(S, S2)
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, max_iter=its, e_rel=1e-3, **kw)
+    assert_close_fp32_trajectory(A, Ao, scheme + " A")
+    assert_close_fp32_trajectory(S, So, scheme + " S")
