@@ -1,0 +1,105 @@
+"""GPU, world_size 2: TWO processes on the ONE visible GPU, gloo backend (it reduces CUDA tensors through the host;
+RCCL refuses two ranks on one device).  This runs the real HIP phase entry points with rank != 0 and world > 1 --
+row offsets, the global step rules from the all-reduced Gram matrix / column sums, the deferred stopping test --
+and checks every rank against the single-GPU nmf() of the whole problem.  The 8-GPU RCCL runs are the driver's."""
+import os
+import socket
+from functools import partial
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "adaprox_unity": dict(M=768, N=900, K=24, unity=True, its=9),
+    "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512: the split-bf16 v5 / f32 whole-block kernels
+    "pgm": dict(M=520, N=700, K=12, its=7),
+    "bsdmm": dict(M=480, N=640, K=10, its=6),
+}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import proxmin_amd as pm
+    from proxmin_amd import distributed as pdist
+    from oracle import nmf_oracle as orc
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pm.set_default_mode(mode)
+        c = CASES[name]
+        M, N, K = c["M"], c["N"], c["K"]
+        Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
+        r0, r1 = pdist.shard_rows(M, world)[rank]
+        A_l, S = A0[r0:r1].copy(), S0.copy()
+        ops = pm.operators
+        if name.startswith("adaprox"):
+            pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
+            conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme="amsgrad",
+                                                check_convergence=False, e_rel=1e-3, max_iter=c["its"])
+        elif name == "pgm":
+            conv, n = pdist.nmf_pgm_sharded(Y[r0:r1], A_l, S, M, e_rel=1e-9, max_iter=c["its"])
+        else:
+            pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
+            conv, n = pdist.nmf_bsdmm_sharded(Y[r0:r1], A_l, S, M, proxs_g=pgl, e_rel=1e-9, max_iter=c["its"])
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A_l, S=S, n=n, r0=r0, r1=r1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    g.build()
+    import proxmin_amd as pm
+    from oracle import nmf_oracle as orc
+    c = CASES[name]
+    M, N, K = c["M"], c["N"], c["K"]
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
+    ops = pm.operators
+    pm.set_default_mode(mode)
+    try:
+        A1, S1 = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        if name.startswith("adaprox"):
+            pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
+            pm.nmf.nmf(Y, A1, S1, algorithm=pm.adaprox, scheme="amsgrad", prox_S=pS, max_iter=c["its"], e_rel=1e-3,
+                       check_convergence=False, callback=tb)
+        elif name == "pgm":
+            pm.nmf.nmf(Y, A1, S1, max_iter=c["its"], e_rel=1e-9, callback=tb)
+        else:
+            pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
+            pm.nmf.nmf(Y, A1, S1, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=c["its"], e_rel=1e-9, callback=tb)
+    finally:
+        pm.set_default_mode("f32")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, mode, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "rank process failed (exit code %r)" % p.exitcode
+    S_ranks = []
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert int(z["n"]) == len(tb.trace)
+        # the all-reduce sums the ranks' gS in a different order than the single-GPU slab fold: fp32 rounding only
+        np.testing.assert_allclose(z["A"], A1[int(z["r0"]):int(z["r1"])], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(z["S"], S1, rtol=1e-4, atol=1e-5)
+        S_ranks.append(z["S"])
+    np.testing.assert_array_equal(S_ranks[0], S_ranks[1])      # replicated state stays bit-identical across ranks
