@@ -159,6 +159,8 @@ def main():
     M, N, K, backend, unity, desc = CONFIGS[args.config]
     if args.rows:
         M = args.rows
+    if "PMX_BENCH_DEVICE" in os.environ:      # test-only: several ranks on one GPU (see proxmin_amd/distributed.py)
+        local = int(os.environ["PMX_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

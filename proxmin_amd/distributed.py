@@ -18,6 +18,8 @@ from __future__ import annotations
 import ctypes as C
 import time
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -309,7 +311,11 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
 
     if backend != "adaprox":
         raise NotImplementedError("multi-GPU bench is implemented for the adaprox back-end (BASELINE cfg3/cfg4)")
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    # PMX_DIST_BACKEND / PMX_BENCH_DEVICE: test-only overrides (two ranks on one GPU over gloo; RCCL needs a GPU per rank)
+    dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    if "PMX_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["PMX_BENCH_DEVICE"])
+        torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     r0, r1 = shard_rows(M, world)[rank]
     Ml = r1 - r0
