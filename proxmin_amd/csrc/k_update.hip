@@ -819,6 +819,7 @@ __device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, doub
     if (threadIdx.x == 0) pub = a.status->sub_done[j] ? a.status->sub_tau[j] : 0;   // published by an earlier kernel
     __syncthreads();
     const int tau_pub = pub;
+    __syncthreads();   // `pub` is rewritten by the next call (k_ada_finish judges both blocks): every wave must have read it
     if (tau_pub > 0) return tau_pub;
     const int t0 = a.t - a.nt;
     const int w = threadIdx.x >> 6;

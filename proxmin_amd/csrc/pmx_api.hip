@@ -100,7 +100,9 @@ struct pmx_ctx {
     float omega_cur = 0.f;
     int nsub_guess = 2;
     int sub_nt = SUB_NT_MAX;               // proximal sub-iteration passes per launch (PMX_SUB_BATCH=1: one launch per pass)
-    int sub_enq = 0;                       // passes enqueued for the iteration in flight (row-sharded protocol)
+    // row-sharded protocol: per enqueued iteration (index & 63: far more than a caller keeps in flight) the launch
+    // size and the number of passes enqueued so far -- pmx_adaprox_more_subs continues the iteration the chain halted in
+    struct SubRec { int it = -1, nt = 0, enq = 0; } sub_rec[64];
     std::vector<void*> allocs;
 
     // K1 timing (HIP events on the launch stream)
@@ -960,6 +962,7 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
     c->it = 0;
     c->nsub_guess = 2;
     c->sub_nt = (getenv("PMX_SUB_BATCH") && atoi(getenv("PMX_SUB_BATCH")) == 1) ? 1 : SUB_NT_MAX;
+    for (auto& r : c->sub_rec) r = pmx_ctx::SubRec{};
     rc = reset_status(c);
     if (rc != PMX_OK) return rc;
     for (int j = 0; j < 2; ++j) {
@@ -1336,8 +1339,10 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
             const int ns = any_prox ? std::max(1, std::min(nsub, p.prox_max_iter)) : 0;
             if (c->sub_nt != 1) c->sub_nt = ns <= 4 ? 4 : SUB_NT_MAX;   // fixed for this iteration (pmx_adaprox_more_subs continues with it)
-            c->sub_enq = ada_enqueue_subs(c, 0, ns);
-            return ada_enqueue_tail(c, c->sub_enq);
+            pmx_ctx::SubRec& r = c->sub_rec[it & 63];
+            r.it = it; r.nt = c->sub_nt;
+            r.enq = ada_enqueue_subs(c, 0, ns);
+            return ada_enqueue_tail(c, r.enq);
         }
         case 2: return shard_pack(c, 0);
         case 3: return shard_post(c, 1);
@@ -1492,10 +1497,17 @@ extern "C" int pmx_adaprox_more_subs(pmx_ctx* c, int t0, int n) {
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
     rc = clear_halt(c);
     if (rc != PMX_OK) return rc;
-    // launches cover whole groups of sub_nt passes: continue from what was really enqueued (>= the caller's t0)
+    // Launches cover whole groups of `nt` passes, so the count really enqueued for the halted iteration is kept here
+    // (the caller's t0 is its own, un-rounded tally), per iteration: the caller re-enqueues the iterations that
+    // followed the halted one before it learns that one of them halted in turn.
     (void)t0;
-    c->sub_enq = ada_enqueue_subs(c, c->sub_enq, n);
-    return ada_enqueue_tail(c, c->sub_enq);
+    const int it_halted = c->hstatus->it_done;           // refreshed by the pmx_chain_status call that reported the halt
+    pmx_ctx::SubRec& r = c->sub_rec[it_halted & 63];
+    if (r.it != it_halted) FAIL(PMX_E_STATE, "iteration %d has not been enqueued by pmx_adaprox_phase(1)", it_halted);
+    c->sub_nt = r.nt;
+    const int t_to = ada_enqueue_subs(c, r.enq, n);
+    r.enq = t_to;
+    return ada_enqueue_tail(c, t_to);
 }
 
 extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {

@@ -99,6 +99,8 @@ class ShardedAdaproxDriver:
                 before = it_done
                 halted, reason, it_done, tau = self.eng.chain_status()
                 if it_done > before:
+                    if self.any_prox:   # the iterations re-enqueued from here on start from the count the last one took
+                        self.nsub = max(2, min(max(tau), self.prox_max_iter))
                     t_enq = self.nsub
             self.it = it_done
             if self.any_prox:
