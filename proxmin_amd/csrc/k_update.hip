@@ -639,20 +639,31 @@ struct AlphaArgs {
     float fixed[2];
     const float* comm_colsum;  // row-sharded runs: all-reduced column sums of A (K floats), else nullptr
 };
-__device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
-    // thread t: component t & 127, block group t >> 7; fixed-order two-level sum of the per-workgroup partials
-    __shared__ double asum[EW_THREADS / MAXK][MAXK];
+// Column sums of block j from the per-workgroup partials, by the whole workgroup (EW_THREADS = 8 groups x MAXK
+// components): thread (k, grp) adds partials grp, grp + 8, ... in that order, then the 8 group sums are added in
+// order.  All of a thread's loads are issued before the first add: the partials were written by other XCDs'
+// workgroups, every access is a trip to memory, and a load-add-load-add loop made this the longest part of the
+// single-workgroup kernels (k_ada_decide: 18 us).  Result in asum[0..NG)[k]; ends with a barrier.
+constexpr int ALPHA_NG = EW_THREADS / MAXK;
+__device__ __forceinline__ void colsum_fold(const double* colpart_j, int K, bool skip, double (*asum)[MAXK]) {
     const int t = threadIdx.x, k = t & (MAXK - 1), grp = t >> 7;
-    constexpr int NG = EW_THREADS / MAXK;
+    constexpr int PER = EW_BLOCKS / ALPHA_NG;
+    double v[PER];
+    const bool on = k < K && !skip;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = on ? colpart_j[(int64_t)(grp + ALPHA_NG * i) * MAXK + k] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    __syncthreads();
+    asum[grp][k] = s;
+    __syncthreads();
+}
+__device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
+    __shared__ double asum[ALPHA_NG][MAXK];
+    const int t = threadIdx.x;
     for (int j = 0; j < 2; ++j) {
-        double s = 0.0;
-        if (k < a.K && !a.use_fixed && !(j == 0 && a.comm_colsum != nullptr)) {
-            const double* p = a.colpart + (int64_t)j * EW_BLOCKS * MAXK + k;
-            for (int b = grp; b < EW_BLOCKS; b += NG) s += p[(int64_t)b * MAXK];
-        }
-        __syncthreads();
-        asum[grp][k] = s;
-        __syncthreads();
+        colsum_fold(a.colpart + (int64_t)j * EW_BLOCKS * MAXK, a.K, a.use_fixed || (j == 0 && a.comm_colsum != nullptr), asum);
         if (t < a.K) {
             float al;
             if (a.use_fixed) al = a.fixed[j];
@@ -660,7 +671,7 @@ __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
                 double tot = 0.0;
                 if (j == 0 && a.comm_colsum != nullptr) tot = (double)a.comm_colsum[t];
                 else
-                    for (int q = 0; q < NG; ++q) tot += asum[q][t];
+                    for (int q = 0; q < ALPHA_NG; ++q) tot += asum[q][t];
                 al = (float)(tot / (double)a.rows_global[j]) / 10.f;
             }
             a.status->alpha[j][t] = al;
@@ -1273,12 +1284,11 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
         else
             for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
         float* cs = ex + a.KP * a.KP;
+        __shared__ double asum[ALPHA_NG][MAXK];
+        colsum_fold(a.colpart, K, false, asum);   // block 0
         if (t < MAXK) {
             double s = 0.0;
-            if (t < K) {
-                const double* p = a.colpart + t;   // block 0
-                for (int b = 0; b < EW_BLOCKS; ++b) s += p[(int64_t)b * MAXK];
-            }
+            for (int q = 0; q < ALPHA_NG; ++q) s += asum[q][t];
             cs[t] = (float)s;
         }
         float* sc = cs + MAXK;
