@@ -137,8 +137,10 @@ int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
 int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
 
 /* ---- measurement --------------------------------------------------------------------------
- * With timing on, every launch of the fused residual-gradient kernel (K1) is bracketed by HIP
- * events on the context's stream; pmx_get_timing returns their summed duration and count since
+ * With timing on, launches of the fused residual-gradient kernel (K1) are bracketed by HIP events
+ * on the context's stream -- every launch for on == 1, every on-th launch for on > 1 (a pair of
+ * event records costs several microseconds of stream time, which matters inside a timed loop);
+ * pmx_get_timing returns the summed duration and count of the bracketed launches since
  * the last pmx_set_timing(ctx, 1) (synchronises the stream).  bench.py derives roofline.achieved
  * from it. */
 int pmx_set_timing(pmx_ctx* ctx, int on);

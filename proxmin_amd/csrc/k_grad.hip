@@ -54,7 +54,9 @@ constexpr int GRAD_THREADS = 512;
 // ((i&3) + 8*(i>>2) + 4*(l>>5), l&31)
 __device__ __forceinline__ int tile_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
-template <int KP>
+// HASW: weighted likelihood (a.W != nullptr).  A template switch, not a run-time branch: the per-element weight
+// addresses in the unweighted instantiation cost it ~100 spilled VGPRs (K1 1.03 -> 1.43 ms at 16384 x 16384 x 64)
+template <int KP, bool HASW>
 __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
     using C = GradCfg<KP>;
     constexpr int BN = C::BN;
@@ -232,13 +234,18 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
 #pragma unroll
         for (int t = 0; t < C::G1T; ++t) {
             const int lc = (g1_nt0 + t) * 32 + l31;
+            // weights: ONE 64-bit row pointer per tile and 32-bit offsets within it (sixteen 64-bit addresses spill)
+            const int gr0 = prow0 + g1_mt * 32 + 4 * hi, gc = bcol0 + lc;
+            const float* wrow = nullptr;
+            if constexpr (HASW) wrow = a.W + (int64_t)gr0 * a.ldW + gc;
+            const int ldw = HASW ? (int)a.ldW : 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int lr = g1_mt * 32 + tile_row(i, lane);
                 float r = p[t][i];
-                if (a.W != nullptr) {        // weighted likelihood: loss 1/2 sum W d^2, D = W d  (uniform branch)
-                    const int gr = prow0 + lr, gc = bcol0 + lc;
-                    const float wv = (gr < M && gc < N) ? a.W[(int64_t)gr * a.ldW + gc] : 0.f;
+                if constexpr (HASW) {        // weighted likelihood: loss 1/2 sum W d^2, D = W d
+                    const int dr = (i & 3) + 8 * (i >> 2);           // tile_row(i, lane) - 4 * hi
+                    const float wv = (gr0 + dr < M && gc < N) ? wrow[dr * ldw] : 0.f;
                     lossAcc += wv * (r * r);
                     r *= wv;
                 } else {
@@ -348,25 +355,18 @@ GradPlan grad_plan_f32(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
-hipError_t grad_launch_f32(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
-    dim3 grid(p.gridX, p.gridY), block(GRAD_THREADS);
-    hipError_t e;
-    switch (p.KP) {
-        case 32:
-            e = hipFuncSetAttribute((const void*)k_grad_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_grad_f32<32>, grid, block, p.ldsBytes, stream, a);
-            break;
-        case 64:
-            e = hipFuncSetAttribute((const void*)k_grad_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_grad_f32<64>, grid, block, p.ldsBytes, stream, a);
-            break;
-        default:
-            e = hipFuncSetAttribute((const void*)k_grad_f32<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_grad_f32<128>, grid, block, p.ldsBytes, stream, a);
-            break;
-    }
+template <int KP, bool HASW>
+static hipError_t grad_launch_f32_t(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f32<KP, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_f32<KP, HASW>), dim3(p.gridX, p.gridY), dim3(GRAD_THREADS), p.ldsBytes, stream, a);
     return hipGetLastError();
+}
+hipError_t grad_launch_f32(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
+    const bool w = a.W != nullptr;
+    switch (p.KP) {
+        case 32: return w ? grad_launch_f32_t<32, true>(p, a, stream) : grad_launch_f32_t<32, false>(p, a, stream);
+        case 64: return w ? grad_launch_f32_t<64, true>(p, a, stream) : grad_launch_f32_t<64, false>(p, a, stream);
+        default: return w ? grad_launch_f32_t<128, true>(p, a, stream) : grad_launch_f32_t<128, false>(p, a, stream);
+    }
 }

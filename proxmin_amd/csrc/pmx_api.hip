@@ -107,6 +107,8 @@ struct pmx_ctx {
 
     // K1 timing (HIP events on the launch stream)
     bool timing = false;
+    int timing_stride = 1;                 // bracket every n-th launch (the two event records cost ~9 us of stream time)
+    unsigned timing_seq = 0;
     std::vector<hipEvent_t> ev;            // pairs
     size_t ev_used = 0;
 
@@ -231,6 +233,8 @@ extern "C" int pmx_set_timing(pmx_ctx* c, int on) {
         for (auto& e : c->ev) HIP_CHECK(hipEventCreate(&e));
     }
     c->timing = on != 0;
+    c->timing_stride = on > 1 ? on : 1;
+    c->timing_seq = 0;
     c->ev_used = 0;
     return PMX_OK;
 }
@@ -413,7 +417,7 @@ static int clear_halt(pmx_ctx* c) {
 }
 
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS) {
-    const bool timed = c->timing && c->ev_used + 2 <= c->ev.size();
+    const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
     if (c->use_bf16) {
         PresplitArgs ps{};
         ps.X[0] = A; ps.X[1] = St;

@@ -129,11 +129,12 @@ class DeviceNMF:
         return out if j == 0 else out.T
 
     # -- measurement --------------------------------------------------------------------------
-    def set_timing(self, on=True):
-        _lib.check(self.lib.pmx_set_timing(self.h, int(bool(on))))
+    def set_timing(self, on=True, every=1):
+        """Bracket K1 launches with HIP events on the launch stream (every `every`-th launch)."""
+        _lib.check(self.lib.pmx_set_timing(self.h, int(every) if on else 0))
 
     def get_timing(self):
-        """(summed K1 duration in ms, number of K1 launches) since set_timing(True)."""
+        """(summed K1 duration in ms, number of bracketed K1 launches) since set_timing(True)."""
         ms, n = C.c_double(), C.c_int()
         _lib.check(self.lib.pmx_get_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
