@@ -56,7 +56,7 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
     gbs = (M * N * 4) / t / 1e9
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
     # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
-    bf16_kernel = (("k_grad_bf16_v6" if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
+    bf16_kernel = (("k_grad_bf16_v7" if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
                    else "k_grad_bf16<%d>" % kp)
     if mode == "f32":
         return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,

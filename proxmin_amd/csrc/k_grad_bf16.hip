@@ -2284,6 +2284,382 @@ static hipError_t grad_launch_bf16_v6(const GradV4Args& a, hipStream_t stream) {
     return a.prof ? grad_launch_bf16_v6_t<true>(a, stream) : grad_launch_bf16_v6_t<false>(a, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_grad_bf16_v7 (K = 64, M % 128 == 0, N % 256 == 0): v6 with fewer joules per slot.
+//
+// K1 runs at the package power cap, so what is left to gain is work that need not be done:
+//   * the S terms of the region's 256 columns stay in LDS for the whole launch (8 blocks x 3 terms = 96 KB): v6
+//     re-split the same 32 x 64 block from fp32 on every row panel (a load, ~100 VALU instructions and six LDS writes per
+//     consumer wave and slot);
+//   * Y goes from HBM straight into registers in the accumulator's layout (16 dword loads per lane and block, two rows
+//     of 128 B per instruction, two blocks in flight per wave) instead of an LDS-DMA landing tile that is written and
+//     read back (32 KB of LDS traffic per slot and CU).  With no inline-asm requests left in the kernel every
+//     s_waitcnt vmcnt is the compiler's own exact count.
+// LDS: Sl 96 KB + Aimg 32 KB + R 32 KB = the full 160 KB of the CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int V7_OFF_A = V5_NB * V5_SL_BYTES, V7_OFF_R = V7_OFF_A + V5_AIMG_BYTES, V7_LDS_BYTES = V7_OFF_R + 2 * V5_R_BYTES;
+static_assert(V7_OFF_R % 256 == 0, "R images must start on a bank row");
+static_assert(V7_LDS_BYTES <= 160 * 1024, "");
+
+template <bool PROF>
+__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
+    constexpr int K = 64, ROWB = 128, NCB = V5_NB;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lq = lane >> 4;
+    const int M = a.M, N = a.N;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V5_BM;
+    const int col0 = colRegion * NCB * V5_BN;          // N % 256 == 0: every region has all 8 column blocks
+    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    const int T = nrp * NCB;                 // blocks of this region (even); slots = T + 2
+    const bool producer = w < 4;          // (the "no Y traffic" ablation switch of the older variants is not implemented here)
+    const int j = w & 3;                     // index within the role
+    float lossAcc = 0.f;
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+
+    if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
+        if (!producer) {
+            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            for (int c = 0; c < NCB; ++c)
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                    if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
+                }
+        }
+        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
+        return;
+    }
+
+    {   // ---- all S terms of the region, once: block cb -> Sl[cb] (all 512 threads, one float4 of each block) -------
+        const float4* ssrc = reinterpret_cast<const float4*>(a.St + (int64_t)col0 * K) + tid;
+        const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
+        float4 sr[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) sr[c] = ssrc[c * (V5_BN * K / 4)];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            bf16x4 t0, t1, t2;
+            v4_split3(sr[c], t0, t1, t2);
+            unsigned char* d = smem + c * V5_SL_BYTES + st_off;
+            *reinterpret_cast<bf16x4*>(d) = t0;
+            *reinterpret_cast<bf16x4*>(d + V5_S_TERM) = t1;
+            *reinterpret_cast<bf16x4*>(d + 2 * V5_S_TERM) = t2;
+        }
+    }
+
+    if (producer) {
+        // ================================ producers: GEMM1 and R =================================================
+        f32x16 p0, p1;
+        float yE[16], yO[16];                // Y of the even / odd blocks in flight (accumulator layout)
+        float4 areg[4][2];
+        bf16x8 afr[4][3];
+        // Y(b): wave-uniform base (scalar registers) + one per-lane offset; row i of the tile is a multiple of ldY further
+        const int jw = __builtin_amdgcn_readfirstlane(j);
+        const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
+        const unsigned ylane = (unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31;
+        auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
+            int brp = b >> 3;
+            if (brp >= nrp) brp = nrp - 1;
+            const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane];
+        };
+        auto load_A = [&](int prow) {
+            const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                areg[ks][0] = src[ks * 4];
+                areg[ks][1] = src[ks * 4 + 1];
+            }
+        };
+        auto make_afr = [&]() {              // split the panel rows into bf16 terms (register fragments of GEMM1's A operand)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
+                                    areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const __bf16 t0 = (__bf16)x[q];
+                    const float e1 = x[q] - (float)t0;
+                    const __bf16 t1 = (__bf16)e1;
+                    afr[ks][0][q] = t0;
+                    afr[ks][1][q] = t1;
+                    afr[ks][2][q] = (__bf16)(e1 - (float)t1);
+                }
+            }
+        };
+        auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
+            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                *reinterpret_cast<bf16x8*>(smem + V7_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<bf16x8*>(smem + V7_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
+            }
+        };
+        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
+        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
+        load_A(row0);
+        load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
+        load_Y(1, yO);
+        make_afr();
+        if (nrp > 1) load_A(row0 + V5_BM);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();        // Sl published
+
+        // One slot.  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
+        auto slot = [&](int s, f32x16& pc, f32x16& pp, float (&y)[16], auto gemm_c, auto epi_c) {
+            constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
+            const int cb = s & 7, rp = s >> 3;       // block s = (rp, cb); NCB == 8
+            if (cb == 2 && rp < nrp) {                   // block s-2 opened this row panel: the consumers start on it in this slot
+                publish_A();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
+            PH(5)
+            if constexpr (GEMM) {
+                if (cb == 0 && s > 0) {      // block s opens a row panel: its A terms (rows requested 8 slots ago)
+                    make_afr();
+                    if (rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
+                }
+            }
+            bf16x8 sv[4][3];
+            if constexpr (GEMM) {
+                const unsigned char* Slb = smem + cb * V5_SL_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int so = s_g1 ^ (ks << 5);
+                    sv[ks][0] = *reinterpret_cast<const bf16x8*>(Slb + so);
+                    sv[ks][1] = *reinterpret_cast<const bf16x8*>(Slb + so + V5_S_TERM);
+                    sv[ks][2] = *reinterpret_cast<const bf16x8*>(Slb + so + 2 * V5_S_TERM);
+                }
+            }
+            PH(2)
+            if constexpr (GEMM) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], sv[ks][0], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], sv[ks][1], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][2], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], sv[ks][0], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][1], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][0], pc, 0, 0, 0);
+                }
+            }
+            if constexpr (EPI) {
+                unsigned char* Rb = smem + V7_OFF_R + ((s - 1) & 1) * V5_R_BYTES;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float r = pp[4 * g + q] - y[4 * g + q];
+                        lossAcc += r * r;
+                        const __bf16 hh = (__bf16)r;
+                        h[q] = hh;
+                        l[q] = (__bf16)(r - (float)hh);
+                    }
+                    const int o = r_w ^ (g << 4);
+                    *reinterpret_cast<bf16x4*>(Rb + o) = h;
+                    *reinterpret_cast<bf16x4*>(Rb + V5_R_TERM + o) = l;
+                }
+                load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+            }
+            PH(3)
+            PH(4)
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
+            __builtin_amdgcn_s_barrier();
+            PH(0)
+        };
+        using yes = std::integral_constant<bool, true>;
+        using no = std::integral_constant<bool, false>;
+        slot(0, p0, p1, yO, yes{}, no{});
+#pragma nounroll
+        for (int s = 1; s + 1 < T; s += 2) {
+            slot(s, p1, p0, yE, yes{}, yes{});
+            slot(s + 1, p0, p1, yO, yes{}, yes{});
+        }
+        slot(T - 1, p1, p0, yE, yes{}, yes{});
+        slot(T, p0, p1, yO, no{}, yes{});
+        slot(T + 1, p1, p0, yE, no{}, no{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();              // Sl published
+
+        f32x16 accS[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
+        f32x16 accA0, accA1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+        const int kt = j & 1, mh = j >> 1;   // GEMM3 tile; GEMM2: rows 32j.., both k tiles
+        int r_t0, r_t1;                      // GEMM2 A operand (R, transposing read)
+        {
+            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
+            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+        }
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
+        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
+        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
+        auto flush_gA = [&](int prow) {
+            float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float* ph_ = p0_ + half * 16 * K;
+                asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
+                    const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                    ph_[ro] = accA0[i];
+                    ph_[ro + 32] = accA1[i];
+                }
+            }
+        };
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            PH(9)
+        };
+        auto consume = [&](int b, int rp, int cb, f32x16& accSc) {     // block b = (rp, cb)
+            const int prow = row0 + rp * V5_BM;
+            const unsigned char* Rb = smem + V7_OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + cb * V5_SL_BYTES;
+            const unsigned char* Ab = smem + V7_OFF_A;
+            if (a.doA & 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const bf16x8 r1 = v3_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+                    const bf16x8 s00 = v3_tr_pair(Slb, so0, so1);
+                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so0, so1);
+                    const bf16x8 s10 = v3_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
+                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s10, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s01, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s11, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s10, accA1, 0, 0, 0);
+                }
+            }
+            PH(6)
+            if (a.doS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ro = r_g3 ^ (ks << 5);
+                    const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);
+                    const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V5_R_TERM + ro);
+                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
+                    const bf16x8 a0 = v3_tr_pair(Ab, ao0, ao1);
+                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao0, ao1);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);
+                }
+            }
+            if ((a.doA & 1) && cb + 1 == NCB) {
+                flush_gA(prow);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+            }
+        };
+        sync();
+        sync();
+        int s = 2;
+#pragma nounroll
+        for (int rp = 0; rp < nrp; ++rp) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                }
+                consume(s - 2, rp, cb, accS[cb]);
+                PH(7)
+                sync();
+                ++s;
+            }
+        }
+        if (a.doS) {
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            const int kk = kt * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const int bcol = col0 + c * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = bcol + tile_row(i, lane);
+                    dst[(int64_t)gn * K + kk] = accS[c][i];
+                }
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 4; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
+#undef PH
+}
+
+template <bool PROF>
+static hipError_t grad_launch_bf16_v7_t(const GradV4Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v7<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_grad_bf16_v7<PROF>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V7_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+static hipError_t grad_launch_bf16_v7(const GradV4Args& a, hipStream_t stream) {
+    return a.prof ? grad_launch_bf16_v7_t<true>(a, stream) : grad_launch_bf16_v7_t<false>(a, stream);
+}
+
 template <int KP>
 static size_t pipe_lds_bytes() {
     constexpr int NW = BG_THREADS / 64;
@@ -2311,8 +2687,9 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     p.BN = BG_BN;
     // PMX_K1_VARIANT (read per context; tuning A/B and the variant tests): 0 guarded kernel only, 1 LDS-DMA pipeline
     // 128 x 64 / 8 waves, 3 LDS-DMA 64 x 64 / 4 waves x 2 per CU, 4 fp32 operands split in-kernel, 5 the same with
-    // producer / consumer wavefronts, 6 (default) those with the deeper pipeline (N % 256 == 0, else 5)
-    p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 6;
+    // producer / consumer wavefronts, 6 those with the deeper pipeline, 7 (default) 6 with resident S terms and Y loaded
+    // straight into registers (6 and 7: N % 256 == 0, else 5)
+    p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 7;
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
     p.gridY = (int)((N + (int64_t)BG_CB * BG_BN - 1) / ((int64_t)BG_CB * BG_BN));
@@ -2357,6 +2734,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
+        if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         if (variant >= 6 && dma_ok && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v6(g, stream);
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }
