@@ -167,6 +167,7 @@ def main():
 
     if world > 1 or os.environ.get("PMX_FORCE_SHARDED"):
         from proxmin_amd import distributed as pdist
+        args.mode_dtype, args.mode_desc = MODE_DTYPE, MODE_DESC
         out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
         if rank == 0:
             print(json.dumps(out))

@@ -233,8 +233,8 @@ def test_full_size_gradient_properties(eng):
 @pytest.mark.parametrize("pitch_extra,offset", [(0, 0), (64, 0), (3, 0), (64, 1)])
 def test_zero_copy_Y_with_row_pitch_and_alignment(eng, orc, pitch_extra, offset):
     """Y adopted zero-copy from a device pointer (pmx_set_Y_device, copy=0) with a row pitch larger than N and with /
-    without 16-byte alignment: aligned pitches take the LDS-DMA producer/consumer kernel, the others fall back to
-    the plain-load variant -- same gradients either way."""
+    without 16-byte alignment (the default split-bf16 kernel loads Y with dword loads and takes any pitch; the LDS-DMA
+    variants need 16-byte aligned rows and fall back otherwise) -- same gradients either way."""
     import torch
     M, N, K = 512, 768, 64
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=77)
