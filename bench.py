@@ -30,6 +30,7 @@ CONFIGS = {
     # name: (M, N, K, backend, unity_S, description)
     "cfg2": (4096, 4096, 32, "pgm", False, "Y 4096x4096, K=32, prox_plus, PGM, fp32"),
     "cfg3": (16384, 16384, 64, "adaprox", True, "Y 16384x16384, K=64, adaprox/AMSGrad, prox_plus(A) + prox_unity_plus(S columns)"),
+    "cfg4": (65536, 16384, 128, "adaprox", False, "Y 65536x16384, K=128, adaprox/AMSGrad, prox_plus (BASELINE's 8-GPU case; K > 64 runs the exact-fp32 K1)"),
     "cfg5": (16384, 16384, 64, "bsdmm", False, "Y 16384x16384, K=64, bSDMM, proxs_g=[prox_plus, prox_soft(1e-3)] per factor"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -138,6 +139,19 @@ def cpu_baseline(M, N, K, backend, unity, budget_s=20.0):
                       "%d iterations, median of iterations 1..%d, scaled by %g to the full row count" % (Ms, M, n_iter, n_iter - 1, M / Ms)}
 
 
+def emit(out):
+    """The ONE JSON line, as the LAST line of stdout: libraries that write through C stdio (RCCL's version banner) have
+    their buffer flushed first, and the process leaves without running exit-time destructors that could print more."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +184,7 @@ def main():
         args.mode_dtype, args.mode_desc = MODE_DTYPE, MODE_DESC
         out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
 
     from proxmin_amd.engine import DeviceNMF
@@ -216,7 +230,7 @@ def main():
         out["roofline"]["traffic_unit"] = "bytes per K1 launch (algorithmic: %d)" % (M * N * 4)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(M, N, K, backend, unity)
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
