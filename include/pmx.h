@@ -123,8 +123,9 @@ int pmx_set_Y_host(pmx_ctx* ctx, const float* Y, int64_t ld);
 int pmx_set_Y_device(pmx_ctx* ctx, const float* dY, int64_t ld, int copy);
 /* Weighted likelihood: W is the M x N weight array of nmf.log_likelihood / grad_likelihood (proxmin/nmf.py:13-41),
  * loss = 1/2 sum W (Y - A S)^2, D = W (A S - Y).  Row-major float32, leading dimension ld >= N.  Without a call
- * W == 1 (the reference's default).  The context must have been created with PMX_MODE_F32: the weighted pass
- * runs on the exact-fp32 kernel (PMX_E_UNSUPPORTED otherwise).  pmx_set_W_host(ctx, NULL, 0) goes back to W == 1.
+ * W == 1 (the reference's default).  A PMX_MODE_F32 context takes weights at any shape; a split-bf16 context where its
+ * default kernel applies (K = 64, M % 128 == 0, N % 256 == 0) and fails with PMX_E_UNSUPPORTED elsewhere (the caller then
+ * creates an F32 context: proxmin_amd/engine.py:open_weighted).  pmx_set_W_host(ctx, NULL, 0) goes back to W == 1.
  * The default PGM / bSDMM step rule does not exist for an array W (nmf.step_pgm tests `W == 1` on it and raises,
  * nmf.py:63): pmx_pgm_begin without fixed or Barzilai-Borwein steps and pmx_bsdmm_begin fail with PMX_E_INVALID.   */
 int pmx_set_W_host(pmx_ctx* ctx, const float* W, int64_t ld);

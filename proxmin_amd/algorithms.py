@@ -15,7 +15,7 @@ from functools import partial
 import numpy as np
 
 from . import _lib, operators, utils
-from .engine import DeviceNMF
+from .engine import DeviceNMF, open_weighted
 
 logger = logging.getLogger("proxmin")
 
@@ -38,11 +38,9 @@ def _problem_from_grad(X, grad):
 
 
 def _open_device(Y, A, S, W):
-    """Context for one solver call; a weighted likelihood (nmf.py:13-41) runs the exact-fp32 kernel."""
-    dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32" if W is not None else None)
+    """Context for one solver call; weights (nmf.py:13-41): engine.open_weighted picks the kernel."""
+    dev = open_weighted(A.shape[0], S.shape[1], A.shape[1], W)
     dev.set_Y(Y)
-    if W is not None:
-        dev.set_W(W)
     dev.set_factors(A, S)
     return dev
 

@@ -106,6 +106,8 @@ struct GradBfArgs {
     int doA, doS;        // doA bit 1: ablation switch "no Y traffic" (tuning only)
     int gridX, gridY;
     unsigned long long* prof;   // tuning only: per-phase cycle sums of wave 0 of every workgroup (nullptr = off)
+    const float* W;      // M x N weights (ldW) or nullptr for W == 1 (nmf.py:13-41); only the v7 variant takes them
+    int64_t ldW;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -1175,6 +1177,8 @@ struct GradV4Args {
     int doA, doS;
     int gridX, gridY;
     unsigned long long* prof;
+    const float* W;      // M x N weights (ldW) or nullptr; only k_grad_bf16_v7 takes them
+    int64_t ldW;
 };
 
 template <bool PROF>
@@ -2296,12 +2300,14 @@ static hipError_t grad_launch_bf16_v6(const GradV4Args& a, hipStream_t stream) {
 //     read back (32 KB of LDS traffic per slot and CU).  With no inline-asm requests left in the kernel every
 //     s_waitcnt vmcnt is the compiler's own exact count.
 // LDS: Sl 96 KB + Aimg 32 KB + R 32 KB = the full 160 KB of the CU.
+// HASW: weighted likelihood (nmf.py:13-41): the weights of a block travel like its Y values (a second pair of register
+// sets), loss = 1/2 sum W R^2 and D = W R is what gets split and parked for the gradient contractions.
 // ------------------------------------------------------------------------------------------------
 constexpr int V7_OFF_A = V5_NB * V5_SL_BYTES, V7_OFF_R = V7_OFF_A + V5_AIMG_BYTES, V7_LDS_BYTES = V7_OFF_R + 2 * V5_R_BYTES;
 static_assert(V7_OFF_R % 256 == 0, "R images must start on a bank row");
 static_assert(V7_LDS_BYTES <= 160 * 1024, "");
 
-template <bool PROF>
+template <bool PROF, bool HASW>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -2372,6 +2378,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         // ================================ producers: GEMM1 and R =================================================
         f32x16 p0, p1;
         float yE[16], yO[16];                // Y of the even / odd blocks in flight (accumulator layout)
+        float wE[HASW ? 16 : 1], wO[HASW ? 16 : 1];   // their weights
         float4 areg[4][2];
         bf16x8 afr[4][3];
         // Y(b): wave-uniform base (scalar registers) + one per-lane offset; row i of the tile is a multiple of ldY further
@@ -2384,6 +2391,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
 #pragma unroll
             for (int i = 0; i < 16; ++i) y[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane];
+        };
+        const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
+        const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
+        auto load_W = [&](int b, float (&wv)[HASW ? 16 : 1]) {
+            if constexpr (HASW) {
+                int brp = b >> 3;
+                if (brp >= nrp) brp = nrp - 1;
+                const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wv[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane];
+            }
         };
         auto load_A = [&](int prow) {
             const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
@@ -2422,13 +2440,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         load_A(row0);
         load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
         load_Y(1, yO);
+        load_W(0, wE);
+        load_W(1, wO);
         make_afr();
         if (nrp > 1) load_A(row0 + V5_BM);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
         // One slot.  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
-        auto slot = [&](int s, f32x16& pc, f32x16& pp, float (&y)[16], auto gemm_c, auto epi_c) {
+        auto slot = [&](int s, f32x16& pc, f32x16& pp, float (&y)[16], float (&wv)[HASW ? 16 : 1], auto gemm_c, auto epi_c) {
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
             const int cb = s & 7, rp = s >> 3;       // block s = (rp, cb); NCB == 8
             if (cb == 2 && rp < nrp) {                   // block s-2 opened this row panel: the consumers start on it in this slot
@@ -2475,8 +2495,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                     bf16x4 h, l;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float r = pp[4 * g + q] - y[4 * g + q];
-                        lossAcc += r * r;
+                        float r = pp[4 * g + q] - y[4 * g + q];
+                        if constexpr (HASW) {
+                            const float ww = wv[4 * g + q];
+                            lossAcc += ww * (r * r);
+                            r *= ww;
+                        } else {
+                            lossAcc += r * r;
+                        }
                         const __bf16 hh = (__bf16)r;
                         h[q] = hh;
                         l[q] = (__bf16)(r - (float)hh);
@@ -2486,6 +2512,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                     *reinterpret_cast<bf16x4*>(Rb + V5_R_TERM + o) = l;
                 }
                 load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+                load_W(s + 1, wv);
             }
             PH(3)
             PH(4)
@@ -2495,15 +2522,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         };
         using yes = std::integral_constant<bool, true>;
         using no = std::integral_constant<bool, false>;
-        slot(0, p0, p1, yO, yes{}, no{});
+        slot(0, p0, p1, yO, wO, yes{}, no{});
 #pragma nounroll
         for (int s = 1; s + 1 < T; s += 2) {
-            slot(s, p1, p0, yE, yes{}, yes{});
-            slot(s + 1, p0, p1, yO, yes{}, yes{});
+            slot(s, p1, p0, yE, wE, yes{}, yes{});
+            slot(s + 1, p0, p1, yO, wO, yes{}, yes{});
         }
-        slot(T - 1, p1, p0, yE, yes{}, yes{});
-        slot(T, p0, p1, yO, no{}, yes{});
-        slot(T + 1, p1, p0, yE, no{}, no{});
+        slot(T - 1, p1, p0, yE, wE, yes{}, yes{});
+        slot(T, p0, p1, yO, wO, no{}, yes{});
+        slot(T + 1, p1, p0, yE, wE, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
@@ -2649,15 +2676,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF>
+template <bool PROF, bool HASW>
 static hipError_t grad_launch_bf16_v7_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v7<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v7<PROF, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_bf16_v7<PROF>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V7_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_bf16_v7<PROF, HASW>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V7_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_bf16_v7(const GradV4Args& a, hipStream_t stream) {
-    return a.prof ? grad_launch_bf16_v7_t<true>(a, stream) : grad_launch_bf16_v7_t<false>(a, stream);
+    if (a.W != nullptr) return grad_launch_bf16_v7_t<false, true>(a, stream);   // (no phase profiling of the weighted instance)
+    return a.prof ? grad_launch_bf16_v7_t<true, false>(a, stream) : grad_launch_bf16_v7_t<false, false>(a, stream);
 }
 
 template <int KP>
@@ -2716,9 +2744,14 @@ static hipError_t grad_launch_bf16_t(const GradPlan& p, const GradBfArgs& a, hip
     return hipGetLastError();
 }
 
+// true when the split-bf16 path of this shape accepts a weighted likelihood (k_grad_bf16_v7<.., HASW = true>)
+bool grad_bf16_takes_weights(const GradPlan& p, int64_t M, int64_t N, int64_t K);
 // true when the launch below will take the variant that reads A and St as fp32 (no presplit pass needed)
 bool grad_bf16_reads_fp32(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
     return p.variant >= 4 && p.KP == 64 && K == 64 && (M % V4_BM) == 0 && (N % V4_BN) == 0;
+}
+bool grad_bf16_takes_weights(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
+    return grad_bf16_reads_fp32(p, M, N, K) && p.variant >= 7 && (N % (V5_NB * V5_BN)) == 0;
 }
 hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float* A, const float* St, hipStream_t stream, int* nloss) {
     GradBfArgs a = a_;
@@ -2732,12 +2765,15 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.slabA = a.slabA; g.slabS = a.slabS; g.lossPart = a.lossPart; g.status = a.status;
         g.M = a.M; g.N = a.N; g.RP = a.RP; g.doA = a.doA; g.doS = a.doS;
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
+        g.W = a.W; g.ldW = a.ldW;
+        if (a.W != nullptr && !(variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0)) return hipErrorInvalidValue;   // see grad_bf16_takes_weights
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         if (variant >= 6 && dma_ok && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v6(g, stream);
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }
+    if (a.W != nullptr) return hipErrorInvalidValue;
     // Whole blocks with 16-byte-aligned rows take an LDS-DMA variant; anything else the guarded kernel.
     const bool aligned = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
     const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || !aligned;

@@ -303,7 +303,8 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!W) { c->W = nullptr; c->ldW = 0; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
-    if (c->use_bf16) FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood needs a context created with PMX_MODE_F32");
+    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
+        FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in split-bf16 mode needs K = 64, M %% 128 = 0, N %% 256 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     HIP_CHECK(hipSetDevice(c->device));
     if (from_host || copy) {
@@ -436,6 +437,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         g.prof = c->k1prof;
+        g.W = c->W; g.ldW = c->ldW;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
     } else {

@@ -89,7 +89,9 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_set_Y_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
 
     def set_W(self, W):
-        """Weights of the likelihood (nmf.py:13-41), an M x N array; None goes back to W == 1.  Needs mode "f32"."""
+        """Weights of the likelihood (nmf.py:13-41), an M x N array; None goes back to W == 1.  Mode "f32" takes any
+        shape; the split-bf16 mode only those of its default kernel (K = 64, M % 128 = 0, N % 256 = 0) and raises
+        NotImplementedError otherwise -- see open_weighted()."""
         if W is None:
             _lib.check(self.lib.pmx_set_W_host(self.h, None, 0))
             return
@@ -225,3 +227,19 @@ class DeviceNMF:
         r = _lib.Result()
         _lib.check(self.lib.pmx_bsdmm_run(self.h, int(n_iter), C.byref(r)))
         return r
+
+
+def open_weighted(M, N, K, W, **kw):
+    """Context for a weighted likelihood: the default arithmetic mode where its kernel takes weights, exact fp32
+    otherwise (never a CPU path: both are device kernels)."""
+    dev = DeviceNMF(M, N, K, **kw)
+    if W is None:
+        return dev
+    try:
+        dev.set_W(W)
+        return dev
+    except NotImplementedError:
+        dev.close()
+    dev = DeviceNMF(M, N, K, **dict(kw, mode="f32"))
+    dev.set_W(W)
+    return dev

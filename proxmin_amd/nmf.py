@@ -17,7 +17,7 @@ from functools import partial
 import numpy as np
 
 from . import algorithms, operators
-from .engine import DeviceNMF
+from .engine import DeviceNMF, open_weighted
 
 logger = logging.getLogger("proxmin")
 
@@ -37,12 +37,10 @@ def _weights(W, shape):
 
 
 def _device_for(A, S, Y, W=None):
-    """Context with Y (and W) and the factors on the device.  A weighted likelihood runs the exact-fp32 kernel."""
+    """Context with Y (and W) and the factors on the device (weights: engine.open_weighted picks the kernel)."""
     A, S, Y = np.asarray(A), np.asarray(S), np.asarray(Y)
-    dev = DeviceNMF(Y.shape[0], Y.shape[1], A.shape[1], mode="f32" if W is not None else None)
+    dev = open_weighted(Y.shape[0], Y.shape[1], A.shape[1], W)
     dev.set_Y(Y)
-    if W is not None:
-        dev.set_W(W)
     dev.set_factors(A, S)
     return dev
 

@@ -280,10 +280,10 @@ def test_split_bf16_default_kernel_on_many_region_shapes(eng):
         assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)
 
 
-@pytest.mark.parametrize("M,N,K", [(33, 47, 3), (257, 513, 33), (1024, 640, 64), (384, 1100, 100), (512, 512, 128)])
+@pytest.mark.parametrize("M,N,K", [(33, 47, 3), (257, 513, 33), (1024, 640, 64), (1024, 768, 64), (2304, 4096, 64), (384, 1100, 100), (512, 512, 128)])
 def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
     """D = W (A S - Y), loss = 1/2 sum W (Y - A S)^2 (nmf.py:13-41) with an M x N weight array incl. zero (masked)
-    entries, ragged and whole-block shapes; a bf16x3 context refuses weights (they run on the exact-fp32 kernel)."""
+    entries, ragged and whole-block shapes, in both arithmetic modes (split-bf16: the shapes of its default kernel)."""
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N + K)
     rng = np.random.default_rng(5)
     W = (0.1 + 2.0 * rng.random((M, N))).astype(np.float32)
@@ -304,7 +304,17 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
     uA, uS = orc.residual_gradients(A64, S64, Y64)
     np.testing.assert_allclose(gA1, uA, rtol=2e-5, atol=2e-5 * np.abs(uA).max())
     if K <= 64:
+        # the split-bf16 mode takes weights where its default kernel applies, and says so loudly elsewhere
         with eng.DeviceNMF(M, N, K, mode="bf16x3") as dev:
             dev.set_Y(Y)
-            with pytest.raises(NotImplementedError):
+            if K == 64 and M % 128 == 0 and N % 256 == 0:
                 dev.set_W(W)
+                dev.set_factors(A, S)
+                bA, bS = dev.grad()
+                bloss = dev.loglike()
+                np.testing.assert_allclose(bA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+                np.testing.assert_allclose(bS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+                assert bloss == pytest.approx(orc.half_sq_residual(A64, S64, Y64, W64), rel=2e-5)
+            else:
+                with pytest.raises(NotImplementedError):
+                    dev.set_W(W)

@@ -380,6 +380,25 @@ def test_weighted_likelihood_matches_reference(pm, tag):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2, algorithm=pm.bsdmm)
 
 
+def test_weighted_nmf_on_the_split_bf16_kernel_shape(pm, orc):
+    """A weighted adaprox run at a shape the default split-bf16 kernel takes (K = 64, M % 128 = 0, N % 256 = 0), so that
+    mode "bf16x3" really runs its own weighted kernel (the fixture's shapes fall back to the exact-fp32 one): factors
+    against the oracle after 8 iterations, masked entries (W = 0) included."""
+    M, N, K = 256, 768, 64
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=True, seed=91)
+    rng = np.random.default_rng(17)
+    W = (0.2 + rng.random((M, N))).astype(np.float32)
+    W[rng.random((M, N)) < 0.1] = 0
+    kw = dict(scheme="adam", check_convergence=False)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, W=W, algorithm=pm.adaprox, prox_S=partial(pm.operators.prox_unity_plus, axis=0), max_iter=8, e_rel=1e-3, **kw)
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), max_iter=8, e_rel=1e-3, W=W, **kw)
+    assert_factors_close(A, Ao, np.float32, "weighted A")
+    assert_factors_close(S, So, np.float32, "weighted S")
+    assert pm.nmf.log_likelihood(A, S, Y=Y, W=W) == pytest.approx(orc.half_sq_residual(Ao.astype(np.float64), So.astype(np.float64), Y.astype(np.float64), W.astype(np.float64)), rel=2e-3)
+
+
 @pytest.mark.parametrize("scheme", ["adamx", "adam"])
 def test_array_valued_b1_schedule(pm, orc, scheme):
     """b1 given per iteration (algorithms.py:327-330); adamx also reads b1[it-1] (b1[-1] at it = 0, :213), which the
