@@ -380,6 +380,31 @@ def test_weighted_likelihood_matches_reference(pm, tag):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2, algorithm=pm.bsdmm)
 
 
+@pytest.mark.parametrize("unity", [False, True])
+def test_proximal_sub_iteration_counts_match_oracle(pm, orc, unity):
+    """The data-dependent inner loop (algorithms.py:383-400) must end after the same number of passes as in the
+    reference's arithmetic: total passes per block over 12 iterations, device chain vs oracle (the
+    per-iteration sub-iteration counts of a timed run must be the CPU run's).  The stopping test compares two fp32 sums
+    against e_rel^2, so one pass of slack per block is allowed for a sum landing on the other side of the threshold."""
+    from proxmin_amd.engine import DeviceNMF
+    M, N, K, its = 384, 640, 16, 12
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=33)
+    specS = ("unity_plus", 0) if unity else ("plus",)
+    pS = partial(pm.operators.prox_unity_plus, axis=0) if unity else pm.operators.prox_plus
+    with DeviceNMF(M, N, K) as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A0, S0)
+        dev.adaprox_begin([pm.operators.device_proxseq(pm.operators.prox_plus, 0), pm.operators.device_proxseq(pS, 1)],
+                          scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
+        res = dev.adaprox_run(np.full(its, 0.9), 0.9)
+        got = [int(res.sub_iterations[0]), int(res.sub_iterations[1])]
+    Ao, So = A0.copy(), S0.copy()
+    out = orc.adaprox_nmf(Y, Ao, So, ("plus",), specS, scheme="amsgrad", max_iter=its, e_rel=1e-3, check_convergence=False)
+    want = [int(out[5][0]), int(out[5][1])]
+    assert res.iterations == its == out[4]
+    assert abs(got[0] - want[0]) <= 1 and abs(got[1] - want[1]) <= 1, (got, want)
+
+
 def test_weighted_nmf_on_the_split_bf16_kernel_shape(pm, orc):
     """A weighted adaprox run at a shape the default split-bf16 kernel takes (K = 64, M % 128 = 0, N % 256 = 0), so that
     mode "bf16x3" really runs its own weighted kernel (the fixture's shapes fall back to the exact-fp32 one): factors
