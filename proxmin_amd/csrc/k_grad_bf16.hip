@@ -771,34 +771,11 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_grad_bf16_pipe(GradBfArgs a) 
 
 
 // ------------------------------------------------------------------------------------------------
-// k_grad_bf16_v3 (KP = 64, whole 64 x 64 blocks): 4 wavefronts per workgroup, TWO workgroups per CU.
-//
-// Why: inside one workgroup every wave is in the same phase at the same time (LDS reads, then a dependent
-// MFMA chain, then a barrier), so the matrix pipe idles while operands are fetched and the LDS idles while
-// the MFMAs run.  Two independent workgroups per CU drift against each other and fill those gaps.  To fit
-// two of them (<= 80 KiB LDS, <= 256 VGPRs each) the step shrinks to 64 x 64 and the LDS images shrink:
-//   * R is parked ONCE, already split into its two bf16 terms, as [n][m] images (128-byte rows, 16-byte chunks
-//     XOR-swizzled by the row so that all three access patterns below are bank-conflict-free):
-//         producer      ds_write_b64        (lane = column n of the accumulator tile, 4 consecutive rows m)
-//         GEMM3 (A^T R) ds_read_b128        (lane = n, 8 consecutive m = the contraction index)
-//         GEMM2 (R S^T) ds_read_b64_tr_b16  (lane = m, 4 consecutive n: the transposing LDS read)
-//     so no consumer converts anything, and the fp32 R image and its strided column reads are gone;
-//   * S^T for GEMM2 comes from the SAME Sl image GEMM1 reads, through the transposing read (no Stl image, no
-//     second orientation of S in flight);
-//   * all operand images arrive by LDS-DMA (Y tile of step s+1, Sl of step s+1, Atl of the next row panel).
-// Wave w: GEMM1 tile (mt, nt) = (w>>1, w&1); GEMM2 tile gA (mt, kt) = (w>>1, w&1) over the block's 64
-// columns; GEMM3 tile gSt (nt, kt) = (w&1, w>>1) over the block's 64 rows (no row split: one gSt slab per
-// row region).  Per step and wave: 24 + 12 + 12 MFMAs, 3 barriers.
-// Waits: every DMA is inline asm; s_waitcnt vmcnt(0) at the top-of-step barrier (everything for this step has
-// landed), vmcnt(4) in front of the barrier that publishes a new Atl (only the 4 Y(s+1) requests are younger).
+// Shared by the fp32-operand variants below: the XOR chunk swizzle of the 128-byte-row LDS images and the transposing
+// read.  (They carry the name of the 64 x 64 / two-workgroups-per-CU variant `v3` they were written for; that variant
+// and `v6` -- v7 with LDS-DMA landing tiles for Y and per-panel S staging -- were measured, superseded and removed:
+// DESIGN.md section 4 keeps their numbers.)
 // ------------------------------------------------------------------------------------------------
-constexpr int V3_BM = 64, V3_BN = 64, V3_THREADS = 256, V3_NW = 4;
-constexpr int V3_SL_BYTES = 3 * 64 * 144, V3_ATL_BYTES = 2 * 64 * 144, V3_R_BYTES = 2 * 64 * 128, V3_Y_BYTES = V3_NW * 4096;
-constexpr int V3_OFF_ATL = V3_SL_BYTES, V3_OFF_R = V3_OFF_ATL + V3_ATL_BYTES, V3_OFF_Y = V3_OFF_R + V3_R_BYTES,
-              V3_OFF_DUMP = V3_OFF_Y + V3_Y_BYTES, V3_LDS_BYTES = V3_OFF_DUMP + 1024;
-static_assert(V3_OFF_R % 256 == 0, "R images must start on a bank row");
-static_assert(2 * V3_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-
 // chunk permutation of the R images: 16-byte chunk c of row n lives at chunk c ^ v3_swz(n)
 __device__ __forceinline__ int v3_swz(int n) {
     const int x = (n >> 1) & 7;
@@ -813,314 +790,6 @@ __device__ __forceinline__ bf16x8 v3_tr_pair(const unsigned char* base, int off0
     r[0] = a0[0]; r[1] = a0[1]; r[2] = a0[2]; r[3] = a0[3];
     r[4] = a1[0]; r[5] = a1[1]; r[6] = a1[2]; r[7] = a1[3];
     return r;
-}
-
-template <bool PROF>
-__global__ __launch_bounds__(V3_THREADS, 2) void k_grad_bf16_v3(GradBfArgs a) {
-    constexpr int KP = 64, KS = 4, NW = V3_NW;
-    constexpr int ROWB = 144, TERMB = 64 * ROWB;            // Sl and Atl: 64 rows of 64 bf16 + 16 bytes of pad
-    constexpr int N_SL = V3_SL_BYTES / 1024, N_ATL = V3_ATL_BYTES / 1024;      // 27 and 18 chunks of 1 KiB
-    constexpr int NI_SL = (N_SL + NW - 1) / NW, NI_ATL = (N_ATL + NW - 1) / NW;
-    static_assert(V3_SL_BYTES % 1024 == 0 && V3_ATL_BYTES % 1024 == 0, "");
-
-    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    unsigned char* Slb = smem;
-    unsigned char* Atlb = smem + V3_OFF_ATL;
-    unsigned char* Rb = smem + V3_OFF_R;
-    float* Yl = reinterpret_cast<float*>(smem + V3_OFF_Y);
-
-    if (chain_halted(a.status)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int M = a.M, N = a.N, K = a.K;
-    int rowRegion, colRegion;
-    {
-        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
-            const int xcd = lin & 7, idx = lin >> 3;
-            rowRegion = idx % gx;
-            colRegion = xcd * (gy >> 3) + idx / gx;
-        } else {
-            rowRegion = lin % gx;
-            colRegion = lin / gx;
-        }
-    }
-    const int row0 = rowRegion * a.RP * V3_BM;
-    const int col0 = colRegion * BG_CB * V3_BN;
-    const int mt = w >> 1, nt = w & 1;       // GEMM1 tile; GEMM2 uses (mt, kt = nt); GEMM3 uses (nt3 = nt, kt3 = mt)
-
-    f32x16 accS[BG_CB];
-#pragma unroll
-    for (int cb = 0; cb < BG_CB; ++cb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
-    f32x16 accA;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
-    f32x16 p;
-    bf16x8 afr[KS][3];
-    float lossAcc = 0.f;
-
-    int nrp = (M - row0 + V3_BM - 1) / V3_BM;
-    if (nrp > a.RP) nrp = a.RP;
-    if (nrp < 0) nrp = 0;
-    int ncb = (N - col0 + V3_BN - 1) / V3_BN;
-    if (ncb > BG_CB) ncb = BG_CB;
-    if (ncb < 0) ncb = 0;
-    const int nsteps = nrp * ncb;
-    const bool noY = (a.doA & 2) != 0;
-
-    // ---- step-invariant per-lane addresses --------------------------------------------------------------
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    int goff_sl[NI_SL];                       // element offsets into a.Sp for the Sl image chunks of this wave
-#pragma unroll
-    for (int i = 0; i < NI_SL; ++i) {
-        const int o = 1024 * (i * NW + w) + 16 * lane;
-        const int t = o / TERMB, wi = o % TERMB, r = wi / ROWB, sl = (wi % ROWB) / 16;
-        goff_sl[i] = (o < V3_SL_BYTES && sl < 8) ? (int)(((int64_t)t * a.NPad + r) * KP + sl * 8) : 0;
-    }
-    auto dma_Sl = [&](int bcol0) {
-        const __bf16* base = a.Sp + (int64_t)bcol0 * KP;
-#pragma unroll
-        for (int i = 0; i < NI_SL; ++i) {
-            const int ci = i * NW + w;
-            lds_dma16(base + goff_sl[i], __builtin_amdgcn_readfirstlane(lds_base + (ci < N_SL ? 1024 * ci : V3_OFF_DUMP)));
-        }
-    };
-    auto dma_Atl = [&](int prow0) {
-#pragma unroll
-        for (int i = 0; i < NI_ATL; ++i) {
-            const int ci = i * NW + w;
-            const int o = 1024 * ci + 16 * lane;
-            const int t = o / TERMB, wi = o % TERMB, r = wi / ROWB, sl = (wi % ROWB) / 16;
-            const int64_t off = (ci < N_ATL && sl < 8) ? ((int64_t)t * KP + r) * a.MPad + prow0 + sl * 8 : 0;
-            lds_dma16(a.At + off, __builtin_amdgcn_readfirstlane(lds_base + (ci < N_ATL ? V3_OFF_ATL + 1024 * ci : V3_OFF_DUMP)));
-        }
-    };
-    float* Ytile = Yl + w * 1024;
-    const unsigned ytile_lds = lds_base + V3_OFF_Y + w * 4096;
-    const int dmaRow = lane >> 3, dmaCol = (lane & 7) * 4;
-    auto dma_Y = [&](int prow0, int bcol0) {
-        const float* src = a.Y + (int64_t)(prow0 + mt * 32 + dmaRow) * a.ldY + bcol0 + nt * 32 + dmaCol;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024));
-    };
-    auto dma_Y_dummy = [&]() {   // keeps "4 requests younger than Atl" true on every step
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds_dma16(a.Sp, __builtin_amdgcn_readfirstlane(lds_base + V3_OFF_DUMP));
-    };
-    auto load_afr = [&](int prow0) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                afr[ks][t] = *reinterpret_cast<const bf16x8*>(a.Ap + ((int64_t)t * a.MPad + prow0 + mt * 32 + l31) * KP + ks * 16 + hi * 8);
-        // consume here: the compiler must not carry a pending-load state into the loop body (it would put its
-        // wait in front of GEMM1 on every step and, blind to the asm DMAs, drain the Y prefetch with it)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(afr[ks][t]));
-    };
-    auto flush_gA = [&](int prow0) {
-        float* dst = a.slabA + (int64_t)colRegion * M * K;
-        const int kk = nt * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int gr = prow0 + mt * 32 + tile_row(i, lane);
-            if (kk < K) dst[(int64_t)gr * K + kk] = accA[i];
-        }
-    };
-    // GEMM1 B operand: Sl[t][nt*32 + l31][ks*16 + hi*8]
-    const unsigned char* sl_g1 = Slb + (nt * 32 + l31) * ROWB + hi * 16;
-    // R producer: row n = nt*32 + l31, chunk (4*mt + g) ^ swz(n), half hi
-    const int n_w = nt * 32 + l31;
-    const int r_wbase = n_w * 128 + (((4 * mt) ^ v3_swz(n_w)) << 4) + 8 * hi;
-    // GEMM2 A operand (R, transposing read): source lane i of a 16-lane group q
-    const int li = lane & 15, lq = lane >> 4;
-    int r_t0, r_t1;
-    {
-        const int m = mt * 32 + 16 * (lq & 1) + 4 * (li & 3);
-        const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
-        r_t0 = n0 * 128 + ((((m >> 3) ^ v3_swz(n0)) & 7) << 4) + 8 * ((m >> 2) & 1);
-        r_t1 = n1 * 128 + ((((m >> 3) ^ v3_swz(n1)) & 7) << 4) + 8 * ((m >> 2) & 1);
-    }
-    // GEMM2 B operand (S^T from Sl, transposing read): row n = ks*16 + 8*hi + 4*u + (li>>2), col kk
-    const int s_t = (8 * hi + (li >> 2)) * ROWB + (nt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;
-    // GEMM3 A operand (R^T): row n = nt*32 + l31, chunk (2*ks + hi) ^ swz(n)
-    const int r_g3 = n_w * 128 + ((hi ^ v3_swz(n_w)) << 4);
-    // GEMM3 B operand: Atl[t][kt3*32 + l31][ks*16 + hi*8]
-    const unsigned char* atl_g3 = Atlb + (mt * 32 + l31) * ROWB + hi * 16;
-
-    unsigned long long ph[PROF ? 10 : 1] = {};
-    const bool prof = PROF && a.prof != nullptr && w == 0;
-#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
-    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
-
-    if (nsteps > 0) {
-        load_afr(row0);
-        if (!noY) dma_Y(row0, col0); else dma_Y_dummy();
-        dma_Sl(col0);
-    }
-    int rp = 0, cb = 0;
-    int flush_row = -1;                       // panel whose gA still sits in accA (flushed at the next panel's start)
-#pragma nounroll
-    for (int step = 0; step < nsteps; ++step) {
-        const int prow0 = row0 + rp * V3_BM;
-        int nrp_ = rp, ncb_ = cb + 1;
-        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
-        const bool more = step + 1 < nsteps;
-        const int nprow0 = row0 + nrp_ * V3_BM, nbcol0 = col0 + ncb_ * V3_BN;
-        // ---- TOP: previous step done everywhere; Y(s), Sl(s) landed --------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        PH(0)
-        if (cb == 0) {
-            if (step > 0) load_afr(prow0);
-            dma_Atl(prow0);                  // every wave is past GEMM3 of the previous panel
-            if (flush_row >= 0) {
-                flush_gA(flush_row);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) accA[i] = 0.f;
-            }
-        }
-        PH(1)
-        if (noY) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) p[i] = 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && !noY) dma_Y(nprow0, nbcol0); else dma_Y_dummy();
-        PH(2)
-        // ---- GEMM1: P = A S - Y -----------------------------------------------------------------------------------
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32);
-            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32 + TERMB);
-            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(sl_g1 + ks * 32 + 2 * TERMB);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
-        }
-        // ---- R: loss, split into two bf16 terms, park as [n][m] images ---------------------------------------------
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float r = p[4 * g + j];
-                lossAcc += r * r;
-                const __bf16 hh = (__bf16)r;
-                h[j] = hh;
-                l[j] = (__bf16)(r - (float)hh);
-            }
-            const int o = r_wbase ^ (g << 4);
-            *reinterpret_cast<bf16x4*>(Rb + o) = h;
-            *reinterpret_cast<bf16x4*>(Rb + 8192 + o) = l;
-        }
-        PH(3)
-        // ---- B_R: R visible; every wave is done with GEMM1's reads of Sl -------------------------------------------
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        PH(4)
-        // ---- GEMM2: gA += R S^T  (both operands through the transposing read) --------------------------------------
-        if (a.doA & 1) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 2048, r_t1 + ks * 2048);
-                const bf16x8 r1 = v3_tr_pair(Rb + 8192, r_t0 + ks * 2048, r_t1 + ks * 2048);
-                const bf16x8 s0 = v3_tr_pair(Slb, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
-                const bf16x8 s1 = v3_tr_pair(Slb + TERMB, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
-            }
-        }
-        PH(5)
-        // ---- B_S: every wave is done with Sl; a new Atl (requested at TOP) has landed ------------------------------
-        if (cb == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        PH(6)
-        if (more) dma_Sl(nbcol0);
-        // ---- GEMM3: gSt += R^T A -----------------------------------------------------------------------------------
-        if (a.doS) {
-#define V3_GEMM3_INTO(ACC)                                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                 \
-        const int ro = r_g3 ^ (ks << 5);                                                                \
-        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);                                    \
-        const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + 8192 + ro);                             \
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(atl_g3 + ks * 32);                           \
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(atl_g3 + ks * 32 + TERMB);                   \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
-    }
-            switch (cb) {
-                case 0: V3_GEMM3_INTO(accS[0]) break;
-                case 1: V3_GEMM3_INTO(accS[1]) break;
-                case 2: V3_GEMM3_INTO(accS[2]) break;
-                default: V3_GEMM3_INTO(accS[3]) break;
-            }
-#undef V3_GEMM3_INTO
-        }
-        PH(7)
-        if (cb + 1 == ncb && (a.doA & 1)) flush_row = prow0;
-        cb = ncb_;
-        rp = nrp_;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (flush_row >= 0) flush_gA(flush_row);
-    PH(8)
-    if (a.doS) {
-        float* dst = a.slabS + (int64_t)rowRegion * N * K;
-        const int kk = mt * 32 + l31;
-#pragma unroll
-        for (int cbi = 0; cbi < BG_CB; ++cbi) {
-            const int bcol0 = col0 + cbi * V3_BN;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gn = bcol0 + nt * 32 + tile_row(i, lane);
-                if (gn < N && kk < K) dst[(int64_t)gn * K + kk] = accS[cbi][i];
-            }
-        }
-    }
-    {
-        float v = lossAcc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        if (lane == 0) red[w] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < NW; ++i) s += (double)red[i];
-            a.lossPart[blockIdx.x] = s;
-        }
-    }
-    PH(9)
-    if constexpr (PROF) {
-        if (prof && lane == 0)
-            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
-    }
-#undef PH
-}
-
-template <bool PROF>
-static hipError_t grad_launch_bf16_v3_t(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v3<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_bf16_v3<PROF>), dim3(a.gridX * a.gridY), dim3(V3_THREADS), V3_LDS_BYTES, stream, a);
-    return hipGetLastError();
 }
 
 
@@ -1882,426 +1551,31 @@ static hipError_t grad_launch_bf16_v5(const GradV4Args& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_grad_bf16_v6 (K = 64, M % 128 == 0, N % 256 == 0): v5's producer / consumer split with a deeper pipeline.
+// k_grad_bf16_v7 (K = 64, M % 128 == 0, N % 256 == 0): v5's producer / consumer split, deeper pipeline, fewer joules.
 //
 // Profiling v5 (PMX_K1_PROF) showed the PRODUCERS' slot as the critical path: a serial chain of "wait for the Y tile,
-// read it into the accumulator, request the next loads, 24 dependent MFMAs, ~100 VALU instructions of R = P -> two
-// bf16 terms", 3500 cycles of which the matrix pipe works 770.  Here
-//   * the accumulator starts at zero and Y is subtracted in the epilogue, so the MFMA chain no longer waits for Y;
-//   * the epilogue of block s-1 (VALU + LDS writes on the OTHER accumulator) sits in the same basic block as the
-//     MFMAs of block s, and the scheduler interleaves them: the producers keep two accumulators;
-//   * Y tiles are double-buffered per wave and requested TWO slots ahead (the only global requests the producers
-//     make in the loop besides the once-per-panel A rows, so the hand-counted s_waitcnt vmcnt(4) is exact);
-//   * the consumers (one block later than in v5: block s-2 in slot s) do all the S staging with plain loads.
-// Sl becomes a ring of four (written in slot b-1, read by the producers in slot b and by the consumers in slot b+2).
-// ------------------------------------------------------------------------------------------------
-constexpr int V6_SL_RING = 4;
-constexpr int V6_OFF_A = V6_SL_RING * V5_SL_BYTES, V6_OFF_R = V6_OFF_A + V5_AIMG_BYTES, V6_OFF_Y = V6_OFF_R + 2 * V5_R_BYTES,
-              V6_LDS_BYTES = V6_OFF_Y + 2 * 4 * 4096;
-static_assert(V6_OFF_R % 256 == 0, "R images must start on a bank row");
-static_assert(V6_LDS_BYTES <= 160 * 1024, "");
-
-template <bool PROF>
-__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v6(GradV4Args a) {
-    constexpr int K = 64, ROWB = 128, NCB = V5_NB;
-    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-
-    if (chain_halted(a.status)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int li = lane & 15, lq = lane >> 4;
-    const int M = a.M, N = a.N;
-    int rowRegion, colRegion;
-    {
-        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
-            const int xcd = lin & 7, idx = lin >> 3;
-            rowRegion = idx % gx;
-            colRegion = xcd * (gy >> 3) + idx / gx;
-        } else {
-            rowRegion = lin % gx;
-            colRegion = lin / gx;
-        }
-    }
-    const int row0 = rowRegion * a.RP * V5_BM;
-    const int col0 = colRegion * NCB * V5_BN;          // N % 256 == 0: every region has all 8 column blocks
-    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
-    if (nrp > a.RP) nrp = a.RP;
-    if (nrp < 0) nrp = 0;
-    const int T = nrp * NCB;                 // blocks of this region (even); slots = T + 2
-    const bool producer = w < 4;          // (the "no Y traffic" ablation switch of the older variants is not implemented here)
-    const int j = w & 3;                     // index within the role
-    float lossAcc = 0.f;
-    unsigned long long ph[PROF ? 10 : 1] = {};
-    const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
-#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
-    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
-
-    if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
-        if (!producer) {
-            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            for (int c = 0; c < NCB; ++c)
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
-                    if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
-                }
-        }
-        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
-        return;
-    }
-
-    if (producer) {
-        // ================================ producers: GEMM1 and R =================================================
-        f32x16 p0, p1;
-        float4 areg[4][2];
-        bf16x8 afr[4][3];
-        float* Ytile = reinterpret_cast<float*>(smem + V6_OFF_Y) + j * 2048;      // two 32 x 32 landing tiles per wave
-        const unsigned ytile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Ytile;
-        const float* ysrc0 = a.Y + (int64_t)(row0 + j * 32 + (lane >> 3)) * a.ldY + col0 + (lane & 7) * 4;
-        auto dma_Y = [&](int b) {            // Y tile of block b (clamped past the end) -> landing buffer b & 1
-            int brp = b >> 3;
-            if (brp >= nrp) brp = nrp - 1;
-            const float* src = ysrc0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + (b & 1) * 4096 + q * 1024));
-        };
-        auto load_A = [&](int prow) {
-            const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                areg[ks][0] = src[ks * 4];
-                areg[ks][1] = src[ks * 4 + 1];
-            }
-        };
-        auto make_afr = [&]() {              // split the panel rows into bf16 terms (register fragments of GEMM1's A operand)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
-                                    areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const __bf16 t0 = (__bf16)x[q];
-                    const float e1 = x[q] - (float)t0;
-                    const __bf16 t1 = (__bf16)e1;
-                    afr[ks][0][q] = t0;
-                    afr[ks][1][q] = t1;
-                    afr[ks][2][q] = (__bf16)(e1 - (float)t1);
-                }
-            }
-        };
-        auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
-            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<bf16x8*>(smem + V6_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
-                *reinterpret_cast<bf16x8*>(smem + V6_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
-            }
-        };
-        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
-        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
-        load_A(row0);
-        dma_Y(0);                            // slot s requests Y(s + 1)
-        make_afr();
-        if (nrp > 1) load_A(row0 + V5_BM);
-        __builtin_amdgcn_s_barrier();        // Sl(0) published by the consumers
-
-        // One slot.  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
-        auto slot = [&](int s, f32x16& pc, f32x16& pp, auto gemm_c, auto epi_c) {
-            constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
-            const int cb = s & 7, rp = s >> 3;       // block s = (rp, cb); NCB == 8
-            if (cb == 2 && rp < nrp) {                   // block s-2 opened this row panel: the consumers start on it in this slot
-                publish_A();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_s_barrier();
-            }
-            PH(5)
-            float y[16];
-            if constexpr (EPI) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile (s-1) has landed; Y(s) may still be in flight
-                if constexpr (GEMM) {
-                    // block s opens a row panel: its A terms.  Here, because the compiler's wait for the rows (requested 8
-                    // slots ago) drains every outstanding request, and at this point that is only Y(s), a slot old
-                    if (cb == 0) {
-                        make_afr();
-                        if (rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
-                    }
-                }
-                const float* Yt = Ytile + ((s - 1) & 1) * 1024;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) y[i] = Yt[tile_row(i, lane) * 32 + l31];
-            }
-            bf16x8 sv[4][3];
-            if constexpr (GEMM) {
-                const unsigned char* Slb = smem + (s & 3) * V5_SL_BYTES;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int so = s_g1 ^ (ks << 5);
-                    sv[ks][0] = *reinterpret_cast<const bf16x8*>(Slb + so);
-                    sv[ks][1] = *reinterpret_cast<const bf16x8*>(Slb + so + V5_S_TERM);
-                    sv[ks][2] = *reinterpret_cast<const bf16x8*>(Slb + so + 2 * V5_S_TERM);
-                }
-            }
-            if constexpr (EPI) {
-                // the tile just read is the landing buffer of Y(s+1): its reads must have returned before the request
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]),
-                                                      "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12]), "+v"(y[13]), "+v"(y[14]), "+v"(y[15]) :: "memory");
-            }
-            dma_Y(s + 1);                    // every slot (clamped past the end): keeps the vmcnt arithmetic uniform
-            PH(2)
-            if constexpr (GEMM) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pc[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], sv[ks][0], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], sv[ks][1], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][2], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], sv[ks][0], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][1], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], sv[ks][0], pc, 0, 0, 0);
-                }
-            }
-            if constexpr (EPI) {
-                unsigned char* Rb = smem + V6_OFF_R + ((s - 1) & 1) * V5_R_BYTES;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 h, l;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float r = pp[4 * g + q] - y[4 * g + q];
-                        lossAcc += r * r;
-                        const __bf16 hh = (__bf16)r;
-                        h[q] = hh;
-                        l[q] = (__bf16)(r - (float)hh);
-                    }
-                    const int o = r_w ^ (g << 4);
-                    *reinterpret_cast<bf16x4*>(Rb + o) = h;
-                    *reinterpret_cast<bf16x4*>(Rb + V5_R_TERM + o) = l;
-                }
-            }
-            PH(3)
-            PH(4)
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
-            __builtin_amdgcn_s_barrier();
-            PH(0)
-        };
-        using yes = std::integral_constant<bool, true>;
-        using no = std::integral_constant<bool, false>;
-        slot(0, p0, p1, yes{}, no{});
-#pragma nounroll
-        for (int s = 1; s + 1 < T; s += 2) {
-            slot(s, p1, p0, yes{}, yes{});
-            slot(s + 1, p0, p1, yes{}, yes{});
-        }
-        slot(T - 1, p1, p0, yes{}, yes{});
-        slot(T, p0, p1, no{}, yes{});
-        slot(T + 1, p1, p0, no{}, no{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        // ================================ consumers: S staging, GEMM2 and GEMM3 of block s-2 =====================
-        float4 sreg0, sreg1;
-        const int ct = tid - 256;
-        const int st_off = (ct >> 4) * ROWB + (((((ct & 15) >> 1) ^ v3_swz(ct >> 4)) & 7) << 4) + 8 * (ct & 1);   // rows ct>>4 and +16 (same swizzle)
-        const float4* ssrc0 = reinterpret_cast<const float4*>(a.St + (int64_t)col0 * K) + ct;
-        auto load_S = [&](int b) {           // rows of column block b & 7
-            const float4* src = ssrc0 + (b & 7) * (V5_BN * K / 4);
-            sreg0 = src[0];
-            sreg1 = src[256];
-        };
-        auto store_S = [&](int t) {
-            unsigned char* d = smem + (t & 3) * V5_SL_BYTES + st_off;
-            bf16x4 t0, t1, t2;
-            v4_split3(sreg0, t0, t1, t2);
-            *reinterpret_cast<bf16x4*>(d) = t0;
-            *reinterpret_cast<bf16x4*>(d + V5_S_TERM) = t1;
-            *reinterpret_cast<bf16x4*>(d + 2 * V5_S_TERM) = t2;
-            v4_split3(sreg1, t0, t1, t2);
-            *reinterpret_cast<bf16x4*>(d + 16 * ROWB) = t0;
-            *reinterpret_cast<bf16x4*>(d + 16 * ROWB + V5_S_TERM) = t1;
-            *reinterpret_cast<bf16x4*>(d + 16 * ROWB + 2 * V5_S_TERM) = t2;
-        };
-        load_S(0);
-        store_S(0);
-        load_S(1);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();              // Sl(0) published
-
-        f32x16 accS[NCB];
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
-        f32x16 accA0, accA1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-        const int kt = j & 1, mh = j >> 1;   // GEMM3 tile; GEMM2: rows 32j.., both k tiles
-        int r_t0, r_t1;                      // GEMM2 A operand (R, transposing read)
-        {
-            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
-            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
-            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
-            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
-        }
-        auto tr_src = [&](int row, int k0) {
-            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
-            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
-        };
-        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
-        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
-        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
-        auto flush_gA = [&](int prow) {
-            float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float* ph_ = p0_ + half * 16 * K;
-                asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
-                    const int ro = ((q & 3) + 8 * (q >> 2)) * K;
-                    ph_[ro] = accA0[i];
-                    ph_[ro + 32] = accA1[i];
-                }
-            }
-        };
-        auto stage = [&](int s) {            // top of slot s: Sl(s+1) from the rows requested a slot ago, request S(s+2)
-            store_S(s + 1);
-            load_S(s + 2);
-            PH(8)
-        };
-        auto sync = [&]() {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_s_barrier();
-            PH(9)
-        };
-        auto consume = [&](int b, int rp, int cb, f32x16& accSc) {     // block b = (rp, cb)
-            const int prow = row0 + rp * V5_BM;
-            const unsigned char* Rb = smem + V6_OFF_R + (b & 1) * V5_R_BYTES;
-            const unsigned char* Slb = smem + (b & 3) * V5_SL_BYTES;
-            const unsigned char* Ab = smem + V6_OFF_A;
-            if (a.doA & 1) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                    const bf16x8 r1 = v3_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
-                    const bf16x8 s00 = v3_tr_pair(Slb, so0, so1);
-                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so0, so1);
-                    const bf16x8 s10 = v3_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
-                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s00, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s10, accA1, 0, 0, 0);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s01, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s11, accA1, 0, 0, 0);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s00, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s10, accA1, 0, 0, 0);
-                }
-            }
-            PH(6)
-            if (a.doS) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int ro = r_g3 ^ (ks << 5);
-                    const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);
-                    const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V5_R_TERM + ro);
-                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
-                    const bf16x8 a0 = v3_tr_pair(Ab, ao0, ao1);
-                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao0, ao1);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, accSc, 0, 0, 0);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, accSc, 0, 0, 0);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);
-                }
-            }
-            if ((a.doA & 1) && cb + 1 == NCB) {
-                flush_gA(prow);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-            }
-        };
-        stage(0);
-        sync();
-        stage(1);
-        sync();
-        int s = 2;
-#pragma nounroll
-        for (int rp = 0; rp < nrp; ++rp) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_s_barrier();
-                }
-                // contractions first, S staging after: the producers open their slot with waits, LDS reads and Y requests,
-                // so the matrix pipe is free for the consumers then; the staging overlaps the producers' MFMAs instead
-                consume(s - 2, rp, cb, accS[cb]);
-                PH(7)
-                stage(s);
-                sync();
-                ++s;
-            }
-        }
-        if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            const int kk = kt * 32 + l31;
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                const int bcol = col0 + c * V5_BN;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = bcol + tile_row(i, lane);
-                    dst[(int64_t)gn * K + kk] = accS[c][i];
-                }
-            }
-        }
-    }
-    {
-        float v = lossAcc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        if (lane == 0) red[w] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < 4; ++i) s += (double)red[i];
-            a.lossPart[blockIdx.x] = s;
-        }
-    }
-    if constexpr (PROF) {
-        if (prof && lane == 0)
-            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
-    }
-#undef PH
-}
-
-template <bool PROF>
-static hipError_t grad_launch_bf16_v6_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v6<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_bf16_v6<PROF>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V6_LDS_BYTES, stream, a);
-    return hipGetLastError();
-}
-static hipError_t grad_launch_bf16_v6(const GradV4Args& a, hipStream_t stream) {
-    return a.prof ? grad_launch_bf16_v6_t<true>(a, stream) : grad_launch_bf16_v6_t<false>(a, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_grad_bf16_v7 (K = 64, M % 128 == 0, N % 256 == 0): v6 with fewer joules per slot.
-//
-// K1 runs at the package power cap, so what is left to gain is work that need not be done:
-//   * the S terms of the region's 256 columns stay in LDS for the whole launch (8 blocks x 3 terms = 96 KB): v6
-//     re-split the same 32 x 64 block from fp32 on every row panel (a load, ~100 VALU instructions and six LDS writes per
-//     consumer wave and slot);
+// read it into the accumulator, request the next loads, 24 dependent MFMAs, ~100 VALU instructions of R -> two bf16
+// terms", 3500 cycles of which the matrix pipe works 770.  Pipeline (slot s):
+//   producers  GEMM1 of block s into one accumulator (starting at zero: Y is subtracted in the epilogue, so the MFMA
+//              chain does not wait for it) while the epilogue of block s-1 -- VALU and LDS writes on the OTHER
+//              accumulator -- sits in the same basic block and is interleaved with the MFMAs by the scheduler;
+//   consumers  both gradient contractions of block s-2 from R[s & 1].
+// And, because K1 runs at the package power cap (removing stall cycles returns only part of them as
+// time, removing work returns all of it), less work per slot than v5:
+//   * the S terms of the region's 256 columns are split ONCE and stay in LDS for the whole launch (8 blocks x 3 terms =
+//     96 KB); v5 re-splits the same 32 x 64 block from fp32 on every row panel (a load, ~100 VALU instructions and six
+//     LDS writes per wave and slot);
 //   * Y goes from HBM straight into registers in the accumulator's layout (16 dword loads per lane and block, two rows
-//     of 128 B per instruction, two blocks in flight per wave) instead of an LDS-DMA landing tile that is written and
-//     read back (32 KB of LDS traffic per slot and CU).  With no inline-asm requests left in the kernel every
-//     s_waitcnt vmcnt is the compiler's own exact count.
+//     of 128 B per instruction, two blocks in flight per wave: the set block s-1 has just left is reloaded with block
+//     s+1) instead of an LDS-DMA landing tile that is written and read back (32 KB of LDS traffic per slot and CU).
+//     With no inline-asm requests left in the kernel every s_waitcnt vmcnt is the compiler's own exact count
+//     (vmcnt(31..16) inside the slot: the older Y set has landed, the younger is in flight).
+// The A terms of a new row panel are split at the top of its first slot (its rows were requested 8 slots earlier).
 // LDS: Sl 96 KB + Aimg 32 KB + R 32 KB = the full 160 KB of the CU.
 // HASW: weighted likelihood (nmf.py:13-41): the weights of a block travel like its Y values (a second pair of register
 // sets), loss = 1/2 sum W R^2 and D = W R is what gets split and parked for the gradient contractions.
+// (An intermediate build, "v6", had the pipeline but kept v5's per-panel S staging and LDS-DMA tiles: 0.427 ms where
+// this one takes 0.394 and v5 0.457, same box, inside the iteration chain at 16384 x 16384.)
 // ------------------------------------------------------------------------------------------------
 constexpr int V7_OFF_A = V5_NB * V5_SL_BYTES, V7_OFF_R = V7_OFF_A + V5_AIMG_BYTES, V7_LDS_BYTES = V7_OFF_R + 2 * V5_R_BYTES;
 static_assert(V7_OFF_R % 256 == 0, "R images must start on a bank row");
@@ -2714,9 +1988,8 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     p.KP = K <= 32 ? 32 : 64;
     p.BN = BG_BN;
     // PMX_K1_VARIANT (read per context; tuning A/B and the variant tests): 0 guarded kernel only, 1 LDS-DMA pipeline
-    // 128 x 64 / 8 waves, 3 LDS-DMA 64 x 64 / 4 waves x 2 per CU, 4 fp32 operands split in-kernel, 5 the same with
-    // producer / consumer wavefronts, 6 those with the deeper pipeline, 7 (default) 6 with resident S terms and Y loaded
-    // straight into registers (6 and 7: N % 256 == 0, else 5)
+    // 128 x 64 / 8 waves, 4 fp32 operands split in-kernel, 5 the same with producer / consumer wavefronts, 7 (default)
+    // those with the deeper pipeline, resident S terms and Y loaded straight into registers (N % 256 == 0, else 5)
     p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 7;
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
@@ -2770,19 +2043,12 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
-        if (variant >= 6 && dma_ok && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v6(g, stream);
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }
     if (a.W != nullptr) return hipErrorInvalidValue;
     // Whole blocks with 16-byte-aligned rows take an LDS-DMA variant; anything else the guarded kernel.
     const bool aligned = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
     const bool edge = (a.M % BG_BM) != 0 || (a.N % BG_BN) != 0 || !aligned;
-    if (variant == 3 && p.KP == 64 && aligned && (a.M % V3_BM) == 0 && (a.N % V3_BN) == 0) {
-        // same regions, each split into two row halves: 2 * gridX row regions of RP 64-row panels (= nSlabS slabs)
-        a.gridX = 2 * p.gridX;
-        *nloss = a.gridX * a.gridY;
-        return a.prof ? grad_launch_bf16_v3_t<true>(p, a, stream) : grad_launch_bf16_v3_t<false>(p, a, stream);
-    }
     if (!edge && variant >= 1) return p.KP == 32 ? grad_launch_bf16_pipe<32>(p, a, stream) : grad_launch_bf16_pipe<64>(p, a, stream);
     if (p.KP == 32) return edge ? grad_launch_bf16_t<32, true>(p, a, stream) : grad_launch_bf16_t<32, false>(p, a, stream);
     return edge ? grad_launch_bf16_t<64, true>(p, a, stream) : grad_launch_bf16_t<64, false>(p, a, stream);

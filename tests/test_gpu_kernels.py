@@ -45,7 +45,7 @@ def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 7])
 @pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1024, 640, 64), (640, 1536, 64), (2304, 832, 64), (5120, 4096, 64), (256, 320, 40), (384, 256, 32)])
 def test_split_bf16_kernel_variants_agree_with_oracle(eng, orc, monkeypatch, M, N, K, variant):
     """Every implementation of the split-bf16 K1 (guarded, LDS-DMA pipelines, fp32-operand variant; selected per
