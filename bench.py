@@ -36,9 +36,13 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s is what a float4 copy achieves)
-MODE_DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32-class accuracy)"}
+MODE_DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32-class accuracy)",
+              "f16x2": "f16x2 (two-term fp16 split MFMA, fp32 accumulate, fp32-class accuracy)"}
 MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
-             "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)"}
+             "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)",
+             "f16x2": "f16x2 (operands scaled by powers of two and split into two fp16 terms: 3 MFMA passes for each of A@S and the "
+                      "two gradients; fp32 accumulate; Y fp32 in HBM)"}
+MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
 
 
 # HBM bytes per K1 launch from the PMC passes committed in profiles/r01_e_pmc_cfg3_bf16x3.json (bf16x3: k_grad_bf16_v7)
@@ -57,16 +61,18 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
     gbs = (M * N * 4) / t / 1e9
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
     # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
-    bf16_kernel = (("k_grad_bf16_v7" if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
+    fast = "k_grad_f16_v8" if mode == "f16x2" else "k_grad_bf16_v7"
+    bf16_kernel = ((fast if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
                    else "k_grad_bf16<%d>" % kp)
+    passes = MFMA_PASSES["f16x2" if bf16_kernel == "k_grad_f16_v8" else "bf16x3"]
     if mode == "f32":
         return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
                 "launches": k1_n, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share}
     return {"kernel": bf16_kernel, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-            "algorithmic_tflops": tflops, "mfma_issued_tflops": 4.0 * tflops,
-            "mfma_issued_frac_of_bf16_peak": 4.0 * tflops / PEAK_BF16_MFMA_TFLOPS, "k1_share_of_step": share}
+            "algorithmic_tflops": tflops, "mfma_issued_tflops": passes * tflops,
+            "mfma_issued_frac_of_bf16_peak": passes * tflops / PEAK_BF16_MFMA_TFLOPS, "k1_share_of_step": share}
 
 
 def make_problem_device(M, N, K, unity, seed, device):
@@ -163,8 +169,8 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
-    ap.add_argument("--mode", default="bf16x3", choices=["f32", "bf16x3"],
-                    help="contraction arithmetic: bf16x3 = split-bf16 MFMA (headline), f32 = exact fp32 MFMA")
+    ap.add_argument("--mode", default="bf16x3", choices=["f32", "bf16x3", "f16x2"],
+                    help="contraction arithmetic: bf16x3 = split-bf16 MFMA, f16x2 = two-term fp16 MFMA, f32 = exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch

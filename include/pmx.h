@@ -41,7 +41,9 @@ enum {
 enum {
     PMX_MODE_F32 = 0,   /* Y fp32 in HBM, A@S / R@S^T / A^T@R on v_mfma_f32_32x32x2_f32 (exact f32) */
     PMX_MODE_BF16 = 1,  /* Y bf16 in HBM, operands rounded to bf16, fp32 accumulate                  */
-    PMX_MODE_BF16X3 = 2 /* Y fp32 in HBM, operands split hi+lo bf16 (3 MFMA passes), fp32 accumulate */
+    PMX_MODE_BF16X3 = 2, /* Y fp32 in HBM, operands split into bf16 terms (3 for A@S, 2 for the gradients), fp32 accumulate */
+    PMX_MODE_F16X2 = 3   /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes run the two-term fp16 kernel
+                            (power-of-two operand scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */

@@ -106,8 +106,10 @@ struct GradBfArgs {
     int doA, doS;        // doA bit 1: ablation switch "no Y traffic" (tuning only)
     int gridX, gridY;
     unsigned long long* prof;   // tuning only: per-phase cycle sums of wave 0 of every workgroup (nullptr = off)
-    const float* W;      // M x N weights (ldW) or nullptr for W == 1 (nmf.py:13-41); only the v7 variant takes them
+    const float* W;      // M x N weights (ldW) or nullptr for W == 1 (nmf.py:13-41); only the v7 / v8 variants take them
     int64_t ldW;
+    const float* absmax; // fp16 two-term path: partial maxima of the factors (k_absmax), nullptr otherwise
+    float ymax, wmax;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -846,8 +848,11 @@ struct GradV4Args {
     int doA, doS;
     int gridX, gridY;
     unsigned long long* prof;
-    const float* W;      // M x N weights (ldW) or nullptr; only k_grad_bf16_v7 takes them
+    const float* W;      // M x N weights (ldW) or nullptr; only k_grad_bf16_v7 / k_grad_f16_v8 take them
     int64_t ldW;
+    const float* absmax; // k_grad_f16_v8: [2][V8_NPART] partial maxima of |A|, |St| (k_absmax)
+    float ymax;          // k_grad_f16_v8: max |Y|
+    float wmax;          // k_grad_f16_v8: max(1, max |W|) (1 without weights): D = W R must fit fp16 as well
 };
 
 template <bool PROF>
@@ -1962,6 +1967,487 @@ static hipError_t grad_launch_bf16_v7(const GradV4Args& a, hipStream_t stream) {
     return a.prof ? grad_launch_bf16_v7_t<true, false>(a, stream) : grad_launch_bf16_v7_t<false, false>(a, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// two-term fp16 split (k_grad_f16_v8): helpers and the factor maxima its operand scales come from
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int V8_NPART = 256;                // partial maxima per factor
+
+__device__ __forceinline__ void v8_split2(const float4& x, float sc, f16x4& h, f16x4& l) {
+    const float v[4] = {x.x * sc, x.y * sc, x.z * sc, x.w * sc};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 t = (_Float16)v[i];
+        h[i] = t;
+        l[i] = (_Float16)(v[i] - (float)t);
+    }
+}
+__device__ __forceinline__ f16x8 v8_tr_pair(const unsigned char* base, int off0, int off1) {
+    return __builtin_bit_cast(f16x8, v3_tr_pair(base, off0, off1));   // the transposing read moves 16-bit payloads
+}
+
+// absmax[f * V8_NPART + b] = max |X_f| over workgroup b's share (f = 0: A, M x 64; f = 1: St, N x 64)
+struct AbsmaxArgs {
+    const float* X[2];
+    int64_t count[2];        // elements (multiples of 4)
+    float* out;              // [2][V8_NPART]
+    const DevStatus* status;
+};
+__global__ __launch_bounds__(256) void k_absmax(AbsmaxArgs a) {
+    __shared__ float red[4];
+    if (chain_halted(a.status)) return;
+    const int f = blockIdx.y;
+    const float4* x = reinterpret_cast<const float4*>(a.X[f]);
+    const int64_t n4 = a.count[f] >> 2;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)V8_NPART * 256) {
+        const float4 v = x[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) a.out[f * V8_NPART + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// max |Y| of an M x N matrix with row pitch ld: out[b] = partial of workgroup b (V8_NPART of them)
+__global__ __launch_bounds__(256) void k_absmax_pitched(const float* Y, int64_t ld, int64_t M, int64_t N, float* out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t r = blockIdx.x; r < M; r += V8_NPART) {
+        const float* row = Y + r * ld;
+        for (int64_t c = threadIdx.x; c < N; c += 256) m = fmaxf(m, fabsf(row[c]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+void launch_absmax_pitched(const float* Y, int64_t ld, int64_t M, int64_t N, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_absmax_pitched, dim3(V8_NPART), dim3(256), 0, s, Y, ld, M, N, out);
+}
+void launch_absmax(const AbsmaxArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_absmax, dim3(V8_NPART, 2), dim3(256), 0, s, a); }
+
+// ------------------------------------------------------------------------------------------------
+// k_grad_f16_v8 (K = 64, M % 128 == 0, N % 256 == 0): v7's kernel with TWO-term fp16 splits instead of three-term bf16.
+//
+// fp16 carries 11 significant bits, so x ~ (h + l) with h = fp16(x), l = fp16(x - h) is good to 2^-22 -- as long as l
+// stays out of fp16's subnormal range, which ordinary NMF factors (|x| < 2^-3) would not.  Every operand is therefore
+// scaled by a power of two (exact) before the split:
+//   A by 2^eA, S by 2^eS with max|A| 2^eA, max|S| 2^eS in [2^13, 2^14)   (maxima of the CURRENT factors: k_absmax)
+//   R by 2^eR with (max|Y| + K max|A| max|S|) max(1, max|W|) 2^eR < 2^14   (a bound: W R can never overflow fp16)
+// Entries far below the maximum lose RELATIVE precision in their low term, but their absolute error stays below
+// 2^-25 of the scaled range (2^-39 of the maximum), which is what matters inside a dot product.  Products:
+//   A S      ah sh + ah sl + al sh      (the dropped al sl is 2^-22 of the product)
+//   R S^T    rh sh + rh sl + rl sh      R^T A likewise
+// 9 MFMAs per 32 x 32 x 16 step of the three contractions instead of 12, two S terms in LDS instead of three (64 KB), a
+// third fewer operand reads in GEMM1.  Accumulators come out scaled by 2^(eA+eS) (P, undone before Y is subtracted),
+// 2^(eR+eS) (gA) and 2^(eR+eA) (gSt), undone at the flushes; all of it exact.  Everything else is v7.
+// ------------------------------------------------------------------------------------------------
+constexpr int V8_SL_BYTES = 2 * V5_S_TERM;   // two terms per 32-column block
+constexpr int V8_OFF_A = V5_NB * V8_SL_BYTES, V8_OFF_R = V8_OFF_A + V5_AIMG_BYTES, V8_LDS_BYTES = V8_OFF_R + 2 * V5_R_BYTES;
+static_assert(V8_OFF_R % 256 == 0, "R images must start on a bank row");
+static_assert(V8_LDS_BYTES <= 160 * 1024, "");
+
+template <bool PROF, bool HASW>
+__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
+    constexpr int K = 64, ROWB = 128, NCB = V5_NB;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lq = lane >> 4;
+    const int M = a.M, N = a.N;
+    int rowRegion, colRegion;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if (gy % 8 == 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V5_BM;
+    const int col0 = colRegion * NCB * V5_BN;          // N % 256 == 0: every region has all 8 column blocks
+    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    const int T = nrp * NCB;                 // blocks of this region (even); slots = T + 2
+    const bool producer = w < 4;          // (the "no Y traffic" ablation switch of the older variants is not implemented here)
+    const int j = w & 3;                     // index within the role
+    float lossAcc = 0.f;
+    unsigned long long ph[PROF ? 10 : 1] = {};
+    const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
+#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+
+    if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
+        if (!producer) {
+            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            for (int c = 0; c < NCB; ++c)
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                    if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
+                }
+        }
+        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
+        return;
+    }
+
+    // ---- power-of-two operand scales from the factor maxima (k_absmax partials) and max|Y|; uniform ----------------
+    float scA, scS, scR, unP, unA, unS;
+    {
+        float* red = reinterpret_cast<float*>(smem);
+        float m0 = 0.f, m1 = 0.f;
+        for (int i = tid; i < V8_NPART; i += V5_THREADS) { m0 = fmaxf(m0, a.absmax[i]); m1 = fmaxf(m1, a.absmax[V8_NPART + i]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+        if (lane == 0) { red[w] = m0; red[8 + w] = m1; }
+        __syncthreads();
+        float mA = red[0], mS = red[8];
+        for (int i = 1; i < 8; ++i) { mA = fmaxf(mA, red[i]); mS = fmaxf(mS, red[8 + i]); }
+        __syncthreads();                     // red aliases Sl
+        int qA = 0, qS = 0, qR = 0;
+        (void)frexpf(mA, &qA);               // m = f 2^q, f in [0.5, 1)  ->  m 2^(14-q) < 2^14
+        (void)frexpf(mS, &qS);
+        (void)frexpf((a.ymax + (float)K * mA * mS) * a.wmax, &qR);
+        const int eA = mA > 0.f ? 14 - qA : 0, eS = mS > 0.f ? 14 - qS : 0, eR = 14 - qR;
+        scA = ldexpf(1.f, eA); scS = ldexpf(1.f, eS); scR = ldexpf(1.f, eR);
+        unP = ldexpf(1.f, -(eA + eS)); unA = ldexpf(1.f, -(eR + eS)); unS = ldexpf(1.f, -(eR + eA));
+    }
+    {   // ---- all S terms of the region, once: block cb -> Sl[cb] (all 512 threads, one float4 of each block) -------
+        const float4* ssrc = reinterpret_cast<const float4*>(a.St + (int64_t)col0 * K) + tid;
+        const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
+        float4 sr[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) sr[c] = ssrc[c * (V5_BN * K / 4)];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            f16x4 t0, t1;
+            v8_split2(sr[c], scS, t0, t1);
+            unsigned char* d = smem + c * V8_SL_BYTES + st_off;
+            *reinterpret_cast<f16x4*>(d) = t0;
+            *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+        }
+    }
+
+    if (producer) {
+        // ================================ producers: GEMM1 and R =================================================
+        f32x16 p0, p1;
+        float yE[16], yO[16];                // Y of the even / odd blocks in flight (accumulator layout)
+        float wE[HASW ? 16 : 1], wO[HASW ? 16 : 1];   // their weights
+        float4 areg[4][2];
+        f16x8 afr[4][2];
+        // Y(b): wave-uniform base (scalar registers) + one per-lane offset; row i of the tile is a multiple of ldY further
+        const int jw = __builtin_amdgcn_readfirstlane(j);
+        const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
+        const unsigned ylane = (unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31;
+        auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
+            int brp = b >> 3;
+            if (brp >= nrp) brp = nrp - 1;
+            const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane];
+        };
+        const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
+        const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
+        auto load_W = [&](int b, float (&wv)[HASW ? 16 : 1]) {
+            if constexpr (HASW) {
+                int brp = b >> 3;
+                if (brp >= nrp) brp = nrp - 1;
+                const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wv[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane];
+            }
+        };
+        auto load_A = [&](int prow) {
+            const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                areg[ks][0] = src[ks * 4];
+                areg[ks][1] = src[ks * 4 + 1];
+            }
+        };
+        auto make_afr = [&]() {              // split the scaled panel rows into two fp16 terms (register fragments of GEMM1's A operand)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
+                                    areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float xs = x[q] * scA;
+                    const _Float16 t0 = (_Float16)xs;
+                    afr[ks][0][q] = t0;
+                    afr[ks][1][q] = (_Float16)(xs - (float)t0);
+                }
+            }
+        };
+        auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
+            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
+            }
+        };
+        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
+        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
+        load_A(row0);
+        load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
+        load_Y(1, yO);
+        load_W(0, wE);
+        load_W(1, wO);
+        make_afr();
+        if (nrp > 1) load_A(row0 + V5_BM);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();        // Sl published
+
+        // One slot.  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
+        auto slot = [&](int s, f32x16& pc, f32x16& pp, float (&y)[16], float (&wv)[HASW ? 16 : 1], auto gemm_c, auto epi_c) {
+            constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
+            const int cb = s & 7, rp = s >> 3;       // block s = (rp, cb); NCB == 8
+            if (cb == 2 && rp < nrp) {                   // block s-2 opened this row panel: the consumers start on it in this slot
+                publish_A();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
+            PH(5)
+            if constexpr (GEMM) {
+                if (cb == 0 && s > 0) {      // block s opens a row panel: its A terms (rows requested 8 slots ago)
+                    make_afr();
+                    if (rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
+                }
+            }
+            f16x8 sv[4][2];
+            if constexpr (GEMM) {
+                const unsigned char* Slb = smem + cb * V8_SL_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int so = s_g1 ^ (ks << 5);
+                    sv[ks][0] = *reinterpret_cast<const f16x8*>(Slb + so);
+                    sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                }
+            }
+            PH(2)
+            if constexpr (GEMM) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][1], sv[ks][0], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][1], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][0], pc, 0, 0, 0);
+                }
+            }
+            if constexpr (EPI) {
+                unsigned char* Rb = smem + V8_OFF_R + ((s - 1) & 1) * V5_R_BYTES;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 h, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float r = pp[4 * g + q] * unP - y[4 * g + q];
+                        if constexpr (HASW) {
+                            const float ww = wv[4 * g + q];
+                            lossAcc += ww * (r * r);
+                            r *= ww;
+                        } else {
+                            lossAcc += r * r;
+                        }
+                        const float rs = r * scR;
+                        const _Float16 hh = (_Float16)rs;
+                        h[q] = hh;
+                        l[q] = (_Float16)(rs - (float)hh);
+                    }
+                    const int o = r_w ^ (g << 4);
+                    *reinterpret_cast<f16x4*>(Rb + o) = h;
+                    *reinterpret_cast<f16x4*>(Rb + V5_R_TERM + o) = l;
+                }
+                load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+                load_W(s + 1, wv);
+            }
+            PH(3)
+            PH(4)
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
+            __builtin_amdgcn_s_barrier();
+            PH(0)
+        };
+        using yes = std::integral_constant<bool, true>;
+        using no = std::integral_constant<bool, false>;
+        slot(0, p0, p1, yO, wO, yes{}, no{});
+#pragma nounroll
+        for (int s = 1; s + 1 < T; s += 2) {
+            slot(s, p1, p0, yE, wE, yes{}, yes{});
+            slot(s + 1, p0, p1, yO, wO, yes{}, yes{});
+        }
+        slot(T - 1, p1, p0, yE, wE, yes{}, yes{});
+        slot(T, p0, p1, yO, wO, no{}, yes{});
+        slot(T + 1, p1, p0, yE, wE, no{}, no{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();              // Sl published
+
+        f32x16 accS[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
+        f32x16 accA0, accA1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+        const int kt = j & 1, mh = j >> 1;   // GEMM3 tile; GEMM2: rows 32j.., both k tiles
+        int r_t0, r_t1;                      // GEMM2 A operand (R, transposing read)
+        {
+            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
+            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+        }
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
+        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
+        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
+        auto flush_gA = [&](int prow) {
+            float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float* ph_ = p0_ + half * 16 * K;
+                asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
+                    const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                    ph_[ro] = accA0[i] * unA;
+                    ph_[ro + 32] = accA1[i] * unA;
+                }
+            }
+        };
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            PH(9)
+        };
+        auto consume = [&](int b, int rp, int cb, f32x16& accSc) {     // block b = (rp, cb)
+            const int prow = row0 + rp * V5_BM;
+            const unsigned char* Rb = smem + V8_OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + cb * V8_SL_BYTES;
+            const unsigned char* Ab = smem + V8_OFF_A;
+            if (a.doA & 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 r0 = v8_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const f16x8 r1 = v8_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+                    const f16x8 s00 = v8_tr_pair(Slb, so0, so1);
+                    const f16x8 s01 = v8_tr_pair(Slb + V5_S_TERM, so0, so1);
+                    const f16x8 s10 = v8_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
+                    const f16x8 s11 = v8_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s10, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s01, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s11, accA1, 0, 0, 0);
+                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s00, accA0, 0, 0, 0);
+                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s10, accA1, 0, 0, 0);
+                }
+            }
+            PH(6)
+            if (a.doS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ro = r_g3 ^ (ks << 5);
+                    const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
+                    const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
+                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
+                    const f16x8 a0 = v8_tr_pair(Ab, ao0, ao1);
+                    const f16x8 a1 = v8_tr_pair(Ab + V5_A_TERM, ao0, ao1);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accSc, 0, 0, 0);
+                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accSc, 0, 0, 0);
+                }
+            }
+            if ((a.doA & 1) && cb + 1 == NCB) {
+                flush_gA(prow);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+            }
+        };
+        sync();
+        sync();
+        int s = 2;
+#pragma nounroll
+        for (int rp = 0; rp < nrp; ++rp) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                }
+                consume(s - 2, rp, cb, accS[cb]);
+                PH(7)
+                sync();
+                ++s;
+            }
+        }
+        if (a.doS) {
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            const int kk = kt * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const int bcol = col0 + c * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = bcol + tile_row(i, lane);
+                    dst[(int64_t)gn * K + kk] = accS[c][i] * unS;
+                }
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 4; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+    if constexpr (PROF) {
+        if (prof && lane == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
+    }
+#undef PH
+}
+
+template <bool PROF, bool HASW>
+static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
+    if (a.W != nullptr) return grad_launch_f16_v8_t<false, true>(a, stream);   // (no phase profiling of the weighted instance)
+    return a.prof ? grad_launch_f16_v8_t<true, false>(a, stream) : grad_launch_f16_v8_t<false, false>(a, stream);
+}
+
+
 template <int KP>
 static size_t pipe_lds_bytes() {
     constexpr int NW = BG_THREADS / 64;
@@ -2042,6 +2528,8 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         if (a.W != nullptr && !(variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0)) return hipErrorInvalidValue;   // see grad_bf16_takes_weights
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
+        g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
+        if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_f16_v8(g, stream);   // fp16 two-term mode
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }

@@ -67,7 +67,11 @@ struct pmx_ctx {
 
     // K1
     unsigned long long* k1prof = nullptr;  // tuning: phase cycle sums (PMX_K1_PROF=1)
-    bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 and K <= 64), else exact fp32 MFMA
+    bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
+    bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
+    float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
+    float ymax = 0.f;                      // max |Y|
+    float wmax = 1.f;                      // max(1, max |W|)
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
     int64_t rowsPad[2] = {0, 0};
@@ -162,7 +166,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     if (K > MAXK) FAIL(PMX_E_UNSUPPORTED, "K=%lld > %d components is not supported", (long long)K, MAXK);
     if (M > (1ll << 30) || N > (1ll << 30)) FAIL(PMX_E_UNSUPPORTED, "dimension too large");
-    if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
+    if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) FAIL(PMX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -180,9 +184,11 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         if (e != hipSuccess) { delete c; FAIL(PMX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    c->use_bf16 = (mode == PMX_MODE_BF16X3) && K <= 64;
+    c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64;
     c->plan = c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K);
+    c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
     int rc = PMX_OK;
+    if (c->use_f16) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
     if (c->use_bf16) {
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
             c->rowsPad[j] = (c->rows[j] + 127) / 128 * 128;
@@ -267,6 +273,21 @@ extern "C" int pmx_ctx_sync(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// max |Y| for the fp16 path's residual scale (one pass over Y, once)
+static int measure_ymax(pmx_ctx* c) {
+    if (!c->use_f16) return PMX_OK;
+    launch_absmax_pitched(c->Y, c->ldY, c->M, c->N, c->absmax + 512, c->stream);
+    HIP_CHECK(hipGetLastError());
+    float h[256];
+    HIP_CHECK(hipMemcpyAsync(h, c->absmax + 512, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    float m = 0.f;
+    for (float v : h) m = v > m ? v : m;
+    if (!(m < 3.0e38f)) FAIL(PMX_E_INVALID, "Y contains non-finite values");
+    c->ymax = m;
+    return PMX_OK;
+}
+
 extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
     if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
@@ -278,7 +299,7 @@ extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
     c->Y = c->Yown;
     c->ldY = c->N;
     c->haveY = true;
-    return PMX_OK;
+    return measure_ymax(c);
 }
 
 extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int copy) {
@@ -296,12 +317,28 @@ extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int cop
         c->ldY = ld;
     }
     c->haveY = true;
+    return measure_ymax(c);
+}
+
+// max(1, max |W|) for the fp16 path's residual scale
+static int measure_wmax(pmx_ctx* c) {
+    c->wmax = 1.f;
+    if (!c->use_f16 || !c->W) return PMX_OK;
+    launch_absmax_pitched(c->W, c->ldW, c->M, c->N, c->absmax + 512, c->stream);
+    HIP_CHECK(hipGetLastError());
+    float h[256];
+    HIP_CHECK(hipMemcpyAsync(h, c->absmax + 512, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    float m = 1.f;
+    for (float v : h) m = v > m ? v : m;
+    if (!(m < 3.0e38f)) FAIL(PMX_E_INVALID, "W contains non-finite values");
+    c->wmax = m;
     return PMX_OK;
 }
 
 static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, int copy) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
-    if (!W) { c->W = nullptr; c->ldW = 0; return PMX_OK; }
+    if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
         FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in split-bf16 mode needs K = 64, M %% 128 = 0, N %% 256 = 0; create the context with PMX_MODE_F32");
@@ -321,7 +358,7 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
         c->W = W;
         c->ldW = ld;
     }
-    return PMX_OK;
+    return measure_wmax(c);
 }
 extern "C" int pmx_set_W_host(pmx_ctx* c, const float* W, int64_t ld) { return set_W_common(c, W, ld, 1, 1); }
 extern "C" int pmx_set_W_device(pmx_ctx* c, const float* dW, int64_t ld, int copy) { return set_W_common(c, dW, ld, 0, copy); }
@@ -438,6 +475,15 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.doA = doA; g.doS = doS;
         g.prof = c->k1prof;
         g.W = c->W; g.ldW = c->ldW;
+        if (c->use_f16) {   // operand scales of the two-term fp16 kernel: maxima of THESE factor arrays
+            AbsmaxArgs am{};
+            am.X[0] = A; am.X[1] = St;
+            am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+            am.out = c->absmax;
+            am.status = c->dstatus;
+            launch_absmax(am, c->stream);
+            g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
+        }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
     } else {

@@ -16,13 +16,15 @@ from . import _lib
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
 #   "bf16x3" split-bf16 MFMA with fp32-class accuracy (3-term split for A@S, 2-term for the gradients);
 #            K <= 64, larger K runs the fp32 kernel
+#   "f16x2"  as "bf16x3", but shapes with K = 64, M % 128 = 0, N % 256 = 0 run the two-term fp16 kernel (operands scaled
+#            by powers of two from the factor maxima: 9 instead of 12 MFMA products per multiply-add)
 _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
 def set_default_mode(mode):
-    """Select the contraction arithmetic used by nmf() and friends ("f32" or "bf16x3")."""
+    """Select the contraction arithmetic used by nmf() and friends ("f32", "bf16x3" or "f16x2")."""
     global _DEFAULT_MODE
-    assert mode in ("f32", "bf16x3")
+    assert mode in ("f32", "bf16x3", "f16x2")
     _DEFAULT_MODE = mode
 
 
@@ -47,7 +49,7 @@ class DeviceNMF:
         self.device = device
         mode = mode or _DEFAULT_MODE
         self.mode = mode
-        mode_id = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}[mode]
+        mode_id = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
                                            C.c_void_p(stream) if stream else None))
