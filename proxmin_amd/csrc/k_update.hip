@@ -936,6 +936,8 @@ struct FinishArgs {
     float* Xp[2];
     double* colpart;
     int check_convergence;
+    float* absmax_out;   // [2][EW_BLOCKS] per-workgroup max |X_j| of the iterate written here (the fp16 K1's operand
+                         // scales, saving its own k_absmax pass), or nullptr
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
         }
     }
     float* X = a.s.X[j];
-    float d2 = 0.f, n2 = 0.f;
+    float d2 = 0.f, n2 = 0.f, xmax = 0.f;
     float cs[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) cs[c] = 0.f;
@@ -1012,6 +1014,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
                 const int64_t e = r * K + l32 + 32 * c;
                 const float x = z[c];
                 X[e] = x;
+                xmax = fmaxf(xmax, fabsf(x));
                 if (a.check_convergence) {
                     const float d = x - a.Xp[j][e];
                     d2 += d * d;
@@ -1024,6 +1027,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_finish(FinishArgs a) {
     double red[2] = {(double)d2, (double)n2};
     block_sum_store<2>(red, part_ptr(a.s.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
     colsum_store<NC>(cs, a.colpart, j, sm);
+    if (a.absmax_out != nullptr) {
+        const double m = wave_max((double)xmax);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mm = scratch[0];
+            for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
+            a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
+        }
+    }
 }
 
 // single-block end-of-iteration kernel for adaprox

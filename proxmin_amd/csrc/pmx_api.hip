@@ -454,7 +454,8 @@ static int clear_halt(pmx_ctx* c) {
     return PMX_OK;
 }
 
-static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS) {
+// absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
+static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
     if (c->use_bf16) {
         PresplitArgs ps{};
@@ -481,7 +482,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
             am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
             am.out = c->absmax;
             am.status = c->dstatus;
-            launch_absmax(am, c->stream);
+            if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -1089,6 +1090,8 @@ static int ada_enqueue_tail(pmx_ctx* c, int t) {
     f.Xp[0] = c->Xp[0]; f.Xp[1] = c->Xp[1];
     f.colpart = c->colpart;
     f.check_convergence = p.check_convergence;
+    static_assert(EW_BLOCKS == 256, "k_grad_f16_v8 folds 256 partial maxima per factor");
+    f.absmax_out = c->use_f16 ? c->absmax : nullptr;
     launch_ada_finish(f, c->stream);
     AdaDecideArgs d{};
     d.al = alpha_args(c);
@@ -1133,8 +1136,9 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     return PMX_OK;
 }
 
-static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev) {
-    int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);                     // algorithms.py:369
+// after_tail: the previous kernels on the stream were THIS call's finish + decide of the preceding iteration
+static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev, bool after_tail) {
+    int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, after_tail);         // algorithms.py:369
     if (rc != PMX_OK) return rc;
     return ada_enqueue_moment(c, it, b1t, b1prev);
 }
@@ -1150,6 +1154,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
     const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
     const int it0 = c->hstatus->it_done;
     int done = 0;            // iterations of this call completed
+    int tails = 0;           // iteration tails enqueued by this call (their finish kernel leaves the factor maxima behind)
     while (done < n_iter && !c->hstatus->stopped) {
         // ---- enqueue a chunk of whole iterations ------------------------------------------------
         const int chunk = std::min(n_iter - done, 16);
@@ -1159,9 +1164,10 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
         if (c->sub_nt != 1) c->sub_nt = nsub <= 4 ? 4 : SUB_NT_MAX;
         for (int i = 0; i < chunk; ++i) {
             const int gi = done + i;
-            rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
+            rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1], tails > 0);
             if (rc != PMX_OK) return rc;
             rc = ada_enqueue_tail(c, ada_enqueue_subs(c, 0, nsub));
+            ++tails;
             if (rc != PMX_OK) return rc;
         }
         rc = read_status(c);
@@ -1179,7 +1185,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             // the iterations that followed in the chunk were skipped: re-enqueue them after this one
             const int finished_if_ok = c->hstatus->it_done - it0 + 1;
             for (int gi = finished_if_ok; gi < done + chunk; ++gi) {
-                rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
+                rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1], true);
                 if (rc != PMX_OK) return rc;
                 rc = ada_enqueue_tail(c, ada_enqueue_subs(c, 0, nsub));
                 if (rc != PMX_OK) return rc;

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = {
     "adaprox_unity": dict(M=768, N=900, K=24, unity=True, its=9),
-    "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512: the split-bf16 v5 / f32 whole-block kernels
+    "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512, N % 256 = 0: the fast 16-bit-split kernels / the f32 whole-block kernel
     "pgm": dict(M=520, N=700, K=12, its=7),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
 }
@@ -59,7 +59,7 @@ def _worker(rank, world, port, name, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     import torch.multiprocessing as mp

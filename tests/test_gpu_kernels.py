@@ -26,7 +26,7 @@ SHAPES = [(33, 47, 3), (64, 96, 8), (128, 128, 32), (200, 1000, 5), (257, 513, 3
           (1024, 640, 64), (384, 1100, 100), (512, 512, 128), (4096, 4096, 32)]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     """K1 (nmf.grad_likelihood + log_likelihood) vs NumPy, fp32 tolerance: the contraction runs on
@@ -67,7 +67,7 @@ def test_split_bf16_kernel_variants_agree_with_oracle(eng, orc, monkeypatch, M, 
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 def test_gradient_is_transpose_sensitive(eng, orc, mode):
     """asymmetric inputs: a swapped tile mapping cannot pass (guide rule: A=I with asymmetric B)."""
     M, N, K = 96, 160, 32
@@ -158,14 +158,14 @@ def test_operator_edge_cases():
 
 
 def test_split_bf16_gradient_near_solution_is_fp32_class(eng, orc):
-    """Where cancellation bites (|R| << |A S|): the split-bf16 kernel must be as close to the fp64
-    gradient as the exact-fp32 kernel is (within 3x), and both ~1e-5 of the gradient norm."""
+    """Where cancellation bites (|R| << |A S|): the split-bf16 kernel and the two-term fp16 kernel must be as close to
+    the fp64 gradient as the exact-fp32 kernel is (within 3x), and all ~1e-5 of the gradient norm."""
     M, N, K = 1536, 2048, 64
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=31)
     orc.adaprox_nmf(Y, A, S, scheme="amsgrad", max_iter=60, e_rel=1e-3, check_convergence=False)
     g64 = orc.residual_gradients(A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64))
     err = {}
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "f16x2"):
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
             dev.set_Y(Y)
             dev.set_factors(A, S)
@@ -174,6 +174,7 @@ def test_split_bf16_gradient_near_solution_is_fp32_class(eng, orc):
     for j in range(2):
         assert err["f32"][j] < 5e-5
         assert err["bf16x3"][j] < max(3 * err["f32"][j], 2e-5), err
+        assert err["f16x2"][j] < max(3 * err["f32"][j], 2e-5), err
 
 
 def test_full_size_gradient_properties(eng):
@@ -199,7 +200,7 @@ def test_full_size_gradient_properties(eng):
     Y2[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()] += torch.from_numpy(vv).cuda()
     Yx = torch.from_numpy(A).cuda() @ torch.from_numpy(S).cuda()   # fp32 product: Y - A S is at rounding level
     out = {}
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "f16x2"):
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
             dev.set_factors(A, S)
             dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
@@ -223,11 +224,12 @@ def test_full_size_gradient_properties(eng):
         # (3) exact factorisation: residual entries are fp32 rounding of a K-term dot product (<= ~K eps |A||S|)
         assert lossx < 1e-9 * loss
         assert np.abs(gAx).max() < 2e-5 * scaleA and np.abs(gSx).max() < 2e-5 * scaleS
-    # (1) two implementations, one answer
-    for a, b in zip(out["f32"][:2], out["bf16x3"][:2]):
-        assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
-        np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max())
-    assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)
+    # (1) three implementations, one answer
+    for fast in ("bf16x3", "f16x2"):
+        for a, b in zip(out["f32"][:2], out[fast][:2]):
+            assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a), fast
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max(), err_msg=fast)
+        assert out[fast][2] == pytest.approx(out["f32"][2], rel=1e-6)
 
 
 @pytest.mark.parametrize("pitch_extra,offset", [(0, 0), (64, 0), (3, 0), (64, 1)])
@@ -246,7 +248,7 @@ def test_zero_copy_Y_with_row_pitch_and_alignment(eng, orc, pitch_extra, offset)
         view[:, N:] = 1e30            # must never be read as data
     A64, S64, Y64 = A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64)
     rA, rS = orc.residual_gradients(A64, S64, Y64)
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "f16x2"):
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
             dev.set_Y_device(view.data_ptr(), ld=ld, copy=False, keepalive=buf)
             dev.set_factors(A, S)
@@ -269,15 +271,55 @@ def test_split_bf16_default_kernel_on_many_region_shapes(eng):
         A = rng.random((M, K), dtype=np.float32)
         S = rng.random((K, N), dtype=np.float32)
         out = {}
-        for mode in ("f32", "bf16x3"):
+        for mode in ("f32", "bf16x3", "f16x2"):
             with eng.DeviceNMF(M, N, K, mode=mode) as dev:
                 dev.set_Y(Y)
                 dev.set_factors(A, S)
                 gA, gS = dev.grad()
                 out[mode] = (gA, gS, dev.loglike())
-        for a, b in zip(out["f32"][:2], out["bf16x3"][:2]):
-            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max(), err_msg="shape %dx%d" % (M, N))
-        assert out["bf16x3"][2] == pytest.approx(out["f32"][2], rel=1e-6)
+        for fast in ("bf16x3", "f16x2"):
+            for a, b in zip(out["f32"][:2], out[fast][:2]):
+                np.testing.assert_allclose(b, a, rtol=0, atol=1e-5 * np.abs(a).max(), err_msg="%s shape %dx%d" % (fast, M, N))
+            assert out[fast][2] == pytest.approx(out["f32"][2], rel=1e-6)
+
+
+@pytest.mark.parametrize("case", ["tiny_factors", "huge_factors", "mixed_magnitudes", "zero_A", "big_Y", "big_weights"])
+def test_fp16_two_term_kernel_operand_scaling(eng, orc, case):
+    """k_grad_f16_v8 scales A, S and the residual by powers of two taken from their maxima so that the fp16 terms stay
+    in the normal range: factors of very different magnitudes (1e-4 .. 1e3, entries spanning eight decades, an all-zero
+    factor, |Y| ~ 1e4, weights up to 50) must still give fp32-class gradients -- no overflow to inf, no flush to zero."""
+    M, N, K = 384, 768, 64
+    rng = np.random.default_rng(hash(case) % 1000)
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=5)
+    W = None
+    if case == "tiny_factors":
+        A *= 1e-4
+        S *= 3e-3
+    elif case == "huge_factors":
+        A *= 1e3
+        S *= 40.0
+    elif case == "mixed_magnitudes":
+        A *= (10.0 ** rng.uniform(-6, 2, size=A.shape)).astype(np.float32)
+        S *= (10.0 ** rng.uniform(-6, 2, size=S.shape)).astype(np.float32)
+    elif case == "zero_A":
+        A[:] = 0
+    elif case == "big_Y":
+        Y = (Y * 1e4).astype(np.float32)
+    elif case == "big_weights":
+        W = (50.0 * rng.random((M, N))).astype(np.float32)
+    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        dev.set_Y(Y)
+        if W is not None:
+            dev.set_W(W)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+    x64 = [x.astype(np.float64) for x in (A, S, Y)] + ([W.astype(np.float64)] if W is not None else [])
+    rA, rS = orc.residual_gradients(*x64)
+    assert np.isfinite(gA).all() and np.isfinite(gS).all()
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * max(np.abs(rA).max(), 1e-30))
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * max(np.abs(rS).max(), 1e-30))
+    assert loss == pytest.approx(orc.half_sq_residual(*x64), rel=2e-5)
 
 
 @pytest.mark.parametrize("M,N,K", [(33, 47, 3), (257, 513, 33), (1024, 640, 64), (1024, 768, 64), (2304, 4096, 64), (384, 1100, 100), (512, 512, 128)])
@@ -304,17 +346,18 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
     uA, uS = orc.residual_gradients(A64, S64, Y64)
     np.testing.assert_allclose(gA1, uA, rtol=2e-5, atol=2e-5 * np.abs(uA).max())
     if K <= 64:
-        # the split-bf16 mode takes weights where its default kernel applies, and says so loudly elsewhere
-        with eng.DeviceNMF(M, N, K, mode="bf16x3") as dev:
-            dev.set_Y(Y)
-            if K == 64 and M % 128 == 0 and N % 256 == 0:
-                dev.set_W(W)
-                dev.set_factors(A, S)
-                bA, bS = dev.grad()
-                bloss = dev.loglike()
-                np.testing.assert_allclose(bA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
-                np.testing.assert_allclose(bS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
-                assert bloss == pytest.approx(orc.half_sq_residual(A64, S64, Y64, W64), rel=2e-5)
-            else:
-                with pytest.raises(NotImplementedError):
+        # the 16-bit split modes take weights where their fast kernels apply, and say so loudly elsewhere
+        for fast in ("bf16x3", "f16x2"):
+            with eng.DeviceNMF(M, N, K, mode=fast) as dev:
+                dev.set_Y(Y)
+                if K == 64 and M % 128 == 0 and N % 256 == 0:
                     dev.set_W(W)
+                    dev.set_factors(A, S)
+                    bA, bS = dev.grad()
+                    bloss = dev.loglike()
+                    np.testing.assert_allclose(bA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max(), err_msg=fast)
+                    np.testing.assert_allclose(bS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max(), err_msg=fast)
+                    assert bloss == pytest.approx(orc.half_sq_residual(A64, S64, Y64, W64), rel=2e-5)
+                else:
+                    with pytest.raises(NotImplementedError):
+                        dev.set_W(W)

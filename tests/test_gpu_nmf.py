@@ -18,8 +18,8 @@ RTOL, ATOL = 2e-4, 2e-5
 # ~8e-6 relative noise in the heavily cancelling gradient sums (2-term bf16 split) against ~1e-6 for exact fp32;
 # AMSGrad's eps clamp amplifies that on near-zero entries, so a few more entries per thousand drift.
 MODE = {"name": "f32"}
-FRAC_SMALL = {"f32": 0.998, "bf16x3": 0.995}      # fixtures (10^3 .. 10^4 entries)
-FRAC_LARGE = {"f32": 0.9999, "bf16x3": 0.999}     # medium problems (10^5 .. 10^6 entries)
+FRAC_SMALL = {"f32": 0.998, "bf16x3": 0.995, "f16x2": 0.995}      # fixtures (10^3 .. 10^4 entries)
+FRAC_LARGE = {"f32": 0.9999, "bf16x3": 0.999, "f16x2": 0.999}     # medium problems (10^5 .. 10^6 entries)
 
 
 def assert_close_fp32_trajectory(actual, desired, err_msg=""):
@@ -48,7 +48,7 @@ def assert_factors_close(actual, desired, ref_dtype, err_msg=""):
     np.testing.assert_allclose(actual, desired, rtol=hard * RTOL, atol=hard * ATOL, err_msg=err_msg)
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+@pytest.fixture(scope="module", params=["f32", "bf16x3", "f16x2"])
 def pm(request):
     """both contraction arithmetics must meet the same parity bars"""
     import __graft_entry__ as g
@@ -318,7 +318,7 @@ def test_full_size_modes_agree_and_loss_decreases():
     M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
     Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 99, torch.device("cuda", 0))
     res = {}
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "f16x2"):
         with DeviceNMF(M, N, K, mode=mode) as dev:
             dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
             dev.set_factors(A0, S0)
@@ -328,14 +328,14 @@ def test_full_size_modes_agree_and_loss_decreases():
             assert r.iterations == 6
             A, S = dev.get_factors()
             l1 = dev.loglike()
-            if mode == "bf16x3":
+            if mode != "f32":
                 assert run(34).iterations == 34
                 assert dev.loglike() < 0.5 * l0
         assert np.isfinite(A).all() and np.isfinite(S).all()
         np.testing.assert_allclose(S.sum(0), 1.0, rtol=1e-5)          # prox_unity_plus on the columns of S
         assert (A >= 0).all() and (S >= 0).all()
         res[mode] = (A, S, l1)
-    for a, b in zip(res["f32"][:2], res["bf16x3"][:2]):
+    for a, b in list(zip(res["f32"][:2], res["bf16x3"][:2])) + list(zip(res["f32"][:2], res["f16x2"][:2])):
         ok = np.abs(a - b) <= 2e-5 + 2e-4 * np.abs(a)
         assert ok.mean() >= 0.999, ok.mean()
         # the tail is AMSGrad's eps clamp amplifying a rounding difference on near-zero gradient entries;
@@ -344,6 +344,7 @@ def test_full_size_modes_agree_and_loss_decreases():
         assert (ratio > 25).mean() <= 1e-4, (ratio > 25).mean()
         assert ratio.max() <= 1000, ratio.max()
     assert res["bf16x3"][2] == pytest.approx(res["f32"][2], rel=1e-4)
+    assert res["f16x2"][2] == pytest.approx(res["f32"][2], rel=1e-4)
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
