@@ -45,11 +45,11 @@ MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
 MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
 
 
-# HBM bytes per K1 launch from the PMC passes committed in profiles/r01_e_pmc_cfg3_bf16x3.json (bf16x3: k_grad_bf16_v7)
-# and profiles/r01_c_pmc_traffic_cfg3.json (f32)
+# HBM bytes per K1 launch from the PMC passes committed in profiles/r01_f_pmc_cfg3_f16x2.json (f16x2: k_grad_f16_v8),
+# profiles/r01_e_pmc_cfg3_bf16x3.json (bf16x3: k_grad_bf16_v7) and profiles/r01_c_pmc_traffic_cfg3.json (f32)
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command; FETCH_SIZE doubled per the gfx950 correction).
 # Only known for the configuration that was profiled; null otherwise.
-PMC_TRAFFIC_BYTES = {("cfg3", "bf16x3"): 2 * 542917 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
+PMC_TRAFFIC_BYTES = {("cfg3", "f16x2"): 2 * 543047 * 1024 + 295432 * 1024, ("cfg3", "bf16x3"): 2 * 542917 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
@@ -169,8 +169,9 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
-    ap.add_argument("--mode", default="bf16x3", choices=["f32", "bf16x3", "f16x2"],
-                    help="contraction arithmetic: bf16x3 = split-bf16 MFMA, f16x2 = two-term fp16 MFMA, f32 = exact fp32 MFMA")
+    ap.add_argument("--mode", default="f16x2", choices=["f32", "bf16x3", "f16x2"],
+                    help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (headline), bf16x3 = three-term bf16 split MFMA, "
+                         "f32 = exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch

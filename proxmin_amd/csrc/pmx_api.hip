@@ -72,6 +72,9 @@ struct pmx_ctx {
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
     float ymax = 0.f;                      // max |Y|
     float wmax = 1.f;                      // max(1, max |W|)
+    // row-sharded adaprox: the last kernels enqueued were an iteration tail (k_ada_finish left the factor maxima in
+    // `absmax`); every entry point that can change the factors otherwise clears it
+    bool absmax_by_finish = false;
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
     int64_t rowsPad[2] = {0, 0};
@@ -393,6 +396,7 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
 }
 
 extern "C" int pmx_upload(pmx_ctx* c, int buf, const float* host, int64_t count) {
+    if (c) c->absmax_by_finish = false;
     if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     float** slot; int64_t n;
@@ -417,6 +421,7 @@ extern "C" int pmx_download(pmx_ctx* c, int buf, float* host, int64_t count) {
 }
 
 extern "C" int pmx_buffer_ptr(pmx_ctx* c, int buf, void** dptr, int64_t* count) {
+    if (c) c->absmax_by_finish = false;
     if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
     float** slot; int64_t n;
     int rc = buf_lookup(c, buf, &slot, &n, true);
@@ -723,6 +728,7 @@ extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
 }
 
 extern "C" int pmx_prox_apply(pmx_ctx* c, int buf, const pmx_proxseq* prox, const float* step_k) {
+    if (c) c->absmax_by_finish = false;
     if (!c || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     int rc = check_prox(*prox, "prox_apply");
@@ -772,6 +778,7 @@ extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const p
 // PGM / FISTA                                             (proxmin/algorithms.py:12-144)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -971,6 +978,7 @@ static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
 }
 
 extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
@@ -999,6 +1007,7 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
 // adaprox                                                 (proxmin/algorithms.py:248-423)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int warm_moments) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -1144,6 +1153,7 @@ static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev, bool 
 }
 
 extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double b1_prev, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
@@ -1207,6 +1217,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
 // block-SDMM                                              (proxmin/algorithms.py:653-850)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -1276,6 +1287,7 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
 }
 
 extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
@@ -1384,7 +1396,7 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
     }
     switch (phase) {
         case 0:
-            rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
+            rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, c->absmax_by_finish);
             if (rc != PMX_OK) return rc;
             return shard_pack(c, 1);
         case 1: {
@@ -1400,7 +1412,9 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             pmx_ctx::SubRec& r = c->sub_rec[it & 63];
             r.it = it; r.nt = c->sub_nt;
             r.enq = ada_enqueue_subs(c, 0, ns);
-            return ada_enqueue_tail(c, r.enq);
+            rc = ada_enqueue_tail(c, r.enq);
+            c->absmax_by_finish = rc == PMX_OK;
+            return rc;
         }
         case 2: return shard_pack(c, 0);
         case 3: return shard_post(c, 1);
@@ -1437,6 +1451,7 @@ static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
 }
 
 extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
@@ -1508,6 +1523,7 @@ static int bsdmm_enqueue_decide(pmx_ctx* c, int j, const float* comm_scalars, in
 }
 
 extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
+    if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
@@ -1565,7 +1581,9 @@ extern "C" int pmx_adaprox_more_subs(pmx_ctx* c, int t0, int n) {
     c->sub_nt = r.nt;
     const int t_to = ada_enqueue_subs(c, r.enq, n);
     r.enq = t_to;
-    return ada_enqueue_tail(c, t_to);
+    rc = ada_enqueue_tail(c, t_to);
+    c->absmax_by_finish = rc == PMX_OK;
+    return rc;
 }
 
 extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {

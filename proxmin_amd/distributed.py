@@ -381,7 +381,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         "roofline": ({"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                       "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
                       "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)} if dev.mode == "f32" or K > 64 else
-                     {"kernel": (("k_grad_bf16_v7" if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
+                     {"kernel": ((("k_grad_f16_v8" if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
                                  else "k_grad_bf16"), "bound": "hbm",
                       "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,
                       "unit": "GB/s", "frac": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,

@@ -11,7 +11,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 for (M, N) in ((16384, 16384), (2048, 16384), (5120, 4096), (128, 256)):
     K = 64
     Y, A0, S0 = bench.make_problem_device(M, N, K, True, 1234, torch.device("cuda", 0))
-    for mode in ("bf16x3", "f32"):
+    for mode in ("f16x2", "bf16x3", "f32"):
         dev = DeviceNMF(M, N, K, device=0, mode=mode)
         dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
         dev.set_factors(A0, S0)

@@ -9,7 +9,7 @@ from proxmin_amd.engine import DeviceNMF
 M, N, K, backend, unity, desc = bench.CONFIGS["cfg3"]
 Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
 out = {}
-for tag, mode in (("b1", "bf16x3"), ("b2", "bf16x3"), ("f", "f32")):
+for tag, mode in (("b1", sys.argv[1] if len(sys.argv) > 1 else "bf16x3"),) * 1 + (("b2", sys.argv[1] if len(sys.argv) > 1 else "bf16x3"), ("f", "f32")):
     dev = DeviceNMF(M, N, K, device=0, mode=mode)
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)

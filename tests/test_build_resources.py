@@ -14,7 +14,9 @@ import __graft_entry__ as g
 
 # mangled-name fragment -> max spilled VGPRs (current values in the comments)
 LIMITS = {
-    "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   default split-bf16 K1 at K = 64
+    "13k_grad_f16_v8ILb0ELb0E": 4,     # 1   two-term fp16 K1 (bench default)
+    "13k_grad_f16_v8ILb0ELb1E": 16,    #     its weighted instance
+    "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   split-bf16 K1 at K = 64
     "14k_grad_bf16_v7ILb0ELb1E": 16,   # 6   its weighted instance
     "14k_grad_bf16_v5ILb0E": 8,
     "10k_grad_f32ILi64ELb0E": 32,      # 19  exact-fp32 K1, unweighted
