@@ -12,7 +12,7 @@ Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, device)
 for rep in range(2):
     for variant in sys.argv[1:]:
         os.environ["PMX_K1_VARIANT"] = variant
-        dev = DeviceNMF(M, N, K, device=0, mode="bf16x3")
+        dev = DeviceNMF(M, N, K, device=0, mode=os.environ.get("PMX_AB_MODE", "bf16x3"))
         dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
         dev.set_factors(A0, S0)
         run = bench.begin_solver(dev, backend, unity)
