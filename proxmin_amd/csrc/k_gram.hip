@@ -88,8 +88,17 @@ __global__ __launch_bounds__(256) void k_gram_reduce(GramReduceArgs a) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + e;
+    // fixed summation order, but 16 loads are issued before the first add (the partials come from other XCDs: a
+    // load-add-load-add loop pays one memory round trip per term)
     double s = 0.0;
-    for (int b = 0; b < GRAM_BLOCKS; ++b) s += (double)p[(int64_t)b * n];
+    static_assert(GRAM_BLOCKS % 16 == 0, "");
+    for (int b0 = 0; b0 < GRAM_BLOCKS; b0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i) * n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += (double)v[i];
+    }
     a.G[(int64_t)f * n + e] = s;
 }
 
