@@ -169,10 +169,13 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
-    ap.add_argument("--mode", default="f16x2", choices=["f32", "bf16x3", "f16x2"],
-                    help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (headline), bf16x3 = three-term bf16 split MFMA, "
-                         "f32 = exact fp32 MFMA")
+    ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2"],
+                    help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (default for cfg3 / cfg5, the headline), "
+                         "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in "
+                         "fp32, and cfg4, whose K = 128 runs the fp32 kernel anyway)")
     args = ap.parse_args()
+    if args.mode is None:
+        args.mode = "f32" if args.config in ("cfg2", "cfg4") else "f16x2"
 
     import torch
     import __graft_entry__ as g
