@@ -9,7 +9,7 @@ from proxmin_amd.engine import DeviceNMF
 M, N, K, backend, unity, desc = bench.CONFIGS["cfg3"]
 device = torch.device("cuda", 0)
 Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, device)
-dev = DeviceNMF(M, N, K, device=0, mode="bf16x3")
+dev = DeviceNMF(M, N, K, device=0, mode=os.environ.get("PMX_AB_MODE", "bf16x3"))
 dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
 dev.set_factors(A0, S0)
 run = bench.begin_solver(dev, backend, unity)
