@@ -172,6 +172,8 @@ def test_batched_sub_iterations_equal_one_pass_per_launch(pm, orc, monkeypatch, 
 CONFIGS = [
     ("pgm", dict(), 1024, 1536, 32, False),
     ("fista", dict(accelerated=True), 1024, 1536, 32, False),
+    ("pgm", dict(), 1024, 1280, 64, False),                          # K = 64 whole-block shape: the fast 16-bit-split kernels
+    ("fista", dict(accelerated=True), 896, 1024, 64, False),         # (K1 evaluated at the extrapolated point)
     ("amsgrad_unity", dict(scheme="amsgrad"), 1536, 2048, 64, True),
     ("adam", dict(scheme="adam"), 777, 1290, 64, False),
     ("bsdmm", dict(), 1024, 1024, 64, False),
