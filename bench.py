@@ -182,15 +182,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
+    if "PMX_BENCH_DEVICE" in os.environ:      # test-only: several ranks on one GPU (see proxmin_amd/distributed.py)
+        local = int(os.environ["PMX_BENCH_DEVICE"])
+    torch.cuda.set_device(local)              # before any collective: RCCL binds a rank to the current device
+    device = torch.device("cuda", local)
+    if world > 1:
+        # rank 0 (re)builds the library if it is stale; nobody loads it before that is done
+        import torch.distributed as dist
+        dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        if rank == 0:
+            g.build()
+        dist.barrier()
+    else:
         g.build()
     M, N, K, backend, unity, desc = CONFIGS[args.config]
     if args.rows:
         M = args.rows
-    if "PMX_BENCH_DEVICE" in os.environ:      # test-only: several ranks on one GPU (see proxmin_amd/distributed.py)
-        local = int(os.environ["PMX_BENCH_DEVICE"])
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
 
     if world > 1 or os.environ.get("PMX_FORCE_SHARDED"):
         from proxmin_amd import distributed as pdist

@@ -314,7 +314,8 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     if backend != "adaprox":
         raise NotImplementedError("multi-GPU bench is implemented for the adaprox back-end (BASELINE cfg3/cfg4)")
     # PMX_DIST_BACKEND / PMX_BENCH_DEVICE: test-only overrides (two ranks on one GPU over gloo; RCCL needs a GPU per rank)
-    dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if "PMX_BENCH_DEVICE" in os.environ:
         local = int(os.environ["PMX_BENCH_DEVICE"])
         torch.cuda.set_device(local)
