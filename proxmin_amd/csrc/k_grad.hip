@@ -127,7 +127,7 @@ __global__ __launch_bounds__(GRAD_THREADS, 2) void k_grad_f32(GradArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float* rowp = blk + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + t * 32;
-                    p[t][i] = rowp[laneOff];
+                    p[t][i] = __builtin_nontemporal_load(rowp + laneOff);   // Y is read once: keep it out of L2 / MALL (the slabs live there)
                 }
         } else {                                           // edge block: clamp the address, select 0
             const int rmax = M - 1 - prow0, cmax = N - 1 - bcol0;   // >= 0

@@ -1669,7 +1669,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             if (brp >= nrp) brp = nrp - 1;
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane];
+            // nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient slabs this kernel
+            // writes there for the update kernel that folds them (iteration -2.7 % at 16384 x 16384)
+            for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
         };
         const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
         const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
@@ -1679,7 +1681,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                 if (brp >= nrp) brp = nrp - 1;
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wv[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane];
+                for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
             }
         };
         auto load_A = [&](int prow) {
@@ -2154,7 +2156,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             if (brp >= nrp) brp = nrp - 1;
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane];
+            // nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient slabs this kernel
+            // writes there for the update kernel that folds them (iteration -2.7 % at 16384 x 16384)
+            for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
         };
         const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
         const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
@@ -2164,7 +2168,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 if (brp >= nrp) brp = nrp - 1;
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wv[i] = base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane];
+                for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
             }
         };
         auto load_A = [&](int prow) {
