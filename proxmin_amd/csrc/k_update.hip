@@ -203,7 +203,7 @@ __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], 
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? p[u * stride + c * 32] : 0.f;
+            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? __builtin_nontemporal_load(p + u * stride + c * 32) : 0.f;   // read once
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
