@@ -49,7 +49,7 @@ MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0}      # issued MFMA flops per algorit
 # profiles/r01_e_pmc_cfg3_bf16x3.json (bf16x3: k_grad_bf16_v7) and profiles/r01_c_pmc_traffic_cfg3.json (f32)
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command; FETCH_SIZE doubled per the gfx950 correction).
 # Only known for the configuration that was profiled; null otherwise.
-PMC_TRAFFIC_BYTES = {("cfg3", "f16x2"): 2 * 543047 * 1024 + 295432 * 1024, ("cfg3", "bf16x3"): 2 * 542917 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
+PMC_TRAFFIC_BYTES = {("cfg3", "f16x2"): 2 * 543054 * 1024 + 295432 * 1024, ("cfg3", "bf16x3"): 2 * 542917 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
