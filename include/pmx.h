@@ -152,6 +152,13 @@ int pmx_get_timing(pmx_ctx* ctx, double* total_ms, int* launches);
  * only the requested outputs (do_A / do_S; 0,0 = residual + loss only): kernel ablation for tuning. */
 int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
 
+/* How the fused residual-gradient kernel (K1) of this context is laid out -- for tests and bench.py, which must be able
+ * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
+ * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
+ * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault. */
+int pmx_k1_info(pmx_ctx* ctx, int info[8]);
+
 /* ---- single operations (unit parity tests, and what the reference exposes as functions) --- */
 /* nmf.grad_likelihood, W=1 (nmf.py:28-41): gradients at the current A, St into GA / GST.     */
 int pmx_grad(pmx_ctx* ctx);

@@ -110,6 +110,10 @@ struct GradBfArgs {
     int64_t ldW;
     const float* absmax; // fp16 two-term path: partial maxima of the factors (k_absmax), nullptr otherwise
     float ymax, wmax;
+    int chainL;          // k_grad_f16_v8<.., CHAIN>: see GradV4Args
+    unsigned* chainFlags;
+    unsigned chainBase;
+    DevStatus* wstatus;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -853,6 +857,11 @@ struct GradV4Args {
     const float* absmax; // k_grad_f16_v8: [2][V8_NPART] partial maxima of |A|, |St| (k_absmax)
     float ymax;          // k_grad_f16_v8: max |Y|
     float wmax;          // k_grad_f16_v8: max(1, max |W|) (1 without weights): D = W R must fit fp16 as well
+    // k_grad_f16_v8<.., CHAIN>: gA accumulated in place through the XCD's L2 by chains of chainL workgroups (see the kernel)
+    int chainL;          // workgroups per chain (0: slabs, one per column region)
+    unsigned* chainFlags;   // [chains][RP][4] arrival words, monotonic over launches
+    unsigned chainBase;  // launch sequence number * 64
+    DevStatus* wstatus;  // writable view of `status` (fault report)
 };
 
 template <bool PROF>
@@ -2053,7 +2062,7 @@ constexpr int V8_OFF_A = V5_NB * V8_SL_BYTES, V8_OFF_R = V8_OFF_A + V5_AIMG_BYTE
 static_assert(V8_OFF_R % 256 == 0, "R images must start on a bank row");
 static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 
-template <bool PROF, bool HASW>
+template <bool PROF, bool HASW, bool CHAIN>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -2064,9 +2073,18 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     const int li = lane & 15, lq = lane >> 4;
     const int M = a.M, N = a.N;
     int rowRegion, colRegion;
+    int chainId = 0, chainPos = 0;           // CHAIN: which chain, and this workgroup's place in its rotation
     {
         const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
+        if constexpr (CHAIN) {
+            // The chainL workgroups of a chain (same row region, consecutive column regions) are consecutive multiples of 8
+            // apart in dispatch order, i.e. on ONE XCD where workgroup b runs on XCD b % 8 (checked at run time, below).
+            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
+            chainPos = idx % L;
+            chainId = (idx / L) * 8 + xcd;
+            rowRegion = chainId % gx;
+            colRegion = (chainId / gx) * L + chainPos;
+        } else if (gy % 8 == 0) {
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
             colRegion = xcd * (gy >> 3) + idx / gx;
@@ -2088,6 +2106,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
 #define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
     unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+    // CHAIN: the workgroup visits its row panels rotated by its place in the chain -- panel (t - chainPos) mod RP in the
+    // t-th place -- so that at any time the members of a chain work on different panels, and member c reaches a panel one
+    // panel-time after member c - 1 left it (every region has all RP panels in this mode: nrp == RP)
+    auto panel_at = [&](int t) {
+        if constexpr (CHAIN) { const int p = t - chainPos; return p < 0 ? p + nrp : p; }
+        else return t;
+    };
 
     if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
         if (!producer) {
@@ -2154,6 +2179,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 3;
             if (brp >= nrp) brp = nrp - 1;
+            brp = panel_at(brp);
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
 #pragma unroll
             // nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient slabs this kernel
@@ -2166,6 +2192,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             if constexpr (HASW) {
                 int brp = b >> 3;
                 if (brp >= nrp) brp = nrp - 1;
+                brp = panel_at(brp);
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
@@ -2203,13 +2230,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         };
         const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
         const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
-        load_A(row0);
+        load_A(row0 + panel_at(0) * V5_BM);
         load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
         load_Y(1, yO);
         load_W(0, wE);
         load_W(1, wO);
         make_afr();
-        if (nrp > 1) load_A(row0 + V5_BM);
+        if (nrp > 1) load_A(row0 + panel_at(1) * V5_BM);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
@@ -2226,7 +2253,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             if constexpr (GEMM) {
                 if (cb == 0 && s > 0) {      // block s opens a row panel: its A terms (rows requested 8 slots ago)
                     make_afr();
-                    if (rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
+                    if (rp + 1 < nrp) load_A(row0 + panel_at(rp + 1) * V5_BM);
                 }
             }
             f16x8 sv[4][2];
@@ -2323,8 +2350,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
         const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
         const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
+        // gA slab this workgroup contributes to: its own (one per column region), or its chain's (accumulated in place)
+        const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+        auto gA_tile = [&](int prow) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31; };
         auto flush_gA = [&](int prow) {
-            float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
+            float* p0_ = gA_tile(prow);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 float* ph_ = p0_ + half * 16 * K;
@@ -2343,8 +2373,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
             PH(9)
         };
-        auto consume = [&](int b, int rp, int cb, f32x16& accSc) {     // block b = (rp, cb)
-            const int prow = row0 + rp * V5_BM;
+        auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
             const unsigned char* Rb = smem + V8_OFF_R + (b & 1) * V5_R_BYTES;
             const unsigned char* Slb = smem + cb * V8_SL_BYTES;
             const unsigned char* Ab = smem + V8_OFF_A;
@@ -2381,10 +2410,53 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accSc, 0, 0, 0);
                 }
             }
-            if ((a.doA & 1) && cb + 1 == NCB) {
+            if (!CHAIN && (a.doA & 1) && cb + 1 == NCB) {
                 flush_gA(prow);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+            }
+        };
+        // ---- CHAIN: gA summed in place, through the XCD's L2 ------------------------------------------------------
+        // The chainL workgroups of a chain own the same rows and consecutive column regions; their contributions to a
+        // panel of gA are added IN PLACE in one slab, one member after the other in a fixed order (deterministic), each
+        // of the four consumer waves handing its 32 x 64 tile to the same wave of the next member through an arrival word:
+        //     wait for arrival k  ->  tile += previous sum (sc1 loads: served by L2, never by this CU's L1)  ->  plain
+        //     stores  ->  s_waitcnt vmcnt(0) (the stores are in L2)  ->  arrival word = k + 1 (relaxed agent-scope store).
+        // No release fence, no write-back: the lines stay dirty in the L2 the members share and reach HBM once.  That is
+        // only a hand-off if both workgroups really sit on the same XCD, which HIP does not promise: every arrival word
+        // carries its writer's XCC_ID, a reader on another XCD (or one whose predecessor never shows up: workgroups not
+        // co-resident) reports a fault through DevStatus instead of using the data, the chain of kernels stops, and the
+        // host repeats the iteration with one slab per column region (pmx_api.hip).  The previous sum is fetched in four
+        // pieces during the panel's last four column blocks (requested before a block's MFMAs, added after them), the
+        // arrival word of a finished panel is published one slot later: no wait of the protocol sits in front of work.
+        const float invUnA = scR * scS;              // 2^(eR+eS): previous sums enter the accumulators in their scale
+        unsigned* cflags = nullptr;
+        unsigned myxcc = 0;
+        if constexpr (CHAIN) {
+            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
+            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        }
+        unsigned* pendFlag = nullptr;                // arrival to publish once this wave's stores of the panel have landed
+        unsigned pendVal = 0;
+        unsigned* curFlag = nullptr;
+        unsigned cwant = 0, cseen = 0;
+        bool cadd = false;                           // this panel has a previous sum to add (not the first of its chain)
+        auto chain_fault = [&](int code) {
+            if (lane == 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            cadd = false;
+        };
+        auto chain_publish = [&]() {
+            if constexpr (CHAIN) {
+                if (pendFlag != nullptr) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pendFlag = nullptr;
+                }
             }
         };
         sync();
@@ -2392,18 +2464,69 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         int s = 2;
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
+            const int pnl = panel_at(rp);
+            const int prow = row0 + pnl * V5_BM;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
+                    if constexpr (CHAIN) {
+                        chain_publish();     // the previous panel's arrival
+                        // place of this workgroup among the members' visits of panel pnl, in time: members that reach
+                        // it after wrapping around (pnl + c >= RP) come first
+                        const int c = chainPos, L = a.chainL;
+                        const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
+                        const int k = pnl + c >= nrp ? pnl + c - nrp : c + nw;
+                        cadd = (a.doA & 1) && k > 0;
+                        cwant = a.chainBase + (unsigned)k;
+                        curFlag = cflags + pnl * 4;
+                    }
                 }
-                consume(s - 2, rp, cb, accS[cb]);
+                float pv0[4], pv1[4];
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cb >= 4 && cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
+                        const float* pb = gA_tile(prow) + (8 * ((cb - 4) & 1) + 16 * ((cb - 4) >> 1)) * K;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            pv0[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            pv1[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    }
+                }
+                consume(s - 2, prow, cb, accS[cb]);
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) {   // the predecessor finished this panel about a panel-time ago: normally no spin
+                        unsigned v = __builtin_amdgcn_readfirstlane(cseen);
+                        for (int spins = 0; (v >> 4) != cwant; ++spins) {
+                            if (spins > (1 << 16)) { chain_fault(1); break; }
+                            __builtin_amdgcn_s_sleep(8);
+                            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                    }
+                    if (cb >= 4 && cadd) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            accA0[4 * (cb - 4) + q] += pv0[q] * invUnA;
+                            accA1[4 * (cb - 4) + q] += pv1[q] * invUnA;
+                        }
+                    }
+                    if (cb + 1 == NCB && (a.doA & 1)) {
+                        flush_gA(prow);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+                        pendFlag = curFlag;
+                        pendVal = ((cwant + 1u) << 4) | myxcc;
+                    }
+                }
                 PH(7)
                 sync();
                 ++s;
             }
         }
+        chain_publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
             const int kk = kt * 32 + l31;
@@ -2439,16 +2562,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW>
+template <bool PROF, bool HASW, bool CHAIN>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
-    if (a.W != nullptr) return grad_launch_f16_v8_t<false, true>(a, stream);   // (no phase profiling of the weighted instance)
-    return a.prof ? grad_launch_f16_v8_t<true, false>(a, stream) : grad_launch_f16_v8_t<false, false>(a, stream);
+    if (a.chainL > 0) return a.W != nullptr ? grad_launch_f16_v8_t<false, true, true>(a, stream) : grad_launch_f16_v8_t<false, false, true>(a, stream);
+    if (a.W != nullptr) return grad_launch_f16_v8_t<false, true, false>(a, stream);   // (no phase profiling of the weighted instance)
+    return a.prof ? grad_launch_f16_v8_t<true, false, false>(a, stream) : grad_launch_f16_v8_t<false, false, false>(a, stream);
 }
 
 
@@ -2499,6 +2623,21 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 
+// Chained in-place accumulation of gA (k_grad_f16_v8<.., CHAIN>): members per chain for this plan, or 0 when the mode
+// does not apply.  Needs: every row region with all its RP panels (the rotation), chains that are whole multiples of 8
+// in number (one XCD each under round-robin dispatch), all workgroups co-resident (one per CU).
+int grad_chain_length(const GradPlan& p, int64_t M, int num_cus) {
+    // PMX_K1_CHAIN: 0 switches the mode off, n >= 2 caps the chain length (tests)
+    const int cap = getenv("PMX_K1_CHAIN") ? atoi(getenv("PMX_K1_CHAIN")) : 32;
+    if (cap < 2) return 0;
+    const int64_t panels = (M + V5_BM - 1) / V5_BM;
+    if (M % V5_BM != 0 || panels % p.RP != 0) return 0;
+    if (p.gridX * p.gridY > num_cus || (p.gridX * p.gridY) % 8 != 0) return 0;
+    for (int L = std::min(std::min(std::min(p.RP, p.gridY), 32), cap); L >= 2; --L)
+        if (p.gridY % L == 0 && ((p.gridX * p.gridY / L) % 8) == 0) return L;
+    return 0;
+}
+
 template <int KP, bool EDGE>
 static hipError_t grad_launch_bf16_t(const GradPlan& p, const GradBfArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16<KP, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
@@ -2533,6 +2672,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
+        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus;
         if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_f16_v8(g, stream);   // fp16 two-term mode
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);

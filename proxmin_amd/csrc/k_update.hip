@@ -226,9 +226,11 @@ struct FoldArgs {
     float* G[2];
     int64_t rows[2];
     int K;
+    const DevStatus* status;
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_fold(FoldArgs a) {
+    if (a.status != nullptr && chain_halted(a.status)) return;
     const int j = blockIdx.y;
     const int64_t rows = a.rows[j];
     const int K = a.K;

@@ -79,6 +79,11 @@ struct pmx_ctx {
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
     int64_t rowsPad[2] = {0, 0};
     GradPlan plan{};
+    int chainL = 0;                        // > 0: the fp16 K1 sums gA in place along chains of this many workgroups (k_grad_f16_v8<CHAIN>)
+    unsigned* chainFlags = nullptr;        // their arrival words
+    unsigned chainSeq = 0;                 // launches so far (arrival words are monotonic: launch n counts from 64 n)
+    int nSlabA = 0;                        // gA slabs the update kernels fold (plan.nSlabA, or one per chain group)
+    int chainFaults = 0;                   // times the chained mode was left after a fault
     float* slab[2] = {nullptr, nullptr};
     const float* W = nullptr;              // weights of the likelihood (nullptr: W == 1), nmf.py:13-41
     int64_t ldW = 0;
@@ -190,7 +195,15 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64;
     c->plan = c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K);
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
+    c->nSlabA = c->plan.nSlabA;
+    if (c->use_f16) {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
+        c->chainL = grad_chain_length(c->plan, M, ncu);
+        if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
+    }
     int rc = PMX_OK;
+    if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
     if (c->use_f16) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
     if (c->use_bf16) {
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
@@ -203,7 +216,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         rc = dallocT(c, &c->X[j], (size_t)c->rows[j] * K);
         if (rc == PMX_OK) rc = dallocT(c, &c->G[j], (size_t)c->rows[j] * K);
     }
-    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->plan.nSlabA * M * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * M * K, false);
     if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * N * K, false);
     if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)2 * c->plan.gridX * c->plan.gridY);
     if (rc == PMX_OK) rc = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
@@ -267,6 +280,19 @@ extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
         if (ms >= 0.05f * mx) { tot += ms; ++n; }
     *total_ms = tot;
     *launches = n;
+    return PMX_OK;
+}
+
+extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
+    if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
+    info[0] = c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0);
+    info[1] = c->chainL;
+    info[2] = c->nSlabA;
+    info[3] = c->plan.nSlabS;
+    info[4] = c->plan.gridX;
+    info[5] = c->plan.gridY;
+    info[6] = c->plan.RP;
+    info[7] = c->chainFaults;
     return PMX_OK;
 }
 
@@ -459,6 +485,39 @@ static int clear_halt(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// Leave the chained gA accumulation of the fp16 K1 for good: one slab per column region, summed by the update kernels.
+static int chain_disable(pmx_ctx* c) {
+    if (c->chainL == 0) return PMX_OK;
+    c->chainL = 0;
+    c->nSlabA = c->plan.nSlabA;
+    float* big = nullptr;
+    int rc = dallocT(c, &big, (size_t)c->nSlabA * c->M * c->K, false);
+    if (rc != PMX_OK) return rc;
+    c->slab[0] = big;
+    return PMX_OK;
+}
+// After read_status: a chained K1 launch found that its hand-off does not hold here (a predecessor on another XCD, or
+// workgroups that are not co-resident: DevStatus::k1_fault) and stopped the chain of kernels before anything was updated.
+// Fall back to slabs and clear the halt; the caller re-enqueues from DevStatus::it_done.  *again = 1 if that happened.
+static int chain_fault_fallback(pmx_ctx* c, int* again) {
+    *again = 0;
+    if (!c->hstatus->k1_fault) return PMX_OK;
+    int rc = chain_disable(c);
+    if (rc != PMX_OK) return rc;
+    c->chainFaults += 1;
+    static const int zeros[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->k1_fault, zeros, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    rc = clear_halt(c);
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->hstatus->k1_fault = 0;
+    c->hstatus->halt = 0;
+    c->hstatus->reason = 0;
+    c->absmax_by_finish = false;
+    *again = 1;
+    return PMX_OK;
+}
+
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
@@ -489,6 +548,13 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
+            if (c->chainL > 0) {
+                if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
+                    HIP_CHECK(hipMemsetAsync(c->chainFlags, 0, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4 * sizeof(unsigned), c->stream));
+                    c->chainSeq = 0;
+                }
+                g.chainL = c->chainL; g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
+            }
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
@@ -517,7 +583,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
 static SlabRef slab_ref(pmx_ctx* c, int j) {
     SlabRef s;
     s.base = c->slab[j];
-    s.n = j == 0 ? c->plan.nSlabA : c->plan.nSlabS;
+    s.n = j == 0 ? c->nSlabA : c->plan.nSlabS;
     return s;
 }
 
@@ -610,15 +676,24 @@ static void fill_result(pmx_ctx* c, pmx_result* r, int it_before) {
 extern "C" int pmx_grad(pmx_ctx* c) {
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
-    HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
-    rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
-    if (rc != PMX_OK) return rc;
-    FoldArgs f{};
-    for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
-    f.K = (int)c->K;
-    launch_fold(f, 2, c->stream);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+        rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
+        if (rc != PMX_OK) return rc;
+        FoldArgs f{};
+        for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
+        f.K = (int)c->K;
+        f.status = c->dstatus;
+        launch_fold(f, 2, c->stream);
+        HIP_CHECK(hipGetLastError());
+        if (c->chainL == 0) { HIP_CHECK(hipStreamSynchronize(c->stream)); break; }
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        int again = 0;
+        rc = chain_fault_fallback(c, &again);
+        if (rc != PMX_OK) return rc;
+        if (!again) break;
+    }
     return PMX_OK;
 }
 
@@ -804,6 +879,10 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
             if (rc != PMX_OK) return rc;
         }
     c->btT[0] = c->btT[1] = 1.0;
+    if (p->backtracking) {   // host-driven trials read device sums after every K1 pass: no room for a repeated iteration
+        rc = chain_disable(c);
+        if (rc != PMX_OK) return rc;
+    }
     if (p->backtracking)
         for (int j = 0; j < 2; ++j) {
             rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
@@ -997,6 +1076,18 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
         }
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
+        int again = 0;
+        rc = chain_fault_fallback(c, &again);
+        if (rc != PMX_OK) return rc;
+        if (again) {                      // iterations after the faulting one were skipped: redo them
+            c->it = c->hstatus->it_done;
+            if (c->pgm.accelerated) {     // the host-side Nesterov sequence ran ahead with the skipped iterations
+                c->nest_t = 1.0;
+                for (int i = 0; i <= c->it; ++i) c->nest_t = 0.5 * (1.0 + sqrt(4.0 * c->nest_t * c->nest_t + 1.0));
+            }
+            left = n_iter - (c->hstatus->it_done - it0);
+            continue;
+        }
         left -= chunk;
     }
     fill_result(c, res, it0);
@@ -1206,6 +1297,12 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             if (c->hstatus->it_done > it_before) t_enq = nsub_enq;   // moved on to a later iteration
         }
         done = c->hstatus->it_done - it0;
+        {
+            int again = 0;
+            rc = chain_fault_fallback(c, &again);
+            if (rc != PMX_OK) return rc;
+            if (again) { tails = 0; continue; }
+        }
         if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
         if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
     }
@@ -1302,6 +1399,13 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
         }
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
+        int again = 0;
+        rc = chain_fault_fallback(c, &again);
+        if (rc != PMX_OK) return rc;
+        if (again) {
+            left = n_iter - (c->hstatus->it_done - it0);
+            continue;
+        }
         left -= chunk;
     }
     fill_result(c, res, it0);

@@ -62,7 +62,7 @@ struct DevStatus {
     double bt[2][5];        // backtracking sums per block: (X-X_).G, (X-X_)^2, max|G|, max|X_|, X^2
     double eigvec[2][MAXK]; // warm start for the power iteration
     int eig_iters[2];
-    int pad;
+    int k1_fault;        // k_grad_f16_v8<CHAIN>: 1 a chain predecessor never arrived, 2 it runs on another XCD (host falls back to slabs)
 };
 enum { HALT_NONE = 0, HALT_CONVERGED = 1, HALT_NEED_SUB = 2, HALT_ERROR = 3 };
 

@@ -149,6 +149,15 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_time_grad(self.h, int(do_A), int(do_S), int(reps), C.byref(ms)))
         return ms.value
 
+    def k1_info(self):
+        """Layout of this context's fused residual-gradient kernel (include/pmx.h: pmx_k1_info)."""
+        v = (C.c_int * 8)()
+        _lib.check(self.lib.pmx_k1_info(self.h, v))
+        keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
+        d = dict(zip(keys, list(v)))
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8")[d["kernel"]]
+        return d
+
     # -- single operations --------------------------------------------------------------------
     def grad(self):
         """nmf.grad_likelihood at the current device factors -> (gA (M x K), gS (K x N))."""

@@ -361,3 +361,80 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
                 else:
                     with pytest.raises(NotImplementedError):
                         dev.set_W(W)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# chained in-place accumulation of gA (k_grad_f16_v8<CHAIN>): the workgroups of a chain add their contributions to one
+# slab through the XCD's L2 instead of writing one slab per column region
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,cap,want", [(4096, 4096, 32, 2), (4096, 16384, 32, 8), (4096, 16384, 4, 4), (8192, 8192, 32, 8),
+                                          (16384, 4096, 32, 8), (2048, 16384, 32, 4)])
+def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, cap, want):
+    """Shapes whose region plan gives chains of 2 .. 16 workgroups: gradients and loss against the fp64 oracle, the same
+    tolerance as every other K1; the chained launch must be the one that ran (no fault, no silent fall-back), twice in a
+    row bit-identically (fixed order of the in-place sums), and equal to the slab path up to summation order."""
+    K = 64
+    monkeypatch.setenv("PMX_K1_CHAIN", str(cap))
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N)
+    A[:, 0] += np.linspace(0.0, 1.0, M, dtype=np.float32)
+    S[K - 1, :] += np.linspace(1.0, 0.0, N, dtype=np.float32)
+    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        info = dev.k1_info()
+        assert info["kernel"] == "k_grad_f16_v8" and info["chain"] == want, info
+        assert info["slabs_A"] == info["col_regions"] // want
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        gA2, gS2 = dev.grad()
+        loss = dev.loglike()
+        assert dev.k1_info()["chain_faults"] == 0 and dev.k1_info()["chain"] == want
+    assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)
+    A64, S64, Y64 = A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64)
+    rA, rS = orc.residual_gradients(A64, S64, Y64)
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
+    monkeypatch.setenv("PMX_K1_CHAIN", "0")
+    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        assert dev.k1_info()["chain"] == 0
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        sA, sS = dev.grad()
+    np.testing.assert_allclose(gA, sA, rtol=0, atol=2e-6 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, sS, rtol=0, atol=2e-6 * np.abs(rS).max())   # (a chain member visits its row panels rotated)
+
+
+def _subsampled_oracle_gradients(A, S, Yd, rows, cols):
+    """fp64 gradients of 1/2 |A S - Y|^2 on a subset: gA[rows] needs only Y[rows, :], gS[:, cols] only Y[:, cols]."""
+    import torch
+    A64, S64 = A.astype(np.float64), S.astype(np.float64)
+    Yr = Yd[torch.as_tensor(rows, device=Yd.device)].cpu().numpy().astype(np.float64)
+    Yc = Yd[:, torch.as_tensor(cols, device=Yd.device)].cpu().numpy().astype(np.float64)
+    gA_rows = (A64[rows] @ S64 - Yr) @ S64.T
+    gS_cols = A64.T @ (A64 @ S64[:, cols] - Yc)
+    return gA_rows, gS_cols
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_full_size_gradient_against_subsampled_oracle(eng, mode):
+    """BASELINE's headline shape (16384 x 16384, K = 64): the gradients of 256 random rows of A and 256 random columns of
+    S against the fp64 oracle (which needs only those rows / columns of Y), every arithmetic mode; mode f16x2 runs the
+    chained kernel with 32 workgroups per chain."""
+    import torch
+    import bench
+    M = N = 16384
+    K = 64
+    Yd, A, S = bench.make_problem_device(M, N, K, True, 1234, torch.device("cuda", 0))
+    rng = np.random.default_rng(99)
+    rows = np.sort(rng.choice(M, 256, replace=False))
+    cols = np.sort(rng.choice(N, 256, replace=False))
+    rA, rS = _subsampled_oracle_gradients(A, S, Yd, rows, cols)
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+        if mode == "f16x2":
+            assert dev.k1_info()["chain"] == 32, dev.k1_info()
+        dev.set_Y_device(Yd.data_ptr(), ld=N, copy=False, keepalive=Yd)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        assert dev.k1_info()["chain_faults"] == 0
+    np.testing.assert_allclose(gA[rows], rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS[:, cols], rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
