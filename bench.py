@@ -45,11 +45,34 @@ MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
 MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
 
 
-# HBM bytes per K1 launch from the PMC passes committed in profiles/r01_f_pmc_cfg3_f16x2.json (f16x2: k_grad_f16_v8),
-# profiles/r01_e_pmc_cfg3_bf16x3.json (bf16x3: k_grad_bf16_v7) and profiles/r01_c_pmc_traffic_cfg3.json (f32)
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command; FETCH_SIZE doubled per the gfx950 correction).
-# Only known for the configuration that was profiled; null otherwise.
-PMC_TRAFFIC_BYTES = {("cfg3", "f16x2"): 2 * 543054 * 1024 + 295432 * 1024, ("cfg3", "bf16x3"): 2 * 542917 * 1024 + 294920 * 1024, ("cfg3", "f32"): 2 * 660595 * 1024 + 198672 * 1024}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "k1_traffic.json")
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources libpmx.so is built from: the key that ties a PMC measurement
+    (profiles/k1_traffic.json, written by scratch/measure_traffic.sh from rocprofv3 --pmc passes over this very command) to
+    the build that prints it."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "proxmin_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(config, mode):
+    """HBM bytes per K1 launch (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE) measured for THIS build, else None:
+    a number from another build would go stale silently."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None
+    e = rec.get("%s/%s" % (config, mode))
+    if not e or e.get("source_hash") != kernel_source_hash():
+        return None
+    return e
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
@@ -112,19 +135,19 @@ def begin_solver(dev, backend, unity):
     return lambda n: dev.bsdmm_run(n)
 
 
-def cpu_baseline(M, N, K, backend, unity, budget_s=20.0):
-    """Oracle (NumPy port of the reference) on this host: a row-subsample of the same workload."""
+def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6):
+    """Oracle (NumPy port of the reference, fp32 like the device data) on this host's cores: the SAME workload at its full
+    size -- the bench's own Y (copied back from the GPU) and initial factors --, n_iter iterations, wall time per iteration
+    from callback time stamps, the first iteration (cold caches, adaprox's long first proximal loop) excluded."""
     from oracle import nmf_oracle as orc
-    Ms = min(M, 2048)
-    Y, A, S = orc.synthetic_problem(Ms, N, K, np.float32, unity_S=unity, seed=1234)
-    its = 0
-    t_used = 0.0
+    M, N = Y.shape
+    K = A0.shape[1]
+    A, S = A0.copy(), S0.copy()
     stamps = []
 
     def cb(*X, it=None):
         stamps.append(time.perf_counter())
 
-    n_iter = 4
     sub_note = ""
     if backend == "pgm":
         orc.pgm_nmf(Y, A, S, max_iter=n_iter, e_rel=1e-12, callback=cb)
@@ -136,16 +159,22 @@ def cpu_baseline(M, N, K, backend, unity, budget_s=20.0):
     else:
         orc.bsdmm_nmf(Y, A, S, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=n_iter, e_rel=1e-12, callback=cb)
     stamps.append(time.perf_counter())
-    per = np.diff(stamps)[1:]            # exclude iteration 0 (cold caches, 250-pass first prox loop)
-    s_per_it_sample = float(np.median(per))
-    s_per_it_full = s_per_it_sample * (M / Ms)
+    per = np.diff(stamps)[1:]            # exclude iteration 0
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    return {"value": 1.0 / s_per_it_full, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": "oracle (NumPy/OpenBLAS, all host threads) on the first %d of %d rows of the same workload, "
-                      "%d iterations, median of iterations 1..%d, scaled by %g to the full row count%s" % (Ms, M, n_iter, n_iter - 1, M / Ms, sub_note)}
+    blas = "?"
+    try:
+        from threadpoolctl import threadpool_info
+        blas = ", ".join("%s %s, %d threads" % (i.get("internal_api"), i.get("version"), i.get("num_threads")) for i in threadpool_info()
+                         if i.get("user_api") == "blas") or "?"
+    except Exception:
+        pass
+    return {"value": 1.0 / float(np.mean(per)), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": "oracle (NumPy fp32; BLAS: %s) on the full %d x %d x %d workload (the bench's own Y and initial factors), "
+                      "%d iterations, mean of iterations 1..%d = %.3f s (min %.3f, max %.3f), no scaling%s"
+                      % (blas, M, N, K, n_iter, n_iter - 1, float(np.mean(per)), float(per.min()), float(per.max()), sub_note)}
 
 
 def emit(out):
@@ -215,7 +244,20 @@ def main():
     dev.set_factors(A0, S0)
     run = begin_solver(dev, backend, unity)
 
-    run(args.warmup)                       # untimed (includes adaprox's long first proximal loop)
+    # Untimed warm-up: the W iterations asked for, then -- adaprox only -- further iterations in groups of 5 until the
+    # proximal sub-iteration loops have left their start-up transient (cold start: 250 passes on S in iteration 0, tens in
+    # the next few, 2-5 in steady state), so that the timed region measures the same steady state whatever --warmup was.
+    res_w = run(args.warmup) if args.warmup > 0 else None
+    warm_total = args.warmup
+    sub_seen = [int(res_w.sub_iterations[0]), int(res_w.sub_iterations[1])] if res_w is not None else [0, 0]
+    if backend == "adaprox":
+        while warm_total < 60:
+            r = run(5)
+            warm_total += 5
+            per_it = (int(r.sub_iterations[1]) - sub_seen[1]) / 5.0
+            sub_seen = [int(r.sub_iterations[0]), int(r.sub_iterations[1])]
+            if per_it <= 6.0 and warm_total >= 20:
+                break
     dev.set_timing(True, every=4)   # HIP events around every 4th K1 launch of the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -225,6 +267,7 @@ def main():
     k1_ms, k1_n = dev.get_timing()
     dev.set_timing(False)
     assert res.iterations == args.steps, "chain ended early (%d of %d iterations)" % (res.iterations, args.steps)
+    sub_timed = [(int(res.sub_iterations[j]) - sub_seen[j]) / float(args.steps) for j in range(2)]
 
     dt = t1 - t0
     flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
@@ -234,22 +277,45 @@ def main():
     achieved_tflops = flop_per_launch / (k1_avg_ms * 1e-3) / 1e12
     out = {
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
-        "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_total,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": MODE_DTYPE[dev.mode if K <= 64 else "f32"], "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
                    "mode": MODE_DESC[dev.mode if K <= 64 else "f32"], "parallelism": "1 GPU"},
         "gflops": flop_per_it * its / 1e9,
-        "sub_iterations_per_step": [float(res.sub_iterations[0]) / max(res.total_iterations, 1),
-                                    float(res.sub_iterations[1]) / max(res.total_iterations, 1)],
+        "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
         "roofline": roofline_entry(dev.mode if K <= 64 else "f32", M, N, K, flop_per_launch, k1_avg_ms, k1_n,
                                    k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt)),
     }
+    info = dev.k1_info()
+    if info["chain"]:
+        out["roofline"]["kernel"] += "<chain %d>" % info["chain"]     # gA summed in place along workgroup chains
+    out["roofline"]["k1_layout"] = info
     if not args.rows:
-        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES.get((args.config, dev.mode if K <= 64 else "f32"))
-        out["roofline"]["traffic_unit"] = "bytes per K1 launch (algorithmic: %d)" % (M * N * 4)
+        tr = pmc_traffic(args.config, dev.mode if K <= 64 else "f32")
+        out["roofline"]["traffic"] = tr["bytes_per_launch"] if tr else None
+        out["roofline"]["traffic_unit"] = "HBM bytes per K1 launch, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this build (%s); null: not measured for this build; algorithmic: %d" % (
+            "fetch %d + write %d, %s" % (tr["fetch_bytes"], tr["write_bytes"], tr.get("when", "")) if tr else "profiles/k1_traffic.json has no entry for source hash %s" % kernel_source_hash(), M * N * 4)
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(M, N, K, backend, unity)
+        if args.config == "cfg3" and dev.mode != "f32":
+            # the package default is the exact-fp32 MFMA mode: the same workload in that mode, short run, beside the headline
+            dev32 = DeviceNMF(M, N, K, device=local, mode="f32")
+            dev32.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+            dev32.set_factors(A0, S0)
+            run32 = begin_solver(dev32, backend, unity)
+            run32(25)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run32(20)
+            torch.cuda.synchronize()
+            out["value_f32_mode"] = {"value": 20.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 20, "warmup": 25,
+                                     "note": "same workload with the library's default arithmetic (exact fp32 MFMA, k_grad_f32)"}
+            dev32.close()
+        dev.close()
+        Yh = Y.cpu().numpy()
+        del Y
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(Yh, A0, S0, backend, unity, n_iter=6 if M * N <= 16384 * 16384 else 3)
     emit(out)
 
 
