@@ -114,6 +114,7 @@ struct GradBfArgs {
     unsigned* chainFlags;
     unsigned chainBase;
     DevStatus* wstatus;
+    int chainInject;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -862,6 +863,7 @@ struct GradV4Args {
     unsigned* chainFlags;   // [chains][RP][4] arrival words, monotonic over launches
     unsigned chainBase;  // launch sequence number * 64
     DevStatus* wstatus;  // writable view of `status` (fault report)
+    int chainInject;     // tests: report a fault from this launch (exercises the host's fall-back)
 };
 
 template <bool PROF>
@@ -2441,14 +2443,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         unsigned* curFlag = nullptr;
         unsigned cwant = 0, cseen = 0;
         bool cadd = false;                           // this panel has a previous sum to add (not the first of its chain)
+        bool cdead = false;                          // a fault was seen: no more waiting, the launch's gA is discarded anyway
         auto chain_fault = [&](int code) {
-            if (lane == 0) {
+            if (lane == 0 && code > 0) {
                 a.wstatus->k1_fault = code;
                 a.wstatus->reason = HALT_ERROR;
                 __threadfence();
                 a.wstatus->halt = 1;
             }
             cadd = false;
+            cdead = true;
         };
         auto chain_publish = [&]() {
             if constexpr (CHAIN) {
@@ -2459,6 +2463,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 }
             }
         };
+        if constexpr (CHAIN) {
+            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+        }
         sync();
         sync();
         int s = 2;
@@ -2478,7 +2485,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         const int c = chainPos, L = a.chainL;
                         const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
                         const int k = pnl + c >= nrp ? pnl + c - nrp : c + nw;
-                        cadd = (a.doA & 1) && k > 0;
+                        cadd = (a.doA & 1) && k > 0 && !cdead;
                         cwant = a.chainBase + (unsigned)k;
                         curFlag = cflags + pnl * 4;
                     }
@@ -2499,10 +2506,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 if constexpr (CHAIN) {
                     if (cb == 3 && cadd) {   // the predecessor finished this panel about a panel-time ago: normally no spin
                         unsigned v = __builtin_amdgcn_readfirstlane(cseen);
-                        for (int spins = 0; (v >> 4) != cwant; ++spins) {
-                            if (spins > (1 << 16)) { chain_fault(1); break; }
-                            __builtin_amdgcn_s_sleep(8);
-                            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if ((v >> 4) != cwant) {
+                            const long long t0 = wall_clock64();          // 100 MHz
+                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
+                                if ((spins & 63) == 0) {
+                                    if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
+                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            }
                         }
                         if (cadd && (v & 15u) != myxcc) chain_fault(2);
                     }
@@ -2672,7 +2685,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
-        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus;
+        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject;
         if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_f16_v8(g, stream);   // fp16 two-term mode
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);

@@ -706,6 +706,90 @@ struct MomentArgs {
     int check_convergence;
     int has_prox[2];
 };
+// scalars of the moment schemes for iteration `it` (algorithms.py:147-245), uniform over the grid
+struct MomentScalars {
+    double b1, bias1, rho;
+    float c1, c2, bias2, epsf, rfac, adamx_factor;
+};
+__device__ __forceinline__ MomentScalars moment_scalars(const MomentArgs& a) {
+    MomentScalars s;
+    s.b1 = a.b1t;
+    s.c1 = (float)(1.0 - a.b2);                                   // python floats are weak scalars: fp32 arithmetic
+    s.c2 = (float)a.b2;
+    const double t = (double)(a.it + 1);
+    s.bias1 = 1.0 - pow(s.b1, t);                                  // 1 - b1[it]**t
+    s.bias2 = (float)(1.0 - pow(a.b2, t));                         // 1 - b2**t
+    s.epsf = (float)a.eps;
+    // radam scalars (algorithms.py:224-245)
+    const double rho_inf = 2.0 / (1.0 - a.b2) - 1.0;
+    s.rho = rho_inf - 2.0 * t * pow(a.b2, t) / (1.0 - pow(a.b2, t));
+    s.rfac = s.rho > 4.0 ? (float)sqrt((s.rho - 4.0) * (s.rho - 2.0) * rho_inf / (rho_inf - 4.0) / (rho_inf - 2.0) / s.rho) : 1.f;
+    s.adamx_factor = (float)(((1.0 - s.b1) * (1.0 - s.b1)) / ((1.0 - a.b1prev) * (1.0 - a.b1prev)));
+    return s;
+}
+// One element of block j: gradient gg, step alpha; updates M, V (, Vhat) in memory and returns the updated iterate
+// x - alpha Phi / Psi (algorithms.py:375-378) and Psi.
+__device__ __forceinline__ float moment_elem(const MomentArgs& a, const MomentScalars& s, int j, int64_t e, float gg, float alpha, float xo, float& psi_out) {
+    float* Mm = a.Mm[j];
+    float* Vv = a.Vv[j];
+    float* Vh = a.Vh[j];
+    // b1[it] is a NumPy float64 scalar in the reference, so M is formed in fp64 and rounded on store
+    const float m = (float)((1.0 - s.b1) * (double)gg + s.b1 * (double)Mm[e]);
+    const float v = s.c1 * (gg * gg) + s.c2 * Vv[e];
+    Mm[e] = m;
+    Vv[e] = v;
+    double upd;   // alpha * Phi / Psi
+    float psi;
+    switch (a.scheme) {
+        case PMX_ADAM:
+            psi = sqrtf(v / s.bias2) + s.epsf;
+            upd = (double)alpha * ((double)m / s.bias1) / (double)psi;
+            break;
+        case PMX_NADAM:
+            psi = sqrtf(v / s.bias2) + s.epsf;
+            upd = (double)alpha * ((s.b1 * (double)m + (1.0 - s.b1) * (double)gg) / s.bias1) / (double)psi;
+            break;
+        case PMX_RADAM:
+            psi = s.rho > 4.0 ? sqrtf(v / s.bias2) / s.rfac : 1.f;
+            if (s.epsf > 0.f) psi = fmaxf(psi, sqrtf(s.epsf));
+            upd = (double)alpha * ((double)m / s.bias1) / (double)psi;
+            break;
+        default: {   // amsgrad / padam / adamx (algorithms.py:170-221)
+            float cap = v;
+            if (Vh != nullptr) {
+                const float old = Vh[e];
+                cap = fmaxf(a.scheme == PMX_ADAMX ? s.adamx_factor * old : old, v);
+                Vh[e] = cap;
+            }
+            if (s.epsf > 0.f) cap = fmaxf(cap, s.epsf);
+            psi = a.scheme == PMX_PADAM ? powf(cap, (float)a.p) : sqrtf(cap);
+            upd = (double)(alpha * m / psi);
+        }
+    }
+    psi_out = psi;
+    return (float)((double)xo - upd);
+}
+// max that lets a NaN through, like np.max (fmaxf / fmax drop NaNs): Psi goes NaN with the iterate, and the reference's
+// gamma = Alpha / np.max(Psi) then poisons the whole proximal loop visibly instead of continuing on a partly NaN block
+__device__ __forceinline__ float nanmaxf(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : fmax(a, b); }
+__device__ __forceinline__ double wave_nanmax(double v) {
+    v = nanmax(v, dpp_d<DPP_XOR1>(v));
+    v = nanmax(v, dpp_d<DPP_XOR2>(v));
+    v = nanmax(v, dpp_d<DPP_HALF_MIRROR>(v));
+    v = nanmax(v, dpp_d<DPP_MIRROR>(v));
+    v = nanmax(v, swz16_d(v));
+    v = nanmax(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ double fold_partials_nanmax(const double* part) {
+    const int lane = threadIdx.x & 63;
+    double v = -1.0;
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v = nanmax(v, part[i * 64 + lane]);
+    return wave_nanmax(v);
+}
+
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
     __shared__ double scratch[EW_WAVES];
@@ -714,20 +798,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
     const int64_t rows = a.rows[j];
     const int K = a.K;
     float* X = a.X[j];
-    float* Mm = a.Mm[j];
-    float* Vv = a.Vv[j];
-    float* Vh = a.Vh[j];
-    const double b1 = a.b1t;
-    const float c1 = (float)(1.0 - a.b2), c2 = (float)a.b2;   // python floats are weak scalars: fp32 arithmetic
-    const double t = (double)(a.it + 1);
-    const double bias1 = 1.0 - pow(b1, t);                     // 1 - b1[it]**t
-    const float bias2 = (float)(1.0 - pow(a.b2, t));           // 1 - b2**t
-    const float epsf = (float)a.eps;
-    // radam scalars (algorithms.py:224-245)
-    const double rho_inf = 2.0 / (1.0 - a.b2) - 1.0;
-    const double rho = rho_inf - 2.0 * t * pow(a.b2, t) / (1.0 - pow(a.b2, t));
-    const float rfac = rho > 4.0 ? (float)sqrt((rho - 4.0) * (rho - 2.0) * rho_inf / (rho_inf - 4.0) / (rho_inf - 2.0) / rho) : 1.f;
-    const float adamx_factor = (float)(((1.0 - b1) * (1.0 - b1)) / ((1.0 - a.b1prev) * (1.0 - a.b1prev)));
+    const MomentScalars ms = moment_scalars(a);
     float alpha[NC];
     {
         const int l32_ = threadIdx.x & 31;
@@ -745,56 +816,23 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_moment(MomentArgs a) {
         for (int c = 0; c < NC; ++c) {
             if (!ok[c]) continue;
             const int64_t e = r * K + l32 + 32 * c;
-            const float gg = g[c];
-            // b1[it] is a NumPy float64 scalar in the reference, so M is formed in fp64 and rounded on store
-            const float m = (float)((1.0 - b1) * (double)gg + b1 * (double)Mm[e]);
-            const float v = c1 * (gg * gg) + c2 * Vv[e];
-            Mm[e] = m;
-            Vv[e] = v;
-            double upd;   // alpha * Phi / Psi
-            float psi;
-            switch (a.scheme) {
-                case PMX_ADAM:
-                    psi = sqrtf(v / bias2) + epsf;
-                    upd = (double)alpha[c] * ((double)m / bias1) / (double)psi;
-                    break;
-                case PMX_NADAM:
-                    psi = sqrtf(v / bias2) + epsf;
-                    upd = (double)alpha[c] * ((b1 * (double)m + (1.0 - b1) * (double)gg) / bias1) / (double)psi;
-                    break;
-                case PMX_RADAM:
-                    psi = rho > 4.0 ? sqrtf(v / bias2) / rfac : 1.f;
-                    if (epsf > 0.f) psi = fmaxf(psi, sqrtf(epsf));
-                    upd = (double)alpha[c] * ((double)m / bias1) / (double)psi;
-                    break;
-                default: {   // amsgrad / padam / adamx (algorithms.py:170-221)
-                    float cap = v;
-                    if (Vh != nullptr) {
-                        const float old = Vh[e];
-                        cap = fmaxf(a.scheme == PMX_ADAMX ? adamx_factor * old : old, v);
-                        Vh[e] = cap;
-                    }
-                    if (epsf > 0.f) cap = fmaxf(cap, epsf);
-                    psi = a.scheme == PMX_PADAM ? powf(cap, (float)a.p) : sqrtf(cap);
-                    upd = (double)(alpha[c] * m / psi);
-                }
-            }
             const float xo = X[e];
+            float psi;
+            const float xn = moment_elem(a, ms, j, e, g[c], alpha[c], xo, psi);
             if (a.check_convergence) a.Xp[j][e] = xo;
-            X[e] = (float)((double)xo - upd);
+            X[e] = xn;
             if (a.has_prox[j]) a.Psi[j][e] = psi;
-            maxpsi = fmaxf(maxpsi, psi);
+            maxpsi = nanmaxf(maxpsi, psi);
         }
     ROW_LOOP_END
-    // NaN-propagating max like np.max: fmaxf drops NaNs, so flag them explicitly
     double mv = (double)maxpsi;
-    mv = wave_max(mv);
+    mv = wave_nanmax(mv);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mv;
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = scratch[0];
-        for (int q = 1; q < EW_WAVES; ++q) m = fmax(m, scratch[q]);
+        for (int q = 1; q < EW_WAVES; ++q) m = nanmax(m, scratch[q]);
         part_ptr(a.partials, SL_MAXPSI, j)[blockIdx.x] = m;
     }
 }
@@ -859,7 +897,8 @@ __device__ __forceinline__ int sub_finished_before(const SubArgs& a, int j, doub
 // step size data of the sub-iteration of block j (algorithms.py:384): gamma = Alpha / max(Psi), ratio = gamma / Alpha
 template <int NC>
 __device__ __forceinline__ void sub_steps(const SubArgs& a, int j, double* scratch, float (&gam)[NC], float (&rat)[NC]) {
-    const double maxpsi = fold_partials_max(part_ptr(a.partials, SL_MAXPSI, j), scratch);
+    (void)scratch;
+    const double maxpsi = fold_partials_nanmax(part_ptr(a.partials, SL_MAXPSI, j));
     const int l32_ = threadIdx.x & 31;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -1097,6 +1136,489 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_decide(AdaDecideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// adaprox: the whole iteration tail as ONE persistent kernel                 (algorithms.py:374-410)
+//
+//   moment + update  ->  [B1]  ->  proximal sub-iterations, 4 passes per round  ->  [B2, one per round]  ->  X <- z,
+//   outer norms, column sums  ->  [B3]  ->  next iteration's step sizes + end-of-iteration bookkeeping
+//
+// instead of the four launches k_ada_moment / k_ada_sub / k_ada_finish / k_ada_decide.  One workgroup per CU, the same
+// rows per thread and the same reduction trees as those kernels: results are bit-identical to the chain of launches.
+// What the fusion removes is memory traffic and dependent round trips, not arithmetic: a workgroup's rows of the
+// updated iterate, of Psi and of the proximal iterate z never leave its LDS between the phases (three arrays, 4 bytes x
+// 1024 threads per row slot), and the only data that crosses workgroups inside the launch are the per-workgroup partial
+// sums the phases already exchanged -- a few hundred bytes per workgroup and barrier.  Those records are stored and
+// loaded write-through (agent-scope relaxed atomics = `sc1`), so the grid barrier is a pure arrival count with NO release
+// / acquire fences: hierarchical (8 group counters of gridDim.x / 8 arrivals -> one top counter -> one generation word
+// per group, all monotonic over the life of the context, MI355X_MICROARCH.md "barrier-xcd"), placement-independent.
+// All workgroups must be co-resident.  Nothing promises that (another process may hold CUs), so the launch opens with a
+// census barrier B0 whose outcome is decided by ONE compare-and-swap: either the last arrival wins it (GO), or a
+// workgroup that has waited 2 ms does (ABORT) -- in which case nothing has been written yet, every workgroup returns,
+// DevStatus::tail_fault stops the chain and the host goes back to the separate kernels for good (pmx_api.hip).  B0's
+// arrival is issued first thing and awaited after the launch's scalar set-up, before the first store.
+// ------------------------------------------------------------------------------------------------
+struct GridBar {                 // zeroed at context creation
+    unsigned cnt[8][16];         // arrivals per group (64-byte spacing)
+    unsigned top[16];
+    unsigned gen[8][16];         // 2 x (barriers completed) [+ 1: aborted] as published to each group
+    unsigned verdict[16];        // census: 2 e = GO, 2 e + 1 = ABORT (CAS from the previous barrier's value)
+    unsigned epoch[16];          // barriers completed when the last launch that used the barrier ended
+};
+__device__ __forceinline__ unsigned gb_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gb_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double sc1_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sc1_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one thread per workgroup.  e = number of this barrier (1-based over the context's life).
+__device__ __forceinline__ void gb_arrive(GridBar* b, unsigned e, bool census) {
+    const unsigned ng = 8, per = gridDim.x / ng, g = blockIdx.x & 7;
+    const unsigned a = __hip_atomic_fetch_add(&b->cnt[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1 == per * e) {
+        const unsigned t = __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == ng * e) {
+            unsigned word = 2 * e;
+            if (census) {
+                unsigned expect = 2 * (e - 1);
+                if (!__hip_atomic_compare_exchange_strong(&b->verdict[0], &expect, word, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) word = expect;   // an impatient workgroup aborted first
+            } else {
+                gb_store(&b->verdict[0], word);
+            }
+            for (unsigned q = 0; q < ng; ++q) gb_store(&b->gen[q][0], word);
+        }
+    }
+}
+// returns the generation word seen (2 e: go, 2 e + 1: aborted); give_up_ticks > 0: after that many 100 MHz ticks try to abort
+__device__ __forceinline__ unsigned gb_wait(GridBar* b, unsigned e, long long give_up_ticks) {
+    const unsigned g = blockIdx.x & 7;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned v = gb_load(&b->gen[g][0]);
+        if ((v >> 1) >= e) return v;
+        __builtin_amdgcn_s_sleep(4);
+        if (give_up_ticks > 0 && wall_clock64() - t0 > give_up_ticks) {
+            unsigned expect = 2 * (e - 1);
+            if (__hip_atomic_compare_exchange_strong(&b->verdict[0], &expect, 2 * e + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                for (unsigned q = 0; q < 8; ++q) gb_store(&b->gen[q][0], 2 * e + 1);
+                return 2 * e + 1;
+            }
+            give_up_ticks = 0;          // the last arrival got there first: the word is on its way
+        }
+    }
+}
+// full barrier for a phase boundary: every wave drains its own (write-through) stores, then one thread arrives and waits
+__device__ __forceinline__ void gb_sync(GridBar* b, unsigned e) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gb_arrive(b, e, false);
+        (void)gb_wait(b, e, 0);
+    }
+    __syncthreads();
+}
+
+// block_sum_store / colsum_store with write-through stores, fold_partials with write-through loads: same trees
+template <int NV>
+__device__ __forceinline__ void block_sum_store_wt(double (&v)[NV], double* dst, int64_t stride, double* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * EW_WAVES + w] = v[i];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) s += scratch[threadIdx.x * EW_WAVES + q];
+        sc1_store(dst + threadIdx.x * stride, s);
+    }
+}
+__device__ __forceinline__ double fold_partials_wt(const double* part) {
+    const int lane = threadIdx.x & 63;
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v += sc1_load(part + i * 64 + lane);
+    return wave_sum(v);
+}
+__device__ __forceinline__ double fold_partials_nanmax_wt(const double* part) {
+    const int lane = threadIdx.x & 63;
+    double v = -1.0;
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v = nanmax(v, sc1_load(part + i * 64 + lane));
+    return wave_nanmax(v);
+}
+
+constexpr int TAIL_NT = 4;       // proximal passes per round (the launch size the chain of kernels settles on)
+struct TailArgs {
+    MomentArgs m;                // moment phase (slabs, M, V, Vhat, X, Xp, scheme scalars); m.Psi is not used
+    ProxSeq prox[2];
+    double e_rel[2];
+    int prox_max_iter;
+    double* colpart;
+    float* absmax_out;           // as FinishArgs
+    AlphaArgs al;                // next iteration's step sizes (as AdaDecideArgs)
+    int decide_check;            // evaluate the outer stopping test here (0 in row-sharded runs: k_shard_post does)
+    GridBar* bar;
+    int slots[2];                // LDS row slots per thread of block j: ceil(rows[j] / 8192)
+    long long* prof;             // tuning (PMX_TAIL_PROF=1): 100 MHz time stamps of workgroup 0 at the phase boundaries, else nullptr
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
+    __shared__ double scratch[2 * TAIL_NT * EW_WAVES];
+    __shared__ double dbuf[EW_BLOCKS + 8];
+    __shared__ unsigned s_word;
+    extern __shared__ float lds[];           // [3 arrays: X, z, Psi][slots[0] + slots[1]][NC][EW_THREADS]
+    static_assert(EW_BLOCKS == 2 * MAXK, "the step-size phase gives one (block, component) to each workgroup");
+    DevStatus* st = a.m.status;
+    if (chain_halted(st)) return;
+    const int tid = threadIdx.x, l32 = tid & 31;
+    const int K = a.m.K;
+    GridBar* bar = a.bar;
+    unsigned ep = bar->epoch[0];             // barriers completed before this launch (written by its predecessor's last act)
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.prof != nullptr && blockIdx.x == 0 && tid == 0) a.prof[nstamp++] = wall_clock64(); };
+    stamp();
+    if (tid == 0) gb_arrive(bar, ep + 1, true);          // census B0: awaited before the first store
+    const int64_t hw = ((int64_t)blockIdx.x * EW_THREADS + tid) >> 5;
+    const int64_t nhw = ((int64_t)EW_BLOCKS * EW_THREADS) >> 5;
+    const int nslot = a.slots[0] + a.slots[1];
+    float* Lx = lds;                                       // updated iterate before the prox (the loop's fixed X)
+    float* Lz = lds + (size_t)nslot * NC * EW_THREADS;     // proximal iterate at the start of the current round
+    float* Lp = lds + (size_t)2 * nslot * NC * EW_THREADS; // Psi; last, at least 16 KB: the finish phase's column-sum scratch
+    auto slot = [&](int j, int i, int c) { return ((size_t)((j ? a.slots[0] : 0) + i) * NC + c) * EW_THREADS + tid; };
+    bool ok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+    const MomentScalars ms = moment_scalars(a.m);
+    const bool any_prox = a.m.has_prox[0] || a.m.has_prox[1];
+
+    // ---------------- phase M: moments and update (k_ada_moment) -------------------------------------------------
+    // (the first rows' loads are requested before the census wait, whose latency they hide)
+    float g_pre[NC], x_pre[NC];
+    const bool pre = a.slots[0] > 0 && hw < a.m.rows[0];
+    if (pre) {
+        load_grad<NC>(g_pre, ok, a.m.slab[0], a.m.rows[0], K, hw, l32);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x_pre[c] = ok[c] ? a.m.X[0][hw * K + l32 + 32 * c] : 0.f;
+    }
+    {   // census B0: every workgroup must be resident before the first store of the launch
+        if (tid == 0) s_word = gb_wait(bar, ep + 1, 200000);
+        __syncthreads();
+        if (s_word & 1u) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st->tail_fault = 1;
+                st->reason = HALT_ERROR;
+                __threadfence();
+                st->halt = 1;
+            }
+            return;
+        }
+        ep += 1;
+    }
+    stamp();
+    float alpha0[NC], alpha1[NC];            // this iteration's step sizes (nmf.py:93), both blocks
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        alpha0[c] = ok[c] ? st->alpha[0][l32 + 32 * c] : 0.f;
+        alpha1[c] = ok[c] ? st->alpha[1][l32 + 32 * c] : 0.f;
+    }
+    for (int j = 0; j < 2; ++j) {
+        const int64_t rows = a.m.rows[j];
+        float alpha[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) alpha[c] = j ? alpha1[c] : alpha0[c];
+        float maxpsi = -1.f;
+        for (int i = 0; i < a.slots[j]; ++i) {
+            const int64_t r = hw + (int64_t)i * nhw;
+            if (r >= rows) break;
+            float g[NC], xo[NC];
+            if (j == 0 && i == 0 && pre) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { g[c] = g_pre[c]; xo[c] = x_pre[c]; }
+            } else {
+                load_grad<NC>(g, ok, a.m.slab[j], rows, K, r, l32);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) xo[c] = ok[c] ? a.m.X[j][r * K + l32 + 32 * c] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!ok[c]) continue;
+                const int64_t e = r * K + l32 + 32 * c;
+                float psi;
+                const float xn = moment_elem(a.m, ms, j, e, g[c], alpha[c], xo[c], psi);
+                if (a.m.check_convergence) a.m.Xp[j][e] = xo[c];
+                Lx[slot(j, i, c)] = xn;
+                Lp[slot(j, i, c)] = psi;
+                maxpsi = nanmaxf(maxpsi, psi);
+            }
+        }
+        double mv = wave_nanmax((double)maxpsi);
+        __syncthreads();
+        if ((tid & 63) == 0) scratch[tid >> 6] = mv;
+        __syncthreads();
+        if (tid == 0) {
+            double m = scratch[0];
+            for (int q = 1; q < EW_WAVES; ++q) m = nanmax(m, scratch[q]);
+            sc1_store(part_ptr(a.m.partials, SL_MAXPSI, j) + blockIdx.x, m);
+        }
+    }
+
+    // ---------------- phase S: proximal sub-iterations (k_ada_sub + the replay of k_ada_finish) -------------------
+    int tau0 = 0, tau1 = 0;
+    stamp();
+    if (any_prox) {
+        gb_sync(bar, ++ep);              // B1: every workgroup's max Psi
+        stamp();
+        bool done0 = !a.m.has_prox[0], done1 = !a.m.has_prox[1];
+        // max Psi per block (algorithms.py:384), kept in two scalars; gamma and gamma / alpha are re-derived where needed
+        double mp0, mp1;
+        {   // both blocks' partials requested before the first of them is reduced: one memory latency, not two
+            const int lane = tid & 63;
+            const double* q0 = part_ptr(a.m.partials, SL_MAXPSI, 0);
+            const double* q1 = part_ptr(a.m.partials, SL_MAXPSI, 1);
+            double u0[EW_BLOCKS / 64], u1[EW_BLOCKS / 64];
+#pragma unroll
+            for (int i = 0; i < EW_BLOCKS / 64; ++i) { u0[i] = sc1_load(q0 + i * 64 + lane); u1[i] = sc1_load(q1 + i * 64 + lane); }
+            double v0 = -1.0, v1 = -1.0;
+#pragma unroll
+            for (int i = 0; i < EW_BLOCKS / 64; ++i) { v0 = nanmax(v0, u0[i]); v1 = nanmax(v1, u1[i]); }
+            mp0 = wave_nanmax(v0);
+            mp1 = wave_nanmax(v1);
+        }
+        stamp();
+        auto steps = [&](int j, float (&gam)[NC], float (&rat)[NC]) {
+            const float mp = (float)(j ? mp1 : mp0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float al = j ? alpha1[c] : alpha0[c];
+                gam[c] = al / mp;
+                rat[c] = gam[c] / al;                    // NaN if alpha == 0, as in the reference
+            }
+        };
+        // up to TAIL_NT passes (n of them) from the round's starting iterate; SUMS: also the two sums of the stopping test
+        auto passes = [&](int j, int i, int n, bool first_round, const float (&gam)[NC], const float (&rat)[NC], float (&z)[NC],
+                          auto sums_c, float (&d2)[TAIL_NT], float (&n2)[TAIL_NT]) {
+            constexpr bool SUMS = decltype(sums_c)::value;
+            float x[NC], ps[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                x[c] = Lx[slot(j, i, c)];
+                ps[c] = Lp[slot(j, i, c)];
+                z[c] = first_round ? x[c] : Lz[slot(j, i, c)];
+                if (!ok[c]) { x[c] = 0.f; ps[c] = 0.f; z[c] = 0.f; }
+            }
+#pragma unroll
+            for (int q = 0; q < TAIL_NT; ++q) {
+                if (q < n) {
+                    float v[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) v[c] = z[c] - rat[c] * ps[c] * (z[c] - x[c]);
+                    prox_row<NC>(v, ok, a.prox[j], gam);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (SUMS && ok[c]) {
+                            const float d = v[c] - z[c];
+                            d2[q] += d * d;
+                            n2[q] += z[c] * z[c];
+                        }
+                        z[c] = v[c];
+                    }
+                }
+            }
+        };
+        using yes = std::integral_constant<bool, true>;
+        using no = std::integral_constant<bool, false>;
+        // Rounds of up to TAIL_NT passes per block, one barrier per round.  Round 0 runs as many passes as the block's loop
+        // took in the previous iteration (the steady state repeats itself) and leaves its end state in Lz: if the loop
+        // ends exactly there, nothing is recomputed.  It starts from Lx, which stays intact, so a loop that ends earlier
+        // inside round 0 is replayed from there; later rounds (start-up transient only) run TAIL_NT passes for the sums
+        // alone and then redo the passes that count from their starting state.  Pass numbers and sums do not depend on
+        // how the passes are grouped into rounds: bit-identical to one launch per pass.
+        int t0_0 = 0, t0_1 = 0;                   // passes done before the current round, per block
+        for (int round = 0; !(done0 && done1); ++round) {
+            int nt_0 = TAIL_NT, nt_1 = TAIL_NT;
+            if (round == 0) {
+                const int l0 = st->last_tau[0], l1 = st->last_tau[1];
+                nt_0 = l0 >= 1 && l0 <= TAIL_NT ? l0 : TAIL_NT;
+                nt_1 = l1 >= 1 && l1 <= TAIL_NT ? l1 : TAIL_NT;
+            }
+            for (int j = 0; j < 2; ++j) {
+                if (j ? done1 : done0) continue;
+                const int nt = j ? nt_1 : nt_0;
+                float gam[NC], rat[NC];
+                steps(j, gam, rat);
+                float d2[TAIL_NT], n2[TAIL_NT];
+#pragma unroll
+                for (int q = 0; q < TAIL_NT; ++q) { d2[q] = 0.f; n2[q] = 0.f; }
+                for (int i = 0; i < a.slots[j]; ++i) {
+                    if (hw + (int64_t)i * nhw >= a.m.rows[j]) break;
+                    float z[NC];
+                    passes(j, i, nt, round == 0, gam, rat, z, yes{}, d2, n2);
+                    if (round == 0) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) Lz[slot(j, i, c)] = z[c];
+                    }
+                }
+                double red[2 * TAIL_NT];
+#pragma unroll
+                for (int q = 0; q < TAIL_NT; ++q) { red[2 * q] = (double)d2[q]; red[2 * q + 1] = (double)n2[q]; }
+                block_sum_store_wt<2 * TAIL_NT>(red, part_ptr(a.m.partials, SL_SUBR0 + 2 * TAIL_NT * (round & 3), j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+            }
+            if (round == 0) stamp();
+            gb_sync(bar, ++ep);          // B2: the round's sums
+            if (round == 0) stamp();
+            for (int j = 0; j < 2; ++j) {
+                if (j ? done1 : done0) continue;
+                const int nt = j ? nt_1 : nt_0, t0 = j ? t0_1 : t0_0;
+                const int w = tid >> 6;
+                __syncthreads();
+                if (w < 2 * nt) {
+                    const double v = fold_partials_wt(part_ptr(a.m.partials, SL_SUBR0 + 2 * TAIL_NT * (round & 3) + w, j));
+                    if ((tid & 63) == 0) scratch[w] = v;
+                }
+                __syncthreads();
+                int tau = 0;
+                for (int q = 0; q < nt && tau == 0; ++q) {
+                    const double d = scratch[2 * q], n = scratch[2 * q + 1];
+                    if ((d <= a.e_rel[j] * a.e_rel[j] * n) || (t0 + q + 1 >= a.prox_max_iter)) tau = t0 + q + 1;
+                }
+                __syncthreads();
+                const int keep = tau > 0 ? tau - t0 : nt;            // passes of this round that count
+                if (!(round == 0 && keep == nt)) {                   // (round 0 already left its end state in Lz)
+                    float gam[NC], rat[NC], dd[TAIL_NT], nn[TAIL_NT];
+                    steps(j, gam, rat);
+                    for (int i = 0; i < a.slots[j]; ++i) {
+                        if (hw + (int64_t)i * nhw >= a.m.rows[j]) break;
+                        float z[NC];
+                        passes(j, i, keep, round == 0, gam, rat, z, no{}, dd, nn);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) Lz[slot(j, i, c)] = z[c];
+                    }
+                }
+                if (j) { t0_1 = t0 + nt; if (tau > 0) { done1 = true; tau1 = tau; } }
+                else { t0_0 = t0 + nt; if (tau > 0) { done0 = true; tau0 = tau; } }
+            }
+        }
+    }
+
+    // ---------------- phase F: X <- z, outer norms, column sums (k_ada_finish) --------------------------------------
+    stamp();
+    float* sm = Lp;                      // colsum_store's scratch (Psi is no longer needed)
+    for (int j = 0; j < 2; ++j) {
+        const int64_t rows = a.m.rows[j];
+        const float* src = a.m.has_prox[j] ? Lz : Lx;
+        float d2 = 0.f, n2 = 0.f, xmax = 0.f;
+        float cs[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cs[c] = 0.f;
+        for (int i = 0; i < a.slots[j]; ++i) {
+            const int64_t r = hw + (int64_t)i * nhw;
+            if (r >= rows) break;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!ok[c]) continue;
+                const int64_t e = r * K + l32 + 32 * c;
+                const float x = src[slot(j, i, c)];
+                a.m.X[j][e] = x;
+                xmax = fmaxf(xmax, fabsf(x));
+                if (a.m.check_convergence) {
+                    const float d = x - a.m.Xp[j][e];
+                    d2 += d * d;
+                    n2 += x * x;
+                }
+                cs[c] += x;
+            }
+        }
+        double red[2] = {(double)d2, (double)n2};
+        block_sum_store_wt<2>(red, part_ptr(a.m.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+        {   // colsum_store, write-through
+            const int hwi = tid >> 5;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sm[hwi * MAXK + l32 + 32 * c] = cs[c];
+            __syncthreads();
+            if (tid < 32 * NC) {
+                double s = 0.0;
+                for (int h = 0; h < EW_THREADS / 32; ++h) s += (double)sm[h * MAXK + tid];
+                sc1_store(a.colpart + ((int64_t)j * EW_BLOCKS + blockIdx.x) * MAXK + tid, s);
+            }
+            __syncthreads();
+        }
+        if (a.absmax_out != nullptr) {
+            const double m = wave_max((double)xmax);
+            __syncthreads();
+            if ((tid & 63) == 0) scratch[tid >> 6] = m;
+            __syncthreads();
+            if (tid == 0) {
+                double mm = scratch[0];
+                for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
+                a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
+            }
+        }
+    }
+    stamp();
+    gb_sync(bar, ++ep);                  // B3: column sums and outer norms of every workgroup
+    stamp();
+
+    // ---------------- phase D: next step sizes, one (block, component) per workgroup; bookkeeping (k_ada_decide) ------
+    {
+        const int j = blockIdx.x / MAXK, k = blockIdx.x % MAXK;
+        if (k < K) {
+            float al;
+            if (a.al.use_fixed) al = a.al.fixed[j];
+            else {
+                double tot;
+                if (j == 0 && a.al.comm_colsum != nullptr) tot = (double)a.al.comm_colsum[k];
+                else {
+                    // colsum_fold's order: 8 groups, group q adds the partials q, q + 8, ... in that order, then the groups in order
+                    if (tid < EW_BLOCKS) dbuf[tid] = sc1_load(a.colpart + ((int64_t)j * EW_BLOCKS + tid) * MAXK + k);
+                    __syncthreads();
+                    if (tid < ALPHA_NG) {
+                        double s = 0.0;
+                        for (int i = 0; i < EW_BLOCKS / ALPHA_NG; ++i) s += dbuf[tid + ALPHA_NG * i];
+                        dbuf[EW_BLOCKS + tid] = s;
+                    }
+                    __syncthreads();
+                    tot = 0.0;
+                    for (int q = 0; q < ALPHA_NG; ++q) tot += dbuf[EW_BLOCKS + q];
+                }
+                al = (float)(tot / (double)a.al.rows_global[j]) / 10.f;
+            }
+            if (tid == 0) st->alpha[j][k] = al;
+        }
+    }
+    if (blockIdx.x == 0) {
+        double d[2] = {0, 0}, n[2] = {0, 0};
+        if (a.m.check_convergence)
+            for (int j = 0; j < 2; ++j) {
+                d[j] = fold_partials_wt(part_ptr(a.m.partials, SL_DIFF2, j));
+                n[j] = fold_partials_wt(part_ptr(a.m.partials, SL_NORM2, j));
+            }
+        if (tid == 0) {
+            int all = 1;
+            for (int j = 0; j < 2; ++j) {
+                const int c = (a.m.check_convergence && a.decide_check) ? (d[j] <= a.e_rel[j] * a.e_rel[j] * n[j]) : 0;
+                st->conv[j] = c;
+                st->norms[j][0] = d[j];
+                st->norms[j][1] = n[j];
+                all &= c;
+                const int tau = a.m.has_prox[j] ? (j ? tau1 : tau0) : 0;
+                st->sub_total[j] += tau;
+                st->last_tau[j] = tau;
+            }
+            st->it_done += 1;
+            bar->epoch[0] = ep;
+            if (a.prof != nullptr) a.prof[nstamp++] = wall_clock64();
+            if (a.m.check_convergence && a.decide_check && all) {
+                st->stopped = 1;
+                st->reason = HALT_CONVERGED;
+                __threadfence();
+                st->halt = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // block-SDMM: update of one block                       (proxmin/utils.py:295-346, nmf.py:181-185)
 // ------------------------------------------------------------------------------------------------
 struct BsdmmArgs {
@@ -1275,10 +1797,18 @@ struct PackArgs {
     int fold_grad;           // 0: only the extras (final convergence flush)
     int n_extra;             // bsdmm: additional block-0 slots SL_G0 .. SL_G0+n_extra-1 -> scalars[2..]
 };
+// scalars[N_SCALARS - 1] of the comm buffer is the ranks' collective halt flag: a rank whose chain is halted (converged,
+// out of proximal passes, a fault) still runs this one store, the all-reduce sums it, and k_shard_post / k_shard_gram_in
+// stop EVERY rank before the update of that iteration -- ranks can never disagree about which iterations were applied,
+// so they always issue the same number of collectives (a rank-local decision there would be a hang, not an error).
+constexpr int SHARD_HALT_SLOT = 31;
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
     __shared__ double scratch[EW_WAVES];
-    if (chain_halted(a.status)) return;
+    if (chain_halted(a.status)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.comm[a.N * a.K + a.KP * a.KP + MAXK + SHARD_HALT_SLOT] = 1.f;
+        return;
+    }
     const int K = a.K;
     if (a.fold_grad) {
         ROW_LOOP_BEGIN(a.N)
@@ -1324,9 +1854,19 @@ struct GramInArgs {
     double* G;               // gramG[0]
     int n;
     const DevStatus* status;
+    const float* peer_halt;  // the all-reduced halt flag (bsdmm: this is the first kernel after the collective) or nullptr
+    DevStatus* wstatus;
 };
 __global__ __launch_bounds__(256) void k_shard_gram_in(GramInArgs a) {
     if (chain_halted(a.status)) return;
+    if (a.peer_halt != nullptr && *a.peer_halt > 0.5f) {     // another rank is halted: stop here, before this iteration's update
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.wstatus->reason = HALT_PEER;
+            __threadfence();
+            a.wstatus->halt = 1;
+        }
+        return;
+    }
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < a.n) a.G[e] = (double)a.comm_gram[e];
 }
@@ -1345,6 +1885,14 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
     __shared__ double scratch[EW_WAVES];
     DevStatus* st = a.al.status;
     if (chain_halted(st)) return;
+    if (a.scalars[SHARD_HALT_SLOT] > 0.5f) {         // another rank is halted: stop before this iteration's update
+        if (threadIdx.x == 0) {
+            st->reason = HALT_PEER;
+            __threadfence();
+            st->halt = 1;
+        }
+        return;
+    }
     if (a.do_alpha) compute_alpha(a.al);
     if (a.check_convergence && a.have_prev) {
         const double dS = fold_partials(part_ptr(a.partials, SL_DIFF2, 1), scratch);
@@ -1402,6 +1950,26 @@ void launch_ada_sub(const SubArgs& a, hipStream_t s) {
 }
 void launch_ada_finish(const FinishArgs& a, hipStream_t s) { DISPATCH_NC(a.s.K, k_ada_finish, dim3(EW_BLOCKS, 2), s, a); }
 void launch_ada_decide(const AdaDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ada_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
+// dynamic LDS of the fused tail: three state arrays of (slots[0] + slots[1]) x NC x 1024 floats
+static size_t ada_tail_lds_bytes(const TailArgs& a) {
+    const int NC = a.m.K <= 32 ? 1 : (a.m.K <= 64 ? 2 : 4);
+    const size_t arr = (size_t)(a.slots[0] + a.slots[1]) * NC * EW_THREADS * sizeof(float);
+    return 2 * arr + std::max(arr, (size_t)(EW_THREADS / 32) * MAXK * sizeof(float));
+}
+constexpr size_t ADA_TAIL_LDS_MAX = 160 * 1024 - 6 * 1024;   // the kernel's static scratch is ~3.2 KB
+template <int NC>
+static hipError_t launch_ada_tail_t(const TailArgs& a, hipStream_t s) {
+    const size_t lds = ada_tail_lds_bytes(a);
+    hipError_t e = hipFuncSetAttribute((const void*)k_ada_tail<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ada_tail<NC>, dim3(EW_BLOCKS), dim3(EW_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_ada_tail(const TailArgs& a, hipStream_t s) {
+    if (a.m.K <= 32) return launch_ada_tail_t<1>(a, s);
+    if (a.m.K <= 64) return launch_ada_tail_t<2>(a, s);
+    return launch_ada_tail_t<4>(a, s);
+}
 void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }
 void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS), s, a); }
 void launch_shard_gram_in(const GramInArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_gram_in, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }

@@ -84,6 +84,10 @@ struct pmx_ctx {
     unsigned chainSeq = 0;                 // launches so far (arrival words are monotonic: launch n counts from 64 n)
     int nSlabA = 0;                        // gA slabs the update kernels fold (plan.nSlabA, or one per chain group)
     int chainFaults = 0;                   // times the chained mode was left after a fault
+    bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
+    GridBar* gridbar = nullptr;            // its barrier state
+    long long* tailprof = nullptr;         // PMX_TAIL_PROF=1: phase time stamps of the last fused tail
+    int tailFaults = 0;
     float* slab[2] = {nullptr, nullptr};
     const float* W = nullptr;              // weights of the likelihood (nullptr: W == 1), nmf.py:13-41
     int64_t ldW = 0;
@@ -292,7 +296,7 @@ extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     info[4] = c->plan.gridX;
     info[5] = c->plan.gridY;
     info[6] = c->plan.RP;
-    info[7] = c->chainFaults;
+    info[7] = c->chainFaults + 1000 * c->tailFaults + (c->tail_fused ? 1000000 : 0);
     return PMX_OK;
 }
 
@@ -499,18 +503,27 @@ static int chain_disable(pmx_ctx* c) {
 // After read_status: a chained K1 launch found that its hand-off does not hold here (a predecessor on another XCD, or
 // workgroups that are not co-resident: DevStatus::k1_fault) and stopped the chain of kernels before anything was updated.
 // Fall back to slabs and clear the halt; the caller re-enqueues from DevStatus::it_done.  *again = 1 if that happened.
+// The same for the fused adaprox tail (DevStatus::tail_fault: its census barrier timed out before anything was written).
 static int chain_fault_fallback(pmx_ctx* c, int* again) {
     *again = 0;
-    if (!c->hstatus->k1_fault) return PMX_OK;
-    int rc = chain_disable(c);
-    if (rc != PMX_OK) return rc;
-    c->chainFaults += 1;
-    static const int zeros[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(&c->dstatus->k1_fault, zeros, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (!c->hstatus->k1_fault && !c->hstatus->tail_fault) return PMX_OK;
+    int rc = PMX_OK;
+    if (c->hstatus->k1_fault) {
+        rc = chain_disable(c);
+        if (rc != PMX_OK) return rc;
+        c->chainFaults += 1;
+    }
+    if (c->hstatus->tail_fault) {
+        c->tail_fused = false;
+        c->tailFaults += 1;
+    }
+    static const int zeros[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->tail_fault, zeros, 3 * sizeof(int), hipMemcpyHostToDevice, c->stream));   // tail_fault, pad2, k1_fault
     rc = clear_halt(c);
     if (rc != PMX_OK) return rc;
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->hstatus->k1_fault = 0;
+    c->hstatus->tail_fault = 0;
     c->hstatus->halt = 0;
     c->hstatus->reason = 0;
     c->absmax_by_finish = false;
@@ -554,6 +567,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
                     c->chainSeq = 0;
                 }
                 g.chainL = c->chainL; g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
+                g.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
             }
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -644,6 +658,8 @@ static int shard_gram_in(pmx_ctx* c) {
     g.G = c->gramG;
     g.n = c->KP * c->KP;
     g.status = c->dstatus;
+    g.peer_halt = c->algo == ALG_BSDMM ? c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK + SHARD_HALT_SLOT : nullptr;
+    g.wstatus = c->dstatus;
     launch_shard_gram_in(g, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1140,6 +1156,22 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
             if (rc != PMX_OK) return rc;
         }
     }
+    // the iteration tail as one persistent kernel where its LDS-resident state fits and one workgroup per CU can be
+    // resident (PMX_TAIL_FUSED=0: the four separate kernels; PMX_SUB_BATCH=1 implies them)
+    c->tail_fused = false;
+    if (!(getenv("PMX_TAIL_FUSED") && atoi(getenv("PMX_TAIL_FUSED")) == 0) && c->sub_nt != 1 && c->tailFaults == 0) {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) ncu = 0;
+        TailArgs probe{};
+        probe.m.K = (int)c->K;
+        for (int j = 0; j < 2; ++j) probe.slots[j] = (int)((c->rows[j] + 8191) / 8192);
+        if (ncu >= EW_BLOCKS && ada_tail_lds_bytes(probe) <= ADA_TAIL_LDS_MAX) {
+            rc = dallocT(c, &c->gridbar, 1);
+            if (rc == PMX_OK && getenv("PMX_TAIL_PROF")) rc = dallocT(c, &c->tailprof, 16);
+            if (rc != PMX_OK) return rc;
+            c->tail_fused = true;
+        }
+    }
     // step sizes of the first iteration from the initial factors (algorithms.py:370 -> nmf.py:93)
     AlphaArgs al = alpha_args(c);
     al.use_fixed = p->use_fixed_steps;
@@ -1236,6 +1268,45 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     return PMX_OK;
 }
 
+// the fused iteration tail (k_ada_tail): moment + update, proximal sub-iterations, finish, next step sizes
+static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev) {
+    const pmx_adaprox_params& p = c->ada;
+    TailArgs t{};
+    MomentArgs& m = t.m;
+    for (int j = 0; j < 2; ++j) {
+        m.X[j] = c->X[j]; m.Xp[j] = c->Xp[j];
+        m.Mm[j] = c->Mm[j]; m.Vv[j] = c->Vv[j];
+        m.Vh[j] = p.warm_vhat ? c->Vh[j] : nullptr;
+        m.Psi[j] = nullptr;
+        m.slab[j] = slab_ref(c, j);
+        m.rows[j] = c->rows[j];
+        m.has_prox[j] = p.prox[j].n > 0;
+        t.prox[j] = to_dev(p.prox[j]);
+        t.e_rel[j] = p.e_rel[j];
+        t.slots[j] = (int)((c->rows[j] + 8191) / 8192);
+    }
+    if (c->shard_grad_from_comm) { m.slab[1].base = c->comm; m.slab[1].n = 1; }
+    m.K = (int)c->K;
+    m.status = c->dstatus;
+    m.partials = c->partials;
+    m.scheme = p.scheme;
+    m.it = it;
+    m.b1t = b1t; m.b1prev = b1prev; m.b2 = p.b2; m.eps = p.eps; m.p = p.p;
+    m.check_convergence = p.check_convergence;
+    t.prox_max_iter = p.prox_max_iter;
+    t.colpart = c->colpart;
+    t.absmax_out = c->use_f16 ? c->absmax : nullptr;
+    t.al = alpha_args(c);
+    t.al.use_fixed = p.use_fixed_steps;
+    t.al.fixed[0] = (float)p.fixed_alpha[0];
+    t.al.fixed[1] = (float)p.fixed_alpha[1];
+    t.decide_check = c->comm ? 0 : 1;     // row-sharded: the outer test is made after the next all-reduce (k_shard_post)
+    t.bar = c->gridbar;
+    t.prof = c->tailprof;
+    HIP_CHECK(launch_ada_tail(t, c->stream));
+    return PMX_OK;
+}
+
 // after_tail: the previous kernels on the stream were THIS call's finish + decide of the preceding iteration
 static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev, bool after_tail) {
     int rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, after_tail);         // algorithms.py:369
@@ -1265,6 +1336,13 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
         if (c->sub_nt != 1) c->sub_nt = nsub <= 4 ? 4 : SUB_NT_MAX;
         for (int i = 0; i < chunk; ++i) {
             const int gi = done + i;
+            if (c->tail_fused) {
+                rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, tails > 0);
+                if (rc == PMX_OK) rc = ada_enqueue_tail_fused(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1]);
+                ++tails;
+                if (rc != PMX_OK) return rc;
+                continue;
+            }
             rc = ada_enqueue_head(c, it0 + gi, b1[gi], gi == 0 ? b1_prev : b1[gi - 1], tails > 0);
             if (rc != PMX_OK) return rc;
             rc = ada_enqueue_tail(c, ada_enqueue_subs(c, 0, nsub));
@@ -1305,6 +1383,14 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
         }
         if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
         if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+    }
+    if (c->tailprof && c->tail_fused) {
+        long long h[16];
+        HIP_CHECK(hipMemcpy(h, c->tailprof, sizeof(h), hipMemcpyDeviceToHost));
+        static const char* nm[] = {"census", "moment", "B1", "maxpsi", "sub", "B2", "judge+replay", "finish", "B3", "decide"};
+        fprintf(stderr, "[tailprof] us:");
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.2f", nm[i], (double)(h[i + 1] - h[i]) / 100.0);
+        fprintf(stderr, " total=%.2f\n", (double)(h[10] - h[0]) / 100.0);
     }
     fill_result(c, res, it0);
     return PMX_OK;
@@ -1506,6 +1592,13 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
         case 1: {
             rc = shard_post(c, it > 0);
             if (rc != PMX_OK) return rc;
+            if (c->tail_fused) {
+                c->shard_grad_from_comm = true;
+                rc = ada_enqueue_tail_fused(c, it, b1_it, b1_prev);
+                c->shard_grad_from_comm = false;
+                c->absmax_by_finish = rc == PMX_OK;
+                return rc;
+            }
             c->shard_grad_from_comm = true;
             rc = ada_enqueue_moment(c, it, b1_it, b1_prev);
             c->shard_grad_from_comm = false;
@@ -1634,6 +1727,10 @@ extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
     if (!c->comm) FAIL(PMX_E_STATE, "pmx_set_comm_buffer has not been called");
     const pmx_bsdmm_params& p = c->bsd;
     const float* scal = c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK;
+    // the A step is applied before the collective: a repeated iteration would apply it twice on the ranks that did not
+    // fault, so the chained K1 (whose faults are repaired by repeating the iteration) is not used here
+    rc = chain_disable(c);
+    if (rc != PMX_OK) return rc;
     if (phase == 0) {
         // A step: everything is local (step_A comes from the replicated S)
         rc = enqueue_steps(c, c->X[0], c->X[1], true, false, 1.0);
@@ -1664,6 +1761,22 @@ extern "C" int pmx_chain_status(pmx_ctx* c, int* halted, int* reason, int* it_do
     *halted = c->hstatus->halt;
     *reason = c->hstatus->reason;
     *it_done = c->hstatus->it_done;
+    if (c->hstatus->tail_fault)    // its update of iteration it_done was not applied here, but the other ranks applied theirs
+        FAIL(PMX_E_STATE, "the fused adaprox tail (k_ada_tail) found its workgroups not co-resident in a row-sharded run: "
+                          "this GPU is shared with other work; set PMX_TAIL_FUSED=0");
+    if (c->hstatus->k1_fault) {    // nothing of iteration it_done was applied on any rank (collective halt flag): fall back, retry
+        int again = 0;
+        rc = chain_fault_fallback(c, &again);
+        if (rc != PMX_OK) return rc;
+        *halted = 1;
+        *reason = HALT_RETRY;
+    } else if (c->hstatus->halt && c->hstatus->reason == HALT_PEER) {
+        rc = clear_halt(c);
+        if (rc != PMX_OK) return rc;
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->hstatus->halt = 0;
+        c->absmax_by_finish = false;
+    }
     last_tau[0] = c->hstatus->last_tau[0];
     last_tau[1] = c->hstatus->last_tau[1];
     return PMX_OK;

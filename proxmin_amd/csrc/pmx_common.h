@@ -62,9 +62,13 @@ struct DevStatus {
     double bt[2][5];        // backtracking sums per block: (X-X_).G, (X-X_)^2, max|G|, max|X_|, X^2
     double eigvec[2][MAXK]; // warm start for the power iteration
     int eig_iters[2];
+    int tail_fault;      // k_ada_tail: its census barrier found the workgroups not co-resident; nothing was written (host falls back to the separate kernels)
+    int pad2;
     int k1_fault;        // k_grad_f16_v8<CHAIN>: 1 a chain predecessor never arrived, 2 it runs on another XCD (host falls back to slabs)
 };
-enum { HALT_NONE = 0, HALT_CONVERGED = 1, HALT_NEED_SUB = 2, HALT_ERROR = 3 };
+enum { HALT_NONE = 0, HALT_CONVERGED = 1, HALT_NEED_SUB = 2, HALT_ERROR = 3,
+       HALT_RETRY = 4,   // (host view) a kernel reported a recoverable fault before anything was updated: re-enqueue from it_done
+       HALT_PEER = 5 };  // row-sharded runs: another rank's chain is halted; this one stopped at the same iteration
 
 struct ProxSeq {           // device copy of pmx_proxseq
     int n, repeat;

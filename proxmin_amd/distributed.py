@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _lib
 
-HALT_CONVERGED, HALT_NEED_SUB = 1, 2
+HALT_CONVERGED, HALT_NEED_SUB, HALT_ERROR, HALT_RETRY, HALT_PEER = 1, 2, 3, 4, 5
 MAXK = 128
 N_SCALARS = 32
 
@@ -107,6 +107,10 @@ class ShardedAdaproxDriver:
                 self.nsub = max(2, min(max(tau), self.prox_max_iter))
             if halted and reason == HALT_CONVERGED:
                 self.stopped = True
+            elif halted and reason == HALT_ERROR:
+                raise _lib.PmxError("the device chain of rank-local kernels reported an error")
+            # HALT_RETRY (this rank fell back after a recoverable kernel fault) / HALT_PEER (another rank did): every rank
+            # stopped before the update of iteration it_done (collective halt flag), the halt is cleared: go on from there
         if self.check and not self.stopped and n_iter > 0:
             # the stopping test of the last iteration has not been evaluated yet (it needs A's global sums)
             self.eng.phase(2, self.it, 0.0, 0.0, 0)
@@ -147,6 +151,8 @@ class ShardedLoop:
             self.it = it_done
             if halted and reason == HALT_CONVERGED:
                 self.stopped = True
+            elif halted and reason == HALT_ERROR:
+                raise _lib.PmxError("the device chain of rank-local kernels reported an error")
         if self.deferred and not self.stopped and n_iter > 0:
             self.eng.phase(2, self.it)
             self._allreduce()

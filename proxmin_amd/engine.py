@@ -156,6 +156,8 @@ class DeviceNMF:
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
         d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8")[d["kernel"]]
+        v7 = d.pop("chain_faults")
+        d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
         return d
 
     # -- single operations --------------------------------------------------------------------

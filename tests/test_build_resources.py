@@ -14,8 +14,12 @@ import __graft_entry__ as g
 
 # mangled-name fragment -> max spilled VGPRs (current values in the comments)
 LIMITS = {
-    "13k_grad_f16_v8ILb0ELb0E": 4,     # 1   two-term fp16 K1 (bench default)
-    "13k_grad_f16_v8ILb0ELb1E": 16,    #     its weighted instance
+    "13k_grad_f16_v8ILb0ELb0ELb1E": 12,   # 7   two-term fp16 K1 with the chained gA accumulation (bench default)
+    "13k_grad_f16_v8ILb0ELb0ELb0E": 4,    # 1   the same with one gA slab per column region
+    "13k_grad_f16_v8ILb0ELb1ELb0E": 16,   # 5   weighted
+    "13k_grad_f16_v8ILb0ELb1ELb1E": 24,   #     weighted, chained
+    "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)
+    "10k_ada_tailILi4E": 0,
     "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   split-bf16 K1 at K = 64
     "14k_grad_bf16_v7ILb0ELb1E": 16,   # 6   its weighted instance
     "14k_grad_bf16_v5ILb0E": 8,

@@ -16,6 +16,10 @@ CASES = {
     "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512, N % 256 = 0: the fast 16-bit-split kernels / the f32 whole-block kernel
     "pgm": dict(M=520, N=700, K=12, its=7),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
+    # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
+    # (PMX_INJECT_K1_FAULT): it falls back to slabs, rank 0 is stopped at the same iteration through the collective halt
+    # flag, both go on from there.  (Two processes on one GPU can also fault for real -- not co-resident -- same path.)
+    "adaprox_chain_fault": dict(M=4096, N=16384, K=64, unity=True, its=6, modes=("f16x2",), inject={1: "3"}),
 }
 
 
@@ -30,6 +34,11 @@ def _free_port():
 def _worker(rank, world, port, name, mode, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    # two processes share the GPU here: the fused adaprox tail needs all of it to itself (its census barrier would abort,
+    # which a row-sharded run cannot repair) -- one process per GPU is the product configuration
+    os.environ["PMX_TAIL_FUSED"] = "0"
+    if rank in CASES[name].get("inject", {}):
+        os.environ["PMX_INJECT_K1_FAULT"] = CASES[name]["inject"][rank]
     import torch
     import torch.distributed as dist
     import proxmin_amd as pm
@@ -68,6 +77,8 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     import proxmin_amd as pm
     from oracle import nmf_oracle as orc
     c = CASES[name]
+    if mode not in c.get("modes", (mode,)):
+        pytest.skip("case is specific to another arithmetic mode")
     M, N, K = c["M"], c["N"], c["K"]
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
     ops = pm.operators
@@ -93,13 +104,27 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
         p.start()
     for p in procs:
         p.join(300)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:                      # never leave a rank behind: it would keep the GPU (and pytest) busy
+        p.terminate()
+        p.join(10)
+    assert not alive, "rank process(es) did not finish within 300 s"
+    for p in procs:
         assert p.exitcode == 0, "rank process failed (exit code %r)" % p.exitcode
     S_ranks = []
     for r in range(2):
         z = np.load(tmp_path / ("rank%d.npz" % r))
         assert int(z["n"]) == len(tb.trace)
         # the all-reduce sums the ranks' gS in a different order than the single-GPU slab fold: fp32 rounding only
-        np.testing.assert_allclose(z["A"], A1[int(z["r0"]):int(z["r1"])], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(z["S"], S1, rtol=1e-4, atol=1e-5)
+        if c.get("inject"):
+            # after the fall-back this rank sums gA over slabs, the single-GPU run along chains: AMSGrad's eps clamp
+            # turns that rounding difference into a visible one on a few entries per ten thousand (test_gpu_nmf.py)
+            for got, want in ((z["A"], A1[int(z["r0"]):int(z["r1"])]), (z["S"], S1)):
+                err = np.abs(got.astype(np.float64) - want)
+                assert (err <= 1e-5 + 1e-4 * np.abs(want)).mean() >= 0.999
+                np.testing.assert_allclose(got, want, rtol=5e-3, atol=5e-4)
+        else:
+            np.testing.assert_allclose(z["A"], A1[int(z["r0"]):int(z["r1"])], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(z["S"], S1, rtol=1e-4, atol=1e-5)
         S_ranks.append(z["S"])
     np.testing.assert_array_equal(S_ranks[0], S_ranks[1])      # replicated state stays bit-identical across ranks

@@ -447,3 +447,107 @@ def test_array_valued_b1_schedule(pm, orc, scheme):
     orc.adaprox_nmf(Y, Ao, So, max_iter=its, e_rel=1e-3, **kw)
     assert_close_fp32_trajectory(A, Ao, scheme + " A")
     assert_close_fp32_trajectory(S, So, scheme + " S")
+
+
+FUSED_CASES = [
+    # M, N, K, scheme, prox_A spec, prox_S spec, e_rel, max_iter
+    (384, 640, 64, "amsgrad", ("plus",), ("unity_plus", 0), 1e-3, 12),
+    (200, 1000, 5, "adam", ("plus",), ("plus",), 1e-3, 10),
+    (777, 1290, 100, "nadam", ("unity_plus", 1), ("soft_plus", 1e-3), 1e-4, 8),
+    (9000, 300, 33, "padam", ("plus",), ("unity_plus", 0), 1e-3, 8),          # more than 8192 rows: two row slots per thread
+    (300, 17000, 64, "adamx", None, ("soft", 2e-3), 1e-3, 8),                  # prox_A = None: block A skips the proximal loop
+    (513, 257, 16, "radam", ("plus",), ("plus",), 1e-6, 40),                   # converges: the outer test stops the chain
+]
+
+
+@pytest.mark.parametrize("M,N,K,scheme,pA,pS,e_rel,max_iter", FUSED_CASES)
+def test_fused_adaprox_tail_equals_the_chain_of_kernels(pm, orc, monkeypatch, M, N, K, scheme, pA, pS, e_rel, max_iter):
+    """k_ada_tail (moment + update, proximal sub-iterations, finish and next step sizes behind grid barriers in ONE
+    persistent launch) against the four separate kernels it replaces: same factors, moments, stopping iteration and
+    sub-iteration counts, bit for bit -- chained and with a per-iteration callback."""
+    from proxmin_amd import engine
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=(pS[0] == "unity_plus"), seed=M + K)
+    if pA is not None and pA[0] == "unity_plus":
+        A0 /= A0.sum(1, keepdims=True)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PMX_TAIL_FUSED", fused)
+        A, S = A0.copy(), S0.copy()
+        ret = pm.nmf.nmf(Y, A, S, max_iter=max_iter, e_rel=e_rel, algorithm=pm.adaprox, scheme=scheme,
+                         prox_A=spec_to_prox(pm, pA), prox_S=spec_to_prox(pm, pS))
+        A2, S2 = A0.copy(), S0.copy()
+        tr = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A2, S2, max_iter=max_iter, e_rel=e_rel, algorithm=pm.adaprox, scheme=scheme,
+                   prox_A=spec_to_prox(pm, pA), prox_S=spec_to_prox(pm, pS), callback=tr)
+        np.testing.assert_array_equal(A, A2)
+        np.testing.assert_array_equal(S, S2)
+        out.append((A, S, ret, len(tr.trace)))
+    (Af, Sf, rf, nf), (Au, Su, ru, nu) = out
+    np.testing.assert_array_equal(Af, Au)
+    np.testing.assert_array_equal(Sf, Su)
+    assert tuple(rf[0]) == tuple(ru[0]) and nf == nu
+    for j in range(2):
+        np.testing.assert_array_equal(rf[1][j], ru[1][j])      # M
+        np.testing.assert_array_equal(rf[2][j], ru[2][j])      # V
+    # and the fused launch is what ran in the first pass
+    with engine.DeviceNMF(M, N, K) as dev:
+        monkeypatch.setenv("PMX_TAIL_FUSED", "1")
+        dev.set_Y(Y)
+        dev.set_factors(A0, S0)
+        from proxmin_amd import operators as ops
+        dev.adaprox_begin([ops.device_proxseq(spec_to_prox(pm, pA), 0), ops.device_proxseq(spec_to_prox(pm, pS), 1)], scheme=scheme, e_rel=(e_rel, e_rel))
+        dev.adaprox_run(np.full(2, 0.9), 0.9)
+        info = dev.k1_info()
+        assert info["tail_fused"] and info["tail_faults"] == 0, info
+
+
+@pytest.mark.parametrize("backend", ["adaprox", "fista", "bsdmm"])
+def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend):
+    """The chained gA accumulation reports a fault (here injected into the 3rd chained launch; for real: a predecessor
+    on another XCD, or workgroups that are not co-resident) before anything of the iteration is applied: the run must
+    continue on the slab path from that iteration -- same iteration count, factors equal to an all-slab run up to the
+    summation order of the first iterations -- with the host-side Nesterov sequence rewound (fista)."""
+    import proxmin_amd as pm
+    M, N, K = 4096, 4096, 64
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=(backend == "adaprox"), seed=8)
+    pm.set_default_mode("f16x2")
+    try:
+        def run():
+            A, S = A0.copy(), S0.copy()
+            tb = pm.utils.Traceback()
+            if backend == "adaprox":
+                pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="amsgrad", prox_S=partial(pm.operators.prox_unity_plus, axis=0),
+                           max_iter=8, e_rel=1e-3, callback=None)
+            elif backend == "fista":
+                pm.nmf.nmf(Y, A, S, accelerated=True, step=pm.nmf.scaled_step_pgm(0.5), max_iter=8, e_rel=1e-9)
+            else:
+                pgl = [[pm.operators.prox_plus, partial(pm.operators.prox_soft, thresh=0.01)]] * 2
+                pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=5, e_rel=1e-9)
+            return A, S
+        monkeypatch.setenv("PMX_K1_CHAIN", "0")
+        As, Ss = run()
+        monkeypatch.setenv("PMX_K1_CHAIN", "32")
+        monkeypatch.setenv("PMX_INJECT_K1_FAULT", "3")
+        Af, Sf = run()
+        monkeypatch.delenv("PMX_INJECT_K1_FAULT")
+        Ac, Sc = run()
+        # the fall-back really happened (and only once): the same through the engine, where the context can be asked
+        from proxmin_amd import engine, operators as ops
+        monkeypatch.setenv("PMX_INJECT_K1_FAULT", "3")
+        with engine.DeviceNMF(M, N, K, mode="f16x2") as dev:
+            assert dev.k1_info()["chain"] == 2
+            dev.set_Y(Y)
+            dev.set_factors(A0, S0)
+            dev.adaprox_begin([ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(ops.prox_plus, 1)], scheme="adam", e_rel=(1e-3, 1e-3))
+            r = dev.adaprox_run(np.full(6, 0.9), 0.9)
+            info = dev.k1_info()
+            assert r.iterations == 6 and info["chain"] == 0 and info["chain_faults"] == 1, (r.iterations, info)
+    finally:
+        pm.set_default_mode("f32")
+    # different summation orders of gA (chains / slabs) from the faulting iteration on: the module's trajectory policy
+    MODE["name"] = "f16x2"
+    try:
+        for got, want, name in ((Af, As, "A after the fault"), (Ac, As, "A chained"), (Sf, Ss, "S after the fault"), (Sc, Ss, "S chained")):
+            assert_close_fp32_trajectory(got, want, err_msg=name)
+    finally:
+        MODE["name"] = "f32"
