@@ -344,7 +344,7 @@ def test_full_size_modes_agree_and_loss_decreases():
         # measured here: A worst entry 1.3 x the bound, S 3.4e-5 of the entries beyond 25 x, worst 182 x
         ratio = np.abs(a - b) / (2e-5 + 2e-4 * np.abs(a))
         assert (ratio > 25).mean() <= 1e-4, (ratio > 25).mean()
-        assert ratio.max() <= 1000, ratio.max()
+        assert ratio.max() <= 500, ratio.max()      # measured 182 x (2.7 x margin); the full-size oracle comparison is in test_gpu_parity_strict.py
     assert res["bf16x3"][2] == pytest.approx(res["f32"][2], rel=1e-4)
     assert res["f16x2"][2] == pytest.approx(res["f32"][2], rel=1e-4)
 
