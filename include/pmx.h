@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 1
+#define PMX_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------- */
 enum {
@@ -97,6 +97,9 @@ enum {
     PMX_BUF_MA = 4, PMX_BUF_MST = 5,   /* adaprox first moments  (algorithms.py:348-349)  */
     PMX_BUF_VA = 6, PMX_BUF_VST = 7,   /* adaprox second moments (algorithms.py:352-353)  */
     PMX_BUF_VHA = 8, PMX_BUF_VHST = 9, /* adaprox Vhat (only when warm-started, :356-359) */
+    PMX_BUF_EVAL_A = 10, PMX_BUF_EVAL_ST = 11, /* pgm: the point the gradient / step were evaluated at (_X, algorithms.py:93-99) */
+    PMX_BUF_TMP_A = 12, PMX_BUF_TMP_ST = 13,   /* host round trip of a user-defined prox: its argument, then its result       */
+    PMX_BUF_PSI_A = 14, PMX_BUF_PSI_ST = 15,   /* adaprox Psi of the current iteration (algorithms.py:375-377)                */
     PMX_BUF_Z0 = 16, /* + block*PMX_MAX_G + i : bsdmm Z_i of block (utils.py:244-254)     */
     PMX_BUF_U0 = 32  /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
 };
@@ -108,6 +111,9 @@ int pmx_abi_version(void);
 const char* pmx_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU; never fails) */
 int pmx_device_count(void);
+/* sizeof of the parameter / result structs below, in this order: pmx_proxseq, pmx_pgm_params, pmx_adaprox_params,
+ * pmx_bsdmm_params, pmx_result -- a binding checks its own mirrors against them (tests/test_abi.py) */
+int pmx_abi_sizes(int sizes[5]);
 
 /* ---- context ------------------------------------------------------------------------------
  * One context = one nmf() call's device state on one GPU: Y (M x N, this rank's rows), the
@@ -192,6 +198,8 @@ typedef struct pmx_pgm_params { /* algorithms.pgm arguments, algorithms.py:12-23
     int32_t bb_type;      /* 0: off; 1 / 2: utils.BarzilaiBorweinStepper(type) as the step rule (utils.py:209-241) */
     double bb_init_r;     /* its init_r */
     int32_t backtracking; /* 1: Beck-Teboulle line search with f = nmf.log_likelihood (algorithms.py:110-127) */
+    int32_t host_prox[2]; /* 1: prox of block j is a user-defined Python callable, applied by the host between the two
+                             halves of pmx_pgm_split (prox[j] is ignored)                                          */
 } pmx_pgm_params;
 
 typedef struct pmx_result {
@@ -205,6 +213,16 @@ typedef struct pmx_result {
 
 int pmx_pgm_begin(pmx_ctx* ctx, const pmx_pgm_params* p);
 int pmx_pgm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
+/* ONE iteration in pieces, for the callbacks the reference takes as Python callables (algorithms.py:37-39, 73-77, 105-108)
+ * when they are not objects of this library -- everything but the callable itself stays on the device:
+ *   phase 0  gradient at the evaluation point (and the Lipschitz steps unless the caller supplies steps): afterwards
+ *            PMX_BUF_EVAL_* and PMX_BUF_GA / GST hold what `step(*_X, it=it, grads=G)` is called with;
+ *   phase 1  (only with host_prox) T_j = _X_j - s_j G_j into PMX_BUF_TMP_* for the blocks with a user prox: the caller
+ *            downloads it, applies `prox(T_j, s_j)`, uploads the result into the same buffer;
+ *   phase 2  the update (built-in operators fused as always), extrapolation, stopping test; fills *res.
+ * `steps` (phases 1, 2): the two step sizes a user `step` returned, or NULL to keep the device's.  Lipschitz / fixed /
+ * user steps; not with Barzilai-Borwein steps or backtracking. */
+int pmx_pgm_split(pmx_ctx* ctx, int phase, const double* steps, pmx_result* res);
 
 typedef struct pmx_adaprox_params { /* algorithms.adaprox arguments, algorithms.py:248-265 */
     pmx_proxseq prox[2];
@@ -213,21 +231,35 @@ typedef struct pmx_adaprox_params { /* algorithms.adaprox arguments, algorithms.
     int32_t check_convergence;
     int32_t prox_max_iter;
     int32_t warm_vhat;    /* 1: Vhat buffers were uploaded (true AMSGrad/PAdam/AdamX running max) */
-    int32_t use_fixed_steps; /* 1: alpha = fixed_alpha (user `step` returning constants)       */
+    int32_t use_fixed_steps; /* 1: alpha = fixed_alpha (user `step` returning constants); 2: a user `step` callable:
+                                the caller writes the per-component steps with pmx_adaprox_set_alpha before every iteration */
     double fixed_alpha[2];
     double e_rel[2];
+    int32_t host_prox[2];   /* 1: prox of block j is a user-defined Python callable: its proximal loop (algorithms.py:383-400)
+                               runs around the callable on the host between the halves of pmx_adaprox_split           */
 } pmx_adaprox_params;
 
 int pmx_adaprox_begin(pmx_ctx* ctx, const pmx_adaprox_params* p, int warm_moments);
 /* b1: n_iter values b1[it] for the iterations of this call (algorithms.py:327-330);
  * b1_prev: b1[it-1] for the first of them (adamx, :213; the reference reads b1[-1] at it=0). */
 int pmx_adaprox_run(pmx_ctx* ctx, int n_iter, const double* b1, double b1_prev, pmx_result* res);
+/* per-component step sizes of the next iteration (use_fixed_steps == 2): alpha[0..K) for A, alpha[K..2K) for S -- what a
+ * user `step(*X, it=it)` returned (algorithms.py:370), broadcast to components by the caller */
+int pmx_adaprox_set_alpha(pmx_ctx* ctx, const float* alpha);
+/* ONE iteration in two halves around the host-side proximal loops of the blocks with host_prox:
+ *   phase 0  gradient, moments, X <- X - alpha Phi / Psi (algorithms.py:369-378); maxpsi[j] = max(Psi_j) (:384);
+ *            PMX_BUF_A / ST hold the updated blocks, PMX_BUF_PSI_* their Psi;
+ *   phase 1  the proximal loops of the other blocks, X <- z, stopping test, next step sizes; host_tau[j] = passes the
+ *            host-side loop of block j took (it is only counted); fills *res. */
+int pmx_adaprox_split(pmx_ctx* ctx, int phase, int it, double b1_it, double b1_prev, const int* host_tau, double* maxpsi, pmx_result* res);
 
 typedef struct pmx_bsdmm_params { /* algorithms.bsdmm as reachable from nmf(), algorithms.py:653-666 */
     pmx_proxseq prox_f[2];              /* prox_A, prox_S inside prox_f (nmf.py:181-185)       */
     int32_t n_g[2];                     /* constraints per block; 0 = proxs_g[j] is None       */
     pmx_proxseq prox_g[2][PMX_MAX_G];
     double e_rel[2], e_abs[2];
+    int32_t n_order;                    /* update_order (algorithms.py:730-736, :805): 0 = the default (A, S); else the  */
+    int32_t order[8];                   /* blocks in the order given (a block may be left out or appear more than once)   */
 } pmx_bsdmm_params;
 
 int pmx_bsdmm_begin(pmx_ctx* ctx, const pmx_bsdmm_params* p);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "libpmx.so")   # PMX
 MAX_SEQ = 4
 MAX_G = 4
 MAXK = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (include/pmx.h)
 MODE_F32, MODE_BF16, MODE_BF16X3, MODE_F16X2 = 0, 1, 2, 3
@@ -24,6 +24,7 @@ PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "m
         "hard": 7, "hard_plus": 8, "soft": 9, "soft_plus": 10}
 SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}
 BUF_A, BUF_ST, BUF_GA, BUF_GST, BUF_MA, BUF_MST, BUF_VA, BUF_VST, BUF_VHA, BUF_VHST = range(10)
+BUF_EVAL_A, BUF_EVAL_ST, BUF_TMP_A, BUF_TMP_ST, BUF_PSI_A, BUF_PSI_ST = 10, 11, 12, 13, 14, 15
 BUF_Z0, BUF_U0 = 16, 32
 
 
@@ -38,7 +39,7 @@ class ProxSeq(C.Structure):
 class PgmParams(C.Structure):
     _fields_ = [("prox", ProxSeq * 2), ("accelerated", C.c_int32), ("step_scale", C.c_float),
                 ("use_fixed_steps", C.c_int32), ("fixed_steps", C.c_double * 2), ("e_rel", C.c_double * 2),
-                ("bb_type", C.c_int32), ("bb_init_r", C.c_double), ("backtracking", C.c_int32)]
+                ("bb_type", C.c_int32), ("bb_init_r", C.c_double), ("backtracking", C.c_int32), ("host_prox", C.c_int32 * 2)]
 
 
 class Result(C.Structure):
@@ -50,18 +51,19 @@ class AdaproxParams(C.Structure):
     _fields_ = [("prox", ProxSeq * 2), ("scheme", C.c_int32), ("b2", C.c_double), ("eps", C.c_double),
                 ("p", C.c_double), ("check_convergence", C.c_int32), ("prox_max_iter", C.c_int32),
                 ("warm_vhat", C.c_int32), ("use_fixed_steps", C.c_int32), ("fixed_alpha", C.c_double * 2),
-                ("e_rel", C.c_double * 2)]
+                ("e_rel", C.c_double * 2), ("host_prox", C.c_int32 * 2)]
 
 
 class BsdmmParams(C.Structure):
     _fields_ = [("prox_f", ProxSeq * 2), ("n_g", C.c_int32 * 2), ("prox_g", (ProxSeq * MAX_G) * 2),
-                ("e_rel", C.c_double * 2), ("e_abs", C.c_double * 2)]
+                ("e_rel", C.c_double * 2), ("e_abs", C.c_double * 2), ("n_order", C.c_int32), ("order", C.c_int32 * 8)]
 
 
 _SIGNATURES = {
     "pmx_abi_version": (C.c_int, []),
     "pmx_last_error": (C.c_char_p, []),
     "pmx_device_count": (C.c_int, []),
+    "pmx_abi_sizes": (C.c_int, [C.POINTER(C.c_int)]),
     "pmx_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "pmx_ctx_destroy": (C.c_int, [C.c_void_p]),
     "pmx_ctx_sync": (C.c_int, [C.c_void_p]),
@@ -84,6 +86,9 @@ _SIGNATURES = {
     "pmx_prox_array": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(ProxSeq), C.c_void_p]),
     "pmx_pgm_begin": (C.c_int, [C.c_void_p, C.POINTER(PgmParams)]),
     "pmx_pgm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
+    "pmx_pgm_split": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Result)]),
+    "pmx_adaprox_set_alpha": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pmx_adaprox_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(Result)]),
     "pmx_adaprox_begin": (C.c_int, [C.c_void_p, C.POINTER(AdaproxParams), C.c_int]),
     "pmx_adaprox_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.POINTER(Result)]),
     "pmx_bsdmm_begin": (C.c_int, [C.c_void_p, C.POINTER(BsdmmParams)]),
@@ -131,6 +136,11 @@ def load():
         fn.argtypes = args
     if lib.pmx_abi_version() != ABI_VERSION:
         raise PmxError("libpmx.so ABI %d != expected %d; rebuild" % (lib.pmx_abi_version(), ABI_VERSION))
+    sizes = (C.c_int * 5)()
+    lib.pmx_abi_sizes(sizes)
+    mine = [C.sizeof(t) for t in (ProxSeq, PgmParams, AdaproxParams, BsdmmParams, Result)]
+    if list(sizes) != mine:
+        raise PmxError("struct layouts of libpmx.so %r differ from the ctypes mirrors %r; rebuild" % (list(sizes), mine))
     _lib = lib
     return lib
 

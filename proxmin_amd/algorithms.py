@@ -3,9 +3,15 @@ pgm :12-23, adaprox :248-265, bsdmm :653-666).  They are the objects `nmf()` com
 against by identity (nmf.py:141) and the host-side drivers of the device kernel chains.
 
 Scope: the gradient must be the NMF likelihood gradient built by `proxmin_amd.nmf` (a
-`functools.partial(nmf.grad_likelihood, Y=..., W=1)`) -- that is what carries Y to the device --
-and constraints must be operators from `proxmin_amd.operators`.  Generic user `grad` callables are
-outside this build's scope and raise NotImplementedError (no silent CPU fallback).
+`functools.partial(nmf.grad_likelihood, Y=..., W=1)`) -- that is what carries Y to the device.
+Constraints and step rules that are objects of this library (`proxmin_amd.operators.*`, bare,
+`functools.partial` or `AlternatingProjections`; `nmf.step_pgm`, `nmf.step_adaprox`,
+`nmf.scaled_step_pgm`, `nmf.constant_step`, `utils.BarzilaiBorweinStepper`) run fused inside the kernel
+chains.  ANY OTHER Python callable keeps the reference's contract -- `prox(X, step) -> X'`
+(algorithms.py:37-39), `step(*X, it=None[, grads=None])` (:73-77, :370) -- through a host round trip:
+one iteration per call, the callable's arguments copied to the host ((M + N) K floats), its result
+copied back, everything else (gradient, update, norms, built-in operators) still on the device.  A
+one-time warning says so.  Generic user `grad` callables remain out of scope.
 """
 from __future__ import annotations
 
@@ -70,6 +76,66 @@ def _wants_iterates(callback):
     return callback is not None and not isinstance(callback, utils.NullCallback)
 
 
+_warned = set()
+
+
+def _warn_host_path(what):
+    if what not in _warned:
+        _warned.add(what)
+        logger.warning("proxmin_amd: %s is a user-defined Python callable: it is applied on the host once per iteration "
+                       "(device -> host -> device copies of the factors); use the operators / step rules of this package to keep "
+                       "the whole iteration on the GPU" % what)
+
+
+def _split_prox(prox, none_is_id):
+    """-> (device operator sequences, [callable or None per block]): operators of this library become device sequences,
+    anything else is kept for the host round trip (its device slot is prox_id / no operator)."""
+    seqs, host = [], []
+    for j, p in enumerate(prox):
+        q = operators.prox_id if (p is None and none_is_id) else p
+        try:
+            seqs.append(operators.device_proxseq(q, j, for_solver=True))
+            host.append(None)
+        except NotImplementedError as exc:
+            if not callable(q):
+                raise
+            if isinstance(exc, operators.NotFusable):
+                if "unity-long-%d" % j not in _warned:
+                    _warned.add("unity-long-%d" % j)
+                    logger.warning("proxmin_amd: %s: one iteration per call, its argument goes through the host" % exc)
+            else:
+                _warn_host_path("prox of block %d (%r)" % (j, q))
+            seqs.append(operators.device_proxseq(operators.prox_id if none_is_id else None, j))
+            host.append(q)
+    return seqs, host
+
+
+def _scalar_steps(s, what):
+    s = utils._as_tuple(s)
+    if len(s) == 1:
+        s = s * 2
+    assert len(s) == 2, "%s must return one step per block" % what
+    out = []
+    for v in s:
+        v = np.asarray(v)
+        if v.size != 1:
+            raise NotImplementedError("array-valued step sizes from a user `step` are not supported in pgm (scalars per block only)")
+        out.append(float(v.reshape(())))
+    return tuple(out)
+
+
+def _component_steps(alpha, K, j):
+    """adaprox: a user step's Alpha[j] (scalar, or anything that broadcasts over the K components of block j like
+    nmf.step_adaprox's (K,) for A and (K, 1) for S) -> K per-component values."""
+    a = np.asarray(alpha, dtype=np.float64)
+    if a.size == 1:
+        return np.full(K, float(a.reshape(())), np.float32)
+    want = (K,) if j == 0 else (K, 1)
+    if a.shape in (want, (K,), (1, K) if j == 0 else (K, 1)) and a.size == K:
+        return a.reshape(K).astype(np.float32)
+    raise NotImplementedError("user `step` for adaprox must return scalars or per-component arrays (shape (K,) for A, (K, 1) for S); got %r" % (a.shape,))
+
+
 # ---------------------------------------------------------------------------------------------
 def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None, e_rel=1e-6, max_iter=1000, callback=None):
     """Proximal Gradient Method / FISTA for the two NMF blocks (algorithms.py:12-144).
@@ -83,7 +149,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     Y, A, S, W = _problem_from_grad(X, grad)
     prox = _prox_pair(prox)
     # prox=None means prox_id in pgm (algorithms.py:63-64)
-    seqs = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]
+    seqs, host_prox = _split_prox(prox, none_is_id=True)
     e_rel = _e_rel_pair(e_rel)
     assert backtracking is False or f is not None
     if backtracking:
@@ -95,7 +161,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         fW = f.keywords.get("W", 1)
         if not (fW is grad.keywords.get("W", 1) or (np.isscalar(fW) and np.isscalar(grad.keywords.get("W", 1)) and fW == grad.keywords.get("W", 1))):
             raise NotImplementedError("backtracking: f and grad must carry the same weights W")
-    scale, fixed, bb = 1.0, None, None
+    scale, fixed, bb, user_step = 1.0, None, None, None
     bb_owner = getattr(step, "__self__", step)
     if isinstance(bb_owner, utils.BarzilaiBorweinStepper):
         bb = bb_owner
@@ -106,18 +172,65 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     elif step is _nmf.step_pgm or (isinstance(step, partial) and step.func is _nmf.step_pgm):
         if W is not None:            # nmf.step_pgm tests `W == 1` on the array and raises (nmf.py:63)
             raise ValueError(_nmf._AMBIGUOUS)
+    elif callable(step):
+        user_step = step
+        _warn_host_path("step (%r)" % (step,))
     else:
-        raise NotImplementedError("user-defined `step` callables are not supported on the device; use "
-                                  "nmf.scaled_step_pgm(c) or nmf.constant_step(a, b)")
+        raise TypeError("step must be callable")
+    slow = user_step is not None or any(h is not None for h in host_prox)
+    if slow and (bb is not None or backtracking):
+        raise NotImplementedError("a user-defined prox / step together with Barzilai-Borwein steps or backtracking is not implemented")
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
     with _open_device(Y, A, S, W) as dev:
-        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=fixed, e_rel=e_rel,
-                      bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking)
+        dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
+                      e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
+                      host_prox=[h is not None for h in host_prox])
         res = None
         it_done = 0
-        if _wants_iterates(callback):
+        dt = A.dtype
+        if slow:
+            # One iteration per pass, in pieces (algorithms.py:87-135): the gradient at the (extrapolated) point on the
+            # device, the user's step / prox on the host with exactly the arguments the reference passes, the update,
+            # extrapolation and stopping test on the device again.
+            takes_grads = False
+            if user_step is not None:                           # the reference's signature probe (algorithms.py:73-77)
+                try:
+                    user_step(A, S, it=0, grads=(A, S))
+                    takes_grads = True
+                except TypeError:
+                    takes_grads = False
+            for it in range(max_iter):
+                if _wants_iterates(callback):
+                    try:
+                        callback(A, S, it=it)
+                    except StopIteration:
+                        break
+                r0 = dev.pgm_split(0)
+                steps = None
+                if user_step is not None:
+                    Xe = (dev.get(_lib.BUF_EVAL_A, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_EVAL_A, 1)).astype(dt))
+                    if takes_grads:
+                        Gh = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
+                        steps = _scalar_steps(user_step(*Xe, it=it, grads=Gh), "step")
+                    else:
+                        steps = _scalar_steps(user_step(*Xe, it=it), "step")
+                if any(h is not None for h in host_prox):
+                    dev.pgm_split(1, steps)
+                    for j, h in enumerate(host_prox):
+                        if h is None:
+                            continue
+                        T = np.ascontiguousarray(dev.get(_lib.BUF_TMP_A, j)).astype(dt)
+                        sj = dt.type(steps[j] if steps is not None else r0.steps[j])
+                        out = h(T, sj)                           # prox(X, step) -> X' (algorithms.py:37-39, :108)
+                        dev.put(_lib.BUF_TMP_A, j, np.asarray(out))
+                res = dev.pgm_split(2, steps)
+                _write_back(dev, A, S)
+                it_done = res.total_iterations
+                if res.stopped:
+                    break
+        elif _wants_iterates(callback):
             for it in range(max_iter):
                 try:
                     callback(A, S, it=it)                       # algorithms.py:90 (pre-update iterate)
@@ -132,7 +245,6 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
             res = dev.pgm_run(max_iter)
             it_done = res.total_iterations
             _write_back(dev, A, S)
-        dt = A.dtype
         G = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
     converged = tuple(bool(c) for c in res.converged) if res is not None else (False, False)
     steps = (dt.type(res.steps[0]), dt.type(res.steps[1])) if res is not None else (None, None)
@@ -154,7 +266,7 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
 
     Y, A, S, W = _problem_from_grad(X, grad)
     prox = _prox_pair(prox)
-    seqs = [operators.device_proxseq(q, j) for j, q in enumerate(prox)]
+    seqs, host_prox = _split_prox(prox, none_is_id=False)       # prox=None: no proximal loop at all (algorithms.py:380)
     e_rel = _e_rel_pair(e_rel)
     if not hasattr(b1, "__iter__"):
         b1 = np.array((b1,) * max_iter)
@@ -166,11 +278,15 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
     assert p > 0 and p <= 0.5
     scheme = scheme.lower()
     assert scheme in ["adam", "nadam", "adamx", "amsgrad", "padam", "radam"]
-    fixed = None
+    fixed, user_step = None, None
     if isinstance(step, _nmf.constant_step):
         fixed = step.steps
     elif step is not _nmf.step_adaprox:
-        raise NotImplementedError("user-defined `step` callables are not supported on the device; use nmf.constant_step(a, b)")
+        if not callable(step):
+            raise TypeError("step must be callable")
+        user_step = step
+        _warn_host_path("step (%r)" % (step,))
+    slow = user_step is not None or any(h is not None for h in host_prox)
 
     Xs = (A, S)
     warm = M is not None or V is not None
@@ -190,10 +306,64 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
                 dev.put(_lib.BUF_VHA, j, Vhat[j])
         dev.adaprox_begin(seqs, scheme=scheme, b2=b2, eps=eps, p=p, check_convergence=check_convergence,
                           prox_max_iter=prox_max_iter, warm_moments=warm, warm_vhat=Vhat is not None,
-                          fixed_alpha=fixed, e_rel=e_rel)
+                          fixed_alpha=fixed, e_rel=e_rel, host_step=user_step is not None,
+                          host_prox=[h is not None for h in host_prox])
         res = None
         it_done = 0
-        if max_iter > 0:
+        host_sub = [0, 0]
+        if max_iter > 0 and slow:
+            # One iteration per pass (algorithms.py:365-410): user step -> device moments and update -> the proximal loop
+            # of a block with a user-defined prox around that callable on the host (:383-400, with the reference's own
+            # expressions) -> the other block's loop, X <- z, stopping test and next step sizes on the device.
+            dt = A.dtype
+            K = A.shape[1]
+            for it in range(max_iter):
+                if _wants_iterates(callback):
+                    try:
+                        callback(A, S, it=it)
+                    except StopIteration:
+                        break
+                alpha = None
+                if user_step is not None:
+                    alpha = utils._as_tuple(user_step(A, S, it=it))                  # algorithms.py:370
+                    assert len(alpha) == 2, "step must return one Alpha per block"
+                    dev.adaprox_set_alpha(_component_steps(alpha[0], K, 0), _component_steps(alpha[1], K, 1))
+                elif any(h is not None for h in host_prox):
+                    aA, aS = dev.step_adaprox()                                    # the rule the device applies (nmf.py:93)
+                    alpha = (aA.astype(dt), aS.astype(dt)[:, None])
+                if not any(h is not None for h in host_prox):                      # only the step rule is the user's
+                    res = dev.adaprox_run(b1[it:it + 1], b1[it - 1])
+                    _write_back(dev, A, S)
+                    it_done = res.total_iterations
+                    if res.stopped:
+                        break
+                    continue
+                _, maxpsi = dev.adaprox_split(0, it, b1[it], b1[it - 1])
+                taus = [0, 0]
+                for j, h in enumerate(host_prox):
+                    if h is None:
+                        continue
+                    Xj = np.ascontiguousarray(dev.get(_lib.BUF_A, j)).astype(dt)
+                    Psi = np.ascontiguousarray(dev.get(_lib.BUF_PSI_A, j)).astype(dt)
+                    Alpha = alpha[j] if not np.isscalar(alpha[j]) else dt.type(alpha[j])
+                    z = Xj.copy()
+                    gamma = Alpha / dt.type(maxpsi[j])                              # algorithms.py:384
+                    tau = 0
+                    for tau in range(1, prox_max_iter + 1):                        # :386-393
+                        z_ = h(z - gamma / Alpha * Psi * (z - Xj), gamma)
+                        converged_ = utils.l2sq(z_ - z) <= e_rel[j] ** 2 * utils.l2sq(z)
+                        z = z_
+                        if converged_:
+                            break
+                    dev.put(_lib.BUF_A, j, z)                                      # X[j][:] = z (:400)
+                    taus[j] = tau
+                    host_sub[j] += tau
+                res, _ = dev.adaprox_split(1, it, b1[it], b1[it - 1], taus)
+                _write_back(dev, A, S)
+                it_done = res.total_iterations
+                if res.stopped:
+                    break
+        elif max_iter > 0:
             if _wants_iterates(callback):
                 for it in range(max_iter):
                     try:
@@ -242,12 +412,17 @@ def bsdmm(X, proxs_f, steps_f_cb, proxs_g=None, steps_g=None, Ls=None, update_or
           max_iter=1000, e_rel=1e-6, e_abs=0, callback=None):
     """Block-Simultaneous Direction Method of Multipliers (algorithms.py:653-850).
 
-    On the device this solver is reachable through `nmf.nmf(..., algorithm=bsdmm, proxs_g=...)`,
-    which is how the reference builds `proxs_f` / `steps_f_cb` from the NMF gradient
-    (nmf.py:178-203).  A direct call with user closures cannot be mapped to kernels.
+    `proxs_f(X, step, j=, Xs=)` and `steps_f_cb(Xs, j=)` must be the closures `nmf.bsdmm_closures(Y, prox)` builds --
+    the ones the reference's nmf() builds inline (nmf.py:181-193): prox_j(X - step grad_j(Xs), step) and step_pgm(Xs)[j] --
+    because they are what carries Y and the operators to the device.  Generic closures cannot be mapped to kernels.
     """
-    raise NotImplementedError("call bsdmm through proxmin_amd.nmf.nmf(..., algorithm=bsdmm, proxs_g=...); "
-                              "generic proxs_f / steps_f_cb closures are out of scope of the device path")
+    tag_f, tag_s = getattr(proxs_f, "_pmx_nmf", None), getattr(steps_f_cb, "_pmx_nmf", None)
+    if tag_f is None or tag_s is None or tag_f is not tag_s:
+        raise NotImplementedError("bsdmm on the device takes the closures of proxmin_amd.nmf.bsdmm_closures(Y, prox) (what nmf(..., "
+                                  "algorithm=bsdmm) passes); generic proxs_f / steps_f_cb closures are out of scope")
+    grad, prox = tag_f
+    return _bsdmm_nmf(X, grad, prox, proxs_g=proxs_g, steps_g=steps_g, Ls=Ls, update_order=update_order,
+                      steps_g_update=steps_g_update, max_iter=max_iter, e_rel=e_rel, e_abs=e_abs, callback=callback)
 
 
 def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=None, steps_g_update="steps_f",
@@ -265,11 +440,16 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
     steps_g_update = steps_g_update.lower()
     assert steps_g_update in ["steps_f", "fixed", "relative"]
     if steps_g_update != "steps_f" and steps_g is not None:
-        raise NotImplementedError("steps_g_update='%s' with explicit steps_g is not implemented on the device" % steps_g_update)
+        # not reachable in the reference either: its per-iteration container steps_g_ is only ever filled by the "steps_f"
+        # strategy (algorithms.py:773-781, :815-819), "fixed" hands update_variables a list holding None (TypeError) and
+        # "relative" divides by the initial steps_f = None (:808-810)
+        raise NotImplementedError("steps_g_update='%s' with explicit steps_g raises TypeError in the reference (algorithms.py:773-819) "
+                                  "and is not implemented" % steps_g_update)
     if Ls is not None and any(L is not None for L in np.ravel(np.array(Ls, dtype=object))):
         raise NotImplementedError("linear operators Ls are not implemented on the device (identity only)")
-    if update_order is not None and list(update_order) != [0, 1]:
-        raise NotImplementedError("only the default update order (A, then S) is implemented on the device")
+    order = None if update_order is None else [int(j) for j in update_order]
+    if order is not None:
+        assert all(j in (0, 1) for j in order), "update_order refers to a block that does not exist"
     er = [e_rel] * N if np.isscalar(e_rel) else list(e_rel)
     ea = [e_abs] * N if np.isscalar(e_abs) else list(e_abs)
     seq_f = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]
@@ -284,7 +464,7 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
         seq_g.append([operators.device_proxseq(q if q is not None else operators.prox_id, j) for q in g])
 
     with _open_device(Y, A, S, None) as dev:
-        dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea)
+        dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea, update_order=order)
         res = None
         if _wants_iterates(callback):
             for it in range(max_iter):
@@ -297,6 +477,8 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
             res = dev.bsdmm_run(max_iter)
             _write_back(dev, A, S)
     converged = [bool(c) for c in res.converged] if res is not None else [None, None]
+    if order is not None:                # a block that is never updated keeps the reference's initial None (algorithms.py:794)
+        converged = [converged[j] if j in order else None for j in range(2)]
     logger.info("Completed {0} iterations".format(res.total_iterations if res is not None else 0))
     if not all(converged):
         logger.warning("Solution did not converge")

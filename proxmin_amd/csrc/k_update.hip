@@ -292,12 +292,20 @@ struct PgmArgs {
     double* partials;
     int accelerated;
     float omega_next;
+    // host round trip for a user-defined prox of block j (algorithms.py:107-108 with a Python callable):
+    //   mode 0  the whole update in one launch (operators of this library);
+    //   mode 1  "pre":  T_j = Xe_j - s_j G_j and nothing else -- the host applies the callable to T_j;
+    //   mode 2  "post": the update with prox(...) := T_j as the host left it;      mode 3: block not touched by this launch
+    int mode[2];
+    float* T[2];
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
+    if (a.mode[j] == 3) return;
+    const int mode = a.mode[j];
     const int64_t rows = a.rows[j];
     const int K = a.K;
     const float s = (float)a.status->step[j];
@@ -316,10 +324,16 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
             const int64_t e = r * K + l32 + 32 * c;
             xo[c] = ok[c] ? X[e] : 0.f;
             const float xe = a.accelerated ? (ok[c] ? Xe[e] : 0.f) : xo[c];
-            v[c] = xe - s * g[c];
+            v[c] = mode == 2 ? (ok[c] ? a.T[j][e] : 0.f) : xe - s * g[c];
             sk[c] = s;
         }
-        prox_row<NC>(v, ok, px, sk);
+        if (mode == 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) a.T[j][r * K + l32 + 32 * c] = v[c];
+            continue;
+        }
+        if (mode == 0) prox_row<NC>(v, ok, px, sk);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (ok[c]) {
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
             }
         }
     ROW_LOOP_END
+    if (mode == 1) return;
     double red[2] = {(double)d2, (double)n2};
     // SL_DIFF2 and SL_NORM2 are adjacent slots: stride between them = 2 * EW_BLOCKS doubles
     block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
@@ -617,7 +632,7 @@ __device__ __forceinline__ void colsum_store(const float (&cs)[NC], double* colp
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_colsum(ColsumArgs a) {
     __shared__ float sm[(EW_THREADS / 32) * MAXK];
-    if (chain_halted(a.status)) return;
+    if (a.status != nullptr && chain_halted(a.status)) return;
     const int j = blockIdx.y;
     const int K = a.K;
     float cs[NC];
@@ -664,6 +679,7 @@ __device__ __forceinline__ void colsum_fold(const double* colpart_j, int K, bool
 __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
     __shared__ double asum[ALPHA_NG][MAXK];
     const int t = threadIdx.x;
+    if (a.use_fixed == 2) return;            // a user `step` callable: the host writes DevStatus::alpha before every iteration
     for (int j = 0; j < 2; ++j) {
         colsum_fold(a.colpart + (int64_t)j * EW_BLOCKS * MAXK, a.K, a.use_fixed || (j == 0 && a.comm_colsum != nullptr), asum);
         if (t < a.K) {
@@ -683,6 +699,38 @@ __device__ __forceinline__ void compute_alpha(const AlphaArgs& a) {
 __global__ __launch_bounds__(EW_THREADS) void k_alpha_init(AlphaArgs a) {
     if (chain_halted(a.status)) return;
     compute_alpha(a);
+}
+
+// prox_unity / prox_unity_plus ALONG THE ROWS (numpy axis = 0 of a rows x K array: every component's column is divided
+// by its sum, operators.py:41-52), for the stand-alone operator entry points: k_colsum's per-workgroup partial column sums
+// (block 0 of `colpart`), folded here by every workgroup in colsum_fold's fixed order, then the scaling.  No zero guard,
+// like the reference.  `plus`: the projection onto the non-negative numbers comes first (it has been applied by the caller
+// before the column sums were taken); this kernel only divides.
+struct ColScaleArgs {
+    float* X;
+    int64_t rows;
+    int K;
+    const double* colpart;   // [EW_BLOCKS][MAXK]
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_colscale(ColScaleArgs a) {
+    __shared__ double asum[ALPHA_NG][MAXK];
+    __shared__ float tot[MAXK];
+    colsum_fold(a.colpart, a.K, false, asum);
+    if (threadIdx.x < MAXK) {
+        double t = 0.0;
+        for (int q = 0; q < ALPHA_NG; ++q) t += asum[q][threadIdx.x];
+        tot[threadIdx.x] = (float)t;
+    }
+    __syncthreads();
+    const int K = a.K;
+    ROW_LOOP_BEGIN(a.rows)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int kk = l32 + 32 * c;
+            if (kk < K) a.X[r * K + kk] = a.X[r * K + kk] / tot[kk];
+        }
+    ROW_LOOP_END
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1088,6 +1136,7 @@ struct AdaDecideArgs {
     double e_rel[2];
     int check_convergence;
     int has_prox[2];
+    int host_tau[2];     // passes of a proximal loop that ran around a user-defined prox on the host (block j), else 0
 };
 __global__ __launch_bounds__(EW_THREADS) void k_ada_decide(AdaDecideArgs a) {
     __shared__ double scratch[EW_WAVES];
@@ -1119,7 +1168,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_decide(AdaDecideArgs a) {
             st->norms[j][0] = d[j];
             st->norms[j][1] = n[j];
             all &= c;
-            const int tau = a.has_prox[j] ? st->sub_tau[j] : 0;
+            const int tau = a.has_prox[j] ? st->sub_tau[j] : a.host_tau[j];
             st->sub_total[j] += tau;
             st->last_tau[j] = tau;
             st->sub_done[j] = 0;
@@ -1562,7 +1611,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
     // ---------------- phase D: next step sizes, one (block, component) per workgroup; bookkeeping (k_ada_decide) ------
     {
         const int j = blockIdx.x / MAXK, k = blockIdx.x % MAXK;
-        if (k < K) {
+        if (k < K && a.al.use_fixed != 2) {
             float al;
             if (a.al.use_fixed) al = a.al.fixed[j];
             else {
@@ -1936,6 +1985,7 @@ void launch_bt_finish(const BtFinishArgs& a, hipStream_t s) { hipLaunchKernelGGL
 void launch_pgm_decide(const DecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pgm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_colsum(const ColsumArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colsum, dim3(EW_BLOCKS, 2), s, a); }
 void launch_alpha_init(const AlphaArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_alpha_init, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_colscale(const ColScaleArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_colscale, dim3(EW_BLOCKS), s, a); }
 void launch_ada_moment(const MomentArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_ada_moment, dim3(EW_BLOCKS, 2), s, a); }
 #define DISPATCH_NC_NT(K, NT, KERNEL, grid, stream, args)                                                          \
     do {                                                                                                           \

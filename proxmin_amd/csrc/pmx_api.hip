@@ -109,6 +109,7 @@ struct pmx_ctx {
     pmx_pgm_params pgm{};
     pmx_adaprox_params ada{};
     pmx_bsdmm_params bsd{};
+    int host_tau[2] = {0, 0};              // adaprox: passes of the host-side proximal loops of the current iteration
     int it = 0;                            // iterations enqueued AND completed (host view)
     double nest_t = 1.0;                   // NesterovAccelerator.t (utils.py:195)
     double btT[2] = {1.0, 1.0};            // backtracking step multipliers T (algorithms.py:85), never reset inside a run
@@ -153,20 +154,78 @@ static ProxSeq to_dev(const pmx_proxseq& p) {
     for (int i = 0; i < PMX_MAX_SEQ; ++i) d.seq[i] = p.seq[i];
     return d;
 }
-static int check_prox(const pmx_proxseq& p, const char* what) {
+// standalone: the stand-alone operator entry points (pmx_prox_apply / pmx_prox_array), which also normalise along the rows
+static int check_prox(const pmx_proxseq& p, const char* what, bool standalone = false) {
     if (p.n < 0 || p.n > PMX_MAX_SEQ) FAIL(PMX_E_INVALID, "%s: bad operator count %d", what, p.n);
     for (int i = 0; i < p.n; ++i) {
         const pmx_prox& q = p.seq[i];
         if (q.op < PMX_PROX_ID || q.op > PMX_PROX_SOFT_PLUS) FAIL(PMX_E_INVALID, "%s: unknown prox op %d", what, q.op);
-        if ((q.op == PMX_PROX_UNITY || q.op == PMX_PROX_UNITY_PLUS) && q.unit != 0)
-            FAIL(PMX_E_UNSUPPORTED, "%s: prox_unity along the row dimension (numpy axis=0 on A / axis=1 on S) is not implemented on the device", what);
+        if ((q.op == PMX_PROX_UNITY || q.op == PMX_PROX_UNITY_PLUS) && q.unit != 0 && !standalone)
+            FAIL(PMX_E_UNSUPPORTED, "%s: prox_unity along the row dimension (numpy axis=0 on A / axis=1 on S) needs a grid-wide sum per "
+                                    "application and is not part of the fused solver kernels (the host wrappers apply it between kernel "
+                                    "launches through pmx_prox_apply)", what);
     }
+    return PMX_OK;
+}
+
+// one operator sequence on a rows x K device array, incl. prox_unity* along the rows (column sums over all rows).
+// `colpart` is scratch of EW_BLOCKS * MAXK doubles.
+static int apply_prox_standalone(float* X, int64_t rows, int K, const pmx_proxseq& prox, const float* step_k, double* colpart, hipStream_t stream) {
+    bool along_rows = false;
+    for (int i = 0; i < prox.n; ++i)
+        along_rows |= (prox.seq[i].op == PMX_PROX_UNITY || prox.seq[i].op == PMX_PROX_UNITY_PLUS) && prox.seq[i].unit != 0;
+    ProxArgs a{};
+    a.X = X;
+    a.rows = rows;
+    a.K = K;
+    for (int k = 0; k < K; ++k) a.stepk[k] = step_k[k];
+    if (!along_rows) {
+        a.prox = to_dev(prox);
+        launch_prox_apply(a, stream);
+        return PMX_OK;
+    }
+    const int repeat = prox.repeat < 1 ? 1 : prox.repeat;
+    for (int r = 0; r < repeat; ++r)
+        for (int i = 0; i < prox.n; ++i) {
+            pmx_proxseq one{};
+            one.n = 1; one.repeat = 1; one.seq[0] = prox.seq[i];
+            const bool rows_unity = (one.seq[0].op == PMX_PROX_UNITY || one.seq[0].op == PMX_PROX_UNITY_PLUS) && one.seq[0].unit != 0;
+            if (!rows_unity) {
+                a.prox = to_dev(one);
+                launch_prox_apply(a, stream);
+                continue;
+            }
+            if (one.seq[0].op == PMX_PROX_UNITY_PLUS) {           // plus first (operators.py:48-52)
+                one.seq[0].op = PMX_PROX_PLUS; one.seq[0].unit = 0;
+                a.prox = to_dev(one);
+                launch_prox_apply(a, stream);
+            }
+            ColsumArgs cs{};
+            cs.X[0] = X; cs.X[1] = X;
+            cs.rows[0] = rows; cs.rows[1] = 0;
+            cs.K = K;
+            cs.colpart = colpart;
+            cs.status = nullptr;
+            launch_colsum(cs, stream);
+            ColScaleArgs sc{};
+            sc.X = X; sc.rows = rows; sc.K = K; sc.colpart = colpart;
+            launch_colscale(sc, stream);
+        }
     return PMX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_abi_version(void) { return PMX_ABI_VERSION; }
 extern "C" const char* pmx_last_error(void) { return g_err; }
+extern "C" int pmx_abi_sizes(int sizes[5]) {
+    if (!sizes) FAIL(PMX_E_INVALID, "NULL argument");
+    sizes[0] = (int)sizeof(pmx_proxseq);
+    sizes[1] = (int)sizeof(pmx_pgm_params);
+    sizes[2] = (int)sizeof(pmx_adaprox_params);
+    sizes[3] = (int)sizeof(pmx_bsdmm_params);
+    sizes[4] = (int)sizeof(pmx_result);
+    return PMX_OK;
+}
 extern "C" int pmx_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -399,7 +458,7 @@ extern "C" int pmx_set_W_device(pmx_ctx* c, const float* dW, int64_t ld, int cop
 static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool create) {
     int j;
     float** p = nullptr;
-    if (buf >= PMX_BUF_A && buf <= PMX_BUF_VHST) {
+    if (buf >= PMX_BUF_A && buf <= PMX_BUF_PSI_ST) {
         j = buf & 1;
         switch (buf >> 1) {
             case 0: p = &c->X[j]; break;
@@ -407,6 +466,9 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
             case 2: p = &c->Mm[j]; break;
             case 3: p = &c->Vv[j]; break;
             case 4: p = &c->Vh[j]; break;
+            case 5: p = (c->algo == ALG_PGM && c->pgm.accelerated) ? &c->Xe[j] : &c->X[j]; break;
+            case 6: p = &c->Xp[j]; break;
+            case 7: p = &c->Psi[j]; break;
         }
     } else if (buf >= PMX_BUF_Z0 && buf < PMX_BUF_Z0 + 2 * PMX_MAX_G) {
         j = (buf - PMX_BUF_Z0) / PMX_MAX_G;
@@ -822,18 +884,13 @@ extern "C" int pmx_prox_apply(pmx_ctx* c, int buf, const pmx_proxseq* prox, cons
     if (c) c->absmax_by_finish = false;
     if (!c || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
-    int rc = check_prox(*prox, "prox_apply");
+    int rc = check_prox(*prox, "prox_apply", true);
     if (rc != PMX_OK) return rc;
     float** slot; int64_t n;
     rc = buf_lookup(c, buf, &slot, &n, false);
     if (rc != PMX_OK) return rc;
-    ProxArgs a{};
-    a.X = *slot;
-    a.rows = n / c->K;
-    a.K = (int)c->K;
-    a.prox = to_dev(*prox);
-    for (int k = 0; k < c->K; ++k) a.stepk[k] = step_k[k];
-    launch_prox_apply(a, c->stream);
+    rc = apply_prox_standalone(*slot, n / c->K, (int)c->K, *prox, step_k, c->colpart, c->stream);
+    if (rc != PMX_OK) return rc;
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return PMX_OK;
@@ -842,21 +899,16 @@ extern "C" int pmx_prox_apply(pmx_ctx* c, int buf, const pmx_proxseq* prox, cons
 extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const pmx_proxseq* prox, const float* step_k) {
     if (!X || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
     if (rows <= 0 || K <= 0 || K > MAXK) FAIL(PMX_E_INVALID, "bad shape rows=%lld K=%d", (long long)rows, K);
-    int rc = check_prox(*prox, "prox_array");
+    int rc = check_prox(*prox, "prox_array", true);
     if (rc != PMX_OK) return rc;
     HIP_CHECK(hipSetDevice(device));
     float* d = nullptr;
-    const size_t bytes = (size_t)rows * K * sizeof(float);
-    HIP_CHECK(hipMalloc((void**)&d, bytes));
+    const size_t bytes = (size_t)rows * K * sizeof(float), scratch = (size_t)2 * EW_BLOCKS * MAXK * sizeof(double);
+    HIP_CHECK(hipMalloc((void**)&d, bytes + scratch + 16));
+    double* colpart = reinterpret_cast<double*>(reinterpret_cast<char*>(d) + ((bytes + 15) / 16) * 16);
     hipError_t e = hipMemcpy(d, X, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        ProxArgs a{};
-        a.X = d;
-        a.rows = rows;
-        a.K = K;
-        a.prox = to_dev(*prox);
-        for (int k = 0; k < K; ++k) a.stepk[k] = step_k[k];
-        launch_prox_apply(a, nullptr);
+        rc = apply_prox_standalone(d, rows, K, *prox, step_k, colpart, nullptr);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(X, d, bytes, hipMemcpyDeviceToHost);
     }
@@ -892,6 +944,13 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
         for (int j = 0; j < 2; ++j) {
             rc = dallocT(c, &c->bbX[j], (size_t)c->rows[j] * c->K, false);
             if (rc == PMX_OK) rc = dallocT(c, &c->bbG[j], (size_t)c->rows[j] * c->K, false);
+            if (rc != PMX_OK) return rc;
+        }
+    if ((p->host_prox[0] || p->host_prox[1]) && (p->bb_type || p->backtracking))
+        FAIL(PMX_E_UNSUPPORTED, "a user-defined prox together with Barzilai-Borwein steps or backtracking is not implemented");
+    for (int j = 0; j < 2; ++j)
+        if (p->host_prox[j]) {
+            rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
             if (rc != PMX_OK) return rc;
         }
     c->btT[0] = c->btT[1] = 1.0;
@@ -1110,6 +1169,84 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     return PMX_OK;
 }
 
+extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
+    const pmx_pgm_params& p = c->pgm;
+    if (p.bb_type || p.backtracking) FAIL(PMX_E_UNSUPPORTED, "pmx_pgm_split: not with Barzilai-Borwein steps or backtracking");
+    const float* A = p.accelerated ? c->Xe[0] : c->X[0];
+    const float* St = p.accelerated ? c->Xe[1] : c->X[1];
+    const bool any_host = p.host_prox[0] || p.host_prox[1];
+    auto update = [&](int stage) {       // stage 1: "pre" of the host blocks; stage 2: the update
+        PgmArgs u{};
+        for (int j = 0; j < 2; ++j) {
+            u.X[j] = c->X[j];
+            u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
+            u.G[j] = c->G[j];
+            u.slab[j].base = c->G[j];    // folded by phase 0
+            u.slab[j].n = 1;
+            u.rows[j] = c->rows[j];
+            u.prox[j] = to_dev(p.prox[j]);
+            u.T[j] = c->Xp[j];
+            u.mode[j] = stage == 1 ? (p.host_prox[j] ? 1 : 3) : (p.host_prox[j] ? 2 : 0);
+        }
+        u.K = (int)c->K;
+        u.status = c->dstatus;
+        u.partials = c->partials;
+        u.accelerated = p.accelerated;
+        u.omega_next = stage == 2 ? next_omega(c) : 0.f;
+        launch_pgm_update(u, c->stream);
+    };
+    switch (phase) {
+        case 0: {
+            if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }   // (one iteration per call: nothing to repeat into)
+            if (!p.use_fixed_steps) {
+                rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);
+                if (rc != PMX_OK) return rc;
+            }
+            rc = enqueue_grad(c, A, St, 1, 1);
+            if (rc != PMX_OK) return rc;
+            FoldArgs f{};
+            for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
+            f.K = (int)c->K;
+            f.status = c->dstatus;
+            launch_fold(f, 2, c->stream);
+            HIP_CHECK(hipGetLastError());
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (res) { res->steps[0] = c->hstatus->step[0]; res->steps[1] = c->hstatus->step[1]; }
+            return PMX_OK;
+        }
+        case 1:
+            if (!any_host) return PMX_OK;
+            if (steps) { rc = set_fixed_steps(c, steps); if (rc != PMX_OK) return rc; }
+            update(1);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            return PMX_OK;
+        case 2: {
+            const int it0 = c->hstatus->it_done;
+            if (steps) { rc = set_fixed_steps(c, steps); if (rc != PMX_OK) return rc; }
+            update(2);
+            DecideArgs d{};
+            d.status = c->dstatus;
+            d.partials = c->partials;
+            d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+            d.check = 1;
+            launch_pgm_decide(d, c->stream);
+            HIP_CHECK(hipGetLastError());
+            c->it += 1;
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            fill_result(c, res, it0);
+            return PMX_OK;
+        }
+        default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // adaprox                                                 (proxmin/algorithms.py:248-423)
 // ------------------------------------------------------------------------------------------------
@@ -1149,7 +1286,7 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
             rc = dallocT(c, &c->Xp[j], n, false);
             if (rc != PMX_OK) return rc;
         }
-        if (p->prox[j].n > 0) {
+        if (p->prox[j].n > 0 || p->host_prox[j]) {
             rc = dallocT(c, &c->Psi[j], n, false);
             if (rc == PMX_OK) rc = dallocT(c, &c->zb[j][0], n, false);
             if (rc == PMX_OK) rc = dallocT(c, &c->zb[j][1], n, false);
@@ -1159,7 +1296,8 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
     // the iteration tail as one persistent kernel where its LDS-resident state fits and one workgroup per CU can be
     // resident (PMX_TAIL_FUSED=0: the four separate kernels; PMX_SUB_BATCH=1 implies them)
     c->tail_fused = false;
-    if (!(getenv("PMX_TAIL_FUSED") && atoi(getenv("PMX_TAIL_FUSED")) == 0) && c->sub_nt != 1 && c->tailFaults == 0) {
+    if (!(getenv("PMX_TAIL_FUSED") && atoi(getenv("PMX_TAIL_FUSED")) == 0) && c->sub_nt != 1 && c->tailFaults == 0 &&
+        !p->host_prox[0] && !p->host_prox[1]) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) ncu = 0;
         TailArgs probe{};
@@ -1235,6 +1373,7 @@ static int ada_enqueue_tail(pmx_ctx* c, int t) {
     // row-sharded: A's sums are only local here; the test is made after the next all-reduce (k_shard_post)
     d.check_convergence = c->comm ? 0 : p.check_convergence;
     d.has_prox[0] = p.prox[0].n > 0; d.has_prox[1] = p.prox[1].n > 0;
+    d.host_tau[0] = c->host_tau[0]; d.host_tau[1] = c->host_tau[1];
     launch_ada_decide(d, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -1250,7 +1389,7 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
         m.Psi[j] = c->Psi[j];
         m.slab[j] = slab_ref(c, j);
         m.rows[j] = c->rows[j];
-        m.has_prox[j] = p.prox[j].n > 0;
+        m.has_prox[j] = p.prox[j].n > 0 || p.host_prox[j];   // (Psi is kept for a host-side proximal loop as well)
     }
     if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer
         m.slab[1].base = c->comm;
@@ -1396,6 +1535,69 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
     return PMX_OK;
 }
 
+extern "C" int pmx_adaprox_set_alpha(pmx_ctx* c, const float* alpha) {
+    if (!c || !alpha) FAIL(PMX_E_INVALID, "NULL argument");
+    if (c->algo != ALG_ADAPROX || c->ada.use_fixed_steps != 2) FAIL(PMX_E_STATE, "pmx_adaprox_begin with use_fixed_steps = 2 has not been called");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->alpha[0][0], alpha, sizeof(float) * c->K, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(&c->dstatus->alpha[1][0], alpha + c->K, sizeof(float) * c->K, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, double b1_prev, const int* host_tau, double* maxpsi, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
+    if (c->tail_fused) FAIL(PMX_E_STATE, "pmx_adaprox_split needs a context begun with host_prox");
+    if (!(b1_it >= 0 && b1_it < 1)) FAIL(PMX_E_INVALID, "b1 out of [0,1)");
+    const pmx_adaprox_params& p = c->ada;
+    if (phase == 0) {
+        if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+        rc = ada_enqueue_head(c, it, b1_it, b1_prev, false);
+        if (rc != PMX_OK) return rc;
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        if (maxpsi) {                     // np.max(Psi) per block (NaN lets through): fold of the per-workgroup partials
+            std::vector<double> h(2 * EW_BLOCKS);
+            HIP_CHECK(hipMemcpy(h.data(), c->partials + (size_t)SL_MAXPSI * 2 * EW_BLOCKS, sizeof(double) * 2 * EW_BLOCKS, hipMemcpyDeviceToHost));
+            for (int j = 0; j < 2; ++j) {
+                double m = -1.0;
+                for (int b = 0; b < EW_BLOCKS; ++b) { const double v = h[j * EW_BLOCKS + b]; m = (m != m || v != v) ? NAN : std::max(m, v); }
+                maxpsi[j] = m;
+            }
+        }
+        return PMX_OK;
+    }
+    if (phase != 1) FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    c->host_tau[0] = host_tau ? host_tau[0] : 0;
+    c->host_tau[1] = host_tau ? host_tau[1] : 0;
+    const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
+    const int it0 = c->hstatus->it_done;
+    const int nsub = any_prox ? std::max(1, std::min(c->nsub_guess, p.prox_max_iter)) : 0;
+    if (c->sub_nt != 1) c->sub_nt = nsub <= 4 ? 4 : SUB_NT_MAX;
+    int t_enq = ada_enqueue_subs(c, 0, nsub);
+    rc = ada_enqueue_tail(c, t_enq);
+    if (rc != PMX_OK) return rc;
+    rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    while (c->hstatus->halt && c->hstatus->reason == HALT_NEED_SUB) {
+        rc = clear_halt(c);
+        if (rc != PMX_OK) return rc;
+        t_enq = ada_enqueue_subs(c, t_enq, std::min(std::max(4, t_enq), 64));
+        rc = ada_enqueue_tail(c, t_enq);
+        if (rc != PMX_OK) return rc;
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+    }
+    if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
+    c->host_tau[0] = c->host_tau[1] = 0;
+    if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+    fill_result(c, res, it0);
+    return PMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // block-SDMM                                              (proxmin/algorithms.py:653-850)
 // ------------------------------------------------------------------------------------------------
@@ -1415,6 +1617,9 @@ extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
             if (rc != PMX_OK) return rc;
         }
     }
+    if (p->n_order < 0 || p->n_order > 8) FAIL(PMX_E_INVALID, "update_order: at most 8 entries");
+    for (int i = 0; i < p->n_order; ++i)
+        if (p->order[i] != 0 && p->order[i] != 1) FAIL(PMX_E_INVALID, "update_order: block %d out of range", p->order[i]);
     c->bsd = *p;
     c->algo = ALG_BSDMM;
     c->it = 0;
@@ -1437,7 +1642,11 @@ extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
 
 static int bsdmm_enqueue_iteration(pmx_ctx* c) {
     const pmx_bsdmm_params& p = c->bsd;
-    for (int j = 0; j < 2; ++j) {                                          // Gauss-Seidel, algorithms.py:805
+    static const int default_order[2] = {0, 1};
+    const int n_order = p.n_order > 0 ? p.n_order : 2;
+    const int* order = p.n_order > 0 ? p.order : default_order;
+    for (int o = 0; o < n_order; ++o) {                                    // Gauss-Seidel in update_order, algorithms.py:805
+        const int j = order[o];
         int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
         if (rc != PMX_OK) return rc;
         rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1);             // nmf.py:181-185 (only grads[j] is used)
@@ -1462,7 +1671,7 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
         d.size = c->rows[j] * c->K;
         d.e_rel = p.e_rel[j];
         d.e_abs = p.e_abs[j];
-        d.last_block = j == 1;
+        d.last_block = o == n_order - 1;
         launch_bsdmm_decide(d, c->stream);
         HIP_CHECK(hipGetLastError());
     }
@@ -1731,6 +1940,8 @@ extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
     // fault, so the chained K1 (whose faults are repaired by repeating the iteration) is not used here
     rc = chain_disable(c);
     if (rc != PMX_OK) return rc;
+    if (p.n_order > 0 && !(p.n_order == 2 && p.order[0] == 0 && p.order[1] == 1))
+        FAIL(PMX_E_UNSUPPORTED, "row-sharded bsdmm runs the default update order (A, then S) only");
     if (phase == 0) {
         // A step: everything is local (step_A comes from the replicated S)
         rc = enqueue_steps(c, c->X[0], c->X[1], true, false, 1.0);

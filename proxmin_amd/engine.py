@@ -182,7 +182,8 @@ class DeviceNMF:
         return out[: self.K].copy(), out[self.K:].copy()
 
     # -- solvers ------------------------------------------------------------------------------
-    def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6), bb=None, backtracking=False):
+    def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6), bb=None, backtracking=False,
+                  host_prox=(False, False)):
         p = _lib.PgmParams()
         p.prox[0], p.prox[1] = prox
         p.accelerated = int(bool(accelerated))
@@ -194,7 +195,15 @@ class DeviceNMF:
         if bb is not None:
             p.bb_type, p.bb_init_r = int(bb[0]), float(bb[1])
         p.backtracking = int(bool(backtracking))
+        p.host_prox[0], p.host_prox[1] = int(bool(host_prox[0])), int(bool(host_prox[1]))
         _lib.check(self.lib.pmx_pgm_begin(self.h, C.byref(p)))
+
+    def pgm_split(self, phase, steps=None):
+        """One piece of ONE iteration (include/pmx.h: pmx_pgm_split): 0 gradient, 1 argument of the user prox, 2 update."""
+        r = _lib.Result()
+        st = (C.c_double * 2)(float(steps[0]), float(steps[1])) if steps is not None else None
+        _lib.check(self.lib.pmx_pgm_split(self.h, int(phase), st, C.byref(r)))
+        return r
 
     def pgm_run(self, n_iter):
         r = _lib.Result()
@@ -202,7 +211,8 @@ class DeviceNMF:
         return r
 
     def adaprox_begin(self, prox, scheme="adam", b2=0.999, eps=1e-8, p=0.25, check_convergence=True,
-                      prox_max_iter=1000, warm_moments=False, warm_vhat=False, fixed_alpha=None, e_rel=(1e-6, 1e-6)):
+                      prox_max_iter=1000, warm_moments=False, warm_vhat=False, fixed_alpha=None, e_rel=(1e-6, 1e-6),
+                      host_step=False, host_prox=(False, False)):
         q = _lib.AdaproxParams()
         q.prox[0], q.prox[1] = prox
         q.scheme = _lib.SCHEME[scheme]
@@ -210,7 +220,8 @@ class DeviceNMF:
         q.check_convergence = int(bool(check_convergence))
         q.prox_max_iter = int(prox_max_iter)
         q.warm_vhat = int(bool(warm_vhat))
-        q.use_fixed_steps = int(fixed_alpha is not None)
+        q.use_fixed_steps = 2 if host_step else int(fixed_alpha is not None)
+        q.host_prox[0], q.host_prox[1] = int(bool(host_prox[0])), int(bool(host_prox[1]))
         if fixed_alpha is not None:
             q.fixed_alpha[0], q.fixed_alpha[1] = float(fixed_alpha[0]), float(fixed_alpha[1])
         q.e_rel[0], q.e_rel[1] = float(e_rel[0]), float(e_rel[1])
@@ -223,8 +234,29 @@ class DeviceNMF:
                                             float(b1_prev), C.byref(r)))
         return r
 
-    def bsdmm_begin(self, prox_f, proxs_g, e_rel=(1e-6, 1e-6), e_abs=(0.0, 0.0)):
+    def adaprox_set_alpha(self, alpha_A, alpha_S):
+        """per-component step sizes of the next iteration (a user `step` callable's return value, K values per block)"""
+        a = np.ascontiguousarray(np.concatenate([np.asarray(alpha_A, np.float32).ravel(), np.asarray(alpha_S, np.float32).ravel()]))
+        assert a.size == 2 * self.K
+        _lib.check(self.lib.pmx_adaprox_set_alpha(self.h, _vp(a)))
+
+    def adaprox_split(self, phase, it, b1_it, b1_prev, host_tau=(0, 0)):
+        """One half of ONE iteration (include/pmx.h: pmx_adaprox_split).  Returns (Result, (maxpsi_A, maxpsi_S))."""
+        r = _lib.Result()
+        tau = (C.c_int * 2)(int(host_tau[0]), int(host_tau[1]))
+        mp = (C.c_double * 2)()
+        _lib.check(self.lib.pmx_adaprox_split(self.h, int(phase), int(it), float(b1_it), float(b1_prev), tau, mp, C.byref(r)))
+        return r, (mp[0], mp[1])
+
+    def bsdmm_begin(self, prox_f, proxs_g, e_rel=(1e-6, 1e-6), e_abs=(0.0, 0.0), update_order=None):
         p = _lib.BsdmmParams()
+        if update_order is not None:
+            order = [int(j) for j in update_order]
+            if len(order) > 8:
+                raise NotImplementedError("update_order with more than 8 entries")
+            p.n_order = len(order)
+            for i, j in enumerate(order):
+                p.order[i] = j
         p.prox_f[0], p.prox_f[1] = prox_f
         for j in range(2):
             g = proxs_g[j] or []

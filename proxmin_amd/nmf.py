@@ -45,6 +45,14 @@ def _device_for(A, S, Y, W=None):
     return dev
 
 
+def _factors_only(A, S):
+    """Context holding just the factors (the step rules never touch Y: nothing M x N is allocated or uploaded)."""
+    A, S = np.asarray(A), np.asarray(S)
+    dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
+    dev.set_factors(A, S)
+    return dev
+
+
 def log_likelihood(*X, Y=0, W=1):
     """1/2 sum W (Y - A S)^2 (nmf.py:13-25), reduced inside the fused residual kernel."""
     A, S = X
@@ -81,16 +89,14 @@ def step_pgm(*X, it=None, W=1):
     if W != 1:
         raise NotImplementedError("the weighted step rule of nmf.step_pgm (nmf.py:64-88) is not implemented; pass `step`")
     A, S = X
-    Yd = np.zeros((A.shape[0], S.shape[1]), dtype=np.float32)
-    with _device_for(A, S, Yd) as dev:
+    with _factors_only(A, S) as dev:       # no Y: the rule needs the two K x K Gram matrices only
         return dev.step_pgm()
 
 
 def step_adaprox(*X, it=None):
     """(mean(A, axis=0) / 10, mean(S, axis=1)[:, None] / 10) (nmf.py:91-93)."""
     A, S = X
-    Yd = np.zeros((A.shape[0], S.shape[1]), dtype=np.float32)
-    with _device_for(A, S, Yd) as dev:
+    with _factors_only(A, S) as dev:
         aA, aS = dev.step_adaprox()
     dt = np.asarray(A).dtype
     return aA.astype(dt), aS.astype(dt)[:, None]
@@ -118,6 +124,24 @@ class constant_step:
 
     def __call__(self, *X, it=None, grads=None):
         return self.steps
+
+
+def bsdmm_closures(Y, prox, W=1):
+    """(proxs_f, steps_f_cb) for `algorithms.bsdmm(X, proxs_f, steps_f_cb, ...)`: the two closures the reference's nmf()
+    builds inline (nmf.py:181-193) -- prox_f(X, step, Xs, j) = prox[j](X - step * grad(*Xs)[j], step) and
+    step_f(Xs, j) = step_pgm(*Xs)[j].  Called directly they run the library's stand-alone device entry points; passed to
+    algorithms.bsdmm they identify the problem (Y, the operators), and the whole solver runs as kernel chains."""
+    grad = partial(grad_likelihood, Y=Y, W=W)
+    prox = list(prox)
+
+    def prox_f(X, step, Xs=None, j=None):
+        return prox[j](X - step * grad(*Xs)[j], step)
+
+    def step_f(Xs, j=None):
+        return step_pgm(*Xs)[j]
+
+    prox_f._pmx_nmf = step_f._pmx_nmf = (grad, prox)
+    return prox_f, step_f
 
 
 def nmf(
@@ -161,4 +185,5 @@ def nmf(
         if step is not None:
             # the reference raises UnboundLocalError here (nmf.py:187-198 passes the undefined step_f)
             raise NotImplementedError("a user `step` is not supported with bsdmm (it crashes in the reference too)")
-        return algorithms._bsdmm_nmf(X, grad, prox, max_iter=max_iter, e_rel=e_rel, callback=callback, **algorithm_args)
+        prox_f, step_f = bsdmm_closures(Y, prox, W=W)
+        return algorithm(X, prox_f, step_f, max_iter=max_iter, e_rel=e_rel, callback=callback, **algorithm_args)

@@ -54,10 +54,15 @@ def _apply(X, step, op, axis=None, thresh=0.0, kind="relative"):
         if X.ndim != 2 or axis not in (0, 1):
             raise NotImplementedError("prox_unity on the device needs a 2-D array and axis in (0, 1)")
         V = X if axis == 1 else X.T
-        if V.shape[1] > _lib.MAXK:
-            raise NotImplementedError("prox_unity: at most %d entries along the normalised axis" % _lib.MAXK)
-        out = _run_rows(V, _seq([(op, 0, 0.0, 0)]), 0.0)
-        X[...] = out if axis == 1 else out.T
+        if V.shape[1] <= _lib.MAXK:
+            out = _run_rows(V, _seq([(op, 0, 0.0, 0)]), 0.0)
+            X[...] = out if axis == 1 else out.T
+            return X
+        # long normalised axis: sums over the ROWS of the device array (column sums folded across the grid), the other axis
+        # in groups of at most MAXK independent columns
+        Wm = X if axis == 0 else X.T
+        for c0 in range(0, Wm.shape[1], _lib.MAXK):
+            Wm[:, c0:c0 + _lib.MAXK] = _run_rows(np.ascontiguousarray(Wm[:, c0:c0 + _lib.MAXK]), _seq([(op, 1, 0.0, 0)]), 0.0)
         return X
     ps = _seq([(op, 0, thresh, rel)])
     if step_arr.ndim == 0 or step_arr.size == 1 or not rel or op in ("id", "zero", "plus"):
@@ -194,10 +199,22 @@ def _one_entry(prox, block):
     return (op, 0, float(thresh), kind == "relative")
 
 
-def device_proxseq(prox, block):
+class NotFusable(NotImplementedError):
+    """An operator of this module that the fused solver kernels do not contain (prox_unity* along the long axis: a
+    grid-wide sum per application).  The solvers then apply it between kernel launches by calling it on the host copy of
+    its argument -- which runs the stand-alone device operator kernel -- one iteration per call."""
+
+
+def device_proxseq(prox, block, for_solver=False):
     """Translate a prox callable into a device operator sequence for factor `block` (0 = A, 1 = S).
     Returns a _lib.ProxSeq (n == 0 for prox=None) or raises NotImplementedError for callables that
-    are not (compositions of) this module's operators."""
+    are not (compositions of) this module's operators.  for_solver: also raise (NotFusable) for operators that exist
+    only as stand-alone kernels."""
+    if for_solver and prox is not None:
+        seq = device_proxseq(prox, block)
+        if any(seq.seq[i].unit != 0 for i in range(seq.n)):
+            raise NotFusable("prox_unity along the long axis of block %d is applied between kernel launches" % block)
+        return seq
     if prox is None:
         return _seq([])
     if isinstance(prox, AlternatingProjections):

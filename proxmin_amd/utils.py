@@ -3,7 +3,6 @@ here (callback plumbing and the scalar Nesterov sequence); everything array-size
 """
 from __future__ import annotations
 
-import math
 
 
 def _as_tuple(X):
@@ -28,28 +27,16 @@ class Traceback(object):
         self._trace = []
 
 
+def l2sq(x):
+    """sum of squares (proxmin/utils.py:257-260) -- used by the host-side proximal loop around a user-defined prox"""
+    return (x ** 2).sum()
+
+
 class NullCallback(object):
     """proxmin/utils.py:119-121.  nmf() treats it like callback=None: no per-iteration D2H copies."""
 
     def __call__(self, *X, it):
         pass
-
-
-class NesterovAccelerator(object):
-    """FISTA momentum sequence (proxmin/utils.py:193-206); the device keeps its own copy of `t`."""
-
-    def __init__(self, accelerated=False):
-        self.t = 1.0
-        self.accelerated = accelerated
-
-    @property
-    def omega(self):
-        if not self.accelerated:
-            return 0
-        t_ = 0.5 * (1 + math.sqrt(4 * self.t * self.t + 1))
-        om = (self.t - 1) / t_
-        self.t = t_
-        return om
 
 
 class BarzilaiBorweinStepper:

@@ -42,6 +42,10 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Prox) == 16
     assert ctypes.sizeof(_lib.ProxSeq) == 8 + 16 * _lib.MAX_SEQ
     assert ctypes.sizeof(_lib.Result) == 4 * 5 + 4 + 16 + 16   # 5 ints + pad, 2 doubles, 2 int64
+    # and every parameter struct against the compiled library's own sizeof
+    sizes = (ctypes.c_int * 5)()
+    assert _lib.load().pmx_abi_sizes(sizes) == 0
+    assert list(sizes) == [ctypes.sizeof(t) for t in (_lib.ProxSeq, _lib.PgmParams, _lib.AdaproxParams, _lib.BsdmmParams, _lib.Result)]
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -1,0 +1,220 @@
+"""GPU: the reference's callback surface with callables that are NOT objects of this library:
+`step(*X, it=None[, grads=None])` (algorithms.py:73-77, :370) and `prox(X, step) -> X'` (:37-39) written by the user run
+through a host round trip, one iteration per call -- the reference's own idioms must work unchanged:
+`step=lambda *X, it=None: tuple(0.5 * s for s in step_pgm(*X))` and `step=lambda *X, it: (alpha, alpha)`
+(examples/unmixing.py:139-143)."""
+import logging
+from functools import partial
+
+import numpy as np
+import pytest
+
+from conftest import as_spec, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import __graft_entry__ as g
+    g.build()
+    import proxmin_amd
+    proxmin_amd.set_default_mode("f32")
+    return proxmin_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import nmf_oracle
+    return nmf_oracle
+
+
+def test_lambda_step_reproduces_the_fista_half_fixture(pm, caplog):
+    """SURVEY.md section 4's `fista_half` row was generated from the reference with exactly this lambda."""
+    from test_gpu_nmf import assert_factors_close
+    for fname in ("nmf_200x1000_k5_f64.npz", "nmf_33x47_k3_f64.npz"):
+        z, meta = load_golden(fname)
+        c = meta["cases"]["fista_half"]
+        from oracle import nmf_oracle as orc
+        tag = "unity" if c["unity_S"] else "plain"
+        if "inputs_%s/Y" % tag in z.files:
+            Y, A0, S0 = z["inputs_%s/Y" % tag], z["inputs_%s/A0" % tag], z["inputs_%s/S0" % tag]
+        else:
+            Y, A0, S0 = orc.synthetic_problem(meta["M"], meta["N"], meta["K"], np.dtype(meta["dtype"]).type, c["unity_S"], meta["seed"])
+        A, S = A0.copy(), S0.copy()
+        with caplog.at_level(logging.WARNING, logger="proxmin"):
+            ret = pm.nmf.nmf(Y, A, S, accelerated=True, step=lambda *X, it=None: tuple(0.5 * s for s in pm.nmf.step_pgm(*X)),
+                             max_iter=meta["max_iter"], e_rel=meta["e_rel"])
+        assert_factors_close(A, z["fista_half/A"], meta["dtype"], fname + " A")
+        assert_factors_close(S, z["fista_half/S"], meta["dtype"], fname + " S")
+        np.testing.assert_allclose(np.array(ret[2], dtype=np.float64), z["fista_half/steps"], rtol=1e-4)
+        # and it equals the fused form of the same rule
+        A2, S2 = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A2, S2, accelerated=True, step=pm.nmf.scaled_step_pgm(0.5), max_iter=meta["max_iter"], e_rel=meta["e_rel"])
+        np.testing.assert_allclose(A, A2, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(S, S2, rtol=1e-5, atol=1e-6)
+
+
+def test_lambda_learning_rate_for_adaprox_equals_constant_step(pm, orc):
+    """examples/unmixing.py:139-143: `step=lambda *X, it: (alpha, alpha)`; the same numbers as the fused constant_step."""
+    Y, A0, S0 = orc.synthetic_problem(300, 500, 12, np.float32, seed=9)
+    out = []
+    for step in (lambda *X, it: (0.01, 0.02), pm.nmf.constant_step(0.01, 0.02)):
+        A, S = A0.copy(), S0.copy()
+        ret = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", step=step, max_iter=15, e_rel=1e-4,
+                         prox_S=partial(pm.operators.prox_soft_plus, thresh=1e-3))
+        out.append((A, S, ret))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][2][0] == out[1][2][0]
+    # per-component arrays, the shapes nmf.step_adaprox itself returns
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", step=lambda *X, it=None: pm.nmf.step_adaprox(*X), max_iter=6, e_rel=1e-4)
+    A2, S2 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A2, S2, algorithm=pm.adaprox, scheme="adam", max_iter=6, e_rel=1e-4)
+    np.testing.assert_array_equal(A, A2)
+    np.testing.assert_array_equal(S, S2)
+
+
+def test_unmixing_example_with_its_own_lambda(pm):
+    """examples/unmixing.py:126-161 as written there: the solver called DIRECTLY with the example's own step lambda
+    (`lambda *X, it: (alpha, alpha)`), e_rel 1e-4, prox_max_iter 100; the reference's final losses and iteration counts are
+    in tests/golden/unmixing.npz (generated from the reference)."""
+    z, meta = load_golden("unmixing.npz")
+    Y, A0, S0 = z["Y"], z["A0"], z["S0"]
+    rows = [r for r in meta["runs"] if r["mode"] == "nmf" and r["cfg"] is not None and r["cfg"][0] == "adam"]
+    assert rows
+    for r in rows:
+        alpha = r["cfg"][1]
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        grad = partial(pm.nmf.grad_likelihood, Y=Y)
+        pm.adaprox((A, S), grad, lambda *X, it: (alpha, alpha), prox=[pm.operators.prox_plus, pm.operators.prox_plus], max_iter=1000,
+                   callback=tb, e_rel=1e-4, b1=0.9, b2=0.999, prox_max_iter=100, scheme="adam")
+        loss = pm.nmf.log_likelihood(A, S, Y=Y)
+        assert abs(loss / r["loss"] - 1) < 5e-3, (alpha, loss, r["loss"])
+        assert abs(len(tb.trace) - r["iters"]) <= 0.15 * r["iters"], (alpha, len(tb.trace), r["iters"])
+
+
+def my_plus(X, step):
+    """a user-written projection onto the non-negative numbers"""
+    X[X < 0] = 0
+    return X
+
+
+def my_soft(X, step, thresh=1e-3):
+    return np.sign(X) * np.maximum(np.abs(X) - thresh * step, 0)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(accelerated=True, half=True)])
+def test_user_written_prox_in_pgm(pm, orc, kw):
+    Y, A0, S0 = orc.synthetic_problem(400, 640, 24, np.float32, seed=2)
+    kw = dict(kw)
+    step = pm.nmf.scaled_step_pgm(0.5) if kw.pop("half", False) else None
+    runs = {}
+    for name, pA, pS in (("lib", pm.operators.prox_plus, pm.operators.prox_plus), ("user", my_plus, my_plus), ("mixed", my_plus, pm.operators.prox_plus)):
+        A, S = A0.copy(), S0.copy()
+        ret = pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, step=step, max_iter=10, e_rel=1e-9, **kw)
+        runs[name] = (A, S, ret)
+    for name in ("user", "mixed"):
+        np.testing.assert_array_equal(runs[name][0], runs["lib"][0])      # same arithmetic: v = Xe - s G, then the projection
+        np.testing.assert_array_equal(runs[name][1], runs["lib"][1])
+        np.testing.assert_array_equal(runs[name][2][1][0], runs["lib"][2][1][0])
+
+
+def test_user_written_prox_in_adaprox(pm, orc):
+    """the proximal loop of the block with a user-defined prox runs around the callable on the host: same iterates as the
+    library operator up to fp32 rounding (numpy rounds the loop's expression twice where the device fuses a multiply-add),
+    same sub-iteration counts; the callback sees every iterate; StopIteration ends the run."""
+    Y, A0, S0 = orc.synthetic_problem(300, 420, 8, np.float32, seed=7)
+    lib = partial(pm.operators.prox_soft, thresh=1e-3)
+    res = {}
+    for name, pS in (("lib", lib), ("user", my_soft)):
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        ret = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="amsgrad", prox_A=pm.operators.prox_plus if name == "lib" else my_plus,
+                         prox_S=pS, max_iter=8, e_rel=1e-3, callback=tb)
+        res[name] = (A, S, ret, len(tb.trace))
+    np.testing.assert_allclose(res["user"][0], res["lib"][0], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(res["user"][1], res["lib"][1], rtol=2e-4, atol=2e-5)
+    assert res["user"][3] == res["lib"][3]
+    np.testing.assert_allclose(res["user"][2][1][0], res["lib"][2][1][0], rtol=1e-3, atol=1e-6)     # M of block A
+
+    def stopper(*X, it=None):
+        if it == 3:
+            raise StopIteration
+
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, prox_S=my_soft, max_iter=8, e_rel=1e-3, callback=stopper)
+    A3, S3 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A3, S3, algorithm=pm.adaprox, prox_S=my_soft, max_iter=3, e_rel=1e-3)
+    np.testing.assert_array_equal(A, A3)
+    np.testing.assert_array_equal(S, S3)
+
+
+def test_slow_path_warns_once(pm, orc, caplog):
+    from proxmin_amd import algorithms
+    algorithms._warned.clear()
+    Y, A0, S0 = orc.synthetic_problem(64, 96, 4, np.float32, seed=1)
+    with caplog.at_level(logging.WARNING, logger="proxmin"):
+        for _ in range(2):
+            A, S = A0.copy(), S0.copy()
+            pm.nmf.nmf(Y, A, S, prox_A=my_plus, max_iter=2, e_rel=1e-9)
+    msgs = [r.getMessage() for r in caplog.records if "user-defined Python callable" in r.getMessage()]
+    assert len(msgs) == 1, msgs
+
+
+def test_prox_unity_along_the_long_axis(pm, orc):
+    """operators.prox_unity(axis=0) -- the reference's default axis (operators.py:41-52) -- normalises the COLUMNS of its
+    argument: a sum over the long dimension of a factor.  Stand-alone it runs the column-sum + scale kernels; inside the
+    solvers it is applied between kernel launches (one iteration per call) and must reproduce the oracle."""
+    rng = np.random.default_rng(3)
+    for shape, axis in (((700, 5), 0), ((5, 900), 1), ((300, 260), 0), ((4, 40000), 1)):
+        X = (rng.random(shape) - 0.2).astype(np.float32)
+        for fn, ref in ((pm.operators.prox_unity, lambda V: V / V.sum(axis=axis, keepdims=True)),
+                        (pm.operators.prox_unity_plus, lambda V: np.maximum(V, 0) / np.maximum(V, 0).sum(axis=axis, keepdims=True))):
+            got = fn(X.copy(), 1.0, axis=axis)
+            np.testing.assert_allclose(got, ref(X.astype(np.float64)), rtol=2e-6, atol=1e-9)
+    # inside nmf(): A's columns normalised (axis=0 on A), pgm and adaprox, against the oracle
+    Y, A0, S0 = orc.synthetic_problem(260, 380, 6, np.float32, seed=5)
+    A0 /= A0.sum(0, keepdims=True)
+    for alg, kw, okw in ((pm.pgm, dict(), dict()), (pm.adaprox, dict(scheme="adam"), dict(scheme="adam"))):
+        A, S = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A, S, algorithm=alg, prox_A=partial(pm.operators.prox_unity_plus, axis=0), max_iter=6, e_rel=1e-4, **kw)
+        Ao, So = A0.astype(np.float64), S0.astype(np.float64)
+        if alg is pm.pgm:
+            orc.pgm_nmf(Y.astype(np.float64), Ao, So, prox_A=("unity_plus", 0), max_iter=6, e_rel=1e-4)
+        else:
+            orc.adaprox_nmf(Y.astype(np.float64), Ao, So, ("unity_plus", 0), ("plus",), max_iter=6, e_rel=1e-4, **okw)
+        np.testing.assert_allclose(A, Ao, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(S, So, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(A.sum(0), 1.0, rtol=1e-5)
+
+
+def test_bsdmm_update_order_and_direct_entry(pm, orc):
+    """bsdmm's update_order (algorithms.py:730-736, :805) -- S before A, and a block left out -- and the direct entry
+    algorithms.bsdmm(X, proxs_f, steps_f_cb, ...) with the closures nmf() itself builds."""
+    Y, A0, S0 = orc.synthetic_problem(200, 300, 6, np.float32, seed=12)
+    pgl = [[pm.operators.prox_plus, partial(pm.operators.prox_soft, thresh=0.01)]] * 2
+    A, S = A0.copy(), S0.copy()
+    conv = pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=5, e_rel=1e-9)
+    A2, S2 = A0.copy(), S0.copy()
+    pf, sf = pm.nmf.bsdmm_closures(Y, [pm.operators.prox_plus, pm.operators.prox_plus])
+    conv2 = pm.bsdmm([A2, S2], pf, sf, proxs_g=pgl, max_iter=5, e_rel=1e-9)
+    np.testing.assert_array_equal(A, A2)
+    np.testing.assert_array_equal(S, S2)
+    assert conv == conv2
+    with pytest.raises(NotImplementedError):
+        pm.bsdmm([A2, S2], lambda X, step, Xs=None, j=None: X, lambda Xs, j=None: 1.0)
+    # S first: equals the default order on the transposed problem (Y^T = S^T A^T)
+    A3, S3 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A3, S3, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=5, e_rel=1e-9, update_order=[1, 0])
+    At, St = np.ascontiguousarray(S0.T), np.ascontiguousarray(A0.T)
+    pm.nmf.nmf(np.ascontiguousarray(Y.T), At, St, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=5, e_rel=1e-9)
+    np.testing.assert_allclose(S3, At.T, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(A3, St.T, rtol=1e-4, atol=1e-5)
+    # only A is updated: S stays, its convergence flag stays None
+    A4, S4 = A0.copy(), S0.copy()
+    conv4 = pm.nmf.nmf(Y, A4, S4, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=3, e_rel=1e-9, update_order=[0])
+    np.testing.assert_array_equal(S4, S0)
+    assert conv4[1] is None and not np.array_equal(A4, A0)
