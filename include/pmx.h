@@ -40,7 +40,8 @@ enum {
 /* ---- Y storage / contraction arithmetic ---------------------------------------------- */
 enum {
     PMX_MODE_F32 = 0,   /* Y fp32 in HBM, A@S / R@S^T / A^T@R on v_mfma_f32_32x32x2_f32 (exact f32) */
-    PMX_MODE_BF16 = 1,  /* Y bf16 in HBM, operands rounded to bf16, fp32 accumulate                  */
+    /* (1 was a plain-bf16 mode -- Y rounded to bf16 in HBM -- that was never built: 2^-9 relative error on Y cannot meet
+       the path's rtol 1e-4; the split modes below keep Y in fp32)                                                       */
     PMX_MODE_BF16X3 = 2, /* Y fp32 in HBM, operands split into bf16 terms (3 for A@S, 2 for the gradients), fp32 accumulate */
     PMX_MODE_F16X2 = 3   /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes run the two-term fp16 kernel
                             (power-of-two operand scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
@@ -124,8 +125,7 @@ int pmx_ctx_destroy(pmx_ctx* ctx);
 int pmx_ctx_sync(pmx_ctx* ctx);
 
 /* Y: copy from host (row-major float32, leading dimension ld elements) or adopt/convert a
- * device buffer (float32, row-major).  With PMX_MODE_BF16 the data is converted to bf16 on
- * the device.  `copy`=0 adopts the fp32 device pointer without copying (caller keeps it
+ * device buffer (float32, row-major).  `copy`=0 adopts the fp32 device pointer without copying (caller keeps it
  * alive).  Y is read-only for the solvers (nmf.py:116). */
 int pmx_set_Y_host(pmx_ctx* ctx, const float* Y, int64_t ld);
 int pmx_set_Y_device(pmx_ctx* ctx, const float* dY, int64_t ld, int copy);

@@ -115,7 +115,7 @@ struct EigArgs {
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
 __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
-    __shared__ double vec[MAXK], wv[MAXK], red[8];
+    __shared__ double vec[MAXK], wv[MAXK], red[8], eigred2[4];
     DevStatus* st = a.status;
     if (chain_halted(st)) return;
     const int f = blockIdx.x;
@@ -190,8 +190,49 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     __syncthreads();
     const double resid = sqrt((red[0] + red[1] + red[2] + red[3]) / (rq_d > 0.0 ? rq_d : 1.0));
     __syncthreads();
+    // ---- a small residual says l is AN eigenvalue, not that it is the largest: the iteration is warm-started from the
+    //      previous call's vector, and when two eigenvalues cross (factors with mixed signs under prox_id / soft / hard: no
+    //      Perron argument) the iterate can sit on the pair that has just become second.  Two lower bounds on lmax of the
+    //      positive semi-definite Gram matrix that such an l would violate: the largest column norm (|G e_i| <= lmax), and
+    //      the Rayleigh quotient of three power steps from a fixed vector unrelated to the warm start.  Either above
+    //      l (1 + 1e-5) sends the call to the exact solver below. ------------------------------------------------------
+    double probe = 0.0;
+    {
+        double cn = 0.0;
+        if (t < K) {
+            for (int k = 0; k < K; ++k) { const double g = G[(int64_t)k * KP + t]; cn += g * g; }
+            cn = sqrt(cn);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cn = fmax(cn, __shfl_xor(cn, o));
+        if ((t & 63) == 0) red[t >> 6] = cn;
+        __syncthreads();
+        probe = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        __syncthreads();
+        if (t < K) wv[t] = 1.0 + 0.37 * (double)((t * 7) % 5) - 0.61 * (double)(t & 1);      // fixed, sign-mixed start
+        __syncthreads();
+        double un = 0.0, ud = 1.0;
+        for (int stepi = 0; stepi < 3; ++stepi) {
+            double s2 = 0.0;
+            if (t < K) for (int k = 0; k < K; ++k) s2 += G[(int64_t)k * KP + t] * wv[k];
+            double a2 = (t < K) ? s2 * wv[t] : 0.0, b2 = (t < K) ? wv[t] * wv[t] : 0.0, c2 = (t < K) ? s2 * s2 : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a2 += __shfl_xor(a2, o); b2 += __shfl_xor(b2, o); c2 += __shfl_xor(c2, o); }
+            __syncthreads();
+            if ((t & 63) == 0) { red[t >> 6] = a2; red[4 + (t >> 6)] = b2; eigred2[t >> 6] = c2; }
+            __syncthreads();
+            un = red[0] + red[1] + red[2] + red[3];
+            ud = red[4] + red[5] + red[6] + red[7];
+            const double nn = sqrt(eigred2[0] + eigred2[1] + eigred2[2] + eigred2[3]);
+            __syncthreads();
+            if (t < K) wv[t] = nn > 0.0 ? s2 / nn : 0.0;
+            __syncthreads();
+        }
+        if (ud > 0.0) probe = fmax(probe, un / ud);
+    }
+    const bool not_dominant = probe > l * (1.0 + 1e-5);
     int used_exact = 0;
-    if (l > 0.0 && l == l && l < 1e300 && !(resid <= 1e-6 * l)) {
+    if (l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant)) {
         // ---- Lanczos tridiagonalisation with full re-orthogonalisation (fp64), K steps = exact ---------
         __shared__ double al[MAXK], be[MAXK + 1], cdot[MAXK];
         __shared__ int nT;

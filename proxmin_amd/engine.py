@@ -49,7 +49,7 @@ class DeviceNMF:
         self.device = device
         mode = mode or _DEFAULT_MODE
         self.mode = mode
-        mode_id = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2}[mode]
+        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
                                            C.c_void_p(stream) if stream else None))

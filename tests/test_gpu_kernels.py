@@ -438,3 +438,23 @@ def test_full_size_gradient_against_subsampled_oracle(eng, mode):
         assert dev.k1_info()["chain_faults"] == 0
     np.testing.assert_allclose(gA[rows], rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
     np.testing.assert_allclose(gS[:, cols], rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+
+
+def test_lambda_max_after_an_eigenvalue_crossing(eng, orc):
+    """The power iteration is warm-started from the previous call's eigenvector.  Orthogonal columns make A^T A diagonal:
+    after the first call the iterate is exactly e_1; swap the column scales and e_1 is still an exact eigenvector -- of the
+    SMALLER eigenvalue now, zero residual.  The dominance probe (largest column norm / an independent Rayleigh quotient)
+    must send the call to the exact solver: a step from the second eigenvalue would be 4 x too long."""
+    M, N, K = 64, 48, 2
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((M, K)))
+    S = rng.standard_normal((K, N)).astype(np.float32)          # mixed signs: no Perron argument
+    with eng.DeviceNMF(M, N, K) as dev:
+        dev.set_Y(np.zeros((M, N), np.float32))
+        for scales in ((2.0, 1.0), (1.0, 2.0), (1.0, 2.0)):
+            A = (Q * np.array(scales)).astype(np.float32)
+            dev.set_factors(A, S)
+            sA, sS = dev.step_pgm()
+            oA, oS = orc.lipschitz_steps(A.astype(np.float64), S.astype(np.float64))
+            assert sS == pytest.approx(oS, rel=1e-5), scales        # 1 / lmax(A^T A) = 1 / 4
+            assert sA == pytest.approx(oA, rel=1e-5)
