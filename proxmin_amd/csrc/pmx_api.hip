@@ -83,6 +83,7 @@ struct pmx_ctx {
     unsigned* chainFlags = nullptr;        // their arrival words
     unsigned chainSeq = 0;                 // launches so far (arrival words are monotonic: launch n counts from 64 n)
     int nSlabA = 0;                        // gA slabs the update kernels fold (plan.nSlabA, or one per chain group)
+    int nSlabS = 0;                        // gSt slabs
     int chainFaults = 0;                   // times the chained mode was left after a fault
     bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
     GridBar* gridbar = nullptr;            // its barrier state
@@ -259,6 +260,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->plan = c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K);
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
     c->nSlabA = c->plan.nSlabA;
+    c->nSlabS = c->plan.nSlabS;
     if (c->use_f16) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
@@ -351,7 +353,7 @@ extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     info[0] = c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0);
     info[1] = c->chainL;
     info[2] = c->nSlabA;
-    info[3] = c->plan.nSlabS;
+    info[3] = c->nSlabS;
     info[4] = c->plan.gridX;
     info[5] = c->plan.gridY;
     info[6] = c->plan.RP;
@@ -659,7 +661,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
 static SlabRef slab_ref(pmx_ctx* c, int j) {
     SlabRef s;
     s.base = c->slab[j];
-    s.n = j == 0 ? c->nSlabA : c->plan.nSlabS;
+    s.n = j == 0 ? c->nSlabA : c->nSlabS;
     return s;
 }
 
