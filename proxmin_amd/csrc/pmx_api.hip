@@ -1470,7 +1470,8 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
     int tails = 0;           // iteration tails enqueued by this call (their finish kernel leaves the factor maxima behind)
     while (done < n_iter && !c->hstatus->stopped) {
         // ---- enqueue a chunk of whole iterations ------------------------------------------------
-        const int chunk = std::min(n_iter - done, 16);
+        // (the fused tail decides its proximal loops on the device: nothing to speculate on, longer chunks between host syncs)
+        const int chunk = std::min(n_iter - done, c->tail_fused ? 64 : 16);
         const int nsub = any_prox ? std::max(1, std::min(c->nsub_guess, p.prox_max_iter)) : 0;
         // passes per launch for this chunk: 4 when the loops have been ending within 4 passes (the usual steady state:
         // 1 pass for a projection, 2-3 for prox_unity_plus), else 8; PMX_SUB_BATCH=1 keeps one pass per launch

@@ -317,9 +317,9 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     from . import operators as ops
     from .engine import DeviceNMF
 
-    if backend != "adaprox":
-        raise NotImplementedError("multi-GPU bench is implemented for the adaprox back-end (BASELINE cfg3/cfg4)")
     # PMX_DIST_BACKEND / PMX_BENCH_DEVICE: test-only overrides (two ranks on one GPU over gloo; RCCL needs a GPU per rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")      # (PMX_FORCE_SHARDED=1 without a launcher: a world of one)
+    os.environ.setdefault("MASTER_PORT", "29531")
     if not dist.is_initialized():
         dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if "PMX_BENCH_DEVICE" in os.environ:
@@ -349,19 +349,30 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream, mode=getattr(args, "mode", None))
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
-    eng = ShardEngine(dev, world, rank, M)
+    eng = ShardEngine(dev, world, rank, M, backend)
     pA = ops.device_proxseq(ops.prox_plus, 0)
     pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
-    dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
-    drv = ShardedAdaproxDriver(eng, None, False, True, 1000)
     total = args.warmup + args.steps
-    b1 = np.full(total, 0.9)
-    drv.run(args.warmup, b1)
+    if backend == "adaprox":
+        dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
+        drv = ShardedAdaproxDriver(eng, None, False, True, 1000)
+        b1 = np.full(total, 0.9)
+        run = lambda n: drv.run(n, b1)
+    elif backend == "pgm":
+        dev.pgm_begin([pA, pS], accelerated=False, e_rel=(1e-12, 1e-12))
+        loop = ShardedLoop(eng, None, deferred_test=True)
+        run = loop.run
+    else:
+        pg = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=1e-3), 0)]
+        dev.bsdmm_begin([pA, pS], [pg, pg], e_rel=(1e-12, 1e-12), e_abs=(0.0, 0.0))
+        loop = ShardedLoop(eng, None, deferred_test=False)
+        run = loop.run
+    run(args.warmup)
     dev.set_timing(True, every=4)   # HIP events around every 4th K1 launch of the timed region
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    drv.run(args.steps, b1)
+    run(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
@@ -372,10 +383,12 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     k1 = torch.tensor([k1_ms / max(k1_n, 1)], dtype=torch.float64, device=device)
     dist.all_reduce(k1, op=dist.ReduceOp.MAX)
     k1_avg_ms = float(k1.item())
-    flop_per_it = 6.0 * M * N * K
+    nk1 = 2 if backend == "bsdmm" else 1            # bsdmm: two K1 launches of 4 MNK each per iteration
+    flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
     eff_mode = dev.mode if K <= 64 else "f32"      # K > 64 runs the exact-fp32 kernel in either mode
     its = args.steps / dt
-    ach = (6.0 * Ml * N * K) / (k1_avg_ms * 1e-3) / 1e12
+    ach = (flop_per_it / nk1 * Ml / M) / (k1_avg_ms * 1e-3) / 1e12
+    info = dev.k1_info()
     out = {
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -387,13 +400,13 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         "gflops": flop_per_it * its / 1e9,
         "roofline": ({"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                       "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                      "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)} if dev.mode == "f32" or K > 64 else
-                     {"kernel": ((("k_grad_f16_v8" if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
-                                 else "k_grad_bf16"), "bound": "hbm",
+                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info} if dev.mode == "f32" or K > 64 else
+                     {"kernel": ((("k_grad_f16_v8" + ("<chain %d>" % info["chain"] if info["chain"] else "") if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
+                                 else "k_grad_bf16"), "bound": "hbm", "k1_layout": info,
                       "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,
                       "unit": "GB/s", "frac": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                       "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
-                      "k1_share_of_step": k1_avg_ms * args.steps / (1e3 * dt)}),
+                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt)}),
     }
     dev.close()
     dist.destroy_process_group()
