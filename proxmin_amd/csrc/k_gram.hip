@@ -110,6 +110,12 @@ struct EigArgs {
     double scale;          // step = scale / lmax   (user `step = c * step_pgm` support)
     int max_iter;
     double* Q;             // [2][KP*KP] Lanczos basis scratch (exact fallback)
+    // small problems (K <= 16, a few thousand rows): the Gram matrix is formed HERE, by this workgroup, instead of by
+    // k_gram_partial + k_gram_reduce -- one launch for the whole step rule instead of three (each is pure launch latency
+    // at that size).  X[f] == nullptr: G was prepared by the caller.
+    const float* X[2];
+    int64_t rows[2];
+    double* Gw;            // writable view of G
 };
 // one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
@@ -123,6 +129,32 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     const int KP = a.KP, K = a.K, ld = KP + 1;
     const double* G = a.G + (int64_t)f * KP * KP;
     const int t = threadIdx.x;
+    if (a.X[f] != nullptr) {                 // K <= 16: thread (i, j) = (t / 16, t % 16) owns G[i][j]; rows staged 256 at a time
+        __shared__ float xs[256][17];
+        const float* X = a.X[f];
+        const int64_t rows = a.rows[f];
+        const int gi = t >> 4, gj = t & 15;
+        double acc = 0.0;
+        for (int64_t r0 = 0; r0 < rows; r0 += 256) {
+            __syncthreads();
+            for (int e = t; e < 256 * K; e += 256) {
+                const int rr = e / K, k = e - rr * K;
+                xs[rr][k] = r0 + rr < rows ? X[(r0 + rr) * K + k] : 0.f;
+            }
+            __syncthreads();
+            if (gi < K && gj < K) {
+                float part = 0.f;            // fp32 products and sum over one tile of rows, fp64 across tiles (as k_gram_*)
+                for (int rr = 0; rr < 256; ++rr) part += xs[rr][gi] * xs[rr][gj];
+                acc += (double)part;
+            }
+        }
+        double* Gw = a.Gw + (int64_t)f * KP * KP;
+        for (int e = t; e < KP * KP; e += 256) Gw[e] = 0.0;
+        __syncthreads();
+        if (gi < K && gj < K) Gw[gi * KP + gj] = acc;
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int e = t; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
     // warm start (all-ones on the first call: the Perron vector of a non-negative Gram matrix is positive)
     {

@@ -298,10 +298,19 @@ struct PgmArgs {
     //   mode 2  "post": the update with prox(...) := T_j as the host left it;      mode 3: block not touched by this launch
     int mode[2];
     float* T[2];
+    // stopping test by the LAST workgroup to finish (algorithms.py:130-135) instead of a separate single-workgroup launch:
+    // every workgroup publishes its partial sums (release), takes a ticket, and the one that draws the last ticket of
+    // this launch folds all partials in the usual fixed order and decides.  tickets == nullptr: the caller launches
+    // k_pgm_decide itself (row-sharded runs, split iterations).
+    unsigned* tickets;
+    unsigned ticket_last;    // value the counter shows to the last arrival: launches so far x workgroups per launch - 1
+    double e_rel[2];
 };
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check);
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
+    __shared__ int s_last;
     if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
     if (a.mode[j] == 3) return;
@@ -351,6 +360,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     double red[2] = {(double)d2, (double)n2};
     // SL_DIFF2 and SL_NORM2 are adjacent slots: stride between them = 2 * EW_BLOCKS doubles
     block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    if (a.tickets != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();                                      // this workgroup's partials (and factors) are out
+            const unsigned old = atomicAdd(a.tickets, 1u);
+            s_last = old == a.ticket_last;
+            if (s_last) __threadfence();                          // ... and everybody else's are in
+        }
+        __syncthreads();
+        if (s_last) pgm_decide_body(a.status, a.partials, a.e_rel, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,32 +598,33 @@ struct DecideArgs {
     double e_rel[2];
     int check;          // evaluate the convergence test
 };
-__global__ __launch_bounds__(EW_THREADS) void k_pgm_decide(DecideArgs a) {
-    __shared__ double scratch[EW_WAVES];
-    if (chain_halted(a.status)) return;
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check) {
     double d[2], n[2];
     for (int j = 0; j < 2; ++j) {
-        d[j] = fold_partials(part_ptr(a.partials, SL_DIFF2, j), scratch);
-        n[j] = fold_partials(part_ptr(a.partials, SL_NORM2, j), scratch);
+        d[j] = fold_partials(part_ptr(partials, SL_DIFF2, j), nullptr);
+        n[j] = fold_partials(part_ptr(partials, SL_NORM2, j), nullptr);
     }
     if (threadIdx.x == 0) {
-        DevStatus* st = a.status;
         int all = 1;
         for (int j = 0; j < 2; ++j) {
-            const int c = d[j] <= a.e_rel[j] * a.e_rel[j] * n[j];
+            const int c = d[j] <= e_rel[j] * e_rel[j] * n[j];
             st->conv[j] = c;
             st->norms[j][0] = d[j];
             st->norms[j][1] = n[j];
             all &= c;
         }
         st->it_done += 1;
-        if (a.check && all) {
+        if (check && all) {
             st->stopped = 1;
             st->reason = HALT_CONVERGED;
             __threadfence();
             st->halt = 1;
         }
     }
+}
+__global__ __launch_bounds__(EW_THREADS) void k_pgm_decide(DecideArgs a) {
+    if (chain_halted(a.status)) return;
+    pgm_decide_body(a.status, a.partials, a.e_rel, a.check);
 }
 
 // ------------------------------------------------------------------------------------------------

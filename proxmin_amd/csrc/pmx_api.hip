@@ -67,6 +67,7 @@ struct pmx_ctx {
 
     // K1
     unsigned long long* k1prof = nullptr;  // tuning: phase cycle sums (PMX_K1_PROF=1)
+    bool use_small = false;                // small problem (K <= 16, few million entries): k_grad_small in every mode
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
     bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
@@ -88,6 +89,8 @@ struct pmx_ctx {
     bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
     GridBar* gridbar = nullptr;            // its barrier state
     long long* tailprof = nullptr;         // PMX_TAIL_PROF=1: phase time stamps of the last fused tail
+    unsigned* tickets = nullptr;           // pgm: arrival counter of the update kernel's last-workgroup stopping test
+    unsigned ticketLaunches = 0;           // update launches that took tickets so far
     int tailFaults = 0;
     float* slab[2] = {nullptr, nullptr};
     const float* W = nullptr;              // weights of the likelihood (nullptr: W == 1), nmf.py:13-41
@@ -256,8 +259,9 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         if (e != hipSuccess) { delete c; FAIL(PMX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64;
-    c->plan = c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K);
+    c->use_small = grad_small_applies(M, N, K);
+    c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
+    c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K));
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
@@ -350,7 +354,7 @@ extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0);
+    info[0] = c->use_small ? 4 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -586,6 +590,11 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
     rc = clear_halt(c);
     if (rc != PMX_OK) return rc;
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->tickets) {                        // the update launches that followed the fault were skipped: start the count over
+        HIP_CHECK(hipMemsetAsync(c->tickets, 0, sizeof(unsigned), c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->ticketLaunches = 0;
+    }
     c->hstatus->k1_fault = 0;
     c->hstatus->tail_fault = 0;
     c->hstatus->halt = 0;
@@ -648,7 +657,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
-        HIP_CHECK(grad_launch_f32(c->plan, g, c->stream));
+        HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
     }
     if (timed) {
@@ -667,6 +676,18 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
 
 // Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
 static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale) {
+    if (c->K <= 16 && c->M <= 8192 && c->N <= 8192) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig forms G itself)
+        EigArgs e{};
+        e.G = c->gramG; e.Gw = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+        e.want[0] = wantStepS; e.want[1] = wantStepA;
+        e.scale = scale;
+        e.max_iter = 200;
+        e.Q = c->eigQ;
+        e.X[0] = A; e.X[1] = St;
+        e.rows[0] = c->M; e.rows[1] = c->N;
+        HIP_CHECK(launch_eig(e, c->stream));
+        return PMX_OK;
+    }
     GramArgs g{};
     g.X[0] = A; g.X[1] = St;
     g.rows[0] = c->M; g.rows[1] = c->N;
@@ -933,6 +954,10 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     }
     if (c->W && !p->use_fixed_steps && !p->bb_type)   // nmf.step_pgm with an array W raises (nmf.py:63)
         FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
+    rc = dallocT(c, &c->tickets, 4);
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipMemsetAsync(c->tickets, 0, sizeof(unsigned), c->stream));   // (launches skipped by a halted chain took no tickets)
+    c->ticketLaunches = 0;
     c->pgm = *p;
     c->algo = ALG_PGM;
     c->it = 0;
@@ -1032,13 +1057,15 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     u.partials = c->partials;
     u.accelerated = p.accelerated;
     u.omega_next = next_omega(c);
+    // the stopping test (algorithms.py:130-135) is made by the last of the update kernel's 2 x EW_BLOCKS workgroups
+    if (c->ticketLaunches >= (1u << 22)) {
+        HIP_CHECK(hipMemsetAsync(c->tickets, 0, sizeof(unsigned), c->stream));
+        c->ticketLaunches = 0;
+    }
+    u.tickets = c->tickets;
+    u.ticket_last = (++c->ticketLaunches) * (2u * EW_BLOCKS) - 1u;
+    u.e_rel[0] = p.e_rel[0]; u.e_rel[1] = p.e_rel[1];
     launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
-    DecideArgs d{};
-    d.status = c->dstatus;
-    d.partials = c->partials;
-    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
-    d.check = 1;
-    launch_pgm_decide(d, c->stream);                                      // algorithms.py:130-135
     HIP_CHECK(hipGetLastError());
     c->it += 1;
     return PMX_OK;
