@@ -230,9 +230,11 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     //      l (1 + 1e-5) sends the call to the exact solver below. ------------------------------------------------------
     double probe = 0.0;
     {
+        // (the fp32 copy of G in LDS is accurate enough for a bound with a 1e-5 margin, and three more trips to the fp64
+        // matrix in memory cost 5 us)
         double cn = 0.0;
         if (t < K) {
-            for (int k = 0; k < K; ++k) { const double g = G[(int64_t)k * KP + t]; cn += g * g; }
+            for (int k = 0; k < K; ++k) { const double gg = (double)g[k * ld + t]; cn += gg * gg; }
             cn = sqrt(cn);
         }
 #pragma unroll
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
         double un = 0.0, ud = 1.0;
         for (int stepi = 0; stepi < 3; ++stepi) {
             double s2 = 0.0;
-            if (t < K) for (int k = 0; k < K; ++k) s2 += G[(int64_t)k * KP + t] * wv[k];
+            if (t < K) for (int k = 0; k < K; ++k) s2 += (double)g[k * ld + t] * wv[k];
             double a2 = (t < K) ? s2 * wv[t] : 0.0, b2 = (t < K) ? wv[t] * wv[t] : 0.0, c2 = (t < K) ? s2 * s2 : 0.0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { a2 += __shfl_xor(a2, o); b2 += __shfl_xor(b2, o); c2 += __shfl_xor(c2, o); }

@@ -113,6 +113,46 @@ __device__ __forceinline__ double* part_ptr(double* partials, int slot, int blk)
     return partials + ((int64_t)slot * 2 + blk) * EW_BLOCKS;
 }
 
+// Write-through (`sc1`, agent-scope relaxed) stores and loads of per-workgroup records: what one workgroup publishes for
+// another INSIDE a launch (the last-arrival stopping test of k_pgm_update, the grid barriers of k_ada_tail) without
+// release / acquire fences -- MI355X_MICROARCH.md, "sc0 sc1 stores and loads both sides".
+__device__ __forceinline__ double sc1_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sc1_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// block_sum_store / colsum_store with write-through stores, fold_partials with write-through loads: same trees
+template <int NV>
+__device__ __forceinline__ void block_sum_store_wt(double (&v)[NV], double* dst, int64_t stride, double* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * EW_WAVES + w] = v[i];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) s += scratch[threadIdx.x * EW_WAVES + q];
+        sc1_store(dst + threadIdx.x * stride, s);
+    }
+}
+__device__ __forceinline__ double fold_partials_wt(const double* part) {
+    const int lane = threadIdx.x & 63;
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v += sc1_load(part + i * 64 + lane);
+    return wave_sum(v);
+}
+__device__ __forceinline__ double nanmax(double a, double b);
+__device__ __forceinline__ double wave_nanmax(double v);
+__device__ __forceinline__ double fold_partials_nanmax_wt(const double* part) {
+    const int lane = threadIdx.x & 63;
+    double v = -1.0;
+#pragma unroll
+    for (int i = 0; i < EW_BLOCKS / 64; ++i) v = nanmax(v, sc1_load(part + i * 64 + lane));
+    return wave_nanmax(v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // proximal operators on one row held across 32 lanes          (proxmin/operators.py:20-160)
 // v[c] is component l32 + 32c; ok[c] says whether that component exists (< K).
@@ -306,7 +346,7 @@ struct PgmArgs {
     unsigned ticket_last;    // value the counter shows to the last arrival: launches so far x workgroups per launch - 1
     double e_rel[2];
 };
-__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check);
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt = false);
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
@@ -359,18 +399,22 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     if (mode == 1) return;
     double red[2] = {(double)d2, (double)n2};
     // SL_DIFF2 and SL_NORM2 are adjacent slots: stride between them = 2 * EW_BLOCKS doubles
-    block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
-    if (a.tickets != nullptr) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();                                      // this workgroup's partials (and factors) are out
-            const unsigned old = atomicAdd(a.tickets, 1u);
-            s_last = old == a.ticket_last;
-            if (s_last) __threadfence();                          // ... and everybody else's are in
-        }
-        __syncthreads();
-        if (s_last) pgm_decide_body(a.status, a.partials, a.e_rel, 1);
+    if (a.tickets == nullptr) {
+        block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+        return;
     }
+    // the partial sums go out write-through, the ticket follows them (vmcnt(0): they have landed), and the last arrival
+    // reads everybody's partials write-through as well: no fence (a release here would write back the whole L2 -- the
+    // factors this kernel has just stored -- once per workgroup: 30 us at 4096 x 4096 x 32 instead of 12)
+    block_sum_store_wt<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == a.ticket_last;
+    }
+    __syncthreads();
+    if (s_last) pgm_decide_body(a.status, a.partials, a.e_rel, 1, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,11 +642,25 @@ struct DecideArgs {
     double e_rel[2];
     int check;          // evaluate the convergence test
 };
-__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check) {
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt) {
     double d[2], n[2];
-    for (int j = 0; j < 2; ++j) {
-        d[j] = fold_partials(part_ptr(partials, SL_DIFF2, j), nullptr);
-        n[j] = fold_partials(part_ptr(partials, SL_NORM2, j), nullptr);
+    {   // the four sums' partials are requested together (one memory latency), then folded in fold_partials' order
+        const int lane = threadIdx.x & 63;
+        const double* q[4] = {part_ptr(partials, SL_DIFF2, 0), part_ptr(partials, SL_NORM2, 0), part_ptr(partials, SL_DIFF2, 1), part_ptr(partials, SL_NORM2, 1)};
+        double u[4][EW_BLOCKS / 64];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < EW_BLOCKS / 64; ++i) u[k][i] = wt ? sc1_load(q[k] + i * 64 + lane) : q[k][i * 64 + lane];
+        double r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < EW_BLOCKS / 64; ++i) v += u[k][i];
+            r[k] = wave_sum(v);
+        }
+        d[0] = r[0]; n[0] = r[1]; d[1] = r[2]; n[1] = r[3];
     }
     if (threadIdx.x == 0) {
         int all = 1;
@@ -1235,9 +1293,6 @@ struct GridBar {                 // zeroed at context creation
 };
 __device__ __forceinline__ unsigned gb_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gb_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double sc1_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sc1_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // one thread per workgroup.  e = number of this barrier (1-based over the context's life).
 __device__ __forceinline__ void gb_arrive(GridBar* b, unsigned e, bool census) {
     const unsigned ng = 8, per = gridDim.x / ng, g = blockIdx.x & 7;
@@ -1274,47 +1329,28 @@ __device__ __forceinline__ unsigned gb_wait(GridBar* b, unsigned e, long long gi
         }
     }
 }
-// full barrier for a phase boundary: every wave drains its own (write-through) stores, then one thread arrives and waits
-__device__ __forceinline__ void gb_sync(GridBar* b, unsigned e) {
+// full barrier for a phase boundary: every wave drains its own (write-through) stores, then one thread arrives and waits.
+// After a passed census every workgroup is resident, so the wait is bounded only as a last line of defence (100 ms: a
+// workgroup that died): the launch then marks the chain failed (tail_fault = 2, the host raises) instead of spinning on.
+__device__ __forceinline__ void gb_sync(GridBar* b, unsigned e, DevStatus* st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         gb_arrive(b, e, false);
-        (void)gb_wait(b, e, 0);
+        const unsigned g = blockIdx.x & 7;
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 1; (gb_load(&b->gen[g][0]) >> 1) < e; ++spins) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((spins & 1023u) == 0 && wall_clock64() - t0 > 10000000) {
+                st->tail_fault = 2;
+                st->reason = HALT_ERROR;
+                __threadfence();
+                st->halt = 1;
+                break;
+            }
+        }
     }
     __syncthreads();
-}
-
-// block_sum_store / colsum_store with write-through stores, fold_partials with write-through loads: same trees
-template <int NV>
-__device__ __forceinline__ void block_sum_store_wt(double (&v)[NV], double* dst, int64_t stride, double* scratch) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) scratch[i * EW_WAVES + w] = v[i];
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        double s = 0.0;
-        for (int q = 0; q < EW_WAVES; ++q) s += scratch[threadIdx.x * EW_WAVES + q];
-        sc1_store(dst + threadIdx.x * stride, s);
-    }
-}
-__device__ __forceinline__ double fold_partials_wt(const double* part) {
-    const int lane = threadIdx.x & 63;
-    double v = 0.0;
-#pragma unroll
-    for (int i = 0; i < EW_BLOCKS / 64; ++i) v += sc1_load(part + i * 64 + lane);
-    return wave_sum(v);
-}
-__device__ __forceinline__ double fold_partials_nanmax_wt(const double* part) {
-    const int lane = threadIdx.x & 63;
-    double v = -1.0;
-#pragma unroll
-    for (int i = 0; i < EW_BLOCKS / 64; ++i) v = nanmax(v, sc1_load(part + i * 64 + lane));
-    return wave_nanmax(v);
 }
 
 constexpr int TAIL_NT = 4;       // proximal passes per round (the launch size the chain of kernels settles on)
@@ -1436,7 +1472,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
     int tau0 = 0, tau1 = 0;
     stamp();
     if (any_prox) {
-        gb_sync(bar, ++ep);              // B1: every workgroup's max Psi
+        gb_sync(bar, ++ep, st);              // B1: every workgroup's max Psi
         stamp();
         bool done0 = !a.m.has_prox[0], done1 = !a.m.has_prox[1];
         // max Psi per block (algorithms.py:384), kept in two scalars; gamma and gamma / alpha are re-derived where needed
@@ -1534,7 +1570,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
                 block_sum_store_wt<2 * TAIL_NT>(red, part_ptr(a.m.partials, SL_SUBR0 + 2 * TAIL_NT * (round & 3), j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
             }
             if (round == 0) stamp();
-            gb_sync(bar, ++ep);          // B2: the round's sums
+            gb_sync(bar, ++ep, st);          // B2: the round's sums
             if (round == 0) stamp();
             for (int j = 0; j < 2; ++j) {
                 if (j ? done1 : done0) continue;
@@ -1626,7 +1662,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
         }
     }
     stamp();
-    gb_sync(bar, ++ep);                  // B3: column sums and outer norms of every workgroup
+    gb_sync(bar, ++ep, st);                  // B3: column sums and outer norms of every workgroup
     stamp();
 
     // ---------------- phase D: next step sizes, one (block, component) per workgroup; bookkeeping (k_ada_decide) ------

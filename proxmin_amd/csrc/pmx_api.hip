@@ -575,6 +575,8 @@ static int chain_disable(pmx_ctx* c) {
 static int chain_fault_fallback(pmx_ctx* c, int* again) {
     *again = 0;
     if (!c->hstatus->k1_fault && !c->hstatus->tail_fault) return PMX_OK;
+    if (c->hstatus->tail_fault == 2)         // a barrier inside the fused tail never completed: the iteration is half applied
+        FAIL(PMX_E_HIP, "k_ada_tail: a grid barrier timed out after the census had passed (a workgroup was lost); the factors are not usable");
     int rc = PMX_OK;
     if (c->hstatus->k1_fault) {
         rc = chain_disable(c);
