@@ -30,7 +30,7 @@ CONFIGS = {
     # name: (M, N, K, backend, unity_S, description)
     "cfg2": (4096, 4096, 32, "pgm", False, "Y 4096x4096, K=32, prox_plus, PGM, fp32"),
     "cfg3": (16384, 16384, 64, "adaprox", True, "Y 16384x16384, K=64, adaprox/AMSGrad, prox_plus(A) + prox_unity_plus(S columns)"),
-    "cfg4": (65536, 16384, 128, "adaprox", False, "Y 65536x16384, K=128, adaprox/AMSGrad, prox_plus (BASELINE's 8-GPU case; K > 64 runs the exact-fp32 K1)"),
+    "cfg4": (65536, 16384, 128, "adaprox", False, "Y 65536x16384, K=128, adaprox/AMSGrad, prox_plus (BASELINE's 8-GPU case)"),
     "cfg5": (16384, 16384, 64, "bsdmm", False, "Y 16384x16384, K=64, bSDMM, proxs_g=[prox_plus, prox_soft(1e-3)] per factor"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -75,7 +75,12 @@ def pmc_traffic(config, mode):
     return e
 
 
-def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
+def effective_mode(dev):
+    """Arithmetic the context's K1 really runs in: a split-precision mode falls back to exact fp32 where it has no kernel."""
+    return "f32" if dev.k1_info()["kernel"] == "k_grad_f32" else dev.mode
+
+
+def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kernel=None):
     """Dominant kernel = K1 (fused residual-gradient).  f32: matrix-core bound (exact-fp32 MFMA peak).
     bf16x3: at K=64 the algorithmic intensity 6K/4 = 96 flop/B puts the kernel under the HBM roof
     (96 x 8 TB/s = 768 TFLOP/s < bf16 MFMA peak), so the bound is the single pass over Y."""
@@ -88,6 +93,14 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share):
     bf16_kernel = ((fast if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
                    else "k_grad_bf16<%d>" % kp)
     passes = MFMA_PASSES["f16x2" if bf16_kernel == "k_grad_f16_v8" else "bf16x3"]
+    if kernel == "k_grad_f16_k128":
+        # K = 128: 6K/4 = 192 flop/B, x 3 issued MFMA flops per algorithmic flop: the fp16 matrix pipe, not the pass over Y,
+        # is the roof (192 x 3 x 8 TB/s = 4.6 PFLOP/s of issue would be needed to run at HBM speed)
+        issued = MFMA_PASSES["f16x2"] * tflops
+        return {"kernel": kernel, "bound": "mfma", "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
+                "algorithmic_tflops": tflops, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share,
+                "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC); algorithmic = achieved / 3"}
     if mode == "f32":
         return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
@@ -200,11 +213,10 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
     ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (default for cfg3 / cfg5, the headline), "
-                         "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in "
-                         "fp32, and cfg4, whose K = 128 runs the fp32 kernel anyway)")
+                         "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in fp32)")
     args = ap.parse_args()
     if args.mode is None:
-        args.mode = "f32" if args.config in ("cfg2", "cfg4") else "f16x2"
+        args.mode = "f32" if args.config == "cfg2" else "f16x2"
 
     import torch
     import __graft_entry__ as g
@@ -279,20 +291,20 @@ def main():
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_total,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": MODE_DTYPE[dev.mode if K <= 64 else "f32"], "data": "synthetic",
+        "vs_baseline": None, "dtype": MODE_DTYPE[effective_mode(dev)], "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": MODE_DESC[dev.mode if K <= 64 else "f32"], "parallelism": "1 GPU"},
+                   "mode": MODE_DESC[effective_mode(dev)], "parallelism": "1 GPU"},
         "gflops": flop_per_it * its / 1e9,
         "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
-        "roofline": roofline_entry(dev.mode if K <= 64 else "f32", M, N, K, flop_per_launch, k1_avg_ms, k1_n,
-                                   k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt)),
+        "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
+                                   k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"]),
     }
     info = dev.k1_info()
     if info["chain"]:
         out["roofline"]["kernel"] += "<chain %d>" % info["chain"]     # gA summed in place along workgroup chains
     out["roofline"]["k1_layout"] = info
     if not args.rows:
-        tr = pmc_traffic(args.config, dev.mode if K <= 64 else "f32")
+        tr = pmc_traffic(args.config, effective_mode(dev))
         out["roofline"]["traffic"] = tr["bytes_per_launch"] if tr else None
         out["roofline"]["traffic_unit"] = "HBM bytes per K1 launch, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this build (%s); null: not measured for this build; algorithmic: %d" % (
             "fetch %d + write %d, %s" % (tr["fetch_bytes"], tr["write_bytes"], tr.get("when", "")) if tr else "profiles/k1_traffic.json has no entry for source hash %s" % kernel_source_hash(), M * N * 4)

@@ -18,6 +18,7 @@
 #include "pmx_common.h"
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
+#include "k_grad_k128.hip"
 #include "k_update.hip"
 #include "k_gram.hip"
 
@@ -70,6 +71,9 @@ struct pmx_ctx {
     bool use_small = false;                // small problem (K <= 16, few million entries): k_grad_small in every mode
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
     bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
+    bool k128 = false;                     // mode F16X2, K = 128 at a shape k_grad_f16_k128 takes
+    bool f16_scales = false;               // use_f16 || k128: the K1 kernel needs the factor maxima (absmax) and max|Y|
+    _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
     float ymax = 0.f;                      // max |Y|
     float wmax = 1.f;                      // max(1, max |W|)
@@ -263,6 +267,9 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
     c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K));
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
+    c->k128 = mode == PMX_MODE_F16X2 && !c->use_small && grad_k128_applies(M, N, K);
+    if (c->k128) c->plan = grad_plan_k128(M, N);
+    c->f16_scales = c->use_f16 || c->k128;
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
     if (c->use_f16) {
@@ -273,7 +280,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     }
     int rc = PMX_OK;
     if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
-    if (c->use_f16) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
+    if (c->f16_scales) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
+    for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)M * K, false);
     if (c->use_bf16) {
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
             c->rowsPad[j] = (c->rows[j] + 127) / 128 * 128;
@@ -354,7 +362,7 @@ extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->use_small ? 4 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0));
+    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0)));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -373,7 +381,7 @@ extern "C" int pmx_ctx_sync(pmx_ctx* c) {
 
 // max |Y| for the fp16 path's residual scale (one pass over Y, once)
 static int measure_ymax(pmx_ctx* c) {
-    if (!c->use_f16) return PMX_OK;
+    if (!c->f16_scales) return PMX_OK;
     launch_absmax_pitched(c->Y, c->ldY, c->M, c->N, c->absmax + 512, c->stream);
     HIP_CHECK(hipGetLastError());
     float h[256];
@@ -438,8 +446,8 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
-    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
-        FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in split-bf16 mode needs K = 64, M %% 128 = 0, N %% 256 = 0; create the context with PMX_MODE_F32");
+    if ((c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K)) || c->k128)
+        FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64, M %% 128 = 0, N %% 256 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     HIP_CHECK(hipSetDevice(c->device));
     if (from_host || copy) {
@@ -609,7 +617,31 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
-    if (c->use_bf16) {
+    if (c->k128) {
+        AbsmaxArgs am{};
+        am.X[0] = A; am.X[1] = St;
+        am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+        am.out = c->absmax;
+        am.status = c->dstatus;
+        if (!absmax_fresh) launch_absmax(am, c->stream);
+        SplitAArgs sp{};
+        sp.X = A; sp.count = c->M * c->K; sp.absmax = c->absmax; sp.H = c->A16[0]; sp.L = c->A16[1]; sp.status = c->dstatus;
+        launch_split_a_f16(sp, c->stream);
+        GradK128Args g{};
+        g.Y = c->Y; g.ldY = c->ldY;
+        g.Ah = c->A16[0]; g.Al = c->A16[1]; g.St = St;
+        g.slabA = c->slab[0]; g.slabS = c->slab[1];
+        g.lossPart = c->lossPart;
+        g.status = c->dstatus;
+        g.M = (int)c->M; g.N = (int)c->N;
+        g.RP = c->plan.RP;
+        g.doA = doA; g.doS = doS;
+        g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
+        g.absmax = c->absmax; g.ymax = c->ymax;
+        if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
+        HIP_CHECK(grad_launch_k128(g, c->stream));
+        c->nloss = c->plan.gridX * c->plan.gridY;
+    } else if (c->use_bf16) {
         PresplitArgs ps{};
         ps.X[0] = A; ps.X[1] = St;
         for (int j = 0; j < 2; ++j) { ps.Xp[j] = c->Bp[j]; ps.Xt[j] = c->Bt[j]; ps.rows[j] = c->rows[j]; ps.rowsPad[j] = c->rowsPad[j]; }
@@ -1392,7 +1424,7 @@ static int ada_enqueue_tail(pmx_ctx* c, int t) {
     f.colpart = c->colpart;
     f.check_convergence = p.check_convergence;
     static_assert(EW_BLOCKS == 256, "k_grad_f16_v8 folds 256 partial maxima per factor");
-    f.absmax_out = c->use_f16 ? c->absmax : nullptr;
+    f.absmax_out = c->f16_scales ? c->absmax : nullptr;
     launch_ada_finish(f, c->stream);
     AdaDecideArgs d{};
     d.al = alpha_args(c);
@@ -1465,7 +1497,7 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
     m.check_convergence = p.check_convergence;
     t.prox_max_iter = p.prox_max_iter;
     t.colpart = c->colpart;
-    t.absmax_out = c->use_f16 ? c->absmax : nullptr;
+    t.absmax_out = c->f16_scales ? c->absmax : nullptr;
     t.al = alpha_args(c);
     t.al.use_fixed = p.use_fixed_steps;
     t.al.fixed[0] = (float)p.fixed_alpha[0];

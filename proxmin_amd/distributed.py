@@ -388,10 +388,10 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     k1_avg_ms = float(k1.item())
     nk1 = 2 if backend == "bsdmm" else 1            # bsdmm: two K1 launches of 4 MNK each per iteration
     flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
-    eff_mode = dev.mode if K <= 64 else "f32"      # K > 64 runs the exact-fp32 kernel in either mode
+    info = dev.k1_info()
+    eff_mode = "f32" if info["kernel"] == "k_grad_f32" else dev.mode      # a split mode falls back to fp32 where it has no kernel
     its = args.steps / dt
     ach = (flop_per_it / nk1 * Ml / M) / (k1_avg_ms * 1e-3) / 1e12
-    info = dev.k1_info()
     out = {
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm,
@@ -403,7 +403,11 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         "gflops": flop_per_it * its / 1e9,
         "roofline": ({"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                       "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info} if dev.mode == "f32" or K > 64 else
+                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info} if eff_mode == "f32" else
+                     {"kernel": "k_grad_f16_k128", "bound": "mfma", "achieved": 3.0 * ach, "peak": 2500.0, "unit": "TFLOP/s",
+                      "frac": 3.0 * ach / 2500.0, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
+                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info,
+                      "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC)"} if info["kernel"] == "k_grad_f16_k128" else
                      {"kernel": ((("k_grad_f16_v8" + ("<chain %d>" % info["chain"] if info["chain"] else "") if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
                                  else "k_grad_bf16"), "bound": "hbm", "k1_layout": info,
                       "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,

@@ -17,7 +17,8 @@ from . import _lib
 #   "bf16x3" split-bf16 MFMA with fp32-class accuracy (3-term split for A@S, 2-term for the gradients);
 #            K <= 64, larger K runs the fp32 kernel
 #   "f16x2"  as "bf16x3", but shapes with K = 64, M % 128 = 0, N % 256 = 0 run the two-term fp16 kernel (operands scaled
-#            by powers of two from the factor maxima: 9 instead of 12 MFMA products per multiply-add)
+#            by powers of two from the factor maxima: 9 instead of 12 MFMA products per multiply-add), and so do shapes
+#            with K = 128, M % 128 = 0, N % 128 = 0 (k_grad_f16_k128; no weights there)
 _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
@@ -155,7 +156,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
         return d

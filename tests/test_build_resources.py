@@ -18,6 +18,8 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb0ELb0E": 4,    # 1   the same with one gA slab per column region
     "13k_grad_f16_v8ILb0ELb1ELb0E": 16,   # 5   weighted
     "13k_grad_f16_v8ILb0ELb1ELb1E": 24,   #     weighted, chained
+    "15k_grad_f16_k128": 32,              # 29  two-term fp16 K1 at K = 128: 192 accumulator registers in the consumers
+                                          #     (a handful of reloads per panel in their loop, the rest in the final flush)
     "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)
     "10k_ada_tailILi4E": 0,
     "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   split-bf16 K1 at K = 64

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "adaprox_unity": dict(M=768, N=900, K=24, unity=True, its=9),
     "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512, N % 256 = 0: the fast 16-bit-split kernels / the f32 whole-block kernel
+    "adaprox_k128": dict(M=512, N=640, K=128, unity=False, its=5, modes=("f32", "f16x2")),   # 256 rows per rank: k_grad_f16_k128 in mode f16x2
     "pgm": dict(M=520, N=700, K=12, its=7),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault

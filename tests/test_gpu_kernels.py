@@ -283,12 +283,16 @@ def test_split_bf16_default_kernel_on_many_region_shapes(eng):
             assert out[fast][2] == pytest.approx(out["f32"][2], rel=1e-6)
 
 
+@pytest.mark.parametrize("K", [64, 128])
 @pytest.mark.parametrize("case", ["tiny_factors", "huge_factors", "mixed_magnitudes", "zero_A", "big_Y", "big_weights"])
-def test_fp16_two_term_kernel_operand_scaling(eng, orc, case):
-    """k_grad_f16_v8 scales A, S and the residual by powers of two taken from their maxima so that the fp16 terms stay
-    in the normal range: factors of very different magnitudes (1e-4 .. 1e3, entries spanning eight decades, an all-zero
-    factor, |Y| ~ 1e4, weights up to 50) must still give fp32-class gradients -- no overflow to inf, no flush to zero."""
-    M, N, K = 384, 768, 64
+def test_fp16_two_term_kernel_operand_scaling(eng, orc, case, K):
+    """k_grad_f16_v8 / k_grad_f16_k128 scale A, S and the residual by powers of two taken from their maxima so that the
+    fp16 terms stay in the normal range: factors of very different magnitudes (1e-4 .. 1e3, entries spanning eight decades,
+    an all-zero factor, |Y| ~ 1e4, weights up to 50) must still give fp32-class gradients -- no overflow to inf, no flush
+    to zero."""
+    M, N = 384, 768
+    if K == 128 and case == "big_weights":
+        pytest.skip("k_grad_f16_k128 takes no weights (set_W raises: test_k128_two_term_fp16_kernel)")
     rng = np.random.default_rng(hash(case) % 1000)
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=5)
     W = None
@@ -308,6 +312,7 @@ def test_fp16_two_term_kernel_operand_scaling(eng, orc, case):
     elif case == "big_weights":
         W = (50.0 * rng.random((M, N))).astype(np.float32)
     with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        assert dev.k1_info()["kernel"] == ("k_grad_f16_v8" if K == 64 else "k_grad_f16_k128")
         dev.set_Y(Y)
         if W is not None:
             dev.set_W(W)
@@ -413,6 +418,35 @@ def _subsampled_oracle_gradients(A, S, Yd, rows, cols):
     gA_rows = (A64[rows] @ S64 - Yr) @ S64.T
     gS_cols = A64.T @ (A64 @ S64[:, cols] - Yc)
     return gA_rows, gS_cols
+
+
+@pytest.mark.parametrize("M,N", [(128, 128), (2048, 1024), (1024, 4096), (3200, 2176), (8192, 384), (8320, 16384)])
+def test_k128_two_term_fp16_kernel(eng, orc, M, N):
+    """K = 128 in mode f16x2 (k_grad_f16_k128: BASELINE's 8-GPU case, 8192-row shards of 65536 x 16384): one region, many
+    regions, row regions whose last one is short (3200 rows = 25 panels over 13 regions of 2; 8320 = 65 panels), more
+    workgroups than CUs; gradients and loss against the fp64 oracle at the tolerance of the fp32 kernel.  Shapes it does
+    not take (ragged M or N) run the exact-fp32 kernel, and a weighted likelihood is refused loudly."""
+    Y, A, S = orc.synthetic_problem(M, N, 128, np.float32, seed=M + N)
+    with eng.DeviceNMF(M, N, 128, mode="f16x2") as dev:
+        info = dev.k1_info()
+        assert info["kernel"] == "k_grad_f16_k128" and info["col_regions"] == N // 128, info
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+        gA2, gS2 = dev.grad()
+        with pytest.raises(NotImplementedError):
+            dev.set_W(np.ones((M, N), np.float32))
+    assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)          # fixed summation order: bitwise repeatable
+    A64, S64, Y64 = (x.astype(np.float64) for x in (A, S, Y))
+    rA, rS = orc.residual_gradients(A64, S64, Y64)
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
+    if M == 128:
+        for Mr, Nr in ((136, 128), (128, 192)):
+            with eng.DeviceNMF(Mr, Nr, 128, mode="f16x2") as dev:
+                assert dev.k1_info()["kernel"] == "k_grad_f32"
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])

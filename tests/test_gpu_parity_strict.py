@@ -234,26 +234,34 @@ def test_full_size_cfg5_against_the_oracle(orc):
     assert fA == 1.0 and fS == 1.0, (fA, fS, wA, wS)
 
 
-def test_full_size_cfg4_rows_of_one_rank_against_the_oracle(orc):
+_CFG4_ORACLE = {}
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+def test_full_size_cfg4_rows_of_one_rank_against_the_oracle(orc, mode):
     """BASELINE cfg4's per-GPU share (8192 of its 65536 rows x 16384, K = 128, adaprox / AMSGrad, prox_plus): 2 iterations
-    on one GPU against the fp64 oracle (K = 128 runs the exact-fp32 K1 in every mode)."""
+    on one GPU against the fp64 oracle, in the exact-fp32 mode and in the two-term fp16 mode (k_grad_f16_k128)."""
     import torch
     import bench
     from proxmin_amd.engine import DeviceNMF
     _, N, K, backend, unity, _ = bench.CONFIGS["cfg4"]
     M = 8192
     Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 77, torch.device("cuda", 0))
-    with DeviceNMF(M, N, K, mode="f32") as dev:
+    with DeviceNMF(M, N, K, mode=mode) as dev:
+        assert dev.k1_info()["kernel"] == ("k_grad_f32" if mode == "f32" else "k_grad_f16_k128")
         dev.set_Y_device(Yd.data_ptr(), ld=N, copy=False, keepalive=Yd)
         dev.set_factors(A0, S0)
         run = bench.begin_solver(dev, backend, unity)
         assert run(2).iterations == 2
         A, S = dev.get_factors()
-    Y64 = Yd.cpu().numpy().astype(np.float64)
+    if not _CFG4_ORACLE:
+        Y64 = Yd.cpu().numpy().astype(np.float64)
+        Ao, So = A0.astype(np.float64), S0.astype(np.float64)
+        orc.adaprox_nmf(Y64, Ao, So, ("plus",), ("plus",), scheme="amsgrad", max_iter=2, e_rel=1e-3, check_convergence=False)
+        _CFG4_ORACLE["A"], _CFG4_ORACLE["S"] = Ao, So
     del Yd
-    Ao, So = A0.astype(np.float64), S0.astype(np.float64)
-    orc.adaprox_nmf(Y64, Ao, So, ("plus",), ("plus",), scheme="amsgrad", max_iter=2, e_rel=1e-3, check_convergence=False)
+    Ao, So = _CFG4_ORACLE["A"], _CFG4_ORACLE["S"]
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
-    REPORT["cfg4 share 8192x16384x128 f32, 2 iterations vs fp64 oracle"] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
+    REPORT["cfg4 share 8192x16384x128 %s, 2 iterations vs fp64 oracle" % mode] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
     assert fA >= 0.9999 and fS >= 0.9999, (fA, fS)
