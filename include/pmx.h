@@ -43,8 +43,9 @@ enum {
     /* (1 was a plain-bf16 mode -- Y rounded to bf16 in HBM -- that was never built: 2^-9 relative error on Y cannot meet
        the path's rtol 1e-4; the split modes below keep Y in fp32)                                                       */
     PMX_MODE_BF16X3 = 2, /* Y fp32 in HBM, operands split into bf16 terms (3 for A@S, 2 for the gradients), fp32 accumulate */
-    PMX_MODE_F16X2 = 3   /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes run the two-term fp16 kernel
-                            (power-of-two operand scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
+    PMX_MODE_F16X2 = 3   /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes and K = 128 / M % 128 = 0 / N % 128 = 0
+                            shapes (the latter without weights) run the two-term fp16 kernels (power-of-two operand
+                            scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */
@@ -160,7 +161,8 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
 
 /* How the fused residual-gradient kernel (K1) of this context is laid out -- for tests and bench.py, which must be able
  * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
- * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small, 5 two-term fp16 at K = 128
+ * k_grad_f16_k128), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
  * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now. */
