@@ -359,33 +359,41 @@ GradPlan grad_plan_f32(int64_t M, int64_t N, int64_t K) {
 // k_grad_small: the fused residual-gradient pass for SMALL problems (K <= 16, a few million entries of Y -- the
 // reference's own examples are 100 x 50 x 3 and 200 x 1000 x 5).  The matrix-core kernels above are all latency at that
 // size (k_grad_f32<32> on a ragged 200 x 1000 x 5: 54 us of staging, barriers and guarded loads for 6 MFLOP); here a
-// workgroup of 256 threads owns a 32 x 256 tile of Y, thread = column:
-//   phase 1  r[m] = A[m,:] . S[:,n] - Y[m,n] for the tile's 32 rows (A tile broadcast from LDS, S column in registers),
+// workgroup of 256 threads owns a 16 x 256 tile of Y, thread = column:
+//   phase 1  r[m] = A[m,:] . S[:,n] - Y[m,n] for the tile's 16 rows (A tile broadcast from LDS, S column in registers),
 //            gS[:,n] += A[m,:] r  in registers, r parked in LDS;
-//   phase 2  gA[m,:] over the tile's 256 columns from the parked r and the S tile (thread = (row, component)).
+//   phase 2  gA[m,:] over the tile's 256 columns from the parked r and the S tile (16 lanes per (row, component)).
 // Plain fp32 FMAs in a fixed order; same outputs as the other K1s: one gSt slab per row tile, one gA slab per column
 // tile (summed in a fixed order by the update kernels), a loss partial per workgroup.  Weights W as a run-time branch.
 // ------------------------------------------------------------------------------------------------
-constexpr int SG_ROWS = 32, SG_COLS = 256, SG_KMAX = 16;
-__global__ __launch_bounds__(SG_COLS) void k_grad_small(GradArgs a) {
-    __shared__ float As[SG_ROWS][SG_KMAX + 1];
-    __shared__ float Ss[SG_KMAX][SG_COLS + 1];
-    __shared__ float Rs[SG_ROWS][SG_COLS + 1];
-    __shared__ float lred[SG_COLS / 64];
-    if (chain_halted(a.status)) return;
+constexpr int SG_ROWS = 16, SG_COLS = 256, SG_KMAX = 16;
+// shared memory of one tile, carved out of a caller-provided pool (k_small_front shares the pool with the step-rule role)
+template <int KM>
+struct SmallTileSmem {
+    float As[SG_ROWS][KM + 1];
+    float Ss[KM][SG_COLS + 1];
+    float Rs[SG_ROWS][SG_COLS + 1];
+    float lred[SG_COLS / 64];
+};
+// tile (bx, by) of a (gx column tiles) x (row tiles) grid; KM = 8 or 16 >= K: the loops over components are unrolled to KM
+template <int KM>
+__device__ __forceinline__ void grad_small_tile(const GradArgs& a, SmallTileSmem<KM>& sm, int bx, int by, int gx) {
     const int tid = threadIdx.x, K = a.K;
-    const int row0 = blockIdx.y * SG_ROWS, col0 = blockIdx.x * SG_COLS;
+    const int row0 = by * SG_ROWS, col0 = bx * SG_COLS;
     const int n = col0 + tid;
     const bool nval = n < a.N;
-    float sv[SG_KMAX];
+    // the halt flag is requested together with the operands and looked at when they are there: at this size a dependent
+    // round trip to memory (~1.3 us) is a sixth of the kernel
+    const int halted = __builtin_nontemporal_load(&a.status->halt);
+    float sv[KM];
 #pragma unroll
-    for (int k = 0; k < SG_KMAX; ++k) {
+    for (int k = 0; k < KM; ++k) {
         sv[k] = (nval && k < K) ? a.St[(int64_t)n * K + k] : 0.f;
-        Ss[k][tid] = sv[k];
+        sm.Ss[k][tid] = sv[k];
     }
-    for (int e = tid; e < SG_ROWS * SG_KMAX; e += SG_COLS) {
-        const int r = e / SG_KMAX, k = e - r * SG_KMAX;
-        As[r][k] = (row0 + r < a.M && k < K) ? a.A[(int64_t)(row0 + r) * K + k] : 0.f;
+    for (int e = tid; e < SG_ROWS * KM; e += SG_COLS) {
+        const int r = e / KM, k = e - r * KM;
+        sm.As[r][k] = (row0 + r < a.M && k < K) ? a.A[(int64_t)(row0 + r) * K + k] : 0.f;
     }
     float yv[SG_ROWS], wv[SG_ROWS];
     const bool hasw = a.W != nullptr;
@@ -395,45 +403,59 @@ __global__ __launch_bounds__(SG_COLS) void k_grad_small(GradArgs a) {
         yv[r] = ok ? a.Y[(int64_t)(row0 + r) * a.ldY + n] : 0.f;
         wv[r] = (ok && hasw) ? a.W[(int64_t)(row0 + r) * a.ldW + n] : 1.f;
     }
+    if (halted) return;                      // (uniform; nothing has been written yet)
     __syncthreads();
-    float gs[SG_KMAX];
+    float gs[KM];
 #pragma unroll
-    for (int k = 0; k < SG_KMAX; ++k) gs[k] = 0.f;
+    for (int k = 0; k < KM; ++k) gs[k] = 0.f;
     float loss = 0.f;
 #pragma unroll
     for (int r = 0; r < SG_ROWS; ++r) {
         float p = 0.f;
 #pragma unroll
-        for (int k = 0; k < SG_KMAX; ++k) p += As[r][k] * sv[k];
+        for (int k = 0; k < KM; ++k) p += sm.As[r][k] * sv[k];
         float rr = (nval && row0 + r < a.M) ? p - yv[r] : 0.f;
         loss += wv[r] * (rr * rr);
         rr *= wv[r];
-        Rs[r][tid] = rr;
+        sm.Rs[r][tid] = rr;
 #pragma unroll
-        for (int k = 0; k < SG_KMAX; ++k) gs[k] += As[r][k] * rr;
+        for (int k = 0; k < KM; ++k) gs[k] += sm.As[r][k] * rr;
     }
     if (a.doS && nval) {
-        float* dst = a.slabS + ((int64_t)blockIdx.y * a.N + n) * K;
+        float* dst = a.slabS + ((int64_t)by * a.N + n) * K;
         for (int k = 0; k < K; ++k) dst[k] = gs[k];
     }
     __syncthreads();
     if (a.doA & 1) {
-        for (int e = tid; e < SG_ROWS * K; e += SG_COLS) {
-            const int r = e / K, k = e - r * K;
+        // gA[m, k] = sum over the tile's 256 columns of r[m, c] S[k, c]: 16 lanes per output (columns sub, sub + 16, ..),
+        // 16 outputs per pass of the workgroup, fixed order within a lane and across the 16 lanes
+        const int sub = tid & 15, og = tid >> 4;
+        for (int o0 = 0; o0 < SG_ROWS * K; o0 += SG_COLS / 16) {
+            const int o = o0 + og;
+            const bool oval = o < SG_ROWS * K;
+            const int r = oval ? o / K : 0, k = oval ? o - r * K : 0;
             float s = 0.f;
-            for (int c = 0; c < SG_COLS; ++c) s += Rs[r][c] * Ss[k][c];
-            if (row0 + r < a.M) a.slabA[((int64_t)blockIdx.x * a.M + row0 + r) * K + k] = s;
+#pragma unroll
+            for (int c = 0; c < SG_COLS / 16; ++c) s += sm.Rs[r][sub + 16 * c] * sm.Ss[k][sub + 16 * c];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (oval && sub == 0 && row0 + r < a.M) a.slabA[((int64_t)bx * a.M + row0 + r) * K + k] = s;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
-    if ((tid & 63) == 0) lred[tid >> 6] = loss;
+    if ((tid & 63) == 0) sm.lred[tid >> 6] = loss;
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
-        for (int i = 0; i < SG_COLS / 64; ++i) s += (double)lred[i];
-        a.lossPart[blockIdx.y * gridDim.x + blockIdx.x] = s;
+        for (int i = 0; i < SG_COLS / 64; ++i) s += (double)sm.lred[i];
+        a.lossPart[by * gx + bx] = s;
     }
+}
+template <int KM>
+__global__ __launch_bounds__(SG_COLS) void k_grad_small(GradArgs a) {
+    __shared__ SmallTileSmem<KM> sm;
+    grad_small_tile<KM>(a, sm, blockIdx.x, blockIdx.y, gridDim.x);
 }
 // the small-problem kernel takes: K <= 16 and a Y of at most 1 M entries (at 2000 x 2000 x 16 the matrix-core kernels are
 // ahead again: 163 against 183 us per pgm iteration)
@@ -456,7 +478,8 @@ GradPlan grad_plan_small(int64_t M, int64_t N, int64_t K) {
     return p;
 }
 hipError_t grad_launch_small(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_grad_small, dim3(p.gridY, p.gridX), dim3(SG_COLS), 0, stream, a);
+    if (a.K <= 8) hipLaunchKernelGGL(k_grad_small<8>, dim3(p.gridY, p.gridX), dim3(SG_COLS), 0, stream, a);
+    else hipLaunchKernelGGL(k_grad_small<16>, dim3(p.gridY, p.gridX), dim3(SG_COLS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -119,43 +119,15 @@ struct EigArgs {
 };
 // one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
-__global__ __launch_bounds__(256) void k_eig(EigArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+//
+// eig_solve_block: warm-started power iteration + checks + exact fallback, by a whole workgroup of 256 threads.
+// G: fp64 Gram matrix (row stride GS; memory or LDS), g: its fp32 copy in LDS [KP][KP+1] (filled by the caller; the first
+// barrier inside publishes it).
+__device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, const double* G, const int GS, float* g) {
     __shared__ double vec[MAXK], wv[MAXK], red[8], eigred2[4];
     DevStatus* st = a.status;
-    if (chain_halted(st)) return;
-    const int f = blockIdx.x;
-    if (!a.want[f]) return;
     const int KP = a.KP, K = a.K, ld = KP + 1;
-    const double* G = a.G + (int64_t)f * KP * KP;
     const int t = threadIdx.x;
-    if (a.X[f] != nullptr) {                 // K <= 16: thread (i, j) = (t / 16, t % 16) owns G[i][j]; rows staged 256 at a time
-        __shared__ float xs[256][17];
-        const float* X = a.X[f];
-        const int64_t rows = a.rows[f];
-        const int gi = t >> 4, gj = t & 15;
-        double acc = 0.0;
-        for (int64_t r0 = 0; r0 < rows; r0 += 256) {
-            __syncthreads();
-            for (int e = t; e < 256 * K; e += 256) {
-                const int rr = e / K, k = e - rr * K;
-                xs[rr][k] = r0 + rr < rows ? X[(r0 + rr) * K + k] : 0.f;
-            }
-            __syncthreads();
-            if (gi < K && gj < K) {
-                float part = 0.f;            // fp32 products and sum over one tile of rows, fp64 across tiles (as k_gram_*)
-                for (int rr = 0; rr < 256; ++rr) part += xs[rr][gi] * xs[rr][gj];
-                acc += (double)part;
-            }
-        }
-        double* Gw = a.Gw + (int64_t)f * KP * KP;
-        for (int e = t; e < KP * KP; e += 256) Gw[e] = 0.0;
-        __syncthreads();
-        if (gi < K && gj < K) Gw[gi * KP + gj] = acc;
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (int e = t; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
     // warm start (all-ones on the first call: the Perron vector of a non-negative Gram matrix is positive)
     {
         double v0 = (t < K) ? st->eigvec[f][t] : 0.0;
@@ -198,7 +170,7 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     // Rayleigh quotient in fp64 with the fp64 Gram matrix (error quadratic in the eigenvector error)
     if (t < K) {
         double s = 0.0;
-        for (int k = 0; k < K; ++k) s += G[t * KP + k] * vec[k];
+        for (int k = 0; k < K; ++k) s += G[t * GS + k] * vec[k];
         wv[t] = s;
     }
     __syncthreads();
@@ -280,7 +252,7 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
             double w = 0.0;
             if (t < K) {
                 const double* qj = Q + (int64_t)j * KP;
-                for (int k = 0; k < K; ++k) w += G[(int64_t)k * KP + t] * qj[k];
+                for (int k = 0; k < K; ++k) w += G[(int64_t)k * GS + t] * qj[k];
                 wv[t] = w;
             }
             __syncthreads();
@@ -367,6 +339,205 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     if (t < K) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vec[t] : 1.0;
 }
 
+__global__ __launch_bounds__(256) void k_eig(EigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+    if (chain_halted(a.status)) return;
+    const int f = blockIdx.x;
+    if (!a.want[f]) return;
+    const int KP = a.KP, ld = KP + 1;
+    const double* G = a.G + (int64_t)f * KP * KP;
+    for (int e = threadIdx.x; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
+    eig_solve_block(a, f, G, KP, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_eig_small<KM>: the whole step rule of a SMALL factor (K <= KM <= 16, a few thousand rows) in one launch and, as far
+// as possible, one trip to memory.  At this size nothing is bound by arithmetic or bandwidth: a dependent round trip to
+// memory costs ~3000 cycles (1.3 us) and a __syncthreads() that follows a global store waits for its acknowledgement.  So:
+//   * everything the kernel will read -- the halt flag, the previous eigenvector, the factor's rows (thread t: rows t,
+//     t + 256, ...; four per batch) -- is requested up front, before the first use of any of it;
+//   * the Gram matrix is folded in fp64 through LDS and STAYS there; the copy in memory (for pmx_* readers) is written
+//     last, and the barriers on the way are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier: no store is waited for);
+//   * the solve runs in ONE wave: entry t of a vector in lane t, sums over the 16 lanes of a DPP row by row_shr shifts
+//     (~10 cycles a level, a ds_bpermute shuffle > 100), broadcasts by v_readlane; same operations as eig_solve_block,
+//     which the rare call that needs the exact solver (clustered or crossing eigenvalues) takes from the top.
+// 200 x 1000 x 5: 25 us (Gram prologue inside k_eig, round 2 start) -> 7 us.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+}
+template <int KM>
+__global__ __launch_bounds__(256) void k_eig_small(EigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+    constexpr int NP = KM * (KM + 1) / 2;
+    __shared__ double Gd[16 * 16];
+    constexpr int CH = 32;                   // entries of the triangle folded per round
+    __shared__ float pbuf[CH][256 + 1];
+    __shared__ int s_accepted;
+    DevStatus* st = a.status;
+    const int f = blockIdx.x;
+    if (!a.want[f]) return;
+    const int KP = a.KP, K = a.K, ld = KP + 1;
+    const int t = threadIdx.x;
+    const float* X = a.X[f];
+    const int64_t rows = a.rows[f];
+    // ---- requests first ------------------------------------------------------------------------------------------
+    const int halted = __builtin_nontemporal_load(&st->halt);
+    const double ev0 = t < K ? st->eigvec[f][t] : 0.0;
+    float acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+    for (int64_t r0 = t; r0 < rows; r0 += 1024) {
+        float x[4][KM];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + 256 * u;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) x[u][k] = (r < rows && k < K) ? X[r * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int idx = 0;
+#pragma unroll
+            for (int i = 0; i < KM; ++i)
+#pragma unroll
+                for (int j = i; j < KM; ++j) acc[idx++] += x[u][i] * x[u][j];   // fp32 over a thread's <= 32 rows, fp64 from here on
+        }
+    }
+    if (halted) return;                      // (uniform: one flag)
+    // ---- Gram matrix: the threads' partial sums go through LDS, 32 entries of the triangle per round: 16 lanes per entry
+    //      add 16 partials each in fp64, a DPP row reduction adds the 16 lanes (fp64 shuffles over 64 lanes cost 8.6 us
+    //      here, this 1 us); the matrix stays in LDS -----------------------------------------------------------------------
+    for (int e = t; e < KP * ld; e += 256) g[e] = 0.f;
+    for (int e = t; e < 16 * 16; e += 256) Gd[e] = 0.0;
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += CH) {
+        if (c0 > 0) lds_barrier();
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < NP) pbuf[i][t] = acc[c0 + i];
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < CH / 16; ++h) {
+            const int e = h * 16 + (t >> 4), part = t & 15;
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += (double)pbuf[e][part + 16 * q];
+#define PMX_ROW_SHR(n)                                                                                         \
+            {                                                                                                  \
+                const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + n, 0xf, 0xf, true);  \
+                const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + n, 0xf, 0xf, true);  \
+                v += __hiloint2double(hi_, lo_);                                                               \
+            }
+            PMX_ROW_SHR(1) PMX_ROW_SHR(2) PMX_ROW_SHR(4) PMX_ROW_SHR(8)
+#undef PMX_ROW_SHR
+            const int idx = c0 + e;
+            if (part == 15 && idx < NP) {
+                int i = 0, rem = idx;        // idx -> (i, j) of the upper triangle, row-major
+                while (rem >= KM - i) { rem -= KM - i; ++i; }
+                const int j = i + rem;
+                Gd[i * 16 + j] = v;
+                Gd[j * 16 + i] = v;
+                g[i * ld + j] = (float)v;
+                g[j * ld + i] = (float)v;
+            }
+        }
+    }
+    lds_barrier();
+    const double* G = Gd;
+    const int GS = 16;
+    if (t < 64) {
+        const bool in = t < K;
+        const int tt = in ? t : 0;
+    auto wsum = [&](double v) {
+#define PMX_ROW_SHR(n)                                                                                         \
+        {                                                                                              \
+            const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + n, 0xf, 0xf, true); \
+            const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + n, 0xf, 0xf, true); \
+            v += __hiloint2double(hi_, lo_);                                                           \
+        }
+        PMX_ROW_SHR(1) PMX_ROW_SHR(2) PMX_ROW_SHR(4) PMX_ROW_SHR(8)
+#undef PMX_ROW_SHR
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 15), __builtin_amdgcn_readlane(__double2loint(v), 15));
+    };
+    auto bcast = [&](double v, int k) {                   // k uniform
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+    };
+    const double v0 = in ? ev0 : 0.0;
+    const double n0 = sqrt(wsum(v0 * v0));
+    double vr = in ? ((n0 > 0.0 && n0 == n0 && n0 < 1e300) ? v0 / n0 : 1.0 / sqrt((double)K)) : 0.0;
+    double lam_prev = -1.0, lam = 0.0;
+    int it = 0, calm = 0;
+    for (; it < a.max_iter; ++it) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) sacc += g[tt * ld + k] * (float)bcast(vr, k);    // (entries >= K: exact zeros; unrolled so that the LDS reads go out together)
+        const double w = in ? (double)sacc : 0.0;
+        const double nrm = sqrt(wsum(w * w));
+        lam = nrm;
+        if (nrm == 0.0 || !(nrm == nrm)) break;
+        vr = in ? w / nrm : 0.0;
+        if (fabs(lam - lam_prev) <= 1e-7 * lam) {
+            if (++calm >= 2) { ++it; break; }
+        } else calm = 0;
+        lam_prev = lam;
+    }
+    double gv = 0.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) gv += G[tt * GS + k] * bcast(vr, k);
+    if (!in) gv = 0.0;
+    const double rq_n = wsum(gv * vr), rq_d = wsum(vr * vr);
+    double l = (rq_d > 0.0) ? rq_n / rq_d : lam;
+    if (!(lam == lam)) l = lam;
+    const double r1 = in ? gv - l * vr : 0.0;
+    const double resid = sqrt(wsum(r1 * r1) / (rq_d > 0.0 ? rq_d : 1.0));
+    double cn = 0.0;
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { const double gg = (double)g[k * ld + t]; cn += gg * gg; }
+        cn = sqrt(cn);
+    }
+    double probe = 0.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) probe = fmax(probe, bcast(cn, k));
+    double w2 = in ? 1.0 + 0.37 * (double)((t * 7) % 5) - 0.61 * (double)(t & 1) : 0.0;
+    double un = 0.0, ud = 1.0;
+    for (int stepi = 0; stepi < 3; ++stepi) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) s2 += (double)g[k * ld + tt] * bcast(w2, k);
+        if (!in) s2 = 0.0;
+        un = wsum(s2 * w2);
+        ud = wsum(w2 * w2);
+        const double nn = sqrt(wsum(s2 * s2));
+        w2 = in ? (nn > 0.0 ? s2 / nn : 0.0) : 0.0;
+    }
+    if (ud > 0.0) probe = fmax(probe, un / ud);
+    const bool not_dominant = probe > l * (1.0 + 1e-5);
+    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant);
+    if (!need_exact) {
+        if (t == 0) {
+            st->lam[f] = l;
+            st->step[1 - f] = a.scale / l;
+            st->eig_iters[f] = it;
+        }
+        if (in) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vr : 1.0;
+    }
+        if (t == 0) s_accepted = !need_exact;
+    }
+    lds_barrier();
+    {   // the copy in memory, for whoever reads G later (row-sharded drivers, tests): nobody in this launch waits for it
+        double* Gw = a.Gw + (int64_t)f * KP * KP;
+        for (int e = t; e < KP * KP; e += 256) {
+            const int i = e / KP, j = e % KP;
+            Gw[e] = (i < K && j < K) ? Gd[i * 16 + j] : 0.0;
+        }
+    }
+    if (s_accepted) return;
+    eig_solve_block(a, f, G, GS, g);
+}
+
 void launch_gram(const GramArgs& a, int KP, hipStream_t s) {
     dim3 grid(GRAM_BLOCKS, 2);
     if (KP == 32) hipLaunchKernelGGL(k_gram_partial<32>, grid, dim3(GRAM_THREADS), 0, s, a);
@@ -378,6 +549,11 @@ void launch_gram_reduce(const GramReduceArgs& a, hipStream_t s) {
 }
 hipError_t launch_eig(const EigArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * a.KP * (a.KP + 1);
+    if (a.X[0] != nullptr) {                 // small factors: Gram + solve in one launch
+        if (a.K <= 8) hipLaunchKernelGGL(k_eig_small<8>, dim3(2), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(k_eig_small<16>, dim3(2), dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_eig, dim3(2), dim3(256), lds, s, a);

@@ -343,7 +343,11 @@ struct PgmArgs {
     // this launch folds all partials in the usual fixed order and decides.  tickets == nullptr: the caller launches
     // k_pgm_decide itself (row-sharded runs, split iterations).
     unsigned* tickets;
-    unsigned ticket_last;    // value the counter shows to the last arrival: launches so far x workgroups per launch - 1
+    unsigned ticket_last;    // value the counter shows to the last arrival: tickets drawn by all launches so far, this one included, - 1
+    int nbx;                 // workgroups per block to launch (0: EW_BLOCKS).  Row r belongs to half-wave r mod 8192 of the full
+                             // grid, so factors of <= 8192 rows need only ceil(rows / 32) workgroups; the others would
+                             // contribute exact zeros to the partial sums (their entries already hold zeros) and one ticket
+                             // each -- 512 atomics on one address are 5 us of a small problem's 13 us update
     double e_rel[2];
 };
 __device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt = false);
@@ -351,13 +355,15 @@ template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
     __shared__ int s_last;
-    if (chain_halted(a.status)) return;
     const int j = blockIdx.y;
+    // (the halt flag and the step size travel together: one round trip to memory instead of two)
+    const int halted = __builtin_nontemporal_load(&a.status->halt);
+    const float s = (float)a.status->step[j];
+    if (halted) return;
     if (a.mode[j] == 3) return;
     const int mode = a.mode[j];
     const int64_t rows = a.rows[j];
     const int K = a.K;
-    const float s = (float)a.status->step[j];
     const ProxSeq& px = a.prox[j];
     float* X = a.X[j];
     float* Xe = a.Xe[j];
@@ -2033,7 +2039,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
 
 void launch_fold(const FoldArgs& a, int nblocks_y, hipStream_t s) { DISPATCH_NC(a.K, k_fold, dim3(EW_BLOCKS, nblocks_y), s, a); }
 void launch_prox_apply(const ProxArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_prox_apply, dim3(EW_BLOCKS), s, a); }
-void launch_pgm_update(const PgmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pgm_update, dim3(EW_BLOCKS, 2), s, a); }
+void launch_pgm_update(const PgmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_pgm_update, dim3(a.nbx > 0 ? a.nbx : EW_BLOCKS, 2), s, a); }
 void launch_bb_reduce(const BBArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bb_reduce, dim3(EW_BLOCKS, 2), s, a); }
 void launch_bb_step(const BBStepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bb_step, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bt_update(const BtArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bt_update, dim3(EW_BLOCKS, 2), s, a); }

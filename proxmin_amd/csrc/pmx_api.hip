@@ -94,7 +94,7 @@ struct pmx_ctx {
     GridBar* gridbar = nullptr;            // its barrier state
     long long* tailprof = nullptr;         // PMX_TAIL_PROF=1: phase time stamps of the last fused tail
     unsigned* tickets = nullptr;           // pgm: arrival counter of the update kernel's last-workgroup stopping test
-    unsigned ticketLaunches = 0;           // update launches that took tickets so far
+    unsigned ticketLaunches = 0;           // tickets drawn by the update launches so far
     int tailFaults = 0;
     float* slab[2] = {nullptr, nullptr};
     const float* W = nullptr;              // weights of the likelihood (nullptr: W == 1), nmf.py:13-41
@@ -1092,12 +1092,17 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     u.accelerated = p.accelerated;
     u.omega_next = next_omega(c);
     // the stopping test (algorithms.py:130-135) is made by the last of the update kernel's 2 x EW_BLOCKS workgroups
-    if (c->ticketLaunches >= (1u << 22)) {
+    if (c->ticketLaunches >= (1u << 30)) {
         HIP_CHECK(hipMemsetAsync(c->tickets, 0, sizeof(unsigned), c->stream));
         c->ticketLaunches = 0;
     }
     u.tickets = c->tickets;
-    u.ticket_last = (++c->ticketLaunches) * (2u * EW_BLOCKS) - 1u;
+    {
+        const int64_t rmax = c->rows[0] > c->rows[1] ? c->rows[0] : c->rows[1];
+        u.nbx = rmax <= (int64_t)EW_BLOCKS * (EW_THREADS / 32) ? (int)((rmax + EW_THREADS / 32 - 1) / (EW_THREADS / 32)) : EW_BLOCKS;
+        c->ticketLaunches += 2u * (unsigned)u.nbx;       // tickets drawn so far
+        u.ticket_last = c->ticketLaunches - 1u;
+    }
     u.e_rel[0] = p.e_rel[0]; u.e_rel[1] = p.e_rel[1];
     launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
     HIP_CHECK(hipGetLastError());
