@@ -22,7 +22,7 @@ def eng():
     return engine
 
 
-SHAPES = [(33, 47, 3), (64, 96, 8), (128, 128, 32), (200, 1000, 5), (257, 513, 33), (300, 260, 64),
+SHAPES = [(33, 47, 3), (64, 96, 8), (100, 300, 12), (513, 700, 16), (128, 128, 32), (200, 1000, 5), (257, 513, 33), (300, 260, 64),
           (1024, 640, 64), (384, 1100, 100), (512, 512, 128), (4096, 4096, 32)]
 
 
@@ -85,7 +85,7 @@ def test_gradient_is_transpose_sensitive(eng, orc, mode):
     np.testing.assert_allclose(gS, rS, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 96, 8), (300, 260, 64), (2048, 1024, 128), (1000, 3000, 5)])
+@pytest.mark.parametrize("M,N,K", [(64, 96, 8), (120, 500, 12), (4000, 200, 16), (8192, 40, 9), (300, 260, 64), (2048, 1024, 128), (1000, 3000, 5)])
 def test_step_rules_match_oracle(eng, orc, M, N, K):
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=3)
     with eng.DeviceNMF(M, N, K) as dev:
@@ -327,7 +327,7 @@ def test_fp16_two_term_kernel_operand_scaling(eng, orc, case, K):
     assert loss == pytest.approx(orc.half_sq_residual(*x64), rel=2e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(33, 47, 3), (257, 513, 33), (1024, 640, 64), (1024, 768, 64), (2304, 4096, 64), (384, 1100, 100), (512, 512, 128)])
+@pytest.mark.parametrize("M,N,K", [(33, 47, 3), (150, 333, 11), (257, 513, 33), (1024, 640, 64), (1024, 768, 64), (2304, 4096, 64), (384, 1100, 100), (512, 512, 128)])
 def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
     """D = W (A S - Y), loss = 1/2 sum W (Y - A S)^2 (nmf.py:13-41) with an M x N weight array incl. zero (masked)
     entries, ragged and whole-block shapes, in both arithmetic modes (split-bf16: the shapes of its default kernel)."""

@@ -178,6 +178,9 @@ CONFIGS = [
     ("adam", dict(scheme="adam"), 777, 1290, 64, False),
     ("bsdmm", dict(), 1024, 1024, 64, False),
     ("amsgrad_k128", dict(scheme="amsgrad"), 2048, 1024, 128, False),
+    ("pgm", dict(), 300, 700, 12, False),                            # small-problem kernels with K > 8 (k_grad_small<16>, k_eig_small<16>)
+    ("fista", dict(accelerated=True), 1500, 90, 16, False),
+    ("amsgrad_unity", dict(scheme="amsgrad"), 240, 900, 10, True),
 ]
 
 
