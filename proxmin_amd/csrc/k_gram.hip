@@ -14,7 +14,9 @@
 
 constexpr int GRAM_BLOCKS = 128;
 constexpr int GRAM_THREADS = 256;
-constexpr int GRAM_CHUNK = 32;     // rows staged per LDS tile
+// rows staged per LDS tile: all of a tile's requests go out before the first is used (a dependent round trip to memory
+// is ~1.3 us; with 32-row tiles a 128-row share took four of them and the kernel 18 us at 16384 x 64, now 7)
+template <int KP> constexpr int gram_chunk() { return KP == 128 ? 64 : 128; }
 
 struct GramArgs {
     const float* X[2];     // factor f: 0 = A (M x K), 1 = St (N x K)
@@ -28,6 +30,7 @@ struct GramArgs {
 template <int KP>
 __global__ __launch_bounds__(GRAM_THREADS) void k_gram_partial(GramArgs a) {
     constexpr int TS = KP / 16;                 // per-thread micro tile (TS x TS)
+    constexpr int GRAM_CHUNK = gram_chunk<KP>(), NLD = GRAM_CHUNK * KP / GRAM_THREADS;
     __shared__ float xs[GRAM_CHUNK][KP + 1];
     if (chain_halted(a.status)) return;
     const int f = blockIdx.y;
@@ -45,16 +48,23 @@ __global__ __launch_bounds__(GRAM_THREADS) void k_gram_partial(GramArgs a) {
     const int64_t r0 = (int64_t)blockIdx.x * per;
     const int64_t r1 = r0 + per < rows ? r0 + per : rows;
     for (int64_t rb = r0; rb < r1; rb += GRAM_CHUNK) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < GRAM_CHUNK * KP; e += GRAM_THREADS) {
+        float ld[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = threadIdx.x + u * GRAM_THREADS;
             const int rr = e / KP, k = e - rr * KP;
-            float v = 0.f;
-            if (rb + rr < r1 && k < K) v = X[(rb + rr) * K + k];
-            xs[rr][k] = v;
+            ld[u] = (rb + rr < r1 && k < K) ? X[(rb + rr) * K + k] : 0.f;
         }
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = threadIdx.x + u * GRAM_THREADS;
+            xs[e / KP][e % KP] = ld[u];
+        }
+        __syncthreads();
+        const int nrow = r1 - rb < GRAM_CHUNK ? (int)(r1 - rb) : GRAM_CHUNK;     // (rows past the share hold zeros: skipped, not added)
 #pragma unroll 4
-        for (int rr = 0; rr < GRAM_CHUNK; ++rr) {
+        for (int rr = 0; rr < nrow; ++rr) {
             float av[TS], bv[TS];
 #pragma unroll
             for (int i = 0; i < TS; ++i) av[i] = xs[rr][ti + 16 * i];

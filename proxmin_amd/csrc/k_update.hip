@@ -344,6 +344,7 @@ struct PgmArgs {
     // k_pgm_decide itself (row-sharded runs, split iterations).
     unsigned* tickets;
     unsigned ticket_last;    // value the counter shows to the last arrival: tickets drawn by all launches so far, this one included, - 1
+    float* absmax_out;       // as FinishArgs ([2][EW_BLOCKS] max |point the next K1 is evaluated at|), or nullptr; full grid only
     int nbx;                 // workgroups per block to launch (0: EW_BLOCKS).  Row r belongs to half-wave r mod 8192 of the full
                              // grid, so factors of <= 8192 rows need only ceil(rows / 32) workgroups; the others would
                              // contribute exact zeros to the partial sums (their entries already hold zeros) and one ticket
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     const ProxSeq& px = a.prox[j];
     float* X = a.X[j];
     float* Xe = a.Xe[j];
-    float d2 = 0.f, n2 = 0.f;
+    float d2 = 0.f, n2 = 0.f, xmax = 0.f;
     ROW_LOOP_BEGIN(rows)
         bool ok[NC];
         float g[NC], xo[NC], v[NC], sk[NC];
@@ -395,7 +396,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
                 const int64_t e = r * K + l32 + 32 * c;
                 X[e] = v[c];
                 a.G[j][e] = g[c];
-                if (a.accelerated) Xe[e] = v[c] + a.omega_next * (v[c] - xo[c]);
+                float xnext = v[c];          // the point the next gradient is evaluated at
+                if (a.accelerated) { xnext = v[c] + a.omega_next * (v[c] - xo[c]); Xe[e] = xnext; }
+                xmax = fmaxf(xmax, fabsf(xnext));
                 const float d = v[c] - xo[c];
                 d2 += d * d;
                 n2 += v[c] * v[c];
@@ -403,6 +406,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
         }
     ROW_LOOP_END
     if (mode == 1) return;
+    if (a.absmax_out != nullptr) {
+        const double m = wave_max((double)xmax);
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mm = scratch[0];
+            for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
+            a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
+        }
+        __syncthreads();
+    }
     double red[2] = {(double)d2, (double)n2};
     // SL_DIFF2 and SL_NORM2 are adjacent slots: stride between them = 2 * EW_BLOCKS doubles
     if (a.tickets == nullptr) {
@@ -1746,6 +1760,7 @@ struct BsdmmArgs {
     ProxSeq prox_g[PMX_MAX_G];
     DevStatus* status;
     double* partials;
+    float* absmax_out;   // as FinishArgs: [2][EW_BLOCKS] per-workgroup max |X_j| of the block written here, or nullptr
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
@@ -1758,7 +1773,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     const float sg = sf * 1.f * 2.f * (float)a.n_g;
     const float w = a.n_g > 0 ? sf / sg : 0.f;         // step_f / step_g[i]
     const float nisg = a.n_g > 0 ? -1.f / sg : 0.f;    // -1 / step_g
-    float d2 = 0.f, x2 = 0.f;
+    float d2 = 0.f, x2 = 0.f, xmax = 0.f;
     float r2[PMX_MAX_G], s2[PMX_MAX_G], z2[PMX_MAX_G], u2[PMX_MAX_G];
 #pragma unroll
     for (int i = 0; i < PMX_MAX_G; ++i) r2[i] = s2[i] = z2[i] = u2[i] = 0.f;
@@ -1786,6 +1801,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
                 const float d = v[c] - xo[c];
                 d2 += d * d;
                 x2 += v[c] * v[c];
+                xmax = fmaxf(xmax, fabsf(v[c]));
             }
         for (int i = 0; i < a.n_g; ++i) {               // do_the_mm, utils.py:295-304
             float zn[NC], zo[NC], uo[NC], sgk[NC];
@@ -1833,6 +1849,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4 * PMX_MAX_G; ++i) tail[i] = red[2 + i];
     block_sum_store<4 * PMX_MAX_G>(tail, part_ptr(a.partials, SL_G0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    if (a.absmax_out != nullptr) {
+        const double m = wave_max((double)xmax);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mm = scratch[0];
+            for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
+            a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
+        }
+    }
 }
 
 // check_constraint_convergence for block j (utils.py:349-391), and end-of-iteration bookkeeping

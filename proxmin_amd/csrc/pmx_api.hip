@@ -1059,7 +1059,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
         if (rc != PMX_OK) return rc;
     }
-    rc = enqueue_grad(c, A, St, 1, 1);                                    // algorithms.py:105
+    rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
     if (rc != PMX_OK) return rc;
     if (p.bb_type) {                                                      // step(*_X, it, grads=G): utils.py:216-241
         BBArgs b{};
@@ -1103,9 +1103,12 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         c->ticketLaunches += 2u * (unsigned)u.nbx;       // tickets drawn so far
         u.ticket_last = c->ticketLaunches - 1u;
     }
+    // the fp16 K1's operand maxima for the next iteration come from this kernel (every workgroup writes its partial: full grid only)
+    u.absmax_out = (c->f16_scales && u.nbx == EW_BLOCKS) ? c->absmax : nullptr;
     u.e_rel[0] = p.e_rel[0]; u.e_rel[1] = p.e_rel[1];
     launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
     HIP_CHECK(hipGetLastError());
+    c->absmax_by_finish = u.absmax_out != nullptr;
     c->it += 1;
     return PMX_OK;
 }
@@ -1718,7 +1721,7 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
         const int j = order[o];
         int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
         if (rc != PMX_OK) return rc;
-        rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1);             // nmf.py:181-185 (only grads[j] is used)
+        rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1, c->absmax_by_finish);   // nmf.py:181-185 (only grads[j] is used)
         if (rc != PMX_OK) return rc;
         BsdmmArgs u{};
         u.X = c->X[j];
@@ -1731,7 +1734,10 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
         u.prox_f = to_dev(p.prox_f[j]);
         u.status = c->dstatus;
         u.partials = c->partials;
+        // this block's maxima for the fp16 K1 (the other block's are still those of the launch that last wrote it)
+        u.absmax_out = c->f16_scales ? c->absmax : nullptr;
         launch_bsdmm_update(u, c->stream);
+        c->absmax_by_finish = u.absmax_out != nullptr;
         BsdmmDecideArgs d{};
         d.status = c->dstatus;
         d.partials = c->partials;

@@ -1,8 +1,10 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -o s -- python bench.py --config cfg5 --steps 20 --warmup 5 --no-cpu > $O/cfg5.json 2> $O/cfg5.err
-python scratch/trace_gaps.py $(ls $O/cfg5/*kernel_trace.csv) 100000 > $O/cfg5_timeline.txt
-find $O/cfg5 -name "*kernel_trace.csv" -delete
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg2 -o s -- python bench.py --config cfg2 --mode f32 --steps 50 --warmup 10 --no-cpu > $O/cfg2.json 2> $O/cfg2.err
-python scratch/trace_gaps.py $(ls $O/cfg2/*kernel_trace.csv) 20000 > $O/cfg2_timeline.txt
-find $O/cfg2 -name "*kernel_trace.csv" -delete
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/cfg5t
+mkdir -p $O
+cd $R
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o s -- python bench.py --config cfg5 --steps 40 --warmup 10 --no-cpu > $O/bench.json 2> $O/err.txt
+python scratch/trace_gaps.py $(ls $O/t/*kernel_trace.csv) 20000 > $O/timeline.txt 2>/dev/null
+sed -n 1,20p $O/timeline.txt
+grep '^{' $O/bench.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
+find $O/t -name "*kernel_trace.csv" -delete
