@@ -1,20 +1,23 @@
 #!/bin/bash
-# round-2 measurement batch: traffic for this build, kernel stats + timeline + SQ counters of the default bench, bench lines of the other configs
+# round-2 final measurement batch (tag r02_d): traffic for this build, kernel stats + timeline + SQ counters of the default bench,
+# bench lines of the other configs, small-problem latency
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_b
+O=$R/gpurun_out/r02_d
 mkdir -p $O
 cd $R
 ./scratch/measure_traffic.sh cfg3 f16x2 > $O/traffic.log 2>&1
 cp gpurun_out/k1_traffic.json profiles/k1_traffic.json
-PMC=1 ./scratch/prof_r2.sh r02_b > $O/prof.log 2>&1
+PMC=1 ./scratch/prof_r2.sh r02_d > $O/prof.log 2>&1
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_20_5.json 2>/dev/null
 python bench.py --mode f32 --no-cpu > $O/bench_f32.json 2>/dev/null
 python bench.py --mode bf16x3 --no-cpu > $O/bench_bf16x3.json 2>/dev/null
 python bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu > $O/bench_cfg2.json 2>/dev/null
-python bench.py --config cfg2 --mode f16x2 --steps 200 --warmup 20 --no-cpu > $O/bench_cfg2_f16x2.json 2>/dev/null
 python bench.py --config cfg5 --steps 40 --warmup 10 --no-cpu > $O/bench_cfg5.json 2>/dev/null
 python bench.py --config cfg4 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg4_1gpu.json 2>/dev/null
 PMX_FORCE_SHARDED=1 python bench.py --rows 2048 --steps 100 --warmup 20 --no-cpu > $O/bench_shard2048.json 2>/dev/null
 PMX_FORCE_SHARDED=1 python bench.py --config cfg4 --rows 8192 --steps 40 --warmup 10 --no-cpu > $O/bench_cfg4_shard8192.json 2>/dev/null
-for f in $O/bench_*.json; do echo "== $f"; tail -1 $f | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:40], '|', d['dtype'][:8], '| it/s %.1f | ms %.4f | k1 %.4f | frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))"; done
+python scratch/small_latency.py 2>&1 | grep "its:" > $O/small_latency.txt
+for f in $O/bench_*.json; do echo "== $f"; grep '^{' $f | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:40], '|', d['dtype'][:8], '| it/s %.1f | ms %.4f | k1 %.4f | frac %.3f | traffic %s' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['roofline'].get('traffic')))"; done
+cat $O/small_latency.txt
