@@ -377,16 +377,21 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
 }
+constexpr int EIG_SMALL_CH = 32;             // entries of the triangle folded per round
+struct EigSmallSmem {
+    double Gd[16 * 16];
+    float pbuf[EIG_SMALL_CH][256 + 1];
+    int s_accepted;
+};
+// g: [KP][KP+1] floats of (dynamic) shared memory
 template <int KM>
-__global__ __launch_bounds__(256) void k_eig_small(EigArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+__device__ __forceinline__ void eig_small_body(const EigArgs& a, const int f, float* g, EigSmallSmem& sm) {
     constexpr int NP = KM * (KM + 1) / 2;
-    __shared__ double Gd[16 * 16];
-    constexpr int CH = 32;                   // entries of the triangle folded per round
-    __shared__ float pbuf[CH][256 + 1];
-    __shared__ int s_accepted;
+    constexpr int CH = EIG_SMALL_CH;
+    double (&Gd)[16 * 16] = sm.Gd;
+    float (&pbuf)[EIG_SMALL_CH][256 + 1] = sm.pbuf;
+    int& s_accepted = sm.s_accepted;
     DevStatus* st = a.status;
-    const int f = blockIdx.x;
     if (!a.want[f]) return;
     const int KP = a.KP, K = a.K, ld = KP + 1;
     const int t = threadIdx.x;
@@ -547,6 +552,32 @@ __global__ __launch_bounds__(256) void k_eig_small(EigArgs a) {
     if (s_accepted) return;
     eig_solve_block(a, f, G, GS, g);
 }
+template <int KM>
+__global__ __launch_bounds__(256) void k_eig_small(EigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
+    __shared__ EigSmallSmem sm;
+    eig_small_body<KM>(a, blockIdx.x, g, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_small_front<KM>: K1 AND the step rule of a small problem in one launch.  A pgm iteration evaluates the gradient and
+// the Lipschitz steps at the same point (algorithms.py:105-106) and the two write disjoint outputs (gradient slabs + loss
+// partials; DevStatus::step + the eigenvector), so their workgroups can simply share a grid: tiles of k_grad_small first,
+// one workgroup per factor of k_eig_small behind them.  One launch (~3 us) and the longer of two latency chains instead
+// of their sum: 200 x 1000 x 5 pgm 26 -> 19 us per iteration.
+// ------------------------------------------------------------------------------------------------
+template <int KM>
+__global__ __launch_bounds__(256) void k_small_front(GradArgs ga, EigArgs ea, int tilesX, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1] (step-rule role)
+    __shared__ union Pool {
+        SmallTileSmem<KM> tile;
+        EigSmallSmem eig;
+        __device__ Pool() {}
+    } sm;
+    const int b = blockIdx.x;
+    if (b < ntiles) grad_small_tile<KM>(ga, sm.tile, b % tilesX, b / tilesX, tilesX);
+    else eig_small_body<KM>(ea, b - ntiles, g, sm.eig);
+}
 
 void launch_gram(const GramArgs& a, int KP, hipStream_t s) {
     dim3 grid(GRAM_BLOCKS, 2);
@@ -567,5 +598,13 @@ hipError_t launch_eig(const EigArgs& a, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_eig, dim3(2), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+// K1 (k_grad_small's tiles: p.gridY column tiles x p.gridX row tiles) + both step rules in one launch
+hipError_t launch_small_front(const GradPlan& p, const GradArgs& ga, const EigArgs& ea, hipStream_t s) {
+    const size_t lds = sizeof(float) * ea.KP * (ea.KP + 1);
+    const int ntiles = p.gridX * p.gridY;
+    if (ga.K <= 8) hipLaunchKernelGGL(k_small_front<8>, dim3(ntiles + 2), dim3(256), lds, s, ga, ea, p.gridY, ntiles);
+    else hipLaunchKernelGGL(k_small_front<16>, dim3(ntiles + 2), dim3(256), lds, s, ga, ea, p.gridY, ntiles);
     return hipGetLastError();
 }

@@ -614,6 +614,46 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
     return PMX_OK;
 }
 
+static GradArgs small_grad_args(pmx_ctx* c, const float* A, const float* St, int doA, int doS) {
+    GradArgs g{};
+    g.Y = c->Y; g.ldY = c->ldY;
+    g.W = c->W; g.ldW = c->ldW;
+    g.A = A; g.St = St;
+    g.slabA = c->slab[0]; g.slabS = c->slab[1];
+    g.lossPart = c->lossPart;
+    g.status = c->dstatus;
+    g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
+    g.RP = c->plan.RP;
+    g.doA = doA; g.doS = doS;
+    return g;
+}
+static bool eig_small_applies(const pmx_ctx* c) { return c->K <= 16 && c->M <= 8192 && c->N <= 8192; }
+static EigArgs small_eig_args(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale) {
+    EigArgs e{};
+    e.G = c->gramG; e.Gw = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+    e.want[0] = wantStepS; e.want[1] = wantStepA;     // factor 0 (A) -> step of block 1 (S), factor 1 (St) -> step of block 0 (A)
+    e.scale = scale;
+    e.max_iter = 200;
+    e.Q = c->eigQ;
+    e.X[0] = A; e.X[1] = St;
+    e.rows[0] = c->M; e.rows[1] = c->N;
+    return e;
+}
+// small problems: K1 and both step rules of a pgm iteration in ONE launch (k_small_front)
+static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, double scale) {
+    const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
+    const GradArgs g = small_grad_args(c, A, St, 1, 1);
+    const EigArgs e = small_eig_args(c, A, St, true, true, scale);
+    if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
+    HIP_CHECK(launch_small_front(c->plan, g, e, c->stream));
+    c->nloss = c->plan.gridX * c->plan.gridY;
+    if (timed) {
+        HIP_CHECK(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    return PMX_OK;
+}
+
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
@@ -680,16 +720,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
     } else {
-        GradArgs g{};
-        g.Y = c->Y; g.ldY = c->ldY;
-        g.W = c->W; g.ldW = c->ldW;
-        g.A = A; g.St = St;
-        g.slabA = c->slab[0]; g.slabS = c->slab[1];
-        g.lossPart = c->lossPart;
-        g.status = c->dstatus;
-        g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
-        g.RP = c->plan.RP;
-        g.doA = doA; g.doS = doS;
+        const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -710,15 +741,8 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
 
 // Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
 static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale) {
-    if (c->K <= 16 && c->M <= 8192 && c->N <= 8192) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig forms G itself)
-        EigArgs e{};
-        e.G = c->gramG; e.Gw = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
-        e.want[0] = wantStepS; e.want[1] = wantStepA;
-        e.scale = scale;
-        e.max_iter = 200;
-        e.Q = c->eigQ;
-        e.X[0] = A; e.X[1] = St;
-        e.rows[0] = c->M; e.rows[1] = c->N;
+    if (eig_small_applies(c)) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig_small forms G itself)
+        const EigArgs e = small_eig_args(c, A, St, wantStepA, wantStepS, scale);
         HIP_CHECK(launch_eig(e, c->stream));
         return PMX_OK;
     }
@@ -1055,12 +1079,17 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     const float* A = p.accelerated ? c->Xe[0] : c->X[0];
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     int rc;
-    if (!p.use_fixed_steps && !p.bb_type) {
-        rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
+    if (c->use_small && eig_small_applies(c) && !p.use_fixed_steps && !p.bb_type && !(getenv("PMX_SMALL_FRONT") && atoi(getenv("PMX_SMALL_FRONT")) == 0)) {
+        rc = enqueue_small_front(c, A, St, (double)p.step_scale);          // algorithms.py:105-106, one launch
+        if (rc != PMX_OK) return rc;
+    } else {
+        if (!p.use_fixed_steps && !p.bb_type) {
+            rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
+            if (rc != PMX_OK) return rc;
+        }
+        rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
         if (rc != PMX_OK) return rc;
     }
-    rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
-    if (rc != PMX_OK) return rc;
     if (p.bb_type) {                                                      // step(*_X, it, grads=G): utils.py:216-241
         BBArgs b{};
         b.X[0] = A; b.X[1] = St;
