@@ -349,6 +349,105 @@ __device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, c
     if (t < K) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vec[t] : 1.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// eig_wave_solve<KM>: eig_solve_block's warm-started power iteration, fp64 Rayleigh quotient, residual and dominance
+// checks for K <= KM <= 64, by ONE wave: entry t of a vector in lane t, sums by DPP row_shr shifts inside the rows of 16
+// lanes (+ the rows' totals by v_readlane), broadcasts by v_readlane, no barrier anywhere -- the workgroup version spends
+// most of its time in ~70 __syncthreads.  Same operations in the same order (the lanes >= K contribute exact zeros).
+// Called by the 64 lanes of wave 0 after g[] (fp32 copy of G, zero beyond K) is complete; returns true when the result was
+// accepted and stored, false when the exact solver (eig_solve_block from the top) has to be run.
+// ------------------------------------------------------------------------------------------------
+template <int KM>
+__device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, const double* G, const int GS, const float* g,
+                                               const int ld, const int K, const double ev0) {
+    DevStatus* st = a.status;
+    const int t = threadIdx.x;
+    const bool in = t < K;
+    const int tt = in ? t : 0;
+    auto wsum = [&](double v) {
+#define PMX_ROW_SHR(n)                                                                                         \
+        {                                                                                              \
+            const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + n, 0xf, 0xf, true); \
+            const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + n, 0xf, 0xf, true); \
+            v += __hiloint2double(hi_, lo_);                                                           \
+        }
+        PMX_ROW_SHR(1) PMX_ROW_SHR(2) PMX_ROW_SHR(4) PMX_ROW_SHR(8)
+#undef PMX_ROW_SHR
+        const int hi_ = __double2hiint(v), lo_ = __double2loint(v);
+        double tot = __hiloint2double(__builtin_amdgcn_readlane(hi_, 15), __builtin_amdgcn_readlane(lo_, 15));
+        if constexpr (KM > 16) {             // the other three DPP rows, in a fixed order
+            tot += __hiloint2double(__builtin_amdgcn_readlane(hi_, 31), __builtin_amdgcn_readlane(lo_, 31));
+            tot += __hiloint2double(__builtin_amdgcn_readlane(hi_, 47), __builtin_amdgcn_readlane(lo_, 47));
+            tot += __hiloint2double(__builtin_amdgcn_readlane(hi_, 63), __builtin_amdgcn_readlane(lo_, 63));
+        }
+        return tot;
+    };
+    auto bcast = [&](double v, int k) {                   // k uniform
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+    };
+    const double v0 = in ? ev0 : 0.0;
+    const double n0 = sqrt(wsum(v0 * v0));
+    double vr = in ? ((n0 > 0.0 && n0 == n0 && n0 < 1e300) ? v0 / n0 : 1.0 / sqrt((double)K)) : 0.0;
+    double lam_prev = -1.0, lam = 0.0;
+    int it = 0, calm = 0;
+    for (; it < a.max_iter; ++it) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) sacc += g[tt * ld + k] * (float)bcast(vr, k);    // (entries >= K: exact zeros; unrolled so that the LDS reads go out together)
+        const double w = in ? (double)sacc : 0.0;
+        const double nrm = sqrt(wsum(w * w));
+        lam = nrm;
+        if (nrm == 0.0 || !(nrm == nrm)) break;
+        vr = in ? w / nrm : 0.0;
+        if (fabs(lam - lam_prev) <= 1e-7 * lam) {
+            if (++calm >= 2) { ++it; break; }
+        } else calm = 0;
+        lam_prev = lam;
+    }
+    double gv = 0.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) gv += G[tt * GS + k] * bcast(vr, k);
+    if (!in) gv = 0.0;
+    const double rq_n = wsum(gv * vr), rq_d = wsum(vr * vr);
+    double l = (rq_d > 0.0) ? rq_n / rq_d : lam;
+    if (!(lam == lam)) l = lam;
+    const double r1 = in ? gv - l * vr : 0.0;
+    const double resid = sqrt(wsum(r1 * r1) / (rq_d > 0.0 ? rq_d : 1.0));
+    double cn = 0.0;
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { const double gg = (double)g[k * ld + t]; cn += gg * gg; }
+        cn = sqrt(cn);
+    }
+    double probe = 0.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) probe = fmax(probe, bcast(cn, k));
+    double w2 = in ? 1.0 + 0.37 * (double)((t * 7) % 5) - 0.61 * (double)(t & 1) : 0.0;
+    double un = 0.0, ud = 1.0;
+    for (int stepi = 0; stepi < 3; ++stepi) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) s2 += (double)g[k * ld + tt] * bcast(w2, k);
+        if (!in) s2 = 0.0;
+        un = wsum(s2 * w2);
+        ud = wsum(w2 * w2);
+        const double nn = sqrt(wsum(s2 * s2));
+        w2 = in ? (nn > 0.0 ? s2 / nn : 0.0) : 0.0;
+    }
+    if (ud > 0.0) probe = fmax(probe, un / ud);
+    const bool not_dominant = probe > l * (1.0 + 1e-5);
+    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant);
+    if (!need_exact) {
+        if (t == 0) {
+            st->lam[f] = l;
+            st->step[1 - f] = a.scale / l;
+            st->eig_iters[f] = it;
+        }
+        if (in) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vr : 1.0;
+    }
+    return !need_exact;
+}
+
 __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     extern __shared__ __attribute__((aligned(16))) float g[];   // [KP][KP+1]
     if (chain_halted(a.status)) return;
@@ -356,7 +455,20 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     if (!a.want[f]) return;
     const int KP = a.KP, ld = KP + 1;
     const double* G = a.G + (int64_t)f * KP * KP;
+    const double ev0 = (int)threadIdx.x < a.K ? a.status->eigvec[f][threadIdx.x] : 0.0;      // (requested with G)
     for (int e = threadIdx.x; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
+    if (KP <= 64) {                          // one wave does the whole solve; the exact solver, if needed, is the block version
+        __shared__ int s_accepted;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x < 64) {
+            const bool ok = KP == 32 ? eig_wave_solve<32>(a, f, G, KP, g, ld, a.K, ev0) : eig_wave_solve<64>(a, f, G, KP, g, ld, a.K, ev0);
+            if (threadIdx.x == 0) s_accepted = ok;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (s_accepted) return;
+    }
     eig_solve_block(a, f, G, KP, g);
 }
 
@@ -463,83 +575,8 @@ __device__ __forceinline__ void eig_small_body(const EigArgs& a, const int f, fl
     const double* G = Gd;
     const int GS = 16;
     if (t < 64) {
-        const bool in = t < K;
-        const int tt = in ? t : 0;
-    auto wsum = [&](double v) {
-#define PMX_ROW_SHR(n)                                                                                         \
-        {                                                                                              \
-            const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + n, 0xf, 0xf, true); \
-            const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + n, 0xf, 0xf, true); \
-            v += __hiloint2double(hi_, lo_);                                                           \
-        }
-        PMX_ROW_SHR(1) PMX_ROW_SHR(2) PMX_ROW_SHR(4) PMX_ROW_SHR(8)
-#undef PMX_ROW_SHR
-        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 15), __builtin_amdgcn_readlane(__double2loint(v), 15));
-    };
-    auto bcast = [&](double v, int k) {                   // k uniform
-        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
-    };
-    const double v0 = in ? ev0 : 0.0;
-    const double n0 = sqrt(wsum(v0 * v0));
-    double vr = in ? ((n0 > 0.0 && n0 == n0 && n0 < 1e300) ? v0 / n0 : 1.0 / sqrt((double)K)) : 0.0;
-    double lam_prev = -1.0, lam = 0.0;
-    int it = 0, calm = 0;
-    for (; it < a.max_iter; ++it) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int k = 0; k < KM; ++k) sacc += g[tt * ld + k] * (float)bcast(vr, k);    // (entries >= K: exact zeros; unrolled so that the LDS reads go out together)
-        const double w = in ? (double)sacc : 0.0;
-        const double nrm = sqrt(wsum(w * w));
-        lam = nrm;
-        if (nrm == 0.0 || !(nrm == nrm)) break;
-        vr = in ? w / nrm : 0.0;
-        if (fabs(lam - lam_prev) <= 1e-7 * lam) {
-            if (++calm >= 2) { ++it; break; }
-        } else calm = 0;
-        lam_prev = lam;
-    }
-    double gv = 0.0;
-#pragma unroll
-    for (int k = 0; k < KM; ++k) gv += G[tt * GS + k] * bcast(vr, k);
-    if (!in) gv = 0.0;
-    const double rq_n = wsum(gv * vr), rq_d = wsum(vr * vr);
-    double l = (rq_d > 0.0) ? rq_n / rq_d : lam;
-    if (!(lam == lam)) l = lam;
-    const double r1 = in ? gv - l * vr : 0.0;
-    const double resid = sqrt(wsum(r1 * r1) / (rq_d > 0.0 ? rq_d : 1.0));
-    double cn = 0.0;
-    if (in) {
-#pragma unroll
-        for (int k = 0; k < KM; ++k) { const double gg = (double)g[k * ld + t]; cn += gg * gg; }
-        cn = sqrt(cn);
-    }
-    double probe = 0.0;
-#pragma unroll
-    for (int k = 0; k < KM; ++k) probe = fmax(probe, bcast(cn, k));
-    double w2 = in ? 1.0 + 0.37 * (double)((t * 7) % 5) - 0.61 * (double)(t & 1) : 0.0;
-    double un = 0.0, ud = 1.0;
-    for (int stepi = 0; stepi < 3; ++stepi) {
-        double s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < KM; ++k) s2 += (double)g[k * ld + tt] * bcast(w2, k);
-        if (!in) s2 = 0.0;
-        un = wsum(s2 * w2);
-        ud = wsum(w2 * w2);
-        const double nn = sqrt(wsum(s2 * s2));
-        w2 = in ? (nn > 0.0 ? s2 / nn : 0.0) : 0.0;
-    }
-    if (ud > 0.0) probe = fmax(probe, un / ud);
-    const bool not_dominant = probe > l * (1.0 + 1e-5);
-    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant);
-    if (!need_exact) {
-        if (t == 0) {
-            st->lam[f] = l;
-            st->step[1 - f] = a.scale / l;
-            st->eig_iters[f] = it;
-        }
-        if (in) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vr : 1.0;
-    }
-        if (t == 0) s_accepted = !need_exact;
+        const bool accepted = eig_wave_solve<KM>(a, f, G, GS, g, ld, K, ev0);
+        if (t == 0) s_accepted = accepted;
     }
     lds_barrier();
     {   // the copy in memory, for whoever reads G later (row-sharded drivers, tests): nobody in this launch waits for it

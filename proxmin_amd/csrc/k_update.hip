@@ -231,19 +231,33 @@ struct SlabRef {
 
 template <int NC>
 __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], const SlabRef& s, int64_t rows, int K, int64_t r, int l32) {
-    // fixed summation order (slab 0, 1, 2, ...), but 4 slabs' loads are issued before the first add so that
-    // the fold is bandwidth- rather than latency-bound
+    // fixed summation order (slab 0, 1, 2, ...), but up to 16 values' loads are issued before the first add so that the fold is
+    // bandwidth- rather than latency-bound (a dependent round trip to memory is ~1.3 us: a small problem's 13 gSt slabs in
+    // batches of 4 were 5 of the 8 us of its moment phase)
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
     const int64_t stride = rows * K;
     const float* p = s.base + r * K + l32;
     int i = 0;
+    constexpr int UB = NC == 1 ? 16 : (NC == 2 ? 8 : 4);
+    for (; i + UB <= s.n; i += UB) {
+        float v[UB][NC];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? __builtin_nontemporal_load(p + u * stride + c * 32) : 0.f;   // read once
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] += v[u][c];
+        p += UB * stride;
+    }
     for (; i + 4 <= s.n; i += 4) {
         float v[4][NC];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? __builtin_nontemporal_load(p + u * stride + c * 32) : 0.f;   // read once
+            for (int c = 0; c < NC; ++c) v[u][c] = ok[c] ? __builtin_nontemporal_load(p + u * stride + c * 32) : 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
