@@ -77,7 +77,7 @@ def pmc_traffic(config, mode):
 
 def effective_mode(dev):
     """Arithmetic the context's K1 really runs in: a split-precision mode falls back to exact fp32 where it has no kernel."""
-    return "f32" if dev.k1_info()["kernel"] == "k_grad_f32" else dev.mode
+    return "f32" if dev.k1_info()["kernel"] in ("k_grad_f32", "k_grad_f32_pc") else dev.mode
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kernel=None):
@@ -102,7 +102,7 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
                 "algorithmic_tflops": tflops, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share,
                 "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC); algorithmic = achieved / 3"}
     if mode == "f32":
-        return {"kernel": "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+        return {"kernel": "k_grad_f32_pc<%d>" % K if kernel == "k_grad_f32_pc" else "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
                 "launches": k1_n, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share}
     return {"kernel": bf16_kernel, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -162,7 +162,7 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
 /* How the fused residual-gradient kernel (K1) of this context is laid out -- for tests and bench.py, which must be able
  * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
  * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small, 5 two-term fp16 at K = 128
- * k_grad_f16_k128), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * k_grad_f16_k128, 6 exact fp32 with producer / consumer wavefronts k_grad_f32_pc), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
  * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now. */

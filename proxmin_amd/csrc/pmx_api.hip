@@ -19,6 +19,7 @@
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
 #include "k_grad_k128.hip"
+#include "k_grad_f32pc.hip"
 #include "k_update.hip"
 #include "k_gram.hip"
 
@@ -72,6 +73,7 @@ struct pmx_ctx {
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
     bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
     bool k128 = false;                     // mode F16X2, K = 128 at a shape k_grad_f16_k128 takes
+    bool f32pc = false;                    // exact-fp32 arithmetic at a shape the producer / consumer kernel k_grad_f32_pc takes
     bool f16_scales = false;               // use_f16 || k128: the K1 kernel needs the factor maxima (absmax) and max|Y|
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
@@ -269,6 +271,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
     c->k128 = mode == PMX_MODE_F16X2 && !c->use_small && grad_k128_applies(M, N, K);
     if (c->k128) c->plan = grad_plan_k128(M, N);
+    c->f32pc = !c->use_small && !c->use_bf16 && !c->k128 && grad_f32pc_applies(M, N, K);
+    if (c->f32pc) c->plan = grad_plan_f32pc(M, N, K);
     c->f16_scales = c->use_f16 || c->k128;
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
@@ -362,7 +366,7 @@ extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : 0)));
+    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -722,7 +726,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     } else {
         const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
-        HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream));
+        HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : (c->f32pc ? grad_launch_f32pc(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream)));
         c->nloss = c->plan.gridX * c->plan.gridY;
     }
     if (timed) {

@@ -389,7 +389,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     nk1 = 2 if backend == "bsdmm" else 1            # bsdmm: two K1 launches of 4 MNK each per iteration
     flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
     info = dev.k1_info()
-    eff_mode = "f32" if info["kernel"] == "k_grad_f32" else dev.mode      # a split mode falls back to fp32 where it has no kernel
+    eff_mode = "f32" if info["kernel"] in ("k_grad_f32", "k_grad_f32_pc") else dev.mode      # a split mode falls back to fp32 where it has no kernel
     its = args.steps / dt
     ach = (flop_per_it / nk1 * Ml / M) / (k1_avg_ms * 1e-3) / 1e12
     out = {
@@ -401,7 +401,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
                    "mode": getattr(args, "mode_desc", {}).get(eff_mode, eff_mode),
                    "parallelism": "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration" % (world, eng.layout.count)},
         "gflops": flop_per_it * its / 1e9,
-        "roofline": ({"kernel": "k_grad_f32", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+        "roofline": ({"kernel": info["kernel"], "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                       "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
                       "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info} if eff_mode == "f32" else
                      {"kernel": "k_grad_f16_k128", "bound": "mfma", "achieved": 3.0 * ach, "peak": 2500.0, "unit": "TFLOP/s",

@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+g.build()
+import torch, bench
+from proxmin_amd import engine
+M = N = 16384; K = 64
+Y, A0, S0 = bench.make_problem_device(M, N, K, False, 1234, torch.device("cuda", 0))
+for pc in ("1", "0"):
+    os.environ["PMX_K1_F32PC"] = pc
+    with engine.DeviceNMF(M, N, K, mode="f32") as dev:
+        dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+        dev.set_factors(A0, S0)
+        for dA, dS in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            print(dev.k1_info()["kernel"], "doA=%d doS=%d %.4f ms" % (dA, dS, dev.time_grad(do_A=dA, do_S=dS, reps=20)), flush=True)

@@ -420,6 +420,41 @@ def _subsampled_oracle_gradients(A, S, Yd, rows, cols):
     return gA_rows, gS_cols
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (1024, 768, 64), (2304, 4096, 64), (8320, 512, 64), (128, 256, 32), (5120, 1024, 32),
+                                   (4096, 4096, 32), (384, 16384, 32)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_exact_fp32_producer_consumer_kernel(eng, orc, M, N, K, weighted):
+    """Mode f32 at K = 32 / 64, M % 128 = 0, N % 256 = 0 runs k_grad_f32_pc (the producer / consumer frame with fp32 MFMA
+    operands; cfg2 and cfg3 / cfg5 in the library's default arithmetic): one region, many regions, short last row regions,
+    more workgroups than CUs, with and without weights (zeros included); fp64 oracle, the tolerance of every fp32 K1;
+    bitwise repeatable.  Neighbouring shapes keep k_grad_f32."""
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N + K)
+    W = None
+    if weighted:
+        rng = np.random.default_rng(8)
+        W = (0.1 + 2.0 * rng.random((M, N))).astype(np.float32)
+        W[rng.random((M, N)) < 0.15] = 0
+    with eng.DeviceNMF(M, N, K, mode="f32") as dev:
+        assert dev.k1_info()["kernel"] == "k_grad_f32_pc", dev.k1_info()
+        dev.set_Y(Y)
+        if weighted:
+            dev.set_W(W)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+        gA2, gS2 = dev.grad()
+    assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)
+    x64 = [x.astype(np.float64) for x in (A, S, Y)] + ([W.astype(np.float64)] if weighted else [])
+    rA, rS = orc.residual_gradients(*x64)
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(*x64), rel=2e-5)
+    if M == 128 and not weighted:
+        for Mr, Nr, Kr in ((128, 128, K), (136, 256, K), (128, 256, 48)):
+            with eng.DeviceNMF(Mr, Nr, Kr, mode="f32") as dev:
+                assert dev.k1_info()["kernel"] in ("k_grad_f32", "k_grad_small")
+
+
 @pytest.mark.parametrize("M,N", [(128, 128), (2048, 1024), (1024, 4096), (3200, 2176), (8192, 384), (8320, 16384)])
 def test_k128_two_term_fp16_kernel(eng, orc, M, N):
     """K = 128 in mode f16x2 (k_grad_f16_k128: BASELINE's 8-GPU case, 8192-row shards of 65536 x 16384): one region, many
