@@ -169,6 +169,20 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
                 for (int i = 0; i < 16; ++i) pc[i] = 0.f;
 #pragma unroll
                 for (int q = 0; q < KH; ++q) pc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q], Sb[q], pc, 0, 0, 0);
+                // Left alone the scheduler fetches each operand right in front of the MFMA that takes it and waits for it (it
+                // minimises registers): ~100 cycles of LDS latency in front of every 64-cycle MFMA.  Imposed order: the
+                // reads run 8 operands ahead; the epilogue of block s-1 (3 VALU, a store and a Y request per element) is
+                // dealt out between the MFMAs.
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int q = 0; q < KH; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q + 8 < KH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if constexpr (EPI) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 48 / KH + 1, 0);
+                        if (q < 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
             }
             if constexpr (EPI) {
                 float* Rb = Rimg + ((s - 1) & 1) * C::R_IMG + r_w;
@@ -243,10 +257,23 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
 #pragma unroll
                     for (int t = 0; t < KT; ++t) accA[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(rv, Sb[s_gA + q * LDK + 32 * t], accA[t], 0, 0, 0);
                 }
+                // operand reads four steps (4 (1 + KT) registers) ahead of the MFMAs (see the producers' note)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 * (1 + KT), 0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, KT, 0);
+                    if (q + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1 + KT, 0);
+                }
             }
             if (a.doS) {
 #pragma unroll
                 for (int q = 0; q < MH; ++q) accSc = __builtin_amdgcn_mfma_f32_32x32x2f32(Rb[r_gS + q * LDR], Aimg[a_gS + q * LDK], accSc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);              // eight steps ahead
+#pragma unroll
+                for (int q = 0; q < MH; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q + 8 < MH) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
             }
             if ((a.doA & 1) && cb + 1 == NCB) {
                 flush_gA(prow);
