@@ -178,16 +178,19 @@ def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6):
     except AttributeError:
         cores = os.cpu_count()
     blas = "?"
+    host_cores = cores
     try:
         from threadpoolctl import threadpool_info
-        blas = ", ".join("%s %s, %d threads" % (i.get("internal_api"), i.get("version"), i.get("num_threads")) for i in threadpool_info()
-                         if i.get("user_api") == "blas") or "?"
+        infos = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        blas = ", ".join("%s %s, %d threads" % (i.get("internal_api"), i.get("version"), i.get("num_threads")) for i in infos) or "?"
+        if infos:
+            cores = max(int(i.get("num_threads") or 1) for i in infos)     # the threads the contractions really use (the rest of NumPy is one thread)
     except Exception:
         pass
     return {"value": 1.0 / float(np.mean(per)), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": "oracle (NumPy fp32; BLAS: %s) on the full %d x %d x %d workload (the bench's own Y and initial factors), "
+            "sample": "oracle (NumPy fp32; BLAS: %s; host: %d hardware threads) on the full %d x %d x %d workload (the bench's own Y and initial factors), "
                       "%d iterations, mean of iterations 1..%d = %.3f s (min %.3f, max %.3f), no scaling%s"
-                      % (blas, M, N, K, n_iter, n_iter - 1, float(np.mean(per)), float(per.min()), float(per.max()), sub_note)}
+                      % (blas, host_cores, M, N, K, n_iter, n_iter - 1, float(np.mean(per)), float(per.min()), float(per.max()), sub_note)}
 
 
 def emit(out):
