@@ -2,7 +2,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PMX_K1_PROF"] = "1"
 os.environ["PMX_K1_CHAIN"] = "0"
-os.environ["PMX_K1_V9"] = "0"
 import __graft_entry__ as g
 g.build()
 import torch, bench
