@@ -39,6 +39,12 @@ struct GradArgs {
     int M, N, K;
     int RP;              // row panels per workgroup
     int doA, doS;        // which gradients are wanted (bsdmm needs one at a time, nmf.py:181-185)
+    // k_grad_f32_pc<.., CHAIN> only: gA accumulated in place along chains of workgroups (see GradV4Args in k_grad_bf16.hip)
+    int chainL;
+    unsigned* chainFlags;
+    unsigned chainBase;
+    DevStatus* wstatus;
+    int chainInject;
 };
 
 template <int KP> struct GradCfg;

@@ -16,7 +16,10 @@
 //   lanes 32-63; step j pairs index j with index j + half, so that each lane walks a contiguous run (its half of the range).
 // LDS (K = 64): S 8 x 32 x 65 + A 128 x 65 + R 2 x 128 x 33 floats = 133 KB.
 // MFMAs per block and SIMD: 32 (producer) + 64 (consumer) at K = 64, 16 + 32 at K = 32.
-// Outputs as every K1: one gA slab per column region, S_SPLIT gSt slabs per row region (the consumers split the block's 128
+// CHAIN: gA summed in place along chains of workgroups on one XCD, exactly as in k_grad_f16_v8<.., CHAIN> (same region map,
+// rotation of the panels, arrival words with the writer's XCC_ID, fault -> the host falls back to slabs): the 64 gA slabs
+// of cfg3 (268 MB written here, read back by the update kernel) become 2.
+// Outputs as every K1: one gA slab per column region (per chain with CHAIN), S_SPLIT gSt slabs per row region (the consumers split the block's 128
 // rows: halves at K = 64 -- two k tiles x two halves --, quarters at K = 32), a loss partial per workgroup.
 // ------------------------------------------------------------------------------------------------
 template <int K> struct F32pcCfg {
@@ -31,7 +34,7 @@ template <int K> struct F32pcCfg {
 };
 static_assert(F32pcCfg<64>::LDS_FLOATS * 4 <= 160 * 1024, "");
 
-template <int K, bool HASW>
+template <int K, bool HASW, bool CHAIN>
 __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, int gridY) {
     using C = F32pcCfg<K>;
     constexpr int LDK = C::LDK, LDR = C::LDR, NCB = 8, KH = K / 2, KT = C::KT, S_SPLIT = C::S_SPLIT, MROWS = 128 / S_SPLIT;
@@ -44,9 +47,16 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int M = a.M, N = a.N;
     int rowRegion, colRegion;
+    int chainId = 0, chainPos = 0;
     {
         const int lin = blockIdx.x;
-        if (gridY % 8 == 0) {                // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
+        if constexpr (CHAIN) {               // the members of a chain: consecutive column regions, 8 apart in dispatch order (one XCD)
+            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
+            chainPos = idx % L;
+            chainId = (idx / L) * 8 + xcd;
+            rowRegion = chainId % gridX;
+            colRegion = (chainId / gridX) * L + chainPos;
+        } else if (gridY % 8 == 0) {                // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gridX;
             colRegion = xcd * (gridY >> 3) + idx / gridX;
@@ -64,6 +74,11 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
     const bool producer = w < 4;
     const int j = w & 3;
     float lossAcc = 0.f;
+    // CHAIN: panel (t - chainPos) mod RP in the t-th place: the members of a chain reach a panel one after the other
+    auto panel_at = [&](int t) {
+        if constexpr (CHAIN) { const int p = t - chainPos; return p < 0 ? p + nrp : p; }
+        else return t;
+    };
 
     if (T <= 0) {                            // region outside the matrix: its gSt slab parts and loss partial are zero
         if (!producer && a.doS) {
@@ -109,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 3;
             if (brp >= nrp) brp = nrp - 1;
+            brp = panel_at(brp);
             const float* base = ybase0 + (int64_t)brp * 128 * a.ldY + (b & 7) * 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
             if constexpr (HASW) {
                 int brp = b >> 3;
                 if (brp >= nrp) brp = nrp - 1;
+                brp = panel_at(brp);
                 const float* base = wbase0 + (int64_t)brp * 128 * a.ldW + (b & 7) * 32;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
@@ -140,13 +157,13 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
         };
         const int s_g1 = l31 * LDK + hi * KH;          // P contraction's B operand: S[n = l31][k = step + KH hi]
         const int r_w = (j * 32 + 4 * hi) * LDR + l31; // R producer: accumulator register i -> row tile_row(i) of the wave's 32
-        load_A(row0);
+        load_A(row0 + panel_at(0) * 128);
         load_Y(0, yE);
         load_Y(1, yO);
         load_W(0, wE);
         load_W(1, wO);
         take_A();
-        if (nrp > 1) load_A(row0 + 128);
+        if (nrp > 1) load_A(row0 + panel_at(1) * 128);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // S images published
 
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
             if constexpr (GEMM) {
                 if (cb == 0 && s > 0) {      // block s opens a row panel: its A rows (requested 8 slots ago)
                     take_A();
-                    if (rp + 1 < nrp) load_A(row0 + (rp + 1) * 128);
+                    if (rp + 1 < nrp) load_A(row0 + panel_at(rp + 1) * 128);
                 }
                 const float* Sb = Simg + cb * C::S_BLOCK + s_g1;
 #pragma unroll
@@ -235,14 +252,51 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
         const int s_gA = (16 * hi) * LDK + l31;                           // gA's B operand: S[n = step + 16 hi][k = 32 tile + l31]
         const int r_gS = (part * MROWS + MH * hi) * LDR + l31;            // gSt's A operand: R[m = part rows + step + MH hi][n = l31]
         const int a_gS = (part * MROWS + MH * hi) * LDK + kt * 32 + l31;  // gSt's B operand: A[m][k = 32 kt + l31]
+        const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+        auto gA_tile = [&](int prow) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31; };
         auto flush_gA = [&](int prow) {
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                float* p_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + t * 32 + l31;
+                float* p_ = gA_tile(prow) + t * 32;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) p_[((i & 3) + 8 * (i >> 2)) * K] = accA[t][i];
             }
         };
+        // ---- CHAIN state: see k_grad_f16_v8 (wait for arrival k -> tile += previous sum, fetched by sc1 loads in four
+        //      pieces during the panel's last four blocks -> plain stores -> vmcnt(0) -> arrival k + 1, one slot later) -------
+        unsigned* cflags = nullptr;
+        unsigned myxcc = 0;
+        if constexpr (CHAIN) {
+            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
+            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        }
+        unsigned* pendFlag = nullptr;
+        unsigned pendVal = 0;
+        unsigned* curFlag = nullptr;
+        unsigned cwant = 0, cseen = 0;
+        bool cadd = false, cdead = false;
+        auto chain_fault = [&](int code) {
+            if (lane == 0 && code > 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            cadd = false;
+            cdead = true;
+        };
+        auto chain_publish = [&]() {
+            if constexpr (CHAIN) {
+                if (pendFlag != nullptr) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pendFlag = nullptr;
+                }
+            }
+        };
+        if constexpr (CHAIN) {
+            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+        }
         auto sync = [&]() {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
@@ -275,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
                     if (q + 8 < MH) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
-            if ((a.doA & 1) && cb + 1 == NCB) {
+            if (!CHAIN && (a.doA & 1) && cb + 1 == NCB) {
                 flush_gA(prow);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -288,18 +342,73 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
         int s = 2;
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
-            const int prow = row0 + rp * 128;
+            const int pnl = panel_at(rp);
+            const int prow = row0 + pnl * 128;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A rows now
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
+                    if constexpr (CHAIN) {
+                        chain_publish();     // the previous panel's arrival
+                        const int c = chainPos, L = a.chainL;
+                        const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
+                        const int k = pnl + c >= nrp ? pnl + c - nrp : c + nw;      // place of this workgroup among the visits of panel pnl
+                        cadd = (a.doA & 1) && k > 0 && !cdead;
+                        cwant = a.chainBase + (unsigned)k;
+                        curFlag = cflags + pnl * 4;
+                    }
+                }
+                float pv[KT][4];
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cb >= 4 && cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
+                        const float* pb = gA_tile(prow) + 8 * (cb - 4) * K;
+#pragma unroll
+                        for (int t = 0; t < KT; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                pv[t][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32 * t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
                 }
                 consume(s - 2, prow, cb, accS[cb]);
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) {   // the predecessor finished this panel about a panel-time ago: normally no spin
+                        unsigned v = __builtin_amdgcn_readfirstlane(cseen);
+                        if ((v >> 4) != cwant) {
+                            const long long t0 = wall_clock64();          // 100 MHz
+                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
+                                if ((spins & 63) == 0) {
+                                    if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
+                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            }
+                        }
+                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                    }
+                    if (cb >= 4 && cadd) {
+#pragma unroll
+                        for (int t = 0; t < KT; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) accA[t][4 * (cb - 4) + q] += pv[t][q];
+                    }
+                    if (cb + 1 == NCB && (a.doA & 1)) {
+                        flush_gA(prow);
+#pragma unroll
+                        for (int t = 0; t < KT; ++t)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) accA[t][i] = 0.f;
+                        pendFlag = curFlag;
+                        pendVal = ((cwant + 1u) << 4) | myxcc;
+                    }
+                }
                 sync();
                 ++s;
             }
         }
+        chain_publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * S_SPLIT + part) * N * K;
 #pragma unroll
@@ -349,15 +458,19 @@ GradPlan grad_plan_f32pc(int64_t M, int64_t N, int64_t K) {
     p.variant = -2;
     return p;
 }
-template <int K, bool HASW>
+template <int K, bool HASW, bool CHAIN>
 static hipError_t grad_launch_f32pc_t(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f32_pc<K, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f32_pc<K, HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.ldsBytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f32_pc<K, HASW>), dim3(p.gridX * p.gridY), dim3(512), p.ldsBytes, stream, a, p.gridX, p.gridY);
+    hipLaunchKernelGGL((k_grad_f32_pc<K, HASW, CHAIN>), dim3(p.gridX * p.gridY), dim3(512), p.ldsBytes, stream, a, p.gridX, p.gridY);
     return hipGetLastError();
 }
-hipError_t grad_launch_f32pc(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
+template <int K>
+static hipError_t grad_launch_f32pc_k(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
     const bool w = a.W != nullptr;
-    if (a.K == 64) return w ? grad_launch_f32pc_t<64, true>(p, a, stream) : grad_launch_f32pc_t<64, false>(p, a, stream);
-    return w ? grad_launch_f32pc_t<32, true>(p, a, stream) : grad_launch_f32pc_t<32, false>(p, a, stream);
+    if (a.chainL > 0) return w ? grad_launch_f32pc_t<K, true, true>(p, a, stream) : grad_launch_f32pc_t<K, false, true>(p, a, stream);
+    return w ? grad_launch_f32pc_t<K, true, false>(p, a, stream) : grad_launch_f32pc_t<K, false, false>(p, a, stream);
+}
+hipError_t grad_launch_f32pc(const GradPlan& p, const GradArgs& a, hipStream_t stream) {
+    return a.K == 64 ? grad_launch_f32pc_k<64>(p, a, stream) : grad_launch_f32pc_k<32>(p, a, stream);
 }

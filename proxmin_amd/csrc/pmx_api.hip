@@ -276,7 +276,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->f16_scales = c->use_f16 || c->k128;
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
-    if (c->use_f16) {
+    if (c->use_f16 || c->f32pc) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
         c->chainL = grad_chain_length(c->plan, M, ncu);
@@ -726,6 +726,16 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     } else {
         const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
+        if (c->f32pc && c->chainL > 0) {
+            if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
+                HIP_CHECK(hipMemsetAsync(c->chainFlags, 0, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4 * sizeof(unsigned), c->stream));
+                c->chainSeq = 0;
+            }
+            GradArgs gc = g;
+            gc.chainL = c->chainL; gc.chainFlags = c->chainFlags; gc.chainBase = (++c->chainSeq) * 64u; gc.wstatus = c->dstatus;
+            gc.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
+            HIP_CHECK(grad_launch_f32pc(c->plan, gc, c->stream));
+        } else
         HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : (c->f32pc ? grad_launch_f32pc(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream)));
         c->nloss = c->plan.gridX * c->plan.gridY;
     }

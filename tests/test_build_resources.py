@@ -20,7 +20,8 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb1ELb1E": 24,   #     weighted, chained
     "15k_grad_f16_k128": 32,              # 29  two-term fp16 K1 at K = 128: 192 accumulator registers in the consumers
                                           #     (a handful of reloads per panel in their loop, the rest in the final flush)
-    "13k_grad_f32_pc": 0,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (all four instances)
+    "13k_grad_f32_pc": 4,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (eight instances: 2 in the
+                                          #     weighted, chained K = 64 one, 0 in the others)
     "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)
     "10k_ada_tailILi4E": 0,
     "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   split-bf16 K1 at K = 64

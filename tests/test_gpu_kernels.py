@@ -372,20 +372,22 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
 # chained in-place accumulation of gA (k_grad_f16_v8<CHAIN>): the workgroups of a chain add their contributions to one
 # slab through the XCD's L2 instead of writing one slab per column region
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,cap,want", [(4096, 4096, 32, 2), (4096, 16384, 32, 8), (4096, 16384, 4, 4), (8192, 8192, 32, 8),
-                                          (16384, 4096, 32, 8), (2048, 16384, 32, 4)])
-def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, cap, want):
-    """Shapes whose region plan gives chains of 2 .. 16 workgroups: gradients and loss against the fp64 oracle, the same
+@pytest.mark.parametrize("M,N,K,mode,cap,want", [(4096, 4096, 64, "f16x2", 32, 2), (4096, 16384, 64, "f16x2", 32, 8), (4096, 16384, 64, "f16x2", 4, 4),
+                                                 (8192, 8192, 64, "f16x2", 32, 8), (16384, 4096, 64, "f16x2", 32, 8), (2048, 16384, 64, "f16x2", 32, 4),
+                                                 (4096, 4096, 64, "f32", 32, 2), (4096, 16384, 64, "f32", 32, 8), (8192, 8192, 32, "f32", 32, 8),
+                                                 (2048, 16384, 32, "f32", 4, 4)])
+def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, cap, want):
+    """Shapes whose region plan gives chains of 2 .. 16 workgroups, in the two kernels that carry the protocol
+    (k_grad_f16_v8 in mode f16x2, k_grad_f32_pc in mode f32): gradients and loss against the fp64 oracle, the same
     tolerance as every other K1; the chained launch must be the one that ran (no fault, no silent fall-back), twice in a
     row bit-identically (fixed order of the in-place sums), and equal to the slab path up to summation order."""
-    K = 64
     monkeypatch.setenv("PMX_K1_CHAIN", str(cap))
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N)
     A[:, 0] += np.linspace(0.0, 1.0, M, dtype=np.float32)
     S[K - 1, :] += np.linspace(1.0, 0.0, N, dtype=np.float32)
-    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         info = dev.k1_info()
-        assert info["kernel"] == "k_grad_f16_v8" and info["chain"] == want, info
+        assert info["kernel"] == ("k_grad_f16_v8" if mode == "f16x2" else "k_grad_f32_pc") and info["chain"] == want, info
         assert info["slabs_A"] == info["col_regions"] // want
         dev.set_Y(Y)
         dev.set_factors(A, S)
@@ -400,7 +402,7 @@ def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, cap, want)
     np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
     monkeypatch.setenv("PMX_K1_CHAIN", "0")
-    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         assert dev.k1_info()["chain"] == 0
         dev.set_Y(Y)
         dev.set_factors(A, S)

@@ -508,16 +508,18 @@ def test_fused_adaprox_tail_equals_the_chain_of_kernels(pm, orc, monkeypatch, M,
         assert info["tail_fused"] and info["tail_faults"] == 0, info
 
 
+@pytest.mark.parametrize("kmode", ["f16x2", "f32"])
 @pytest.mark.parametrize("backend", ["adaprox", "fista", "bsdmm"])
-def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend):
+def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
     """The chained gA accumulation reports a fault (here injected into the 3rd chained launch; for real: a predecessor
     on another XCD, or workgroups that are not co-resident) before anything of the iteration is applied: the run must
     continue on the slab path from that iteration -- same iteration count, factors equal to an all-slab run up to the
-    summation order of the first iterations -- with the host-side Nesterov sequence rewound (fista)."""
+    summation order of the first iterations -- with the host-side Nesterov sequence rewound (fista).  Both kernels that
+    carry the protocol: k_grad_f16_v8 (mode f16x2) and k_grad_f32_pc (mode f32)."""
     import proxmin_amd as pm
     M, N, K = 4096, 4096, 64
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=(backend == "adaprox"), seed=8)
-    pm.set_default_mode("f16x2")
+    pm.set_default_mode(kmode)
     try:
         def run():
             A, S = A0.copy(), S0.copy()
@@ -541,7 +543,7 @@ def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend):
         # the fall-back really happened (and only once): the same through the engine, where the context can be asked
         from proxmin_amd import engine, operators as ops
         monkeypatch.setenv("PMX_INJECT_K1_FAULT", "3")
-        with engine.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        with engine.DeviceNMF(M, N, K, mode=kmode) as dev:
             assert dev.k1_info()["chain"] == 2
             dev.set_Y(Y)
             dev.set_factors(A0, S0)
@@ -552,7 +554,7 @@ def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend):
     finally:
         pm.set_default_mode("f32")
     # different summation orders of gA (chains / slabs) from the faulting iteration on: the module's trajectory policy
-    MODE["name"] = "f16x2"
+    MODE["name"] = kmode
     try:
         for got, want, name in ((Af, As, "A after the fault"), (Ac, As, "A chained"), (Sf, Ss, "S after the fault"), (Sc, Ss, "S chained")):
             assert_close_fp32_trajectory(got, want, err_msg=name)
