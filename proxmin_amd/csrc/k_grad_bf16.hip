@@ -1597,7 +1597,7 @@ constexpr int V7_OFF_A = V5_NB * V5_SL_BYTES, V7_OFF_R = V7_OFF_A + V5_AIMG_BYTE
 static_assert(V7_OFF_R % 256 == 0, "R images must start on a bank row");
 static_assert(V7_LDS_BYTES <= 160 * 1024, "");
 
-template <bool PROF, bool HASW>
+template <bool PROF, bool HASW, bool CHAIN>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -1608,9 +1608,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     const int li = lane & 15, lq = lane >> 4;
     const int M = a.M, N = a.N;
     int rowRegion, colRegion;
+    int chainId = 0, chainPos = 0;           // CHAIN: gA summed in place along chains of workgroups, as in k_grad_f16_v8<.., CHAIN> (see there)
     {
         const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
+        if constexpr (CHAIN) {
+            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
+            chainPos = idx % L;
+            chainId = (idx / L) * 8 + xcd;
+            rowRegion = chainId % gx;
+            colRegion = (chainId / gx) * L + chainPos;
+        } else if (gy % 8 == 0) {
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
             colRegion = xcd * (gy >> 3) + idx / gx;
@@ -1632,6 +1639,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
 #define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
     unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+    auto panel_at = [&](int t) {             // CHAIN: panel (t - chainPos) mod RP in the t-th place
+        if constexpr (CHAIN) { const int p = t - chainPos; return p < 0 ? p + nrp : p; }
+        else return t;
+    };
 
     if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
         if (!producer) {
@@ -1678,6 +1689,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 3;
             if (brp >= nrp) brp = nrp - 1;
+            brp = panel_at(brp);
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
 #pragma unroll
             // nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient slabs this kernel
@@ -1690,6 +1702,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             if constexpr (HASW) {
                 int brp = b >> 3;
                 if (brp >= nrp) brp = nrp - 1;
+                brp = panel_at(brp);
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
@@ -1729,13 +1742,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         };
         const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
         const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
-        load_A(row0);
+        load_A(row0 + panel_at(0) * V5_BM);
         load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
         load_Y(1, yO);
         load_W(0, wE);
         load_W(1, wO);
         make_afr();
-        if (nrp > 1) load_A(row0 + V5_BM);
+        if (nrp > 1) load_A(row0 + panel_at(1) * V5_BM);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
@@ -1752,7 +1765,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             if constexpr (GEMM) {
                 if (cb == 0 && s > 0) {      // block s opens a row panel: its A terms (rows requested 8 slots ago)
                     make_afr();
-                    if (rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
+                    if (rp + 1 < nrp) load_A(row0 + panel_at(rp + 1) * V5_BM);
                 }
             }
             bf16x8 sv[4][3];
@@ -1852,8 +1865,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
         const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
         const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
+        const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+        auto gA_tile = [&](int prow) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31; };
         auto flush_gA = [&](int prow) {
-            float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
+            float* p0_ = gA_tile(prow);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 float* ph_ = p0_ + half * 16 * K;
@@ -1872,8 +1887,40 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
             PH(9)
         };
-        auto consume = [&](int b, int rp, int cb, f32x16& accSc) {     // block b = (rp, cb)
-            const int prow = row0 + rp * V5_BM;
+        unsigned* cflags = nullptr;
+        unsigned myxcc = 0;
+        if constexpr (CHAIN) {
+            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
+            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        }
+        unsigned* pendFlag = nullptr;
+        unsigned pendVal = 0;
+        unsigned* curFlag = nullptr;
+        unsigned cwant = 0, cseen = 0;
+        bool cadd = false, cdead = false;
+        auto chain_fault = [&](int code) {
+            if (lane == 0 && code > 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            cadd = false;
+            cdead = true;
+        };
+        auto chain_publish = [&]() {
+            if constexpr (CHAIN) {
+                if (pendFlag != nullptr) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pendFlag = nullptr;
+                }
+            }
+        };
+        if constexpr (CHAIN) {
+            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+        }
+        auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
             const unsigned char* Rb = smem + V7_OFF_R + (b & 1) * V5_R_BYTES;
             const unsigned char* Slb = smem + cb * V5_SL_BYTES;
             const unsigned char* Ab = smem + V7_OFF_A;
@@ -1910,7 +1957,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);
                 }
             }
-            if ((a.doA & 1) && cb + 1 == NCB) {
+            if (!CHAIN && (a.doA & 1) && cb + 1 == NCB) {
                 flush_gA(prow);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
@@ -1921,18 +1968,73 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         int s = 2;
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
+            const int pnl = panel_at(rp);
+            const int prow = row0 + pnl * V5_BM;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
+                    if constexpr (CHAIN) {
+                        chain_publish();     // the previous panel's arrival
+                        const int c = chainPos, L = a.chainL;
+                        const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
+                        const int kq = pnl + c >= nrp ? pnl + c - nrp : c + nw;     // place of this workgroup among the visits of panel pnl
+                        cadd = (a.doA & 1) && kq > 0 && !cdead;
+                        cwant = a.chainBase + (unsigned)kq;
+                        curFlag = cflags + pnl * 4;
+                    }
                 }
-                consume(s - 2, rp, cb, accS[cb]);
+                float pv0[4], pv1[4];
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cb >= 4 && cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
+                        const float* pb = gA_tile(prow) + 8 * (cb - 4) * K;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            pv0[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            pv1[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    }
+                }
+                consume(s - 2, prow, cb, accS[cb]);
+                if constexpr (CHAIN) {
+                    if (cb == 3 && cadd) {
+                        unsigned v = __builtin_amdgcn_readfirstlane(cseen);
+                        if ((v >> 4) != cwant) {
+                            const long long t0 = wall_clock64();          // 100 MHz
+                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
+                                if ((spins & 63) == 0) {
+                                    if (chain_halted(a.status)) { chain_fault(0); break; }
+                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            }
+                        }
+                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                    }
+                    if (cb >= 4 && cadd) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            accA0[4 * (cb - 4) + q] += pv0[q];
+                            accA1[4 * (cb - 4) + q] += pv1[q];
+                        }
+                    }
+                    if (cb + 1 == NCB && (a.doA & 1)) {
+                        flush_gA(prow);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
+                        pendFlag = curFlag;
+                        pendVal = ((cwant + 1u) << 4) | myxcc;
+                    }
+                }
                 PH(7)
                 sync();
                 ++s;
             }
         }
+        chain_publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
             const int kk = kt * 32 + l31;
@@ -1968,16 +2070,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW>
+template <bool PROF, bool HASW, bool CHAIN>
 static hipError_t grad_launch_bf16_v7_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v7<PROF, HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v7<PROF, HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_bf16_v7<PROF, HASW>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V7_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_bf16_v7<PROF, HASW, CHAIN>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V7_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_bf16_v7(const GradV4Args& a, hipStream_t stream) {
-    if (a.W != nullptr) return grad_launch_bf16_v7_t<false, true>(a, stream);   // (no phase profiling of the weighted instance)
-    return a.prof ? grad_launch_bf16_v7_t<true, false>(a, stream) : grad_launch_bf16_v7_t<false, false>(a, stream);
+    if (a.chainL > 0) return a.W != nullptr ? grad_launch_bf16_v7_t<false, true, true>(a, stream) : grad_launch_bf16_v7_t<false, false, true>(a, stream);
+    if (a.W != nullptr) return grad_launch_bf16_v7_t<false, true, false>(a, stream);   // (no phase profiling of the weighted instance)
+    return a.prof ? grad_launch_bf16_v7_t<true, false, false>(a, stream) : grad_launch_bf16_v7_t<false, false, false>(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

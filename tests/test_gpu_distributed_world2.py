@@ -20,7 +20,7 @@ CASES = {
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
     # (PMX_INJECT_K1_FAULT): it falls back to slabs, rank 0 is stopped at the same iteration through the collective halt
     # flag, both go on from there.  (Two processes on one GPU can also fault for real -- not co-resident -- same path.)
-    "adaprox_chain_fault": dict(M=4096, N=16384, K=64, unity=True, its=6, modes=("f16x2", "f32"), inject={1: "3"}),   # (k_grad_f16_v8 / k_grad_f32_pc)
+    "adaprox_chain_fault": dict(M=4096, N=16384, K=64, unity=True, its=6, modes=("f16x2", "f32", "bf16x3"), inject={1: "3"}),   # (k_grad_f16_v8 / k_grad_f32_pc / k_grad_bf16_v7)
 }
 
 

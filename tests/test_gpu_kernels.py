@@ -375,10 +375,11 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
 @pytest.mark.parametrize("M,N,K,mode,cap,want", [(4096, 4096, 64, "f16x2", 32, 2), (4096, 16384, 64, "f16x2", 32, 8), (4096, 16384, 64, "f16x2", 4, 4),
                                                  (8192, 8192, 64, "f16x2", 32, 8), (16384, 4096, 64, "f16x2", 32, 8), (2048, 16384, 64, "f16x2", 32, 4),
                                                  (4096, 4096, 64, "f32", 32, 2), (4096, 16384, 64, "f32", 32, 8), (8192, 8192, 32, "f32", 32, 8),
-                                                 (2048, 16384, 32, "f32", 4, 4)])
+                                                 (2048, 16384, 32, "f32", 4, 4),
+                                                 (4096, 4096, 64, "bf16x3", 32, 2), (4096, 16384, 64, "bf16x3", 32, 8), (8192, 8192, 64, "bf16x3", 4, 4)])
 def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, cap, want):
-    """Shapes whose region plan gives chains of 2 .. 16 workgroups, in the two kernels that carry the protocol
-    (k_grad_f16_v8 in mode f16x2, k_grad_f32_pc in mode f32): gradients and loss against the fp64 oracle, the same
+    """Shapes whose region plan gives chains of 2 .. 16 workgroups, in the three kernels that carry the protocol
+    (k_grad_f16_v8 in mode f16x2, k_grad_f32_pc in mode f32, k_grad_bf16_v7 in mode bf16x3): gradients and loss against the fp64 oracle, the same
     tolerance as every other K1; the chained launch must be the one that ran (no fault, no silent fall-back), twice in a
     row bit-identically (fixed order of the in-place sums), and equal to the slab path up to summation order."""
     monkeypatch.setenv("PMX_K1_CHAIN", str(cap))
@@ -387,7 +388,7 @@ def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, c
     S[K - 1, :] += np.linspace(1.0, 0.0, N, dtype=np.float32)
     with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         info = dev.k1_info()
-        assert info["kernel"] == ("k_grad_f16_v8" if mode == "f16x2" else "k_grad_f32_pc") and info["chain"] == want, info
+        assert info["kernel"] == {"f16x2": "k_grad_f16_v8", "f32": "k_grad_f32_pc", "bf16x3": "k_grad_bf16"}[mode] and info["chain"] == want, info
         assert info["slabs_A"] == info["col_regions"] // want
         dev.set_Y(Y)
         dev.set_factors(A, S)

@@ -508,14 +508,14 @@ def test_fused_adaprox_tail_equals_the_chain_of_kernels(pm, orc, monkeypatch, M,
         assert info["tail_fused"] and info["tail_faults"] == 0, info
 
 
-@pytest.mark.parametrize("kmode", ["f16x2", "f32"])
+@pytest.mark.parametrize("kmode", ["f16x2", "f32", "bf16x3"])
 @pytest.mark.parametrize("backend", ["adaprox", "fista", "bsdmm"])
 def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
     """The chained gA accumulation reports a fault (here injected into the 3rd chained launch; for real: a predecessor
     on another XCD, or workgroups that are not co-resident) before anything of the iteration is applied: the run must
     continue on the slab path from that iteration -- same iteration count, factors equal to an all-slab run up to the
     summation order of the first iterations -- with the host-side Nesterov sequence rewound (fista).  Both kernels that
-    carry the protocol: k_grad_f16_v8 (mode f16x2) and k_grad_f32_pc (mode f32)."""
+    carry the protocol: k_grad_f16_v8 (mode f16x2), k_grad_f32_pc (mode f32), k_grad_bf16_v7 (mode bf16x3)."""
     import proxmin_amd as pm
     M, N, K = 4096, 4096, 64
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=(backend == "adaprox"), seed=8)
