@@ -328,6 +328,10 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
                     alpha = utils._as_tuple(user_step(A, S, it=it))                  # algorithms.py:370
                     assert len(alpha) == 2, "step must return one Alpha per block"
                     dev.adaprox_set_alpha(_component_steps(alpha[0], K, 0), _component_steps(alpha[1], K, 1))
+                elif fixed is not None:
+                    # nmf.constant_step: the device keeps the two constants (adaprox_begin(fixed_alpha=...)); recomputing the
+                    # default rule here would overwrite DevStatus::alpha with mean(X)/10 (and clear the halt flag mid-run)
+                    alpha = (dt.type(fixed[0]), dt.type(fixed[1]))
                 elif any(h is not None for h in host_prox):
                     aA, aS = dev.step_adaprox()                                    # the rule the device applies (nmf.py:93)
                     alpha = (aA.astype(dt), aS.astype(dt)[:, None])
@@ -450,6 +454,16 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
     order = None if update_order is None else [int(j) for j in update_order]
     if order is not None:
         assert all(j in (0, 1) for j in order), "update_order refers to a block that does not exist"
+        if len(order) == 0:
+            # the reference loops max_iter times over an empty block list (algorithms.py:800-846): nothing is updated, the
+            # callback still sees every iteration, `converged` keeps its initial [None, None] and the warning is logged.
+            # (n_order = 0 means "default order" to the C ABI, so this case never reaches the device.)
+            if _wants_iterates(callback):
+                for it in range(max_iter):
+                    callback(A, S, it=it)
+            logger.info("Completed {0} iterations".format(max_iter))
+            logger.warning("Solution did not converge")
+            return [None, None]
     er = [e_rel] * N if np.isscalar(e_rel) else list(e_rel)
     ea = [e_abs] * N if np.isscalar(e_abs) else list(e_abs)
     seq_f = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]

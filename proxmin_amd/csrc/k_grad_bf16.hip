@@ -1913,6 +1913,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                 if (pendFlag != nullptr) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
                     pendFlag = nullptr;
                 }
             }
@@ -2013,6 +2014,8 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                             }
                         }
                         if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                        // compiler fence: the sc1 loads of the previous sum (next column blocks) stay behind the arrival check
+                        asm volatile("" ::: "memory");
                     }
                     if (cb >= 4 && cadd) {
 #pragma unroll
@@ -2562,6 +2565,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 if (pendFlag != nullptr) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
                     pendFlag = nullptr;
                 }
             }
@@ -2621,6 +2625,8 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                             }
                         }
                         if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                        // compiler fence: the sc1 loads of the previous sum (next column blocks) stay behind the arrival check
+                        asm volatile("" ::: "memory");
                     }
                     if (cb >= 4 && cadd) {
 #pragma unroll

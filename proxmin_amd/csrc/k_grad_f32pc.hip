@@ -290,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
                 if (pendFlag != nullptr) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
                     pendFlag = nullptr;
                 }
             }
@@ -387,6 +388,8 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
                             }
                         }
                         if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                        // compiler fence: the sc1 loads of the previous sum (next column blocks) stay behind the arrival check
+                        asm volatile("" ::: "memory");
                     }
                     if (cb >= 4 && cadd) {
 #pragma unroll

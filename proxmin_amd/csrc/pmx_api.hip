@@ -967,7 +967,13 @@ extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
     if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
-    int rc = enqueue_alpha_from_factors(c, alpha_args(c));
+    AlphaArgs al = alpha_args(c);
+    if (c->algo == ALG_ADAPROX && c->ada.use_fixed_steps == 1) {   // inside a constant_step run the constants ARE the rule
+        al.use_fixed = 1;
+        al.fixed[0] = (float)c->ada.fixed_alpha[0];
+        al.fixed[1] = (float)c->ada.fixed_alpha[1];
+    }
+    int rc = enqueue_alpha_from_factors(c, al);
     if (rc != PMX_OK) return rc;
     rc = read_status(c);
     if (rc != PMX_OK) return rc;
@@ -1319,6 +1325,11 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
             if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }   // (one iteration per call: nothing to repeat into)
             if (!p.use_fixed_steps) {
                 rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);
+                if (rc != PMX_OK) return rc;
+            } else if (!steps) {
+                // nmf.constant_step with a host-side prox: reset_status left DevStatus::step at 0 and only pmx_pgm_run
+                // uploads the constants -- without them the host prox would be handed T = Xe - 0 G
+                rc = set_fixed_steps(c, p.fixed_steps);
                 if (rc != PMX_OK) return rc;
             }
             rc = enqueue_grad(c, A, St, 1, 1);
@@ -2094,10 +2105,21 @@ extern "C" int pmx_chain_status(pmx_ctx* c, int* halted, int* reason, int* it_do
     if (c->hstatus->tail_fault)    // its update of iteration it_done was not applied here, but the other ranks applied theirs
         FAIL(PMX_E_STATE, "the fused adaprox tail (k_ada_tail) found its workgroups not co-resident in a row-sharded run: "
                           "this GPU is shared with other work; set PMX_TAIL_FUSED=0");
+    // The drivers re-enqueue from it_done after a repaired halt: the host-side iteration counter and Nesterov sequence ran
+    // ahead with the iterations of the chunk that were skipped on the device (pmx_pgm_phase(1) draws one omega per ENQUEUED
+    // iteration), so they are rewound exactly as pmx_pgm_run does after a chain fault.
+    auto rewind_host_sequence = [&]() {
+        c->it = c->hstatus->it_done;
+        if (c->algo == ALG_PGM && c->pgm.accelerated) {
+            c->nest_t = 1.0;
+            for (int i = 0; i <= c->it; ++i) c->nest_t = 0.5 * (1.0 + sqrt(4.0 * c->nest_t * c->nest_t + 1.0));
+        }
+    };
     if (c->hstatus->k1_fault) {    // nothing of iteration it_done was applied on any rank (collective halt flag): fall back, retry
         int again = 0;
         rc = chain_fault_fallback(c, &again);
         if (rc != PMX_OK) return rc;
+        rewind_host_sequence();
         *halted = 1;
         *reason = HALT_RETRY;
     } else if (c->hstatus->halt && c->hstatus->reason == HALT_PEER) {
@@ -2106,6 +2128,7 @@ extern "C" int pmx_chain_status(pmx_ctx* c, int* halted, int* reason, int* it_do
         HIP_CHECK(hipStreamSynchronize(c->stream));
         c->hstatus->halt = 0;
         c->absmax_by_finish = false;
+        rewind_host_sequence();
     }
     last_tau[0] = c->hstatus->last_tau[0];
     last_tau[1] = c->hstatus->last_tau[1];

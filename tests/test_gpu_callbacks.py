@@ -221,3 +221,53 @@ def test_bsdmm_update_order_and_direct_entry(pm, orc):
     conv4 = pm.nmf.nmf(Y, A4, S4, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=3, e_rel=1e-9, update_order=[0])
     np.testing.assert_array_equal(S4, S0)
     assert conv4[1] is None and not np.array_equal(A4, A0)
+
+
+def test_constant_step_with_user_prox_in_pgm(pm, orc):
+    """pgm(step=nmf.constant_step(a, b), prox=<user callable>) ran the split phases with
+    DevStatus::step == 0 (only pmx_pgm_run uploaded the constants): X did not move and the run "converged" at once.
+    A user-written projection must reproduce the fused prox_plus run with the same constants."""
+    Y, A0, S0 = orc.synthetic_problem(400, 640, 24, np.float32, seed=2)
+    sA, sS = pm.nmf.step_pgm(A0, S0)
+    step = pm.nmf.constant_step(0.5 * float(sA), 0.5 * float(sS))
+    runs = {}
+    for name, pA, pS in (("lib", pm.operators.prox_plus, pm.operators.prox_plus), ("user", my_plus, my_plus)):
+        A, S = A0.copy(), S0.copy()
+        ret = pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, step=step, max_iter=8, e_rel=1e-9)
+        runs[name] = (A, S, ret)
+    assert np.abs(runs["user"][0] - A0).max() > 1e-3, "the factors did not move"
+    assert not all(runs["user"][2][0]), "8 iterations at e_rel = 1e-9 cannot have converged"
+    np.testing.assert_array_equal(runs["user"][0], runs["lib"][0])
+    np.testing.assert_array_equal(runs["user"][1], runs["lib"][1])
+    np.testing.assert_allclose(np.array(runs["user"][2][2], dtype=np.float64), step.steps, rtol=1e-6)
+
+
+def test_constant_step_with_user_prox_in_adaprox(pm, orc):
+    """constant_step + a user-defined prox recomputed the default rule mean(X)/10 on the device and
+    overwrote the constants.  constant_step + my_soft must match constant_step + the library's prox_soft."""
+    Y, A0, S0 = orc.synthetic_problem(300, 500, 12, np.float32, seed=9)
+    step = pm.nmf.constant_step(0.01, 0.02)
+    out = []
+    for pS in (partial(pm.operators.prox_soft, thresh=1e-3), my_soft):
+        A, S = A0.copy(), S0.copy()
+        ret = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", step=step, max_iter=10, e_rel=1e-4, prox_S=pS)
+        out.append((A, S, ret))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=2e-5, atol=2e-6)
+    # and the oracle with the same constants
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("soft", 1e-3, "relative"), scheme="adam", max_iter=10, e_rel=1e-4,
+                    step=lambda A_, S_, it: (np.float32(0.01), np.float32(0.02)))
+    np.testing.assert_allclose(out[1][0], Ao, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out[1][1], So, rtol=2e-4, atol=2e-5)
+
+
+def test_bsdmm_with_an_empty_update_order(pm, orc):
+    """update_order=[] updates nothing for max_iter iterations (algorithms.py:800-846)."""
+    Y, A0, S0 = orc.synthetic_problem(64, 96, 4, np.float32, seed=1)
+    A, S = A0.copy(), S0.copy()
+    seen = []
+    conv = pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, update_order=[], max_iter=3, callback=lambda *X, it=None: seen.append(it))
+    assert conv == [None, None] and seen == [0, 1, 2]
+    np.testing.assert_array_equal(A, A0)
+    np.testing.assert_array_equal(S, S0)
