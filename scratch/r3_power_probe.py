@@ -16,12 +16,27 @@ os.makedirs(OUT, exist_ok=True)
 mode = os.environ.get("PMX_AB_MODE", "f16x2")
 
 
+def my_bdf():
+    """PCI address of HIP device 0 (the box's sysfs shows every GPU of the host; only one is ours)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    if hip.hipDeviceGetPCIBusId(buf, 64, 0) != 0:
+        return None
+    return buf.value.decode().lower()
+
+
+BDF = my_bdf()
+
+
 def find_hwmon():
     cands = []
     for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
         files = {os.path.basename(f) for f in glob.glob(d + "/*")}
-        cands.append((d, files))
-    return cands
+        real = os.path.realpath(os.path.dirname(os.path.dirname(d)))
+        cands.append((d, files, real))
+    mine = [c for c in cands if BDF and c[2].lower().endswith(BDF)]
+    return [(d, f) for d, f, _ in (mine or cands)]
 
 
 HW = find_hwmon()
@@ -51,8 +66,8 @@ def sample_sysfs():
 
 def smi_snapshot():
     out = {}
-    for name, cmd in (("amd-smi", ["amd-smi", "metric", "-g", "0", "--power", "--clock", "--json"]),
-                      ("rocm-smi", ["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"])):
+    for name, cmd in (("amd-smi", ["amd-smi", "metric", "--power", "--clock", "--csv"]),
+                      ("amd-smi-list", ["amd-smi", "list", "--csv"])):
         try:
             out[name] = subprocess.run(cmd, capture_output=True, text=True, timeout=20).stdout[-6000:]
         except Exception as e:
@@ -148,7 +163,7 @@ phase("K1 producers only, pitch N+64", lambda: "%.4f ms" % devp.time_grad(0, 0, 
 phase("bench chain again", chain)
 json.dump(trace, open(os.path.join(OUT, "trace.json"), "w"), indent=0)
 with open(os.path.join(OUT, "summary.txt"), "w") as f:
-    f.write("mode %s; cfg3 16384 x 16384 x 64; hwmon %s\n" % (mode, [d for d, _ in HW]))
+    f.write("mode %s; cfg3 16384 x 16384 x 64; HIP device 0 = PCI %s; hwmon %s\n" % (mode, BDF, [d for d, _ in HW]))
     for p in trace["phases"]:
         f.write("%-36s %-44s power W (min, mean, max) %s  sclk MHz %s  cap W %s  %s\n" % (
             p["name"], p["result"], p["power_W(min,mean,max)"], p["sclk_MHz(min,mean,max)"], p["cap_W"], p["pp_dpm_sclk"]))

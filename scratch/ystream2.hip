@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+__device__ __forceinline__ unsigned long long wall_clock64_() { return __builtin_amdgcn_s_memrealtime(); }
+#define wall_clock64 wall_clock64_
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,7 +35,7 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
-template <int MODE, int DEPTH, bool MFMA, bool NT>
+template <int MODE, int DEPTH, bool MFMA, bool NT, int MF = 12, bool BAR = true>
 __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t ld, int M, int N, int RP, int gridX, float* out) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int BN = MODE == 4 ? 64 : 32, NCB = 256 / BN;
@@ -47,7 +49,8 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t
     const int row0 = rowRegion * RP * 128, col0 = colRegion * 256;
     const int T = RP * NCB;
     const bool producer = w < 4;
-    float acc = 0.f;
+    float acc = out[2];          // opaque: keeps the no-load variants' MFMAs alive
+    const unsigned long long tc0 = __builtin_readcyclecounter(), tw0 = wall_clock64();
     float y[MODE == 2 || MODE == 3 ? 1 : DEPTH][NY] = {};
     const unsigned ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue = [&](int slotbuf, int t) {
@@ -117,28 +120,31 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t
             if constexpr (MFMA) {
                 if (producer) {
 #pragma unroll
-                    for (int q = 0; q < 12 * NM; ++q) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
+                    for (int q = 0; q < MF * NM; ++q) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 12 * NM; ++q) {
+                    for (int q = 0; q < MF * NM; ++q) {
                         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
                         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, c1, 0, 0, 0);
                     }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (BAR) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (acc == 123.456f) out[0] = acc + c0[0] + c1[3];
+    if (blockIdx.x == 0 && tid == 0) { out[4] = (float)(__builtin_readcyclecounter() - tc0); out[5] = (float)(wall_clock64() - tw0); }
 }
 
 int main(int argc, char** argv) {
     const int M = 16384, N = 16384, RP = 16, gridX = 8;
     const int pads[3] = {0, 64, 2048 + 64};
     float* out;
-    CHECK(hipMalloc(&out, 8));
+    CHECK(hipMalloc(&out, 64)); CHECK(hipMemset(out, 0, 64));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int pi = 0; pi < 3; ++pi) {
         const int64_t ld = N + pads[pi];
@@ -159,10 +165,17 @@ int main(int argc, char** argv) {
                     if (rep) { tot += ms / 20; if (ms / 20 < best) best = ms / 20; }
                 }
                 CHECK(hipGetLastError());
-                printf("%-44s %.4f ms (best %.4f)  %.0f GB/s\n", name, tot / 2, best, (double)M * N * 4 / (tot / 2) / 1e6);
+                float h[8]; CHECK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
+                printf("%-44s %.4f ms (best %.4f)  %.0f GB/s   WG0: %.0f cycles in %.1f us = %.0f MHz\n", name, tot / 2, best, (double)M * N * 4 / (tot / 2) / 1e6, h[4], h[5] / 100.0, h[5] > 0 ? h[4] / (h[5] / 100.0) : 0.0);
                 fflush(stdout);
             };
             run("no loads, 36 MFMA/SIMD/slot", k<3, 1, true, true>, 0);
+            run("no loads, 18 MFMA/SIMD/slot", k<3, 1, true, true, 6>, 0);
+            run("no loads, 36 MFMA/SIMD/slot, no barrier", k<3, 1, true, true, 12, false>, 0);
+            run("dwordx4 nt d4 + 18 MFMA/SIMD/slot", k<1, 4, true, true, 6>, 0);
+            run("dwordx4 nt d4 + 72 MFMA/SIMD/slot", k<1, 4, true, true, 24>, 0);
+            run("dwordx4 nt d4 + 36 MFMA, no barrier", k<1, 4, true, true, 12, false>, 0);
+            run("dwordx4 nt d4, no MFMA, no barrier", k<1, 4, false, true, 12, false>, 0);
             run("dword nt d2, no MFMA", k<0, 2, false, true>, 0);
             run("dword nt d4, no MFMA", k<0, 4, false, true>, 0);
             run("dword nt d2 + MFMA   (= v8's fetch)", k<0, 2, true, true>, 0);
