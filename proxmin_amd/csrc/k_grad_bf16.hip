@@ -2102,6 +2102,31 @@ __device__ __forceinline__ void v8_split2(const float4& x, float sc, f16x4& h, f
         l[i] = (_Float16)(v[i] - (float)t);
     }
 }
+// buffer descriptor over `bytes` bytes at a wave-uniform address (the halves go through readfirstlane: anything derived from
+// threadIdx, even the wave index, is divergent to the compiler, and a descriptor it cannot prove uniform is wrapped in a
+// waterfall loop per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t v8_region_srd(const void* base, int64_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    const unsigned n = bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+// (h, l) of the pair (r0 sc, r1 sc), packed: h = fp16(x), l = fp16(x - h) with x - h formed by ONE mixed-precision fma that reads
+// its fp16 operand directly (v_fma_mix*: fp32 product r sc -- exact, sc is a power of two -- minus h, rounded once: the same
+// value as fp16(x - float(h)), whose difference is exact in fp32).  Left to itself hipcc converts h back to fp32, subtracts
+// with a packed fp32 fma and converts again: five instructions per pair instead of three.
+__device__ __forceinline__ void v8_split_pair(float r0, float r1, float sc, unsigned& h, unsigned& l) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    f16x2_t hv;
+    hv[0] = (_Float16)(r0 * sc);
+    hv[1] = (_Float16)(r1 * sc);
+    h = __builtin_bit_cast(unsigned, hv);
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(r0), "v"(sc), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(r1), "v"(sc), "v"(h));
+    l = lo;
+}
 __device__ __forceinline__ f16x8 v8_tr_pair(const unsigned char* base, int off0, int off1) {
     return __builtin_bit_cast(f16x8, v3_tr_pair(base, off0, off1));   // the transposing read moves 16-bit payloads
 }
@@ -2170,7 +2195,9 @@ constexpr int V8_OFF_A = V5_NB * V8_SL_BYTES, V8_OFF_R = V8_OFF_A + V5_AIMG_BYTE
 static_assert(V8_OFF_R % 256 == 0, "R images must start on a bank row");
 static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 
-template <bool PROF, bool HASW, bool CHAIN>
+// LOSS: the sum of squares (nmf.py:13-25) is accumulated only by the instance the loss-only pass runs (doA = doS = 0:
+// pmx_loglike, the backtracking line search); gradient passes never read it and skip its 16 multiply-adds per lane and block.
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -2283,16 +2310,23 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         // Y(b): wave-uniform base (scalar registers) + one per-lane offset; row i of the tile is a multiple of ldY further
         const int jw = __builtin_amdgcn_readfirstlane(j);
         const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
-        const unsigned ylane = (unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31;
+        // Y(b) through a buffer descriptor: base = this wave's first row of the region (wave-uniform, scalar registers),
+        // voffset = sixteen per-lane byte offsets that never change (row i of the tile in the accumulator's layout, this
+        // lane's column), soffset = the block's byte offset (one scalar per block).  No address arithmetic is left in the
+        // loop (it was sixteen 64-bit vector adds per block).  aux = 2: nontemporal -- Y is read once per launch; keeping
+        // it out of L2 / MALL leaves the gradient slabs this kernel writes there for the update kernel that folds them
+        // (iteration -2.7 % at 16384 x 16384)
+        unsigned yoff[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yoff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldY + (unsigned)l31) * 4u;
+        const __amdgpu_buffer_rsrc_t ysrd = v8_region_srd(ybase0, (int64_t)nrp * V5_BM * a.ldY * 4);
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 3;
             if (brp >= nrp) brp = nrp - 1;
             brp = panel_at(brp);
-            const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 7) * V5_BN;
+            const unsigned soff = (unsigned)brp * (unsigned)(V5_BM * 4) * (unsigned)a.ldY + (unsigned)((b & 7) * V5_BN * 4);
 #pragma unroll
-            // nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient slabs this kernel
-            // writes there for the update kernel that folds them (iteration -2.7 % at 16384 x 16384)
-            for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
+            for (int i = 0; i < 16; ++i) y[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrd, yoff[i], soff, 2));
         };
         const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
         const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
@@ -2328,8 +2362,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 }
             }
         };
+        const int pa0 = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
         auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
-            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
+            int pa = pa0;
+            asm volatile("" : "+v"(pa));     // the eight store addresses are formed HERE (once per panel), not hoisted into every slot
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
@@ -2389,25 +2425,24 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 unsigned char* Rb = smem + V8_OFF_R + ((s - 1) & 1) * V5_R_BYTES;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f16x4 h, l;
+                    float r[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float r = pp[4 * g + q] * unP - y[4 * g + q];
+                        r[q] = pp[4 * g + q] * unP - y[4 * g + q];
                         if constexpr (HASW) {
                             const float ww = wv[4 * g + q];
-                            lossAcc += ww * (r * r);
-                            r *= ww;
+                            if constexpr (LOSS) lossAcc += ww * (r[q] * r[q]);
+                            r[q] *= ww;
                         } else {
-                            lossAcc += r * r;
+                            if constexpr (LOSS) lossAcc += r[q] * r[q];
                         }
-                        const float rs = r * scR;
-                        const _Float16 hh = (_Float16)rs;
-                        h[q] = hh;
-                        l[q] = (_Float16)(rs - (float)hh);
                     }
+                    unsigned h2[2], l2[2];
+                    v8_split_pair(r[0], r[1], scR, h2[0], l2[0]);
+                    v8_split_pair(r[2], r[3], scR, h2[1], l2[1]);
                     const int o = r_w ^ (g << 4);
-                    *reinterpret_cast<f16x4*>(Rb + o) = h;
-                    *reinterpret_cast<f16x4*>(Rb + V5_R_TERM + o) = l;
+                    *reinterpret_cast<uint2*>(Rb + o) = make_uint2(h2[0], h2[1]);
+                    *reinterpret_cast<uint2*>(Rb + V5_R_TERM + o) = make_uint2(l2[0], l2[1]);
                 }
                 load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
                 load_W(s + 1, wv);
@@ -2684,17 +2719,19 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW, bool CHAIN>
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
-    if (a.chainL > 0) return a.W != nullptr ? grad_launch_f16_v8_t<false, true, true>(a, stream) : grad_launch_f16_v8_t<false, false, true>(a, stream);
-    if (a.W != nullptr) return grad_launch_f16_v8_t<false, true, false>(a, stream);   // (no phase profiling of the weighted instance)
-    return a.prof ? grad_launch_f16_v8_t<true, false, false>(a, stream) : grad_launch_f16_v8_t<false, false, false>(a, stream);
+    if (!(a.doA & 1) && !a.doS)      // the loss-only pass (no gradient is written: nothing to chain)
+        return a.W != nullptr ? grad_launch_f16_v8_t<false, true, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, true>(a, stream);
+    if (a.chainL > 0) return a.W != nullptr ? grad_launch_f16_v8_t<false, true, true, false>(a, stream) : grad_launch_f16_v8_t<false, false, true, false>(a, stream);
+    if (a.W != nullptr) return grad_launch_f16_v8_t<false, true, false, false>(a, stream);   // (no phase profiling of the weighted instance)
+    return a.prof ? grad_launch_f16_v8_t<true, false, false, false>(a, stream) : grad_launch_f16_v8_t<false, false, false, false>(a, stream);
 }
 
 
