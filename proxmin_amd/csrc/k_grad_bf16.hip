@@ -2102,26 +2102,15 @@ __device__ __forceinline__ void v8_split2(const float4& x, float sc, f16x4& h, f
         l[i] = (_Float16)(v[i] - (float)t);
     }
 }
-// buffer descriptor over `bytes` bytes at a wave-uniform address (the halves go through readfirstlane: anything derived from
-// threadIdx, even the wave index, is divergent to the compiler, and a descriptor it cannot prove uniform is wrapped in a
-// waterfall loop per load)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t v8_region_srd(const void* base, int64_t bytes) {
-    const uint64_t p = reinterpret_cast<uint64_t>(base);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-    const unsigned n = bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes;
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(n), 0x00020000);
-}
 // (h, l) of the pair (r0 sc, r1 sc), packed: h = fp16(x), l = fp16(x - h) with x - h formed by ONE mixed-precision fma that reads
 // its fp16 operand directly (v_fma_mix*: fp32 product r sc -- exact, sc is a power of two -- minus h, rounded once: the same
 // value as fp16(x - float(h)), whose difference is exact in fp32).  Left to itself hipcc converts h back to fp32, subtracts
 // with a packed fp32 fma and converts again: five instructions per pair instead of three.
 __device__ __forceinline__ void v8_split_pair(float r0, float r1, float sc, unsigned& h, unsigned& l) {
-    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-    f16x2_t hv;
-    hv[0] = (_Float16)(r0 * sc);
-    hv[1] = (_Float16)(r1 * sc);
-    h = __builtin_bit_cast(unsigned, hv);
+    unsigned hh;                             // h = fp16(r sc): the same instruction with a zero addend (one rounding)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(r0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(r1), "v"(sc));
+    h = hh;
     unsigned lo;
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(r0), "v"(sc), "v"(h));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(r1), "v"(sc), "v"(h));
@@ -2230,6 +2219,12 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     }
     const int row0 = rowRegion * a.RP * V5_BM;
     const int col0 = colRegion * NCB * V5_BN;          // N % 256 == 0: every region has all 8 column blocks
+    // Column map: blocks 2q and 2q + 1 of a region share the 64 columns col0 + 64 q ..: block b's local column n is the
+    // global column col0 + 64 (b >> 1) + 2 n + (b & 1) -- even columns to the even block, odd ones to the odd block.  A
+    // producer lane then owns two ADJACENT columns (one per block) and one 8-byte load per row fetches both blocks' Y:
+    // half the memory instructions, 256 contiguous bytes per row and instruction.  Only three places know the map: the S
+    // staging below, the Y / W loads, the gSt flush.
+    auto block_col = [&](int b, int n) { return col0 + 64 * (b >> 1) + 2 * n + (b & 1); };
     int nrp = (M - row0 + V5_BM - 1) / V5_BM;
     if (nrp > a.RP) nrp = a.RP;
     if (nrp < 0) nrp = 0;
@@ -2255,7 +2250,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
             for (int c = 0; c < NCB; ++c)
                 for (int i = 0; i < 16; ++i) {
-                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                    const int gn = block_col(c, tile_row(i, lane));
                     if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
                 }
         }
@@ -2285,11 +2280,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         unP = ldexpf(1.f, -(eA + eS)); unA = ldexpf(1.f, -(eR + eS)); unS = ldexpf(1.f, -(eR + eA));
     }
     {   // ---- all S terms of the region, once: block cb -> Sl[cb] (all 512 threads, one float4 of each block) -------
-        const float4* ssrc = reinterpret_cast<const float4*>(a.St + (int64_t)col0 * K) + tid;
         const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
         float4 sr[NCB];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) sr[c] = ssrc[c * (V5_BN * K / 4)];
+        for (int c = 0; c < NCB; ++c)        // image row tid >> 4 of block c = S^T row block_col(c, tid >> 4)
+            sr[c] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(c, tid >> 4) * K)[tid & 15];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             f16x4 t0, t1;
@@ -2303,42 +2298,58 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     if (producer) {
         // ================================ producers: GEMM1 and R =================================================
         f32x16 p0, p1;
-        float yE[16], yO[16];                // Y of the even / odd blocks in flight (accumulator layout)
-        float wE[HASW ? 16 : 1], wO[HASW ? 16 : 1];   // their weights
+        float yv[2][2][16];                  // Y in flight: [pair set][block of the pair][row i of the tile] (accumulator layout)
+        float wv[HASW ? 2 : 1][2][HASW ? 16 : 1];
         float4 areg[4][2];
         f16x8 afr[4][2];
-        // Y(b): wave-uniform base (scalar registers) + one per-lane offset; row i of the tile is a multiple of ldY further
         const int jw = __builtin_amdgcn_readfirstlane(j);
-        const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
-        // Y(b) through a buffer descriptor: base = this wave's first row of the region (wave-uniform, scalar registers),
-        // voffset = sixteen per-lane byte offsets that never change (row i of the tile in the accumulator's layout, this
-        // lane's column), soffset = the block's byte offset (one scalar per block).  No address arithmetic is left in the
-        // loop (it was sixteen 64-bit vector adds per block).  aux = 2: nontemporal -- Y is read once per launch; keeping
-        // it out of L2 / MALL leaves the gradient slabs this kernel writes there for the update kernel that folds them
-        // (iteration -2.7 % at 16384 x 16384)
+        // Y addresses: ONE wave-uniform base per request group (scalar registers: this wave's first row of the panel, the
+        // block pair's first column) + sixteen per-lane byte offsets that never change (row i of the tile in the
+        // accumulator's layout, this lane's column PAIR): the loads take the base as their scalar operand and no address
+        // arithmetic is left in the loop (it was sixteen 64-bit vector adds per block).  The empty asm statements keep the
+        // 32-bit offsets opaque: hipcc would otherwise widen them to 64 bits once, outside the loop, and add the base with
+        // vector instructions again.  (The raw_buffer_load_b64 / _b128 builtins of this toolchain load ONE dword:
+        // measured, not used.)  Nontemporal: Y is read once per launch; keeping it out of L2 / MALL leaves the gradient
+        // slabs this kernel writes there for the update kernel that folds them (iteration -2.7 % at 16384 x 16384).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         unsigned yoff[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) yoff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldY + (unsigned)l31) * 4u;
-        const __amdgpu_buffer_rsrc_t ysrd = v8_region_srd(ybase0, (int64_t)nrp * V5_BM * a.ldY * 4);
-        auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
-            int brp = b >> 3;
+        for (int i = 0; i < 16; ++i) yoff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldY + 2u * (unsigned)l31) * 4u;
+        const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
+        unsigned woff[HASW ? 16 : 1];
+        const float* wbase0 = nullptr;
+        if constexpr (HASW) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) woff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldW + 2u * (unsigned)l31) * 4u;
+            wbase0 = a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0;
+        }
+        // Y (and W) of the block pair q = blocks 2 q, 2 q + 1 (clamped past the end of the region) into pair set `set`:
+        // rows i0 .. i0 + n - 1 of the sixteen (the requests of a pair are spread over the last MFMAs of a slot)
+        auto pair_base = [&](int q, const float* b0, int64_t ld) {
+            int brp = q >> 2;
             if (brp >= nrp) brp = nrp - 1;
             brp = panel_at(brp);
-            const unsigned soff = (unsigned)brp * (unsigned)(V5_BM * 4) * (unsigned)a.ldY + (unsigned)((b & 7) * V5_BN * 4);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrd, yoff[i], soff, 2));
+            return reinterpret_cast<const char*>(b0 + (int64_t)brp * V5_BM * ld + (q & 3) * 64);
         };
-        const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
-        const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
-        auto load_W = [&](int b, float (&wv)[HASW ? 16 : 1]) {
-            if constexpr (HASW) {
-                int brp = b >> 3;
-                if (brp >= nrp) brp = nrp - 1;
-                brp = panel_at(brp);
-                const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 7) * V5_BN;
+        auto load_pair_rows = [&](const char* base, const char* basew, auto set_c, auto i0_c, auto n_c) {
+            constexpr int set = decltype(set_c)::value, i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
+            for (int i = i0; i < i0 + n; ++i) {
+                asm volatile("" : "+v"(yoff[i]));
+                const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(base + yoff[i]));
+                yv[set][0][i] = v[0];
+                yv[set][1][i] = v[1];
+                if constexpr (HASW) {
+                    asm volatile("" : "+v"(woff[i]));
+                    const f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(basew + woff[i]));
+                    wv[set][0][i] = u[0];
+                    wv[set][1][i] = u[1];
+                }
             }
+        };
+        auto load_pair = [&](int q, auto set_c) {
+            load_pair_rows(pair_base(q, ybase0, a.ldY), HASW ? pair_base(q, wbase0, a.ldW) : nullptr, set_c,
+                           std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
         };
         auto load_A = [&](int prow) {
             const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
@@ -2353,52 +2364,53 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
                                     areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+                unsigned hh[4], ll[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float xs = x[q] * scA;
-                    const _Float16 t0 = (_Float16)xs;
-                    afr[ks][0][q] = t0;
-                    afr[ks][1][q] = (_Float16)(xs - (float)t0);
-                }
+                for (int q = 0; q < 4; ++q) v8_split_pair(x[2 * q], x[2 * q + 1], scA, hh[q], ll[q]);
+                afr[ks][0] = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+                afr[ks][1] = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
             }
         };
         const int pa0 = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
         auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
-            int pa = pa0;
-            asm volatile("" : "+v"(pa));     // the eight store addresses are formed HERE (once per panel), not hoisted into every slot
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
+                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa0 ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + V5_A_TERM + (pa0 ^ (ks << 5))) = afr[ks][1];
             }
         };
         const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
         const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
+        using yes = std::integral_constant<bool, true>;
+        using no = std::integral_constant<bool, false>;
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
         load_A(row0 + panel_at(0) * V5_BM);
-        load_Y(0, yE);                       // slot s requests Y(s + 1) into the set block s - 1 has just left
-        load_Y(1, yO);
-        load_W(0, wE);
-        load_W(1, wO);
-        make_afr();
-        if (nrp > 1) load_A(row0 + panel_at(1) * V5_BM);
+        load_pair(0, set0{});                // slot s (even) requests the pair of blocks s + 2, s + 3 into the set block s - 1 has just left
+        // slot 0 runs the same code as every other slot (no peeled copy: the loop head then sees the same requests in flight
+        // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
+        // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests the pair of blocks 2, 3
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yv[1][1][i] = 0.f; if constexpr (HASW) wv[1][1][i] = 0.f; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
-        // One slot.  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
-        auto slot = [&](int s, f32x16& pc, f32x16& pp, float (&y)[16], float (&wv)[HASW ? 16 : 1], auto gemm_c, auto epi_c) {
+        // One slot; cb (the block's place in its panel) is a compile-time constant: the eight slots of a panel are ONE basic
+        // block, every LDS address is a register plus an immediate, and the compiler counts the loads in flight exactly.
+        // GEMM: block s = (rp, cb) into pc.  EPI: block s - 1 from pp and its Y tile -> R[(s - 1) & 1].
+        auto slot = [&](int rp, auto cb_c, f32x16& pc, f32x16& pp, auto gemm_c, auto epi_c) {
+            constexpr int cb = decltype(cb_c)::value;
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
-            const int cb = s & 7, rp = s >> 3;       // block s = (rp, cb); NCB == 8
-            if (cb == 2 && rp < nrp) {                   // block s-2 opened this row panel: the consumers start on it in this slot
+            constexpr int pset = ((cb + 7) >> 1) & 1, ptile = (cb + 7) & 1;     // pair set and place in its pair of block s - 1 (8 blocks per panel)
+            if constexpr (cb == 2 && GEMM) {         // block s-2 opened this row panel: the consumers start on it in this slot
                 publish_A();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_s_barrier();
             }
             PH(5)
-            if constexpr (GEMM) {
-                if (cb == 0 && s > 0) {      // block s opens a row panel: its A terms (rows requested 8 slots ago)
-                    make_afr();
-                    if (rp + 1 < nrp) load_A(row0 + panel_at(rp + 1) * V5_BM);
-                }
+            if constexpr (GEMM && cb == 0) { // block s opens a row panel: its A terms (rows requested 8 slots ago), then the next panel's rows
+                make_afr();
+                load_A(row0 + panel_at(rp + 1 < nrp ? rp + 1 : nrp - 1) * V5_BM);
             }
             f16x8 sv[4][2];
             if constexpr (GEMM) {
@@ -2411,41 +2423,61 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 }
             }
             PH(2)
-            if constexpr (GEMM) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pc[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][1], sv[ks][0], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][1], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][0], pc, 0, 0, 0);
-                }
+            // The slot's instruction order is laid out by hand, twelve steps of ONE MFMA of block s (a dependent chain: the
+            // wave would sit behind each of them for 32 cycles) + a piece of block s - 1's epilogue that issues in its shadow:
+            // steps 0-7 one pair of R entries each (residual, two-term split: six vector instructions; every second step the
+            // two 8-byte stores of a finished group), steps 8-11 four of the sixteen requests of the next block pair.  The
+            // fences keep hipcc from regrouping it (left alone it ran the whole epilogue first and the twelve MFMAs after it).
+            unsigned char* Rb = smem + V8_OFF_R + ((cb + 1) & 1) * V5_R_BYTES;    // block s - 1 has the other parity
+            unsigned h2[4][2], l2[4][2];
+            const char* ybase_n = nullptr;
+            const char* wbase_n = nullptr;
+            if constexpr (EPI && (cb & 1) == 0) {    // the pair set of block s - 1 (the second of its pair) is free after this epilogue: blocks s + 2, s + 3
+                ybase_n = pair_base(rp * 4 + (cb >> 1) + 1, ybase0, a.ldY);
+                if constexpr (HASW) wbase_n = pair_base(rp * 4 + (cb >> 1) + 1, wbase0, a.ldW);
             }
-            if constexpr (EPI) {
-                unsigned char* Rb = smem + V8_OFF_R + ((s - 1) & 1) * V5_R_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float r[4];
+            for (int t = 0; t < 12; ++t) {
+                if constexpr (GEMM) {
+                    const int ks = t / 3, wh = t % 3;        // al sh, ah sl, ah sh
+                    f32x16 cin = pc;
+                    if (t == 0) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        r[q] = pp[4 * g + q] * unP - y[4 * g + q];
-                        if constexpr (HASW) {
-                            const float ww = wv[4 * g + q];
-                            if constexpr (LOSS) lossAcc += ww * (r[q] * r[q]);
-                            r[q] *= ww;
-                        } else {
-                            if constexpr (LOSS) lossAcc += r[q] * r[q];
-                        }
+                        for (int i = 0; i < 16; ++i) cin[i] = 0.f;
                     }
-                    unsigned h2[2], l2[2];
-                    v8_split_pair(r[0], r[1], scR, h2[0], l2[0]);
-                    v8_split_pair(r[2], r[3], scR, h2[1], l2[1]);
-                    const int o = r_w ^ (g << 4);
-                    *reinterpret_cast<uint2*>(Rb + o) = make_uint2(h2[0], h2[1]);
-                    *reinterpret_cast<uint2*>(Rb + V5_R_TERM + o) = make_uint2(l2[0], l2[1]);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][wh == 0 ? 1 : 0], sv[ks][wh == 1 ? 1 : 0], cin, 0, 0, 0);
                 }
-                load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
-                load_W(s + 1, wv);
+                if constexpr (EPI) {
+                    if (t < 8) {
+                        const int g = t >> 1, hf = t & 1;
+                        float r[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int e = 4 * g + 2 * hf + q;
+                            r[q] = pp[e] * unP - yv[pset][ptile][e];
+                            if constexpr (HASW) {
+                                const float ww = wv[pset][ptile][e];
+                                if constexpr (LOSS) lossAcc += ww * (r[q] * r[q]);
+                                r[q] *= ww;
+                            } else {
+                                if constexpr (LOSS) lossAcc += r[q] * r[q];
+                            }
+                        }
+                        v8_split_pair(r[0], r[1], scR, h2[g][hf], l2[g][hf]);
+                        if (hf == 1) {
+                            const int o = r_w ^ (g << 4);
+                            *reinterpret_cast<uint2*>(Rb + o) = make_uint2(h2[g][0], h2[g][1]);
+                            *reinterpret_cast<uint2*>(Rb + V5_R_TERM + o) = make_uint2(l2[g][0], l2[g][1]);
+                        }
+                    } else if constexpr ((cb & 1) == 0) {
+                        if (t == 8) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+                        if (t == 9) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+                        if (t == 10) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+                        if (t == 11) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             PH(3)
             PH(4)
@@ -2453,17 +2485,24 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
             PH(0)
         };
-        using yes = std::integral_constant<bool, true>;
-        using no = std::integral_constant<bool, false>;
-        slot(0, p0, p1, yO, wO, yes{}, no{});
+        using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
+        using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
+        using c4 = std::integral_constant<int, 4>; using c5 = std::integral_constant<int, 5>;
+        using c6 = std::integral_constant<int, 6>; using c7 = std::integral_constant<int, 7>;
+        // even blocks: accumulator p0; odd blocks: p1
 #pragma nounroll
-        for (int s = 1; s + 1 < T; s += 2) {
-            slot(s, p1, p0, yE, wE, yes{}, yes{});
-            slot(s + 1, p0, p1, yO, wO, yes{}, yes{});
+        for (int rp = 0; rp < nrp; ++rp) {
+            slot(rp, c0{}, p0, p1, yes{}, yes{});
+            slot(rp, c1{}, p1, p0, yes{}, yes{});
+            slot(rp, c2{}, p0, p1, yes{}, yes{});
+            slot(rp, c3{}, p1, p0, yes{}, yes{});
+            slot(rp, c4{}, p0, p1, yes{}, yes{});
+            slot(rp, c5{}, p1, p0, yes{}, yes{});
+            slot(rp, c6{}, p0, p1, yes{}, yes{});
+            slot(rp, c7{}, p1, p0, yes{}, yes{});
         }
-        slot(T - 1, p1, p0, yE, wE, yes{}, yes{});
-        slot(T, p0, p1, yO, wO, no{}, yes{});
-        slot(T + 1, p1, p0, yE, wE, no{}, no{});
+        slot(nrp, c0{}, p0, p1, no{}, yes{});
+        slot(nrp, c1{}, p1, p0, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
@@ -2689,10 +2728,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             const int kk = kt * 32 + l31;
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
-                const int bcol = col0 + c * V5_BN;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int gn = bcol + tile_row(i, lane);
+                    const int gn = block_col(c, tile_row(i, lane));
                     dst[(int64_t)gn * K + kk] = accS[c][i] * unS;
                 }
             }
@@ -2832,7 +2870,10 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
         g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject;
-        if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_f16_v8(g, stream);   // fp16 two-term mode
+        // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
+        // else runs the split-bf16 kernel of the same frame below)
+        const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || ((a.ldW % 2) == 0 && (((uintptr_t)a.W) & 7) == 0));
+        if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0 && pairs_ok) return grad_launch_f16_v8(g, stream);
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }
