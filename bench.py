@@ -148,31 +148,38 @@ def begin_solver(dev, backend, unity):
     return lambda n: dev.bsdmm_run(n)
 
 
-def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6):
+def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6, transient=0):
     """Oracle (NumPy port of the reference, fp32 like the device data) on this host's cores: the SAME workload at its full
-    size -- the bench's own Y (copied back from the GPU) and initial factors --, n_iter iterations, wall time per iteration
-    from callback time stamps, the first iteration (cold caches, adaprox's long first proximal loop) excluded."""
+    size -- the bench's own Y (copied back from the GPU) and initial factors.  `transient` iterations run untimed first (the
+    adaprox start-up: 250 proximal passes on S in iteration 0, tens in the next few), then `n_iter` iterations are timed from
+    callback time stamps: the same steady state the GPU's timed region is in.  Returns the record
+    and the per-iteration proximal pass counts (A, S) of the timed iterations."""
     from oracle import nmf_oracle as orc
     M, N = Y.shape
     K = A0.shape[1]
     A, S = A0.copy(), S0.copy()
     stamps = []
+    total = transient + n_iter
 
     def cb(*X, it=None):
         stamps.append(time.perf_counter())
 
-    sub_note = ""
+    sub_note, sub_timed = "", None
     if backend == "pgm":
-        orc.pgm_nmf(Y, A, S, max_iter=n_iter, e_rel=1e-12, callback=cb)
+        orc.pgm_nmf(Y, A, S, max_iter=total, e_rel=1e-12, callback=cb)
     elif backend == "adaprox":
+        # sub-iteration counts of the timed window alone: the run is split at the window's start (warm moments carried over)
         ret = orc.adaprox_nmf(Y, A, S, ("plus",), ("unity_plus", 0) if unity else ("plus",), scheme="amsgrad",
-                              max_iter=n_iter, e_rel=1e-3, check_convergence=False, callback=cb)
-        sub_note = "; proximal passes per iteration in the sample (incl. the long first loop): A %.2f, S %.2f" % (
-            ret[5][0] / n_iter, ret[5][1] / n_iter)
+                              max_iter=total, e_rel=1e-3, check_convergence=False, callback=cb,
+                              sub_trace=True)
+        per = ret[6]
+        sub_timed = [float(np.mean([p[j] for p in per[transient:]])) for j in range(2)]
+        sub_note = "; proximal passes per iteration inside the timed window: A %.2f, S %.2f (iteration 0: A %d, S %d)" % (
+            sub_timed[0], sub_timed[1], per[0][0], per[0][1])
     else:
-        orc.bsdmm_nmf(Y, A, S, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=n_iter, e_rel=1e-12, callback=cb)
+        orc.bsdmm_nmf(Y, A, S, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=total, e_rel=1e-12, callback=cb)
     stamps.append(time.perf_counter())
-    per = np.diff(stamps)[1:]            # exclude iteration 0
+    per_t = np.diff(stamps)[max(transient, 1):]            # the timed window (never iteration 0)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -187,10 +194,18 @@ def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6):
             cores = max(int(i.get("num_threads") or 1) for i in infos)     # the threads the contractions really use (the rest of NumPy is one thread)
     except Exception:
         pass
-    return {"value": 1.0 / float(np.mean(per)), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": "oracle (NumPy fp32; BLAS: %s; host: %d hardware threads) on the full %d x %d x %d workload (the bench's own Y and initial factors), "
-                      "%d iterations, mean of iterations 1..%d = %.3f s (min %.3f, max %.3f), no scaling%s"
-                      % (blas, host_cores, M, N, K, n_iter, n_iter - 1, float(np.mean(per)), float(per.min()), float(per.max()), sub_note)}
+    phys = None
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    rec = {"value": 1.0 / float(np.mean(per_t)), "unit": "it/s", "cores": cores, "kind": "port",
+           "sample": "oracle (NumPy fp32; BLAS: %s; OPENBLAS_NUM_THREADS=%s; host: %d hardware threads, %s physical cores) on the full %d x %d x %d workload "
+                     "(the bench's own Y and initial factors): %d untimed iterations (start-up transient), then %d timed, mean %.3f s (min %.3f, max %.3f), no scaling%s"
+                     % (blas, os.environ.get("OPENBLAS_NUM_THREADS", "unset"), host_cores, phys, M, N, K, transient, len(per_t),
+                        float(np.mean(per_t)), float(per_t.min()), float(per_t.max()), sub_note)}
+    return rec, sub_timed
 
 
 def emit(out):
@@ -204,6 +219,56 @@ def emit(out):
         pass
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
+
+
+def other_configs(Y3, local):
+    """Short runs of the other BASELINE configurations in the same process as the headline (one line each: it/s, K1 time from
+    HIP events, roofline fraction of K1): cfg2 (4096^2, K=32, PGM, exact fp32), cfg5 (cfg3's Y, bSDMM, f16x2), one rank's
+    8192-row share of cfg4 (K=128, adaprox, f16x2; the first 8192 rows of cfg3's Y serve as its data) on the single-GPU code
+    path.  Bounded to a few seconds."""
+    import torch
+    from proxmin_amd.engine import DeviceNMF
+    device = Y3.device
+    res = {}
+    specs = [("cfg2", "f32", 4096, 4096, 32, "pgm", False, 200, 40, None),
+             ("cfg5", "f16x2", 16384, 16384, 64, "bsdmm", False, 30, 10, Y3),
+             ("cfg4_share8192", "f16x2", 8192, 16384, 128, "adaprox", False, 40, 20, Y3)]
+    for name, mode, M, N, K, backend, unity, steps, warm, Yuse in specs:
+        try:
+            if Yuse is None:
+                Yc, A0, S0 = make_problem_device(M, N, K, unity, 1234, device)
+            else:
+                Yc = Yuse
+                rng = np.random.default_rng(4321)
+                A0 = rng.random((M, K), dtype=np.float32)
+                S0 = rng.random((K, N), dtype=np.float32) * np.float32(16.0 / K)    # A0 @ S0 on the scale of cfg3's Y
+            dev = DeviceNMF(M, N, K, device=local, mode=mode)
+            dev.set_Y_device(Yc.data_ptr(), ld=N, copy=False, keepalive=Yc)
+            dev.set_factors(A0, S0)
+            run = begin_solver(dev, backend, unity)
+            run(warm)
+            dev.set_timing(True, every=2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = run(steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            k1_ms, k1_n = dev.get_timing()
+            dev.set_timing(False)
+            assert r.iterations == steps
+            nk1 = 2 if backend == "bsdmm" else 1
+            flop_launch = (8.0 if backend == "bsdmm" else 6.0) * M * N * K / nk1
+            k1_avg = k1_ms / max(k1_n, 1)
+            info = dev.k1_info()
+            roof = roofline_entry(effective_mode(dev), M, N, K, flop_launch, k1_avg, k1_n, k1_avg * nk1 * steps / (1e3 * dt), info["kernel"])
+            res[name] = {"value": steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
+                         "mode": mode, "backend": backend, "shape": [M, N, K], "k1_kernel": roof["kernel"], "k1_ms": k1_avg,
+                         "roofline_bound": roof["bound"], "roofline_frac": roof["frac"], "k1_share_of_step": roof["k1_share_of_step"]}
+            dev.close()
+            del dev
+        except Exception as exc:                                   # a side measurement must never take the headline down
+            res[name] = {"error": repr(exc)}
+    return res
 
 
 def main():
@@ -265,11 +330,13 @@ def main():
     res_w = run(args.warmup) if args.warmup > 0 else None
     warm_total = args.warmup
     sub_seen = [int(res_w.sub_iterations[0]), int(res_w.sub_iterations[1])] if res_w is not None else [0, 0]
+    sub_window = None                      # proximal passes per iteration (A, S) over the LAST five warm-up iterations
     if backend == "adaprox":
         while warm_total < 60:
             r = run(5)
             warm_total += 5
-            per_it = (int(r.sub_iterations[1]) - sub_seen[1]) / 5.0
+            sub_window = [(int(r.sub_iterations[j]) - sub_seen[j]) / 5.0 for j in range(2)]
+            per_it = sub_window[1]
             sub_seen = [int(r.sub_iterations[0]), int(r.sub_iterations[1])]
             if per_it <= 6.0 and warm_total >= 20:
                 break
@@ -327,10 +394,22 @@ def main():
                                      "note": "same workload with the library's default arithmetic (exact fp32 MFMA, %s)" % dev32.k1_info()["kernel"]}
             dev32.close()
         dev.close()
+        if args.config == "cfg3" and not args.rows:
+            # the other BASELINE configurations, short runs in the same process (same box, same build): driver-visible
+            out["other_configs"] = other_configs(Y, local)
         Yh = Y.cpu().numpy()
         del Y
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(Yh, A0, S0, backend, unity, n_iter=6 if M * N <= 16384 * 16384 else 3)
+        # the CPU leg is timed over the same steady state as the GPU: the last 5 warm-up iterations [warm_total - 5, warm_total)
+        # of the GPU run against the same iteration indices of the oracle (its transient runs untimed)
+        n_cpu = 5 if M * N <= 16384 * 16384 else 3
+        trans = max(warm_total - n_cpu, 1) if backend == "adaprox" else 1
+        rec, cpu_sub = cpu_baseline(Yh, A0, S0, backend, unity, n_iter=n_cpu, transient=trans)
+        out["cpu_baseline"] = rec
+        if backend == "adaprox" and cpu_sub is not None:
+            rec["sub_iterations_per_step"] = cpu_sub
+            rec["gpu_sub_iterations_same_window"] = sub_window
+            rec["sub_iterations_equal"] = bool(sub_window is not None and all(abs(a - b) < 1e-9 for a, b in zip(cpu_sub, sub_window)))
     emit(out)
 
 

@@ -305,8 +305,10 @@ def moment_update(scheme, it, G, M, V, Vhat, b1, b2, eps, p):
 def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="adam",
                 b1=0.9, b2=0.999, eps=1e-8, check_convergence=True, p=0.25, max_iter=1000,
                 e_rel=1e-3, prox_max_iter=1000, M=None, V=None, Vhat=None, callback=None,
-                trace=None, W=None):
+                trace=None, W=None, sub_trace=False):
     """`nmf(Y, A, S, algorithm=adaprox, ...)` (nmf.py:164-176 -> algorithms.py:248-423).
+    sub_trace=True appends a seventh return value: the proximal pass counts [tau_A, tau_S] of every iteration
+    (bench.py compares them with the device's over the same iteration window).
 
     Returns (converged, M, V, Vhat, n_iter, sub_iters) -- the reference returns the first
     four (:423) and logs the last two (:415-417).  prox spec None skips the sub-iteration
@@ -326,10 +328,12 @@ def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="
     if Vhat is None:
         Vhat = [None, None]                                            # :356-357
     sub = [0, 0]
+    per_it = []
     conv = (None, None)
     n_done = 0
     for it in range(max_iter):
         n_done = it + 1
+        per_it.append([0, 0])
         if trace is not None:
             trace.append((A.copy(), S.copy()))
         if callback is not None:
@@ -354,6 +358,7 @@ def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="
                     if done:
                         break
                 sub[j] += tau
+                per_it[-1][j] = tau
                 X[j][:] = z                                            # :400
         if check_convergence:                                          # :403-410
             conv = tuple(bool(_sumsq(X[j] - prev[j]) <= e[j] ** 2 * _sumsq(X[j])) for j in range(2))
@@ -361,6 +366,8 @@ def adaprox_nmf(Y, A, S, prox_A=("plus",), prox_S=("plus",), step=None, scheme="
                 break
     if not check_convergence:
         conv = (None, None)                                            # :420-421
+    if sub_trace:
+        return conv, M, V, Vhat, n_done, sub, per_it
     return conv, M, V, Vhat, n_done, sub
 
 
