@@ -1,0 +1,214 @@
+"""GPU: parity beyond a few iterations and at the full BASELINE sizes that the strict file leaves to bench lines
+(task 4).
+
+* the eps-clamp yardstick as a TEST: at full cfg3 the device's out-of-tolerance fraction against the fp64 oracle is bounded
+  by what the reference's own arithmetic (the oracle run in fp32, NumPy / BLAS like the reference) shows against fp64;
+* 20 iterations of cfg3: the bench's arithmetic (f16x2, chained K1, fused tail) against the library default (exact fp32),
+  and the fp64 oracle on a 512-row x full-N problem over the same 20 iterations;
+* the K = 128 kernel over 30 iterations against the exact-fp32 kernel (cfg4's 8192-row share);
+* cfg2 end to end at its full 4096 x 4096 (PGM and damped FISTA, 10 iterations) against the fp64 oracle, every entry;
+* cfg4 at its FULL size on one GPU (65536 x 16384, K = 128): one gradient pass against the row / column-subsampled fp64
+  oracle.
+Measured fractions go to gpurun_out/parity_long.json (copied to profiles/ when quoted)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+REPORT = {}
+
+
+def frac_within(actual, desired, rtol=RTOL, atol=ATOL):
+    err = np.abs(np.asarray(actual, dtype=np.float64) - np.asarray(desired, dtype=np.float64))
+    bound = atol + rtol * np.abs(desired)
+    return float((err <= bound).mean()), float((err / bound).max())
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import __graft_entry__ as g
+    g.build()
+    from proxmin_amd import engine
+    yield engine
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_long.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import nmf_oracle
+    return nmf_oracle
+
+
+def _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, its, ld=None):
+    import bench
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+        dev.set_Y_device(Yd.data_ptr(), ld=ld or N, copy=False, keepalive=Yd)
+        dev.set_factors(A0, S0)
+        run = bench.begin_solver(dev, backend, unity)
+        r = run(its)
+        assert r.iterations == its
+        A, S = dev.get_factors()
+        return A, S, [int(r.sub_iterations[0]), int(r.sub_iterations[1])], dev.k1_info()
+
+
+def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, orc):
+    """The AMSGrad eps-clamp story as a test.  Full cfg3, 3 iterations from a cold start: the fp64 oracle is the truth; the
+    oracle run in fp32 (NumPy fp32 GEMMs: the reference's own arithmetic for fp32 inputs, nmf.py:39-41) is the yardstick.
+    * The library's default arithmetic (mode f32, exact fp32 MFMA) must stay within 2 x the yardstick's out-of-tolerance
+      fraction (plus 2e-5 of slack for the quantisation of the count) and 3 x its worst ratio: measured A 4.8e-6 against
+      9.5e-7, S 1.42e-4 against 1.28e-4, worst entry 82 x the bound against 62 x.
+    * The bench's arithmetic (mode f16x2) carries 22 significant bits per operand instead of 24 and drops the low x low
+      product: per-product noise up to 2^-21 where fp32 has only its accumulation rounding.  On entries whose second moment
+      sits at AMSGrad's eps clamp that shows: measured A 1.08e-4 / S 5.4e-4 out of tolerance (4 x the yardstick on S, ~100 x
+      on A, where the yardstick is almost zero), worst entry 883 x the bound.  Asserted: the floors below, the pass counts,
+      and that it is NOT claimed to meet the yardstick -- the mode is 4-10 x noisier than exact fp32 on this measure (DESIGN
+      section 2 says so next to the headline number)."""
+    import torch
+    import bench
+    M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
+    Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 4321, torch.device("cuda", 0))
+    dev_out = {}
+    for mode in ("f32", "f16x2"):
+        dev_out[mode] = _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, 3)
+    Y32 = Yd.cpu().numpy()
+    del Yd
+    A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
+    ret64 = orc.adaprox_nmf(Y32.astype(np.float64), A64, S64, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=3, e_rel=1e-3, check_convergence=False)
+    A32, S32 = A0.copy(), S0.copy()
+    ret32 = orc.adaprox_nmf(Y32, A32, S32, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=3, e_rel=1e-3, check_convergence=False)
+    del Y32
+    yard = {"A": frac_within(A32, A64), "S": frac_within(S32, S64)}
+    REPORT["cfg3 full, 3 its: oracle fp32 vs oracle fp64 (yardstick)"] = {"frac_A": yard["A"][0], "frac_S": yard["S"][0], "worst_ratio": max(yard["A"][1], yard["S"][1]),
+                                                                        "sub_iterations_fp32": [int(ret32[5][0]), int(ret32[5][1])], "sub_iterations_fp64": [int(ret64[5][0]), int(ret64[5][1])]}
+    for mode, (A, S, sub, info) in dev_out.items():
+        assert sub == [int(ret64[5][0]), int(ret64[5][1])], (mode, sub, ret64[5])
+        got = {"A": frac_within(A, A64), "S": frac_within(S, S64)}
+        REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode] = {"frac_A": got["A"][0], "frac_S": got["S"][0], "worst_ratio": max(got["A"][1], got["S"][1])}
+        for b in ("A", "S"):
+            out_dev, out_ref = 1.0 - got[b][0], 1.0 - yard[b][0]
+            REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode]["out_of_tolerance_over_yardstick_%s" % b] = out_dev / max(out_ref, 1e-9)
+            if mode == "f32":
+                assert out_dev <= 2.0 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
+                assert got[b][1] <= 3.0 * max(yard[b][1], 1.0), (mode, b, got[b][1], yard[b][1])
+            else:
+                assert out_dev <= (2.5e-4 if b == "A" else 1e-3), (mode, b, out_dev, out_ref)
+                assert got[b][1] <= 2000.0, (mode, b, got[b][1])
+
+
+def test_cfg3_twenty_iterations_bench_mode_against_default_mode(eng):
+    """20 iterations of full cfg3: f16x2 (chained k_grad_f16_v8 + fused tail) against exact fp32 (k_grad_f32_pc): the two
+    K1s share no arithmetic.  Same proximal pass counts, S columns on the simplex, >= 99.99 % of A / 99.95 % of S within the
+    north star's bound of each other (eps-clamp entries excepted); relative Frobenius distance < 2e-5 for A and < 2e-4 for S
+    (measured 3.8e-6 / 8.4e-5: S carries the clamp entries, worst 94 x the bound)."""
+    import torch
+    import bench
+    M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
+    Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
+    Af, Sf, subf, _ = _run_device(eng, "f32", M, N, K, backend, unity, Yd, A0, S0, 20)
+    Ah, Sh, subh, info = _run_device(eng, "f16x2", M, N, K, backend, unity, Yd, A0, S0, 20)
+    Ah2, Sh2, _, _ = _run_device(eng, "f16x2", M, N, K, backend, unity, Yd, A0, S0, 20)
+    assert info["chain"] == 32 and info["tail_fused"] and info["chain_faults"] == 0
+    assert np.array_equal(Ah, Ah2) and np.array_equal(Sh, Sh2), "f16x2 run is not repeatable bit for bit"
+    assert subf == subh, (subf, subh)
+    fA, wA = frac_within(Ah, Af)
+    fS, wS = frac_within(Sh, Sf)
+    relA = np.linalg.norm(Ah.astype(np.float64) - Af) / np.linalg.norm(Af)
+    relS = np.linalg.norm(Sh.astype(np.float64) - Sf) / np.linalg.norm(Sf)
+    REPORT["cfg3 full, 20 its: f16x2 vs f32 mode"] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS), "rel_frobenius": [float(relA), float(relS)], "sub_iterations": subh}
+    assert fA >= 0.9999 and fS >= 0.9995, (fA, fS)
+    assert relA < 2e-5 and relS < 2e-4, (relA, relS)
+    np.testing.assert_allclose(Sh.sum(0), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+def test_cfg3_shape_rows_512_twenty_iterations_against_fp64_oracle(eng, orc, mode):
+    """cfg3's solver on a 512-row x full-N problem (the fast K1 kernels take it: M % 128 = 0, N % 256 = 0), 20 iterations
+    against the fp64 oracle: pass counts equal, >= 99.5 % of S and 99.9 % of A within rtol 1e-4."""
+    import torch
+    import bench
+    M, N, K = 512, 16384, 64
+    Yd, A0, S0 = bench.make_problem_device(M, N, K, True, 99, torch.device("cuda", 0))
+    A, S, sub, info = _run_device(eng, mode, M, N, K, "adaprox", True, Yd, A0, S0, 20)
+    assert info["kernel"] == ("k_grad_f16_v8" if mode == "f16x2" else "k_grad_f32_pc"), info
+    A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
+    ret = orc.adaprox_nmf(Yd.cpu().numpy().astype(np.float64), A64, S64, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=20, e_rel=1e-3, check_convergence=False)
+    assert sub == [int(ret[5][0]), int(ret[5][1])], (sub, ret[5])
+    fA, wA = frac_within(A, A64)
+    fS, wS = frac_within(S, S64)
+    REPORT["512 x 16384 x 64 adaprox/amsgrad unity, 20 its: device %s vs oracle fp64" % mode] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS), "sub_iterations": sub}
+    assert fA >= 0.999 and fS >= 0.995, (fA, fS)
+
+
+@pytest.mark.parametrize("backend", ["pgm", "adaprox"])
+def test_k128_kernel_thirty_iterations_against_exact_fp32(eng, backend):
+    """cfg4's 8192-row share, 30 iterations: k_grad_f16_k128 (twice: bit-identical) against k_grad_f32<128>."""
+    import torch
+    import bench
+    M, N, K = 8192, 16384, 128
+    Yd, A0, S0 = bench.make_problem_device(M, N, K, False, 1234, torch.device("cuda", 0))
+    Af, Sf, subf, inf = _run_device(eng, "f32", M, N, K, backend, False, Yd, A0, S0, 30)
+    Ah, Sh, subh, inh = _run_device(eng, "f16x2", M, N, K, backend, False, Yd, A0, S0, 30)
+    Ah2, Sh2, _, _ = _run_device(eng, "f16x2", M, N, K, backend, False, Yd, A0, S0, 30)
+    assert inh["kernel"] == "k_grad_f16_k128" and inf["kernel"] == "k_grad_f32"
+    assert np.array_equal(Ah, Ah2) and np.array_equal(Sh, Sh2)
+    assert subf == subh
+    fA, wA = frac_within(Ah, Af, rtol=2e-4, atol=2e-5)
+    fS, wS = frac_within(Sh, Sf, rtol=2e-4, atol=2e-5)
+    rel = max(np.linalg.norm(Ah.astype(np.float64) - Af) / np.linalg.norm(Af), np.linalg.norm(Sh.astype(np.float64) - Sf) / np.linalg.norm(Sf))
+    REPORT["cfg4 share, 30 its %s: k_grad_f16_k128 vs k_grad_f32<128>" % backend] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS), "rel_frobenius": float(rel)}
+    assert fA == 1.0 and fS == 1.0, (fA, fS, wA, wS)
+    assert rel < 5e-6, rel
+
+
+@pytest.mark.parametrize("fista", [False, True])
+def test_cfg2_end_to_end_at_full_size(eng, orc, fista):
+    """BASELINE cfg2 (4096 x 4096, K = 32, prox_plus, fp32): PGM and damped FISTA (step = 0.5 step_pgm),
+    10 iterations through nmf() against the fp64 oracle: EVERY entry within rtol 1e-4."""
+    import torch
+    import bench
+    import proxmin_amd as pm
+    M, N, K, _, _, _ = bench.CONFIGS["cfg2"]
+    Yd, A0, S0 = bench.make_problem_device(M, N, K, False, 1234, torch.device("cuda", 0))
+    Y = Yd.cpu().numpy()
+    del Yd
+    pm.set_default_mode("f32")
+    A, S = A0.copy(), S0.copy()
+    kw = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if fista else {}
+    pm.nmf.nmf(Y, A, S, max_iter=10, e_rel=1e-12, **kw)
+    A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
+    step = (lambda A_, S_, it, grads: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_))) if fista else None
+    orc.pgm_nmf(Y.astype(np.float64), A64, S64, max_iter=10, e_rel=1e-12, accelerated=fista, step=step)
+    fA, wA = frac_within(A, A64)
+    fS, wS = frac_within(S, S64)
+    REPORT["cfg2 full %s, 10 its vs fp64 oracle (f32 mode)" % ("fista/2" if fista else "pgm")] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
+    assert fA == 1.0 and fS == 1.0, (fA, fS, wA, wS)
+
+
+def test_cfg4_full_size_gradient_against_subsampled_oracle(eng):
+    """BASELINE cfg4 at its FULL size on one GPU (65536 x 16384, K = 128; Y = 4 GiB): one pass of k_grad_f16_k128 over
+    all of it, the gradients of 256 random rows of A and 256 random columns of S against the fp64 oracle."""
+    import torch
+    import bench
+    from test_gpu_kernels import _subsampled_oracle_gradients
+    M, N, K = 65536, 16384, 128
+    Yd, A, S = bench.make_problem_device(M, N, K, False, 1234, torch.device("cuda", 0))
+    rng = np.random.default_rng(7)
+    rows = np.sort(rng.choice(M, 256, replace=False))
+    cols = np.sort(rng.choice(N, 256, replace=False))
+    rA, rS = _subsampled_oracle_gradients(A, S, Yd, rows, cols)
+    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+        assert dev.k1_info()["kernel"] == "k_grad_f16_k128"
+        dev.set_Y_device(Yd.data_ptr(), ld=N, copy=False, keepalive=Yd)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+    np.testing.assert_allclose(gA[rows], rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS[:, cols], rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    REPORT["cfg4 full 65536 x 16384 x 128 gradient vs subsampled fp64 oracle"] = {
+        "max_err_gA_over_max": float(np.abs(gA[rows] - rA).max() / np.abs(rA).max()), "max_err_gS_over_max": float(np.abs(gS[:, cols] - rS).max() / np.abs(rS).max())}
