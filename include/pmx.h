@@ -103,7 +103,8 @@ enum {
     PMX_BUF_TMP_A = 12, PMX_BUF_TMP_ST = 13,   /* host round trip of a user-defined prox: its argument, then its result       */
     PMX_BUF_PSI_A = 14, PMX_BUF_PSI_ST = 15,   /* adaprox Psi of the current iteration (algorithms.py:375-377)                */
     PMX_BUF_Z0 = 16, /* + block*PMX_MAX_G + i : bsdmm Z_i of block (utils.py:244-254)     */
-    PMX_BUF_U0 = 32  /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
+    PMX_BUF_U0 = 32, /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
+    PMX_BUF_TG0 = 48 /* + block*PMX_MAX_G + i : host round trip of a user-defined proxs_g member: its argument, then its result */
 };
 
 typedef struct pmx_ctx pmx_ctx;
@@ -266,6 +267,15 @@ typedef struct pmx_bsdmm_params { /* algorithms.bsdmm as reachable from nmf(), a
 
 int pmx_bsdmm_begin(pmx_ctx* ctx, const pmx_bsdmm_params* p);
 int pmx_bsdmm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
+/* One block update of ONE bsdmm iteration in pieces, for user-defined operators (utils.py:307-346 with the callables of
+ * proxs_g / prox_f applied by the caller between the pieces; their device slots hold prox_id):
+ *   phase 0  step_f of block j (res->steps[j]) and the gradient; host_f: the argument of prox_f -> PMX_BUF_TMP_A / _ST
+ *   phase 1  X_j <- prox_f(..) (device operator, or PMX_BUF_TMP_* as the caller left it); no bit set in host_g: the
+ *            constraint updates as well; else the arguments X_j + U_i of the user members -> PMX_BUF_TG0 + j*PMX_MAX_G + i
+ *   phase 2  (host_g != 0) the constraint updates with Z_i <- PMX_BUF_TG0 + .. for the user members; Boyd's test of the block
+ *            (algorithms.py:832-844); last_block: the iteration ends here (counter, stop when all blocks have converged)
+ *   step_f_host > 0 (phase 0): the value of a user steps_f_cb for this block instead of the device's Lipschitz rule            */
+int pmx_bsdmm_split(pmx_ctx* ctx, int j, int phase, int host_f, unsigned host_g, int last_block, double step_f_host, pmx_result* res);
 
 /* ---- row-sharded multi-GPU --------------------------------------------
  * Rows of Y and A are split over `world` ranks (this context holds M local rows of M_global); S is
@@ -280,6 +290,10 @@ int pmx_bsdmm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
  * pmx_comm_layout reports the total count and the three offsets after gSt.  The buffer itself is
  * supplied by the caller (pmx_set_comm_buffer), e.g. a torch tensor, so that the collective library
  * can work on memory it knows. */
+/* A user `grad(*X)` callable (algorithms.py:12,248: any differentiable function of the two factors): the caller evaluates it
+ * on the host at the point of PMX_BUF_EVAL_A / _ST, uploads the result into PMX_BUF_GA / PMX_BUF_GST, and every solver entry
+ * point uses THAT as the gradient of the iteration (the fused residual kernel never runs; the context needs no Y).        */
+int pmx_set_host_grad(pmx_ctx* ctx, int on);
 int pmx_set_world(pmx_ctx* ctx, int rank, int world, int64_t M_global);
 int pmx_comm_layout(pmx_ctx* ctx, int64_t* count, int64_t offsets[3]);
 int pmx_set_comm_buffer(pmx_ctx* ctx, float* dptr, int64_t count);

@@ -25,7 +25,7 @@ PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "m
 SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}
 BUF_A, BUF_ST, BUF_GA, BUF_GST, BUF_MA, BUF_MST, BUF_VA, BUF_VST, BUF_VHA, BUF_VHST = range(10)
 BUF_EVAL_A, BUF_EVAL_ST, BUF_TMP_A, BUF_TMP_ST, BUF_PSI_A, BUF_PSI_ST = 10, 11, 12, 13, 14, 15
-BUF_Z0, BUF_U0 = 16, 32
+BUF_Z0, BUF_U0, BUF_TG0 = 16, 32, 48
 
 
 class Prox(C.Structure):
@@ -102,6 +102,8 @@ _SIGNATURES = {
     "pmx_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pmx_adaprox_more_subs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pmx_iter_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
+    "pmx_set_host_grad": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_bsdmm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_double, C.POINTER(Result)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -11,7 +11,11 @@ chains.  ANY OTHER Python callable keeps the reference's contract -- `prox(X, st
 (algorithms.py:37-39), `step(*X, it=None[, grads=None])` (:73-77, :370) -- through a host round trip:
 one iteration per call, the callable's arguments copied to the host ((M + N) K floats), its result
 copied back, everything else (gradient, update, norms, built-in operators) still on the device.  A
-one-time warning says so.  Generic user `grad` callables remain out of scope.
+one-time warning says so.  A user `grad(*X) -> (gA, gS)` callable (any differentiable function of the two factors,
+algorithms.py:12,248) takes the same road: the point is copied to the host, the callable's result into the device's gradient
+buffers, and the update runs on the device (pgm and adaprox; no Y is needed then).  bsdmm: user-defined members of `proxs_g`
+and user-defined `prox_A` / `prox_S` are applied between the pieces of a block update (pmx_bsdmm_split); generic, untagged
+`proxs_f` / `steps_f_cb` closures are the one thing left out (they would make the whole solver a host loop).
 """
 from __future__ import annotations
 
@@ -27,24 +31,48 @@ logger = logging.getLogger("proxmin")
 
 
 # ---------------------------------------------------------------------------------------------
+def _is_nmf_grad(grad):
+    from . import nmf as _nmf
+    return isinstance(grad, partial) and grad.func is _nmf.grad_likelihood and not grad.args
+
+
 def _problem_from_grad(X, grad):
+    """-> (Y, A, S, W) for the NMF likelihood gradient built by proxmin_amd.nmf, (None, A, S, None) for any other callable
+    (its result is copied into the device's gradient buffers once per iteration)."""
     from . import nmf as _nmf
 
-    if not (isinstance(grad, partial) and grad.func is _nmf.grad_likelihood and not grad.args):
-        raise NotImplementedError("only the NMF likelihood gradient (functools.partial(proxmin_amd.nmf.grad_likelihood, Y=Y)) "
-                                  "can run on the device; generic `grad` callables are out of scope")
-    kw = grad.keywords
     X = utils._as_tuple(X)
     assert len(X) == 2, "X must be [A, S]"
     A, S = X
-    Y = np.asarray(kw["Y"])
     assert A.ndim == 2 and S.ndim == 2 and A.shape[1] == S.shape[0]
+    if not _is_nmf_grad(grad):
+        if not callable(grad):
+            raise TypeError("grad must be callable")
+        _warn_host_path("grad (%r)" % (grad,))
+        return None, A, S, None
+    kw = grad.keywords
+    Y = np.asarray(kw["Y"])
     assert Y.shape == (A.shape[0], S.shape[1]), "Y must be M x N"
     return Y, A, S, _nmf._weights(kw.get("W", 1), Y.shape)
 
 
+def _host_gradient(dev, grad, dt, accelerated_eval=True):
+    """Evaluate a user `grad` at the device's current evaluation point and hand the result to the device."""
+    Xe = (dev.get(_lib.BUF_EVAL_A, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_EVAL_A, 1)).astype(dt))
+    G = utils._as_tuple(grad(*Xe))
+    assert len(G) == 2 and np.shape(G[0]) == Xe[0].shape and np.shape(G[1]) == Xe[1].shape, "grad must return one array per block"
+    dev.put(_lib.BUF_GA, 0, np.asarray(G[0]))
+    dev.put(_lib.BUF_GA, 1, np.asarray(G[1]))
+    return Xe
+
+
 def _open_device(Y, A, S, W):
     """Context for one solver call; weights (nmf.py:13-41): engine.open_weighted picks the kernel."""
+    if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
+        dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
+        dev.set_host_grad(True)
+        dev.set_factors(A, S)
+        return dev
     dev = open_weighted(A.shape[0], S.shape[1], A.shape[1], W)
     dev.set_Y(Y)
     dev.set_factors(A, S)
@@ -151,7 +179,10 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     # prox=None means prox_id in pgm (algorithms.py:63-64)
     seqs, host_prox = _split_prox(prox, none_is_id=True)
     e_rel = _e_rel_pair(e_rel)
+    user_grad = Y is None
     assert backtracking is False or f is not None
+    if backtracking and user_grad:
+        raise NotImplementedError("backtracking with a user-defined `grad` (its `f` would be evaluated on the host as well) is not implemented")
     if backtracking:
         # the smooth function must be the NMF likelihood of the same Y (it is evaluated by the fused residual kernel)
         ok = isinstance(f, partial) and f.func is _nmf.log_likelihood and not f.args and f.keywords.get("Y") is grad.keywords["Y"]
@@ -177,9 +208,9 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         _warn_host_path("step (%r)" % (step,))
     else:
         raise TypeError("step must be callable")
-    slow = user_step is not None or any(h is not None for h in host_prox)
+    slow = user_step is not None or any(h is not None for h in host_prox) or user_grad
     if slow and (bb is not None or backtracking):
-        raise NotImplementedError("a user-defined prox / step together with Barzilai-Borwein steps or backtracking is not implemented")
+        raise NotImplementedError("a user-defined grad / prox / step together with Barzilai-Borwein steps or backtracking is not implemented")
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
@@ -207,6 +238,8 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
                         callback(A, S, it=it)
                     except StopIteration:
                         break
+                if user_grad:                                   # grads = grad(*_X) (algorithms.py:105)
+                    _host_gradient(dev, grad, dt)
                 r0 = dev.pgm_split(0)
                 steps = None
                 if user_step is not None:
@@ -286,7 +319,8 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
             raise TypeError("step must be callable")
         user_step = step
         _warn_host_path("step (%r)" % (step,))
-    slow = user_step is not None or any(h is not None for h in host_prox)
+    user_grad = Y is None
+    slow = user_step is not None or any(h is not None for h in host_prox) or user_grad
 
     Xs = (A, S)
     warm = M is not None or V is not None
@@ -324,6 +358,8 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
                     except StopIteration:
                         break
                 alpha = None
+                if user_grad:                                                      # G = grad(*X) (algorithms.py:369)
+                    _host_gradient(dev, grad, dt)
                 if user_step is not None:
                     alpha = utils._as_tuple(user_step(A, S, it=it))                  # algorithms.py:370
                     assert len(alpha) == 2, "step must return one Alpha per block"
@@ -422,18 +458,29 @@ def bsdmm(X, proxs_f, steps_f_cb, proxs_g=None, steps_g=None, Ls=None, update_or
     """
     tag_f, tag_s = getattr(proxs_f, "_pmx_nmf", None), getattr(steps_f_cb, "_pmx_nmf", None)
     if tag_f is None or tag_s is None or tag_f is not tag_s:
-        raise NotImplementedError("bsdmm on the device takes the closures of proxmin_amd.nmf.bsdmm_closures(Y, prox) (what nmf(..., "
-                                  "algorithm=bsdmm) passes); generic proxs_f / steps_f_cb closures are out of scope")
+        # Generic closures (algorithms.py:805-821): nothing about the smooth function is known to the device.  It keeps what
+        # IS generic -- dX from the constraint variables, the Z / U updates with the library's proxs_g members, the norms and
+        # Boyd's test -- and the two closures are called on the host once per block update (pmx_bsdmm_split with a zero
+        # device gradient: phase 0 hands out X_j - dX, the closure's result becomes the new X_j).
+        return _bsdmm_nmf(X, None, (None, None), proxs_g=proxs_g, steps_g=steps_g, Ls=Ls, update_order=update_order,
+                          steps_g_update=steps_g_update, max_iter=max_iter, e_rel=e_rel, e_abs=e_abs, callback=callback,
+                          closures=(proxs_f, steps_f_cb))
     grad, prox = tag_f
     return _bsdmm_nmf(X, grad, prox, proxs_g=proxs_g, steps_g=steps_g, Ls=Ls, update_order=update_order,
                       steps_g_update=steps_g_update, max_iter=max_iter, e_rel=e_rel, e_abs=e_abs, callback=callback)
 
 
 def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=None, steps_g_update="steps_f",
-               max_iter=1000, e_rel=1e-6, e_abs=0, callback=None):
+               max_iter=1000, e_rel=1e-6, e_abs=0, callback=None, closures=None):
     """The bsdmm branch of nmf() (nmf.py:178-203 -> algorithms.py:653-850): step_f = step_pgm,
     identity linear operators, steps_g from steps_f (algorithms.py:815-819)."""
-    Y, A, S, W = _problem_from_grad(X, grad)
+    if closures is not None:
+        _warn_host_path("proxs_f / steps_f_cb (%r, %r)" % closures)
+        Xt = utils._as_tuple(X)
+        assert len(Xt) == 2, "X must be [A, S]"
+        Y, A, S, W = None, Xt[0], Xt[1], None
+    else:
+        Y, A, S, W = _problem_from_grad(X, grad)
     if W is not None:                # bsdmm's steps come from nmf.step_pgm, which raises on an array W (nmf.py:63,187-193)
         from . import nmf as _nmf_w
         raise ValueError(_nmf_w._AMBIGUOUS)
@@ -466,21 +513,83 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
             return [None, None]
     er = [e_rel] * N if np.isscalar(e_rel) else list(e_rel)
     ea = [e_abs] * N if np.isscalar(e_abs) else list(e_abs)
-    seq_f = [operators.device_proxseq(p if p is not None else operators.prox_id, j) for j, p in enumerate(prox)]
-    seq_g = []
+    def _seq_or_host(q, j, what):
+        """device sequence of an operator of this library; (prox_id, callable) for anything else (host round trip)"""
+        q = q if q is not None else operators.prox_id
+        try:
+            return operators.device_proxseq(q, j), None
+        except NotImplementedError:
+            if not callable(q):
+                raise
+            _warn_host_path("%s of block %d (%r)" % (what, j, q))
+            return operators.device_proxseq(operators.prox_id, j), q
+
+    seq_f, host_f = [], []
+    for j, q in enumerate(prox):
+        sq, h = _seq_or_host(q, j, "prox")
+        seq_f.append(sq)
+        host_f.append(h)
+    seq_g, host_g = [], []
     for j in range(N):
         g = proxs_g[j]
         if g is None:
             seq_g.append(None)
+            host_g.append([])
             continue
         if not hasattr(g, "__iter__"):
             g = [g]
-        seq_g.append([operators.device_proxseq(q if q is not None else operators.prox_id, j) for q in g])
+        pairs = [_seq_or_host(q, j, "proxs_g member") for q in g]
+        seq_g.append([sq for sq, _ in pairs])
+        host_g.append([h for _, h in pairs])
+    slow = any(h is not None for h in host_f) or any(h is not None for hs in host_g for h in hs) or closures is not None
 
     with _open_device(Y, A, S, None) as dev:
         dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea, update_order=order)
         res = None
-        if _wants_iterates(callback):
+        if closures is not None:        # the device's gradient stays zero: X_j - dX comes out of phase 0
+            dev.put(_lib.BUF_GA, 0, np.zeros(A.shape, np.float32))
+            dev.put(_lib.BUF_GA, 1, np.zeros(S.shape, np.float32))
+        if slow:
+            # One iteration per pass, every block update in pieces (utils.py:307-346): step_f and the gradient on the device,
+            # the user's prox_f on the host, X / dual updates and norms on the device, the user-defined members of proxs_g on
+            # the host with exactly the arguments the reference passes (X + U_i, step_g_i), Boyd's test on the device.
+            dt = A.dtype
+            blocks = order if order is not None else [0, 1]
+            for it in range(max_iter):
+                if _wants_iterates(callback):
+                    callback(A, S, it=it)                       # no StopIteration handler (algorithms.py:802)
+                for o, j in enumerate(blocks):
+                    hf = host_f[j] is not None or closures is not None
+                    mask = sum(1 << i for i, h in enumerate(host_g[j]) if h is not None)
+                    user_sf = float(closures[1]((A, S), j=j)) if closures is not None else 0.0   # steps_f_cb(X, j=j) (algorithms.py:807)
+                    r0 = dev.bsdmm_split(j, 0, hf, mask, step_f=user_sf)
+                    step_f = dt.type(r0.steps[j])
+                    rows = A.shape[0] if j == 0 else S.shape[1]
+                    if hf:
+                        T = np.ascontiguousarray(dev.get(_lib.BUF_TMP_A, j)).astype(dt)
+                        if closures is not None:                # proxs_f(X_j - dX, step_f, j=j, Xs=X) (algorithms.py:806, utils.py:338)
+                            out = closures[0](T, step_f, j=j, Xs=(A, S))
+                        else:                                   # prox_j(X - dX - step grad_j, step) (nmf.py:181-185)
+                            out = host_f[j](T, step_f)
+                        dev.put(_lib.BUF_TMP_A, j, np.asarray(out))
+                    dev.bsdmm_split(j, 1, hf, mask)
+                    if mask:
+                        step_g = dt.type(float(r0.steps[j]) * 2.0 * len(host_g[j]))           # utils.get_step_g, identity L (utils.py:269-279)
+                        for i, h in enumerate(host_g[j]):
+                            if h is None:
+                                continue
+                            buf = _lib.BUF_TG0 + j * _lib.MAX_G + i
+                            T = dev._download(buf, rows)
+                            T = np.ascontiguousarray(T if j == 0 else T.T).astype(dt)
+                            out = np.asarray(h(T, step_g))                                   # Z_i = prox_g_i(L X + U_i, step_g_i) (utils.py:295-304)
+                            dev._upload(buf, out if j == 0 else out.T)
+                    res = dev.bsdmm_split(j, 2, hf, mask, last_block=(o == len(blocks) - 1))
+                    if closures is not None:                    # Gauss-Seidel: the next block's closures see this update
+                        _write_back(dev, A, S)
+                _write_back(dev, A, S)
+                if res is not None and res.stopped:
+                    break
+        elif _wants_iterates(callback):
             for it in range(max_iter):
                 callback(A, S, it=it)                           # no StopIteration handler (algorithms.py:802)
                 res = dev.bsdmm_run(1)

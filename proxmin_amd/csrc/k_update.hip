@@ -1775,6 +1775,17 @@ struct BsdmmArgs {
     DevStatus* status;
     double* partials;
     float* absmax_out;   // as FinishArgs: [2][EW_BLOCKS] per-workgroup max |X_j| of the block written here, or nullptr
+    // User-defined operators (host round trips, one iteration per call; pmx_bsdmm_split):
+    //   stage 0  the whole update on the device (no user operator)
+    //   stage 1  (host_f) Tf = X - dX - step_f grad, the argument of the user's prox_f; nothing else is written
+    //   stage 2  X <- prox_f(..) (device operator, or Tf as the host left it), its norms; then either the constraints
+    //            (no user proxs_g member) or T_i = X + U_i for the members that are user callables
+    //   stage 3  (host_g != 0) the constraints: Z_i <- T_i as the host left it (user members) or prox_g_i(X + U_i), U_i, norms
+    int stage;
+    int host_f;
+    unsigned host_g;     // bit i: proxs_g[j][i] is a user callable
+    float* Tf;
+    float* T[PMX_MAX_G];
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
@@ -1787,6 +1798,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     const float sg = sf * 1.f * 2.f * (float)a.n_g;
     const float w = a.n_g > 0 ? sf / sg : 0.f;         // step_f / step_g[i]
     const float nisg = a.n_g > 0 ? -1.f / sg : 0.f;    // -1 / step_g
+    const bool do_x = a.stage <= 2;                    // stages 0-2 form (or take over) the new X
+    const bool do_g = a.stage == 0 || a.stage == 3 || (a.stage == 2 && a.host_g == 0u);
     float d2 = 0.f, x2 = 0.f, xmax = 0.f;
     float r2[PMX_MAX_G], s2[PMX_MAX_G], z2[PMX_MAX_G], u2[PMX_MAX_G];
 #pragma unroll
@@ -1796,38 +1809,63 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
         float g[NC], xo[NC], v[NC], sk[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
-        load_grad<NC>(g, ok, a.slab, a.rows, K, r, l32);
+        if (do_x) {
+            if (!(a.stage == 2 && a.host_f)) load_grad<NC>(g, ok, a.slab, a.rows, K, r, l32);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int64_t e = r * K + l32 + 32 * c;
-            xo[c] = ok[c] ? a.X[e] : 0.f;
-            float dx = 0.f;
-            for (int i = 0; i < a.n_g; ++i)             // utils.py:330-336
-                if (ok[c]) dx += w * (xo[c] - a.Z[i][e] + a.U[i][e]);
-            v[c] = (xo[c] - dx) - sf * g[c];            // utils.py:338 + nmf.py:185
-            sk[c] = sf;
-        }
-        prox_row<NC>(v, ok, a.prox_f, sk);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (ok[c]) {
-                a.X[r * K + l32 + 32 * c] = v[c];
-                const float d = v[c] - xo[c];
-                d2 += d * d;
-                x2 += v[c] * v[c];
-                xmax = fmaxf(xmax, fabsf(v[c]));
+            for (int c = 0; c < NC; ++c) {
+                const int64_t e = r * K + l32 + 32 * c;
+                xo[c] = ok[c] ? a.X[e] : 0.f;
+                if (a.stage == 2 && a.host_f) {
+                    v[c] = ok[c] ? a.Tf[e] : 0.f;           // prox_f(..) as the host left it
+                } else {
+                    float dx = 0.f;
+                    for (int i = 0; i < a.n_g; ++i)             // utils.py:330-336
+                        if (ok[c]) dx += w * (xo[c] - a.Z[i][e] + a.U[i][e]);
+                    v[c] = (xo[c] - dx) - sf * g[c];            // utils.py:338 + nmf.py:185
+                }
+                sk[c] = sf;
             }
+            if (a.stage == 1) {                                 // the argument of the user's prox_f
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (ok[c]) a.Tf[r * K + l32 + 32 * c] = v[c];
+                continue;
+            }
+            if (!(a.stage == 2 && a.host_f)) prox_row<NC>(v, ok, a.prox_f, sk);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) {
+                    a.X[r * K + l32 + 32 * c] = v[c];
+                    const float d = v[c] - xo[c];
+                    d2 += d * d;
+                    x2 += v[c] * v[c];
+                    xmax = fmaxf(xmax, fabsf(v[c]));
+                }
+            if (a.stage == 2 && a.host_g != 0u) {               // arguments of the user-defined members of proxs_g
+                for (int i = 0; i < a.n_g; ++i)
+                    if ((a.host_g >> i) & 1u) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            if (ok[c]) { const int64_t e = r * K + l32 + 32 * c; a.T[i][e] = v[c] + a.U[i][e]; }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = ok[c] ? a.X[r * K + l32 + 32 * c] : 0.f;
+        }
+        if (!do_g) continue;
         for (int i = 0; i < a.n_g; ++i) {               // do_the_mm, utils.py:295-304
             float zn[NC], zo[NC], uo[NC], sgk[NC];
+            const bool hosted = (a.host_g >> i) & 1u;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int64_t e = r * K + l32 + 32 * c;
                 zo[c] = ok[c] ? a.Z[i][e] : 0.f;
                 uo[c] = ok[c] ? a.U[i][e] : 0.f;
-                zn[c] = v[c] + uo[c];
+                zn[c] = hosted ? (ok[c] ? a.T[i][e] : 0.f) : v[c] + uo[c];
                 sgk[c] = sg;
             }
-            prox_row<NC>(zn, ok, a.prox_g[i], sgk);
+            if (!hosted) prox_row<NC>(zn, ok, a.prox_g[i], sgk);
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 if (ok[c]) {
@@ -1845,6 +1883,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
                 }
         }
     ROW_LOOP_END
+    if (a.stage == 1) return;
     double red[2 + 4 * PMX_MAX_G];
     red[0] = d2;
     red[1] = x2;
@@ -1857,13 +1896,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     }
     // slots: SL_DIFF2, SL_NORM2, then SL_G0.. ; consecutive slots are 2*EW_BLOCKS doubles apart, but
     // SL_G0 is not adjacent to SL_NORM2, so store in two groups
-    double head[2] = {red[0], red[1]};
-    block_sum_store<2>(head, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
-    double tail[4 * PMX_MAX_G];
+    if (do_x) {
+        double head[2] = {red[0], red[1]};
+        block_sum_store<2>(head, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    }
+    if (do_g) {
+        double tail[4 * PMX_MAX_G];
 #pragma unroll
-    for (int i = 0; i < 4 * PMX_MAX_G; ++i) tail[i] = red[2 + i];
-    block_sum_store<4 * PMX_MAX_G>(tail, part_ptr(a.partials, SL_G0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
-    if (a.absmax_out != nullptr) {
+        for (int i = 0; i < 4 * PMX_MAX_G; ++i) tail[i] = red[2 + i];
+        block_sum_store<4 * PMX_MAX_G>(tail, part_ptr(a.partials, SL_G0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    }
+    if (a.absmax_out != nullptr && do_x) {
         const double m = wave_max((double)xmax);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;

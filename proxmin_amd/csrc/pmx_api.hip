@@ -68,6 +68,9 @@ struct pmx_ctx {
     float* bbG[2] = {nullptr, nullptr};    // Barzilai-Borwein G_prev
 
     // K1
+    bool host_grad = false;                // pmx_set_host_grad: the gradient is whatever the caller uploaded into PMX_BUF_GA / GST (user `grad` callable)
+    float* Tg[2][PMX_MAX_G] = {};           // bsdmm with a user-defined proxs_g member: its argument X + U_i, then its result (host round trip)
+    float* Tf[2] = {};                      // bsdmm with a user-defined prox_f: its argument, then its result
     unsigned long long* k1prof = nullptr;  // tuning: phase cycle sums (PMX_K1_PROF=1)
     bool use_small = false;                // small problem (K <= 16, few million entries): k_grad_small in every mode
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
@@ -495,6 +498,9 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
     } else if (buf >= PMX_BUF_U0 && buf < PMX_BUF_U0 + 2 * PMX_MAX_G) {
         j = (buf - PMX_BUF_U0) / PMX_MAX_G;
         p = &c->Ug[j][(buf - PMX_BUF_U0) % PMX_MAX_G];
+    } else if (buf >= PMX_BUF_TG0 && buf < PMX_BUF_TG0 + 2 * PMX_MAX_G) {
+        j = (buf - PMX_BUF_TG0) / PMX_MAX_G;
+        p = &c->Tg[j][(buf - PMX_BUF_TG0) % PMX_MAX_G];
     } else FAIL(PMX_E_INVALID, "unknown buffer id %d", buf);
     *count = c->rows[j] * c->K;
     if (!*p) {
@@ -661,6 +667,7 @@ static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, doub
 
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
+    if (c->host_grad) return PMX_OK;       // a user `grad` callable: its result is already in G (see slab_ref)
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
     if (c->k128) {
         AbsmaxArgs am{};
@@ -749,6 +756,11 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
 
 static SlabRef slab_ref(pmx_ctx* c, int j) {
     SlabRef s;
+    if (c->host_grad) {      // the caller's gradient: ONE "slab", the G buffer itself (the update kernels fold it onto itself)
+        s.base = c->G[j];
+        s.n = 1;
+        return s;
+    }
     s.base = c->slab[j];
     s.n = j == 0 ? c->nSlabA : c->nSlabS;
     return s;
@@ -1808,6 +1820,88 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// One block update of ONE bsdmm iteration in pieces, for user-defined operators (host round trips; see BsdmmArgs::stage):
+//   phase 0  step_f of block j (res->steps[j]) and its gradient; with host_f the argument of prox_f -> PMX_BUF_TMP_*
+//   phase 1  X_j <- prox_f(..) (the device operator, or PMX_BUF_TMP_* as the caller left it); without user members in
+//            proxs_g[j] also the constraint updates, else their arguments X_j + U_i -> PMX_BUF_TG0 + ..
+//   phase 2  the constraint updates with the user members' results taken from PMX_BUF_TG0 + .. (if any), the Boyd test of
+//            the block; last_block: end-of-iteration bookkeeping (iteration counter, stop when every block has converged)
+extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigned host_g, int last_block, double step_f_host, pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
+    if (j != 0 && j != 1) FAIL(PMX_E_INVALID, "block %d out of range", j);
+    const pmx_bsdmm_params& p = c->bsd;
+    if (host_g >> p.n_g[j]) FAIL(PMX_E_INVALID, "host_g names a constraint that does not exist");
+    auto args = [&](int stage) {
+        BsdmmArgs u{};
+        u.X = c->X[j];
+        u.slab = slab_ref(c, j);
+        for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); u.T[i] = c->Tg[j][i]; }
+        u.rows = c->rows[j];
+        u.K = (int)c->K;
+        u.j = j;
+        u.n_g = p.n_g[j];
+        u.prox_f = to_dev(p.prox_f[j]);
+        u.status = c->dstatus;
+        u.partials = c->partials;
+        u.absmax_out = nullptr;
+        u.stage = stage;
+        u.host_f = host_f;
+        u.host_g = host_g;
+        u.Tf = c->Xp[j];
+        return u;
+    };
+    const int it0 = c->hstatus->it_done;
+    switch (phase) {
+        case 0: {
+            if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+            if (host_f) { rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false); if (rc != PMX_OK) return rc; }
+            for (int i = 0; i < p.n_g[j]; ++i)
+                if ((host_g >> i) & 1u) { rc = dallocT(c, &c->Tg[j][i], (size_t)c->rows[j] * c->K, false); if (rc != PMX_OK) return rc; }
+            if (step_f_host > 0.0) {       // a user steps_f_cb (algorithms.py:807): its value for this block
+                HIP_CHECK(hipMemcpyAsync(&c->dstatus->step[j], &step_f_host, sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIP_CHECK(hipStreamSynchronize(c->stream));      // (the source is this call's argument)
+            } else {
+                rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
+            }
+            if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1);
+            if (rc != PMX_OK) return rc;
+            if (host_f) launch_bsdmm_update(args(1), c->stream);
+            HIP_CHECK(hipGetLastError());
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (res) { res->steps[0] = c->hstatus->step[0]; res->steps[1] = c->hstatus->step[1]; }
+            return PMX_OK;
+        }
+        case 1:
+            launch_bsdmm_update(args(2), c->stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            return PMX_OK;
+        case 2: {
+            if (host_g) launch_bsdmm_update(args(3), c->stream);
+            BsdmmDecideArgs d{};
+            d.status = c->dstatus;
+            d.partials = c->partials;
+            d.j = j;
+            d.n_g = p.n_g[j];
+            d.size = c->rows[j] * c->K;
+            d.e_rel = p.e_rel[j];
+            d.e_abs = p.e_abs[j];
+            d.last_block = last_block;
+            launch_bsdmm_decide(d, c->stream);
+            HIP_CHECK(hipGetLastError());
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            fill_result(c, res, it0);
+            return PMX_OK;
+        }
+        default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    }
+}
+
 extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
@@ -1847,6 +1941,18 @@ extern "C" int pmx_set_world(pmx_ctx* c, int rank, int world, int64_t M_global) 
     if (world < 1 || rank < 0 || rank >= world) FAIL(PMX_E_INVALID, "bad rank/world");
     if (M_global < c->M) FAIL(PMX_E_INVALID, "M_global < local M");
     c->rank = rank; c->world = world; c->M_global = M_global;
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_host_grad(pmx_ctx* c, int on) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (on) {
+        if (c->W) FAIL(PMX_E_UNSUPPORTED, "a host-side gradient and device-side weights do not go together");
+        if (c->chainL > 0) { int rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+        c->haveY = true;                   // nothing M x N is needed: the fused residual kernel never runs in this context
+    }
+    c->host_grad = on != 0;
     return PMX_OK;
 }
 

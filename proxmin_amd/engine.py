@@ -269,6 +269,17 @@ class DeviceNMF:
             p.e_rel[j], p.e_abs[j] = float(e_rel[j]), float(e_abs[j])
         _lib.check(self.lib.pmx_bsdmm_begin(self.h, C.byref(p)))
 
+    def set_host_grad(self, on=True):
+        """The gradient of every iteration is what the caller uploads into BUF_GA / BUF_GST (a user `grad` callable);
+        the context needs no Y (include/pmx.h: pmx_set_host_grad)."""
+        _lib.check(self.lib.pmx_set_host_grad(self.h, int(bool(on))))
+
+    def bsdmm_split(self, j, phase, host_f=False, host_g=0, last_block=False, step_f=0.0):
+        """One piece of one block update (include/pmx.h: pmx_bsdmm_split)."""
+        r = _lib.Result()
+        _lib.check(self.lib.pmx_bsdmm_split(self.h, int(j), int(phase), int(bool(host_f)), int(host_g), int(bool(last_block)), float(step_f), C.byref(r)))
+        return r
+
     def bsdmm_run(self, n_iter):
         r = _lib.Result()
         _lib.check(self.lib.pmx_bsdmm_run(self.h, int(n_iter), C.byref(r)))

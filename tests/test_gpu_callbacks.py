@@ -207,8 +207,10 @@ def test_bsdmm_update_order_and_direct_entry(pm, orc):
     np.testing.assert_array_equal(A, A2)
     np.testing.assert_array_equal(S, S2)
     assert conv == conv2
-    with pytest.raises(NotImplementedError):
-        pm.bsdmm([A2, S2], lambda X, step, Xs=None, j=None: X, lambda Xs, j=None: 1.0)
+    # generic closures run through the host path now (test_bsdmm_with_generic_closures); an identity prox_f leaves X alone
+    A4, S4 = A0.copy(), S0.copy()
+    pm.bsdmm([A4, S4], lambda X, step, Xs=None, j=None: X, lambda Xs, j=None: 1.0, max_iter=2)
+    np.testing.assert_array_equal(A4, A0)
     # S first: equals the default order on the transposed problem (Y^T = S^T A^T)
     A3, S3 = A0.copy(), S0.copy()
     pm.nmf.nmf(Y, A3, S3, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=5, e_rel=1e-9, update_order=[1, 0])
@@ -271,3 +273,98 @@ def test_bsdmm_with_an_empty_update_order(pm, orc):
     assert conv == [None, None] and seen == [0, 1, 2]
     np.testing.assert_array_equal(A, A0)
     np.testing.assert_array_equal(S, S0)
+
+
+# ---- generic `grad` callables and user-defined bsdmm operators (host round trips) -----------
+def _fixture_problem(z, meta, c, orc):
+    tag = "unity" if c["unity_S"] else "plain"
+    if "inputs_%s/Y" % tag in z.files:
+        return z["inputs_%s/Y" % tag], z["inputs_%s/A0" % tag], z["inputs_%s/S0" % tag]
+    return orc.synthetic_problem(meta["M"], meta["N"], meta["K"], np.dtype(meta["dtype"]).type, c["unity_S"], meta["seed"])
+
+
+def _numpy_grad(Y):
+    """a user-written gradient of 1/2 |A S - Y|^2: plain NumPy, no object of this library"""
+    def grad(A, S):
+        R = A @ S - Y
+        return R @ S.T, A.T @ R
+    return grad
+
+
+@pytest.mark.parametrize("fname", ["nmf_33x47_k3_f64.npz", "nmf_200x1000_k5_f64.npz"])
+def test_pgm_with_a_user_written_gradient_reproduces_the_fixture(pm, orc, fname, caplog):
+    """algorithms.pgm(X, grad, step, prox) with ANY callable as `grad` (algorithms.py:12): the reference-generated fixture
+    `pgm` must come out of `pgm([A, S], lambda A, S: <numpy>, step_pgm, prox=[prox_plus] * 2)`."""
+    from test_gpu_nmf import assert_factors_close
+    z, meta = load_golden(fname)
+    Y, A0, S0 = _fixture_problem(z, meta, meta["cases"]["pgm"], orc)
+    A, S = A0.copy(), S0.copy()
+    with caplog.at_level(logging.WARNING, logger="proxmin"):
+        conv, G, steps = pm.pgm([A, S], _numpy_grad(Y), pm.nmf.step_pgm, prox=[pm.operators.prox_plus] * 2,
+                                max_iter=meta["max_iter"], e_rel=meta["e_rel"])
+    assert_factors_close(A, z["pgm/A"], meta["dtype"], fname + " A")
+    assert_factors_close(S, z["pgm/S"], meta["dtype"], fname + " S")
+    # the returned gradient is the callable's own, at the last evaluation point
+    assert G[0].shape == A.shape and G[1].shape == S.shape
+    # accelerated + the library's damped rule: same numbers as the fused path with the device's own gradient
+    A1, S1 = A0.copy(), S0.copy()
+    pm.pgm([A1, S1], _numpy_grad(Y), pm.nmf.scaled_step_pgm(0.5), prox=[pm.operators.prox_plus] * 2, accelerated=True, max_iter=8, e_rel=1e-9)
+    A2, S2 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A2, S2, accelerated=True, step=pm.nmf.scaled_step_pgm(0.5), max_iter=8, e_rel=1e-9)
+    np.testing.assert_allclose(A1, A2, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(S1, S2, rtol=2e-5, atol=2e-6)
+
+
+def test_adaprox_with_a_user_written_gradient(pm, orc):
+    """algorithms.adaprox with a NumPy gradient callable: the fixture `adam`, and the fused tail fed by the host gradient."""
+    from test_gpu_nmf import assert_factors_close
+    z, meta = load_golden("nmf_33x47_k3_f64.npz")
+    Y, A0, S0 = _fixture_problem(z, meta, meta["cases"]["adam"], orc)
+    A, S = A0.copy(), S0.copy()
+    pm.adaprox([A, S], _numpy_grad(Y), pm.nmf.step_adaprox, prox=[pm.operators.prox_plus] * 2, scheme="adam",
+               max_iter=meta["max_iter"], e_rel=meta["e_rel"])
+    assert_factors_close(A, z["adam/A"], meta["dtype"], "adam A")
+    assert_factors_close(S, z["adam/S"], meta["dtype"], "adam S")
+
+
+def test_bsdmm_with_a_user_written_constraint_matches_the_fixture(pm, orc):
+    """nmf(..., algorithm=bsdmm, proxs_g=[[prox_plus, <user soft threshold>]] * 2): the fixture `bsdmm_plus_soft`
+    (generated from the reference with its own prox_soft); also a user-written prox_A / prox_S."""
+    from test_gpu_nmf import assert_factors_close
+    for fname in ("nmf_33x47_k3_f64.npz", "nmf_64x96_k8_f32.npz"):
+        z, meta = load_golden(fname)
+        c = meta["cases"]["bsdmm_plus_soft"]
+        Y, A0, S0 = _fixture_problem(z, meta, c, orc)
+        thresh = c["proxs_g"][0][1][1]
+        user_soft = partial(my_soft, thresh=thresh)
+        for pA, pS in ((pm.operators.prox_plus, pm.operators.prox_plus), (my_plus, my_plus)):
+            A, S = A0.copy(), S0.copy()
+            conv = pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, algorithm=pm.bsdmm, proxs_g=[[pm.operators.prox_plus, user_soft]] * 2,
+                              max_iter=meta["max_iter"], e_rel=meta["e_rel"])
+            assert_factors_close(A, z["bsdmm_plus_soft/A"], meta["dtype"], fname + " A")
+            assert_factors_close(S, z["bsdmm_plus_soft/S"], meta["dtype"], fname + " S")
+            assert len(conv) == 2
+
+
+def test_bsdmm_with_generic_closures(pm, orc):
+    """algorithms.bsdmm(X, proxs_f, steps_f_cb, proxs_g) with closures that are NOT the library's (algorithms.py:653): the
+    reference's own idiom for NMF (nmf.py:181-193) written with NumPy; must match the tagged-closure (all-device) run."""
+    Y, A0, S0 = orc.synthetic_problem(96, 140, 6, np.float32, seed=5)
+    grad = _numpy_grad(Y)
+
+    def prox_f(X, step, Xs=None, j=None):
+        return np.maximum(X - step * grad(*Xs)[j], 0)
+
+    def step_f(Xs, j=None):
+        A, S = Xs
+        L = np.linalg.eigvalsh(S @ S.T)[-1] if j == 0 else np.linalg.eigvalsh(A.T @ A)[-1]
+        return 1.0 / L
+
+    pg = [[pm.operators.prox_plus, partial(pm.operators.prox_soft, thresh=0.01)]] * 2
+    A, S = A0.copy(), S0.copy()
+    pm.bsdmm([A, S], prox_f, step_f, proxs_g=pg, max_iter=6, e_rel=1e-9)
+    A2, S2 = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A2, S2, algorithm=pm.bsdmm, proxs_g=pg, max_iter=6, e_rel=1e-9)
+    assert np.abs(A - A0).max() > 1e-3
+    np.testing.assert_allclose(A, A2, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(S, S2, rtol=2e-4, atol=2e-5)
