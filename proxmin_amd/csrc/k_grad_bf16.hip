@@ -2299,7 +2299,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         // ================================ producers: GEMM1 and R =================================================
         f32x16 p0, p1;
         float yv[2][2][16];                  // Y in flight: [pair set][block of the pair][row i of the tile] (accumulator layout)
-        float wv[HASW ? 2 : 1][2][HASW ? 16 : 1];
+        float wv[2][HASW ? 16 : 1];          // weights of ONE block pair (requested a slot ahead of their first use: registers)
         float4 areg[4][2];
         f16x8 afr[4][2];
         const int jw = __builtin_amdgcn_readfirstlane(j);
@@ -2316,13 +2316,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) yoff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldY + 2u * (unsigned)l31) * 4u;
         const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
-        unsigned woff[HASW ? 16 : 1];
-        const float* wbase0 = nullptr;
-        if constexpr (HASW) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) woff[i] = ((unsigned)((i & 3) + 8 * (i >> 2) + 4 * hi) * (unsigned)a.ldW + 2u * (unsigned)l31) * 4u;
-            wbase0 = a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0;
-        }
+        const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;   // (ldW == ldY: the launch checks it; W shares Y's offsets)
         // Y (and W) of the block pair q = blocks 2 q, 2 q + 1 (clamped past the end of the region) into pair set `set`:
         // rows i0 .. i0 + n - 1 of the sixteen (the requests of a pair are spread over the last MFMAs of a slot)
         auto pair_base = [&](int q, const float* b0, int64_t ld) {
@@ -2339,17 +2333,23 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(base + yoff[i]));
                 yv[set][0][i] = v[0];
                 yv[set][1][i] = v[1];
-                if constexpr (HASW) {
-                    asm volatile("" : "+v"(woff[i]));
-                    const f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(basew + woff[i]));
-                    wv[set][0][i] = u[0];
-                    wv[set][1][i] = u[1];
+            }
+            (void)basew;
+        };
+        auto load_w_rows = [&](const char* basew, auto i0_c, auto n_c) {      // the ONE set of weights
+            constexpr int i0 = decltype(i0_c)::value, n = decltype(n_c)::value;
+            if constexpr (HASW) {
+#pragma unroll
+                for (int i = i0; i < i0 + n; ++i) {
+                    asm volatile("" : "+v"(yoff[i]));
+                    const f32x2 u = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(basew + yoff[i]));
+                    wv[0][i] = u[0];
+                    wv[1][i] = u[1];
                 }
             }
         };
         auto load_pair = [&](int q, auto set_c) {
-            load_pair_rows(pair_base(q, ybase0, a.ldY), HASW ? pair_base(q, wbase0, a.ldW) : nullptr, set_c,
-                           std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+            load_pair_rows(pair_base(q, ybase0, a.ldY), nullptr, set_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
         };
         auto load_A = [&](int prow) {
             const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
@@ -2385,13 +2385,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         using no = std::integral_constant<bool, false>;
         using set0 = std::integral_constant<int, 0>;
         using set1 = std::integral_constant<int, 1>;
-        load_A(row0 + panel_at(0) * V5_BM);
+        if constexpr (!HASW) load_A(row0 + panel_at(0) * V5_BM);
         load_pair(0, set0{});                // slot s (even) requests the pair of blocks s + 2, s + 3 into the set block s - 1 has just left
         // slot 0 runs the same code as every other slot (no peeled copy: the loop head then sees the same requests in flight
         // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
         // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests the pair of blocks 2, 3
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yv[1][1][i] = 0.f; if constexpr (HASW) wv[1][1][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yv[1][1][i] = 0.f; if constexpr (HASW) { wv[0][i] = 0.f; wv[1][i] = 0.f; } }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
@@ -2409,8 +2409,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             }
             PH(5)
             if constexpr (GEMM && cb == 0) { // block s opens a row panel: its A terms (rows requested 8 slots ago), then the next panel's rows
-                make_afr();
-                load_A(row0 + panel_at(rp + 1 < nrp ? rp + 1 : nrp - 1) * V5_BM);
+                if constexpr (HASW) {        // (weighted: the registers of that prefetch hold weights; the rows are fetched here, an L2 trip per panel)
+                    load_A(row0 + panel_at(rp) * V5_BM);
+                    make_afr();
+                } else {
+                    make_afr();
+                    load_A(row0 + panel_at(rp + 1 < nrp ? rp + 1 : nrp - 1) * V5_BM);
+                }
             }
             f16x8 sv[4][2];
             if constexpr (GEMM) {
@@ -2434,7 +2439,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             const char* wbase_n = nullptr;
             if constexpr (EPI && (cb & 1) == 0) {    // the pair set of block s - 1 (the second of its pair) is free after this epilogue: blocks s + 2, s + 3
                 ybase_n = pair_base(rp * 4 + (cb >> 1) + 1, ybase0, a.ldY);
-                if constexpr (HASW) wbase_n = pair_base(rp * 4 + (cb >> 1) + 1, wbase0, a.ldW);
+                if constexpr (HASW) wbase_n = pair_base(rp * 4 + (cb >> 1), wbase0, a.ldW);   // blocks s, s + 1: their epilogues are the next two slots
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2457,7 +2462,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                             const int e = 4 * g + 2 * hf + q;
                             r[q] = pp[e] * unP - yv[pset][ptile][e];
                             if constexpr (HASW) {
-                                const float ww = wv[pset][ptile][e];
+                                const float ww = wv[ptile][e];
                                 if constexpr (LOSS) lossAcc += ww * (r[q] * r[q]);
                                 r[q] *= ww;
                             } else {
@@ -2475,6 +2480,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         if (t == 9) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
                         if (t == 10) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
                         if (t == 11) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+                        if constexpr (HASW) {    // weights of the pair whose first block's epilogue is the NEXT slot's
+                            if (t == 8) load_w_rows(wbase_n, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+                            if (t == 10) load_w_rows(wbase_n, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2872,7 +2881,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject;
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
-        const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || ((a.ldW % 2) == 0 && (((uintptr_t)a.W) & 7) == 0));
+        const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)
         if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0 && pairs_ok) return grad_launch_f16_v8(g, stream);
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);

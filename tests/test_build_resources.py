@@ -14,10 +14,10 @@ import __graft_entry__ as g
 
 # mangled-name fragment -> max spilled VGPRs (current values in the comments)
 LIMITS = {
-    "13k_grad_f16_v8ILb0ELb0ELb1E": 12,   # 7   two-term fp16 K1 with the chained gA accumulation (bench default)
-    "13k_grad_f16_v8ILb0ELb0ELb0E": 4,    # 1   the same with one gA slab per column region
-    "13k_grad_f16_v8ILb0ELb1ELb0E": 16,   # 5   weighted
-    "13k_grad_f16_v8ILb0ELb1ELb1E": 24,   #     weighted, chained
+    "13k_grad_f16_v8ILb0ELb0ELb1E": 8,    # 3   two-term fp16 K1 with the chained gA accumulation (bench default)
+    "13k_grad_f16_v8ILb0ELb0ELb0E": 8,    # 0   the same with one gA slab per column region (6 in its loss-only instance)
+    "13k_grad_f16_v8ILb0ELb1ELb0E": 8,    # 0   weighted (5 in its loss-only instance)
+    "13k_grad_f16_v8ILb0ELb1ELb1E": 8,    # 3   weighted, chained
     "15k_grad_f16_k128": 32,              # 29  two-term fp16 K1 at K = 128: 192 accumulator registers in the consumers
                                           #     (a handful of reloads per panel in their loop, the rest in the final flush)
     "13k_grad_f32_pc": 4,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (eight instances: 2 in the
