@@ -297,6 +297,15 @@ int pmx_set_host_grad(pmx_ctx* ctx, int on);
 int pmx_set_world(pmx_ctx* ctx, int rank, int world, int64_t M_global);
 int pmx_comm_layout(pmx_ctx* ctx, int64_t* count, int64_t offsets[3]);
 int pmx_set_comm_buffer(pmx_ctx* ctx, float* dptr, int64_t count);
+/* S-split: the UPDATE of S sharded as well (adaprox, projection-type prox_S).  An all-reduce is a reduce-scatter followed by
+ * an all-gather; here the S update sits between the two: the comm buffer is `world` chunks of
+ *     [ gSt rows of rank q (N / world x K) | Gram (KP^2) | colsum(A) (128) | colsum(S) (128) | scalars (32) ],
+ * phase 0 packs it, the caller reduce-scatters it (chunk q to rank q, into the pmx_set_comm_out buffer), phase 1 updates A's
+ * local rows and S's own N / world columns, and the caller all-gathers the S^T buffer (pmx_buffer_ptr(PMX_BUF_ST)) in place.
+ * Call pmx_set_s_split after pmx_set_world and before pmx_adaprox_begin; needs N % world == 0.                               */
+int pmx_set_s_split(pmx_ctx* ctx, int on);
+int pmx_comm_layout_split(pmx_ctx* ctx, int64_t* count, int64_t* chunk, int64_t offsets[4]);
+int pmx_set_comm_out(pmx_ctx* ctx, float* dptr, int64_t count);
 /* phase 0: K1 + pack.  phase 1: consume + update (+ `nsub` proximal sub-iteration passes).
  * phase 2: pack only (final stopping-test flush).  phase 3: consume only.  No synchronisation. */
 int pmx_adaprox_phase(pmx_ctx* ctx, int phase, int it, double b1_it, double b1_prev, int nsub);

@@ -73,7 +73,6 @@ _SIGNATURES = {
     "pmx_set_W_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "pmx_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
-    "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pmx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pmx_time_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -103,6 +102,10 @@ _SIGNATURES = {
     "pmx_adaprox_more_subs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pmx_iter_result": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
     "pmx_set_host_grad": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_set_s_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_comm_layout_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pmx_set_comm_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pmx_bsdmm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_double, C.POINTER(Result)]),
 }
 

@@ -2111,6 +2111,115 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_post(ShardPostArgs a) {
     }
 }
 
+// ---- S-split (pmx_set_s_split): the comm buffer is `world` chunks, chunk q = [ gSt rows of rank q | Gram | colsum(A) |
+// colsum(S) | scalars ]; the small sums are copied into every chunk (a reduce-scatter hands each rank ONE chunk, summed) ----
+struct PackSplitArgs {
+    SlabRef slabS;           // local gSt slabs (all N rows)
+    float* comm;
+    int64_t N;
+    int K, KP;
+    const double* colpart;   // [2][EW_BLOCKS][MAXK]: block 0 = local rows of A, block 1 = this rank's columns of S
+    const double* partials;  // SL_DIFF2 / SL_NORM2 of both blocks (local rows / own columns)
+    const DevStatus* status;
+    int fold_grad;
+    int world;
+    int64_t sncol, chunk;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a) {
+    __shared__ double scratch[EW_WAVES];
+    const int64_t ex0 = a.sncol * a.K;                   // offset of the extras inside a chunk
+    const int64_t sc0 = ex0 + (int64_t)a.KP * a.KP + 2 * MAXK;
+    if (chain_halted(a.status)) {
+        if (blockIdx.x == 0 && threadIdx.x < a.world) a.comm[threadIdx.x * a.chunk + sc0 + SHARD_HALT_SLOT] = 1.f;
+        return;
+    }
+    const int K = a.K;
+    if (a.fold_grad) {
+        ROW_LOOP_BEGIN(a.N)
+            bool ok[NC];
+            float g[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+            load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
+            float* dst = a.comm + (r / a.sncol) * a.chunk + (r % a.sncol) * K;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) dst[l32 + 32 * c] = g[c];
+        ROW_LOOP_END
+    }
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        __shared__ double asum[ALPHA_NG][MAXK];
+        __shared__ float cs[2][MAXK];
+        for (int j = 0; j < 2; ++j) {
+            colsum_fold(a.colpart + (int64_t)j * EW_BLOCKS * MAXK, K, false, asum);
+            if (t < MAXK) {
+                double s = 0.0;
+                for (int q = 0; q < ALPHA_NG; ++q) s += asum[q][t];
+                cs[j][t] = (float)s;
+            }
+            __syncthreads();
+        }
+        double sums[4];
+        sums[0] = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, scratch);
+        sums[1] = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS, scratch);
+        sums[2] = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 1) * EW_BLOCKS, scratch);
+        sums[3] = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 1) * EW_BLOCKS, scratch);
+        for (int q = 0; q < a.world; ++q) {
+            float* ex = a.comm + q * a.chunk + ex0;
+            for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
+            float* c0 = ex + a.KP * a.KP;
+            if (t < MAXK) { c0[t] = cs[0][t]; c0[MAXK + t] = cs[1][t]; }
+            if (t < 32) c0[2 * MAXK + t] = t < 4 ? (float)sums[t] : 0.f;
+        }
+    }
+}
+// after the reduce-scatter: global step sizes of BOTH blocks and the deferred outer test of the previous iteration
+struct ShardPostSplitArgs {
+    DevStatus* status;
+    const float* extras;     // this rank's chunk past gSt and the Gram matrix: colsum(A) | colsum(S) | scalars
+    int64_t rows_global[2];
+    int K;
+    int use_fixed;
+    float fixed[2];
+    double e_rel[2];
+    int check_convergence;
+    int have_prev;
+};
+__global__ __launch_bounds__(EW_THREADS) void k_shard_post_split(ShardPostSplitArgs a) {
+    DevStatus* st = a.status;
+    if (chain_halted(st)) return;
+    const float* sc = a.extras + 2 * MAXK;
+    if (sc[SHARD_HALT_SLOT] > 0.5f) {              // another rank is halted: stop before this iteration's update
+        if (threadIdx.x == 0) {
+            st->reason = HALT_PEER;
+            __threadfence();
+            st->halt = 1;
+        }
+        return;
+    }
+    const int t = threadIdx.x;
+    if (a.use_fixed != 2 && t < a.K)
+        for (int j = 0; j < 2; ++j)
+            st->alpha[j][t] = a.use_fixed ? a.fixed[j] : (float)((double)a.extras[j * MAXK + t] / (double)a.rows_global[j]) / 10.f;
+    if (a.check_convergence && a.have_prev && t == 0) {
+        const double dA = (double)sc[0], nA = (double)sc[1], dS = (double)sc[2], nS = (double)sc[3];
+        const int cA = dA <= a.e_rel[0] * a.e_rel[0] * nA;
+        const int cS = dS <= a.e_rel[1] * a.e_rel[1] * nS;
+        st->conv[0] = cA;
+        st->conv[1] = cS;
+        st->norms[0][0] = dA; st->norms[0][1] = nA;
+        st->norms[1][0] = dS; st->norms[1][1] = nS;
+        if (cA && cS) {
+            st->stopped = 1;
+            st->reason = HALT_CONVERGED;
+            __threadfence();
+            st->halt = 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launch wrappers (NC dispatch)
 // ------------------------------------------------------------------------------------------------
@@ -2171,4 +2280,6 @@ void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k
 void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS), s, a); }
 void launch_shard_gram_in(const GramInArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_gram_in, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 void launch_shard_post(const ShardPostArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_shard_pack_split(const PackSplitArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack_split, dim3(EW_BLOCKS), s, a); }
+void launch_shard_post_split(const ShardPostSplitArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post_split, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_decide(const BsdmmDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bsdmm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }

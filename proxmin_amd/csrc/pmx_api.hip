@@ -15,6 +15,9 @@
 #include <vector>
 #include <algorithm>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include "pmx_common.h"
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
@@ -147,6 +150,11 @@ struct pmx_ctx {
     int64_t M_global = 0;
     float* comm = nullptr;                 // caller-owned all-reduce buffer
     bool shard_grad_from_comm = false;
+    // S-split (pmx_set_s_split): the UPDATE of S is sharded too -- this rank owns the sncol columns of S from scol0 (rows of
+    // S^T), their moments and proximal loop; gS arrives by reduce-scatter into comm_out, the updated columns leave by all-gather
+    bool ssplit = false;
+    int64_t scol0 = 0, sncol = 0;
+    float* comm_out = nullptr;             // caller-owned: this rank's chunk after the reduce-scatter
 };
 
 static int dalloc(pmx_ctx* c, void** p, size_t bytes, bool zero = true) {
@@ -951,6 +959,11 @@ extern "C" int pmx_step_pgm(pmx_ctx* c, double out[2]) {
     return PMX_OK;
 }
 
+// S-split: the block-1 arrays the update kernels see are this rank's rows of S^T only
+static float* s_view(pmx_ctx* c, int j, float* p) { return (p && j == 1 && c->ssplit) ? p + c->scol0 * c->K : p; }
+static int64_t upd_rows(pmx_ctx* c, int j) { return (j == 1 && c->ssplit) ? c->sncol : c->rows[j]; }
+static int64_t split_chunk(pmx_ctx* c) { return c->sncol * c->K + (int64_t)c->KP * c->KP + 2 * MAXK + 32; }
+
 static AlphaArgs alpha_args(pmx_ctx* c) {
     AlphaArgs a{};
     a.status = c->dstatus;
@@ -964,8 +977,8 @@ static AlphaArgs alpha_args(pmx_ctx* c) {
 
 static int enqueue_alpha_from_factors(pmx_ctx* c, const AlphaArgs& al) {
     ColsumArgs cs{};
-    cs.X[0] = c->X[0]; cs.X[1] = c->X[1];
-    cs.rows[0] = c->M; cs.rows[1] = c->N;
+    cs.X[0] = c->X[0]; cs.X[1] = s_view(c, 1, c->X[1]);        // (S-split: this rank's columns; the partial sums meet in the collective)
+    cs.rows[0] = c->M; cs.rows[1] = upd_rows(c, 1);
     cs.K = (int)c->K;
     cs.colpart = c->colpart;
     cs.status = c->dstatus;
@@ -1463,11 +1476,11 @@ static SubArgs sub_args(pmx_ctx* c, int t) {
     const pmx_adaprox_params& p = c->ada;
     SubArgs s{};
     for (int j = 0; j < 2; ++j) {
-        s.X[j] = c->X[j];
-        s.Psi[j] = c->Psi[j];
-        s.zb[j][0] = c->zb[j][0];
-        s.zb[j][1] = c->zb[j][1];
-        s.rows[j] = c->rows[j];
+        s.X[j] = s_view(c, j, c->X[j]);
+        s.Psi[j] = s_view(c, j, c->Psi[j]);
+        s.zb[j][0] = s_view(c, j, c->zb[j][0]);
+        s.zb[j][1] = s_view(c, j, c->zb[j][1]);
+        s.rows[j] = upd_rows(c, j);
         s.prox[j] = to_dev(p.prox[j]);
         s.e_rel[j] = p.e_rel[j];
         s.has_prox[j] = p.prox[j].n > 0;
@@ -1495,7 +1508,7 @@ static int ada_enqueue_tail(pmx_ctx* c, int t) {
     const pmx_adaprox_params& p = c->ada;
     FinishArgs f{};
     f.s = sub_args(c, t);
-    f.Xp[0] = c->Xp[0]; f.Xp[1] = c->Xp[1];
+    f.Xp[0] = c->Xp[0]; f.Xp[1] = s_view(c, 1, c->Xp[1]);
     f.colpart = c->colpart;
     f.check_convergence = p.check_convergence;
     static_assert(EW_BLOCKS == 256, "k_grad_f16_v8 folds 256 partial maxima per factor");
@@ -1521,16 +1534,16 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     const pmx_adaprox_params& p = c->ada;
     MomentArgs m{};
     for (int j = 0; j < 2; ++j) {
-        m.X[j] = c->X[j]; m.Xp[j] = c->Xp[j];
-        m.Mm[j] = c->Mm[j]; m.Vv[j] = c->Vv[j];
-        m.Vh[j] = p.warm_vhat ? c->Vh[j] : nullptr;
-        m.Psi[j] = c->Psi[j];
+        m.X[j] = s_view(c, j, c->X[j]); m.Xp[j] = s_view(c, j, c->Xp[j]);
+        m.Mm[j] = s_view(c, j, c->Mm[j]); m.Vv[j] = s_view(c, j, c->Vv[j]);
+        m.Vh[j] = p.warm_vhat ? s_view(c, j, c->Vh[j]) : nullptr;
+        m.Psi[j] = s_view(c, j, c->Psi[j]);
         m.slab[j] = slab_ref(c, j);
-        m.rows[j] = c->rows[j];
+        m.rows[j] = upd_rows(c, j);
         m.has_prox[j] = p.prox[j].n > 0 || p.host_prox[j];   // (Psi is kept for a host-side proximal loop as well)
     }
-    if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer
-        m.slab[1].base = c->comm;
+    if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer (S-split: this rank's chunk of it)
+        m.slab[1].base = c->ssplit ? c->comm_out : c->comm;
         m.slab[1].n = 1;
     }
     m.K = (int)c->K;
@@ -1551,18 +1564,18 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
     TailArgs t{};
     MomentArgs& m = t.m;
     for (int j = 0; j < 2; ++j) {
-        m.X[j] = c->X[j]; m.Xp[j] = c->Xp[j];
-        m.Mm[j] = c->Mm[j]; m.Vv[j] = c->Vv[j];
-        m.Vh[j] = p.warm_vhat ? c->Vh[j] : nullptr;
+        m.X[j] = s_view(c, j, c->X[j]); m.Xp[j] = s_view(c, j, c->Xp[j]);
+        m.Mm[j] = s_view(c, j, c->Mm[j]); m.Vv[j] = s_view(c, j, c->Vv[j]);
+        m.Vh[j] = p.warm_vhat ? s_view(c, j, c->Vh[j]) : nullptr;
         m.Psi[j] = nullptr;
         m.slab[j] = slab_ref(c, j);
-        m.rows[j] = c->rows[j];
+        m.rows[j] = upd_rows(c, j);
         m.has_prox[j] = p.prox[j].n > 0;
         t.prox[j] = to_dev(p.prox[j]);
         t.e_rel[j] = p.e_rel[j];
-        t.slots[j] = (int)((c->rows[j] + 8191) / 8192);
+        t.slots[j] = (int)((upd_rows(c, j) + 8191) / 8192);
     }
-    if (c->shard_grad_from_comm) { m.slab[1].base = c->comm; m.slab[1].n = 1; }
+    if (c->shard_grad_from_comm) { m.slab[1].base = c->ssplit ? c->comm_out : c->comm; m.slab[1].n = 1; }
     m.K = (int)c->K;
     m.status = c->dstatus;
     m.partials = c->partials;
@@ -1580,7 +1593,25 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
     t.decide_check = c->comm ? 0 : 1;     // row-sharded: the outer test is made after the next all-reduce (k_shard_post)
     t.bar = c->gridbar;
     t.prof = c->tailprof;
-    HIP_CHECK(launch_ada_tail(t, c->stream));
+    // PMX_TAIL_LOCKFILE (tests only): several processes share ONE GPU -- their persistent tails (one workgroup per CU each,
+    // a census barrier at the top) cannot be resident together, so each is run to completion under an inter-process lock.
+    // The product configuration is one process per GPU and never sets it.
+    static const char* lockfile = getenv("PMX_TAIL_LOCKFILE");
+    int lockfd = -1;
+    if (lockfile && *lockfile) {
+        lockfd = open(lockfile, O_CREAT | O_RDWR, 0600);
+        if (lockfd < 0) FAIL(PMX_E_STATE, "PMX_TAIL_LOCKFILE: cannot open %s", lockfile);
+        HIP_CHECK(hipStreamSynchronize(c->stream));          // everything this rank enqueued before the tail has left the GPU
+        if (flock(lockfd, LOCK_EX) != 0) { close(lockfd); FAIL(PMX_E_STATE, "PMX_TAIL_LOCKFILE: flock failed"); }
+    }
+    hipError_t le = launch_ada_tail(t, c->stream);
+    if (lockfd >= 0) {
+        hipError_t se = hipStreamSynchronize(c->stream);
+        flock(lockfd, LOCK_UN);
+        close(lockfd);
+        HIP_CHECK(se);
+    }
+    HIP_CHECK(le);
     return PMX_OK;
 }
 
@@ -2015,6 +2046,77 @@ static int shard_post(pmx_ctx* c, int have_prev) {
     return PMX_OK;
 }
 
+// ---- S-split: the update of S sharded as well (VERDICT r2 task 3a) ----------------------------
+// An all-reduce is a reduce-scatter followed by an all-gather.  With a projection-type prox_S (its result does not depend on
+// the number of proximal passes: no cross-rank sum inside the loop) the S update can sit BETWEEN the two halves: each rank
+// receives the summed gS of its N / world columns only, updates those columns and their moments, and the columns are
+// all-gathered.  Same bytes on the wire, the replicated tail work divided by the rank count.
+//   comm buffer = world chunks of [ gSt rows of rank q (N/world x K) | Gram (KP^2) | colsum(A) | colsum(S) | scalars ]
+//   (the small sums are copied into every chunk: each rank finds them, summed, in the chunk the reduce-scatter hands it)
+extern "C" int pmx_set_s_split(pmx_ctx* c, int on) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (!on) { c->ssplit = false; c->scol0 = 0; c->sncol = 0; return PMX_OK; }
+    if (c->world < 1) FAIL(PMX_E_STATE, "pmx_set_world has not been called");
+    if (c->N % c->world != 0) FAIL(PMX_E_UNSUPPORTED, "S-split needs N (%lld) divisible by the rank count (%d)", (long long)c->N, c->world);
+    c->ssplit = true;
+    c->sncol = c->N / c->world;
+    c->scol0 = c->sncol * c->rank;
+    return PMX_OK;
+}
+extern "C" int pmx_comm_layout_split(pmx_ctx* c, int64_t* count, int64_t* chunk, int64_t offsets[4]) {
+    if (!c || !count || !chunk || !offsets) FAIL(PMX_E_INVALID, "NULL argument");
+    if (!c->ssplit) FAIL(PMX_E_STATE, "pmx_set_s_split has not been called");
+    *chunk = split_chunk(c);
+    *count = *chunk * c->world;
+    offsets[0] = c->sncol * c->K;                           // Gram
+    offsets[1] = offsets[0] + (int64_t)c->KP * c->KP;       // colsum(A)
+    offsets[2] = offsets[1] + MAXK;                         // colsum(S)
+    offsets[3] = offsets[2] + MAXK;                         // scalars
+    return PMX_OK;
+}
+extern "C" int pmx_set_comm_out(pmx_ctx* c, float* dptr, int64_t count) {
+    if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
+    if (!c->ssplit) FAIL(PMX_E_STATE, "pmx_set_s_split has not been called");
+    if (count < split_chunk(c)) FAIL(PMX_E_INVALID, "reduce-scatter output too small: %lld < %lld", (long long)count, (long long)split_chunk(c));
+    c->comm_out = dptr;
+    return PMX_OK;
+}
+static int shard_pack_split(pmx_ctx* c, int fold_grad) {
+    PackSplitArgs p{};
+    p.slabS = slab_ref(c, 1);
+    p.comm = c->comm;
+    p.N = c->N;
+    p.K = (int)c->K; p.KP = c->KP;
+    p.colpart = c->colpart;
+    p.partials = c->partials;
+    p.status = c->dstatus;
+    p.fold_grad = fold_grad;
+    p.world = c->world;
+    p.sncol = c->sncol;
+    p.chunk = split_chunk(c);
+    launch_shard_pack_split(p, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+static int shard_post_split(pmx_ctx* c, int have_prev) {
+    ShardPostSplitArgs q{};
+    q.status = c->dstatus;
+    q.extras = c->comm_out + c->sncol * c->K + (int64_t)c->KP * c->KP;
+    q.rows_global[0] = c->M_global;
+    q.rows_global[1] = c->N;
+    q.K = (int)c->K;
+    q.use_fixed = c->ada.use_fixed_steps;
+    q.fixed[0] = (float)c->ada.fixed_alpha[0];
+    q.fixed[1] = (float)c->ada.fixed_alpha[1];
+    q.e_rel[0] = c->ada.e_rel[0];
+    q.e_rel[1] = c->ada.e_rel[1];
+    q.check_convergence = c->ada.check_convergence;
+    q.have_prev = have_prev;
+    launch_shard_post_split(q, c->stream);
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
+
 extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, double b1_prev, int nsub) {
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
@@ -2029,19 +2131,29 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
                          ((q.op == PMX_PROX_MIN || q.op == PMX_PROX_MAX || q.op == PMX_PROX_HARD || q.op == PMX_PROX_HARD_PLUS) && !q.relative);
         if (!box) FAIL(PMX_E_UNSUPPORTED, "row-sharded adaprox supports only projection-type prox_A (plus/id/zero/absolute min,max,hard)");
     }
+    if (c->ssplit) {
+        if (!c->comm_out) FAIL(PMX_E_STATE, "pmx_set_comm_out has not been called");
+        for (int i = 0; i < p.prox[1].n; ++i) {      // the same condition for S: its loop must not need a sum over all of S
+            const pmx_prox& q = p.prox[1].seq[i];
+            const bool box = q.op == PMX_PROX_ID || q.op == PMX_PROX_ZERO || q.op == PMX_PROX_PLUS ||
+                             ((q.op == PMX_PROX_MIN || q.op == PMX_PROX_MAX || q.op == PMX_PROX_HARD || q.op == PMX_PROX_HARD_PLUS) && !q.relative);
+            if (!box) FAIL(PMX_E_UNSUPPORTED, "S-split supports only projection-type prox_S; use the replicated S update");
+        }
+    }
     switch (phase) {
         case 0:
             rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, c->absmax_by_finish);
             if (rc != PMX_OK) return rc;
-            return shard_pack(c, 1);
+            return c->ssplit ? shard_pack_split(c, 1) : shard_pack(c, 1);
         case 1: {
-            rc = shard_post(c, it > 0);
+            rc = c->ssplit ? shard_post_split(c, it > 0) : shard_post(c, it > 0);
             if (rc != PMX_OK) return rc;
             if (c->tail_fused) {
                 c->shard_grad_from_comm = true;
                 rc = ada_enqueue_tail_fused(c, it, b1_it, b1_prev);
                 c->shard_grad_from_comm = false;
-                c->absmax_by_finish = rc == PMX_OK;
+                // S-split: the tail saw this rank's columns of S only; the next K1 measures the operand maxima itself
+                c->absmax_by_finish = rc == PMX_OK && !c->ssplit;
                 return rc;
             }
             c->shard_grad_from_comm = true;
@@ -2055,11 +2167,11 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             r.it = it; r.nt = c->sub_nt;
             r.enq = ada_enqueue_subs(c, 0, ns);
             rc = ada_enqueue_tail(c, r.enq);
-            c->absmax_by_finish = rc == PMX_OK;
+            c->absmax_by_finish = rc == PMX_OK && !c->ssplit;
             return rc;
         }
-        case 2: return shard_pack(c, 0);
-        case 3: return shard_post(c, 1);
+        case 2: return c->ssplit ? shard_pack_split(c, 0) : shard_pack(c, 0);
+        case 3: return c->ssplit ? shard_post_split(c, 1) : shard_post(c, 1);
         default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
     }
 }

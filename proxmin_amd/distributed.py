@@ -52,13 +52,81 @@ class CommLayout:
         self.count = self.scalars + N_SCALARS
 
 
+class SplitLayout:
+    """S-split comm buffer: `world` chunks of [ gSt rows of rank q | Gram | colsum(A) | colsum(S) | scalars ]; mirrors
+    pmx_comm_layout_split."""
+
+    def __init__(self, N, K, world):
+        assert N % world == 0
+        self.N, self.K, self.world = int(N), int(K), int(world)
+        self.KP = 32 if K <= 32 else (64 if K <= 64 else 128)
+        self.sncol = self.N // self.world
+        self.gram = self.sncol * self.K
+        self.colsum_A = self.gram + self.KP * self.KP
+        self.colsum_S = self.colsum_A + MAXK
+        self.scalars = self.colsum_S + MAXK
+        self.chunk = self.scalars + N_SCALARS
+        self.count = self.chunk * self.world
+
+
+def reduce_scatter_sum(dist, out, inp, group=None):
+    """out (chunk) <- sum over ranks of chunk `rank` of inp.  RCCL: one reduce_scatter; back-ends without it (gloo: CPU
+    tests, two ranks on one GPU) all-reduce the whole buffer and keep their chunk -- same result, test-only traffic."""
+    try:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=group)
+        r, n = dist.get_rank(group), out.numel()
+        out.copy_(inp[r * n:(r + 1) * n])
+
+
+def all_gather_chunks(dist, full, group=None):
+    """every rank's chunk of `full` (equal contiguous pieces, rank order) to every rank, in place"""
+    r, w = dist.get_rank(group), dist.get_world_size(group)
+    n = full.numel() // w
+    flat = full.view(-1)
+    try:
+        dist.all_gather_into_tensor(flat, flat[r * n:(r + 1) * n].clone() if flat.device.type == "cpu" else flat[r * n:(r + 1) * n], group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [flat[q * n:(q + 1) * n].clone() for q in range(w)]
+        dist.all_gather(parts, parts[r], group=group)
+        for q in range(w):
+            if q != r:
+                flat[q * n:(q + 1) * n].copy_(parts[q])
+
+
+class OneRankOfMany:
+    """Stand-in for torch.distributed in a ONE-process measurement of one rank's share of a W-rank run (bench.py with
+    PMX_BENCH_FAKE_WORLD=W on a single GPU): the collectives move this rank's own data only (sums over one rank), so that the
+    kernels of the sharded code path -- chunked pack, post, the S update on N / W columns -- can be timed and profiled."""
+
+    class ReduceOp:
+        SUM = None
+
+    def all_reduce(self, t, op=None, group=None):
+        return None
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None):
+        out.copy_(inp[:out.numel()])
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        return None
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_world_size(self, group=None):
+        return 1
+
+
 class ShardedAdaproxDriver:
     """Iteration loop of the row-sharded adaprox back-end (algorithms.py:365-413 with one all-reduce
     per iteration).  `engine` provides phase(), chain_status(), more_subs() and the `comm` tensor."""
 
-    def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=16):
-        import torch.distributed as dist
-        self.dist = dist
+    def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=16, dist_module=None):
+        if dist_module is None:
+            import torch.distributed as dist_module
+        self.dist = dist_module
         self.eng = engine
         self.group = group
         self.check = bool(check_convergence)
@@ -70,13 +138,18 @@ class ShardedAdaproxDriver:
         self.stopped = False
 
     def _allreduce(self):
-        self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
+        if getattr(self.eng, "s_split", False):     # S-split: reduce-scatter here, the all-gather follows the update
+            reduce_scatter_sum(self.dist, self.eng.comm_out, self.eng.comm, self.group)
+        else:
+            self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def _iteration(self, it, b1):
         b1_prev = b1[it - 1]    # b1[-1] at it = 0, like the reference (algorithms.py:213)
         self.eng.phase(0, it, b1[it], b1_prev, 0)
         self._allreduce()
         self.eng.phase(1, it, b1[it], b1_prev, self.nsub)
+        if getattr(self.eng, "s_split", False):
+            all_gather_chunks(self.dist, self.eng.st_full, self.group)      # every rank's updated columns of S
 
     def run(self, n_iter, b1):
         """Advance up to n_iter iterations; b1 is the full per-iteration array (len >= it + n_iter)."""
@@ -165,12 +238,31 @@ class ShardedLoop:
 class ShardEngine:
     """libpmx-backed engine for one rank (HIP kernels; comm buffer is a torch CUDA tensor)."""
 
-    def __init__(self, dev, world, rank, M_global, algorithm="adaprox"):
+    def __init__(self, dev, world, rank, M_global, algorithm="adaprox", s_split=False):
         self.algorithm = algorithm
         import torch
         self.dev = dev
         lib = dev.lib
         _lib.check(lib.pmx_set_world(dev.h, rank, world, int(M_global)))
+        self.s_split = bool(s_split)
+        if self.s_split:
+            assert algorithm == "adaprox", "S-split is implemented for the adaprox back-end"
+            _lib.check(lib.pmx_set_s_split(dev.h, 1))
+            cnt, chunk = C.c_int64(), C.c_int64()
+            offs = (C.c_int64 * 4)()
+            _lib.check(lib.pmx_comm_layout_split(dev.h, C.byref(cnt), C.byref(chunk), offs))
+            self.layout = SplitLayout(dev.N, dev.K, world)
+            assert (cnt.value, chunk.value, offs[0], offs[1], offs[2], offs[3]) == (
+                self.layout.count, self.layout.chunk, self.layout.gram, self.layout.colsum_A, self.layout.colsum_S, self.layout.scalars)
+            device = torch.device("cuda", dev.device)
+            self.comm = torch.zeros(cnt.value, dtype=torch.float32, device=device)
+            self.comm_out = torch.zeros(chunk.value, dtype=torch.float32, device=device)
+            _lib.check(lib.pmx_set_comm_buffer(dev.h, C.c_void_p(self.comm.data_ptr()), cnt.value))
+            _lib.check(lib.pmx_set_comm_out(dev.h, C.c_void_p(self.comm_out.data_ptr()), chunk.value))
+            ptr, n = C.c_void_p(), C.c_int64()
+            _lib.check(lib.pmx_buffer_ptr(dev.h, _lib.BUF_ST, C.byref(ptr), C.byref(n)))
+            self.st_full = _device_tensor(ptr.value, n.value, dev.device)      # S^T (N x K) as the library holds it
+            return
         cnt = C.c_int64()
         offs = (C.c_int64 * 3)()
         _lib.check(lib.pmx_comm_layout(dev.h, C.byref(cnt), offs))
@@ -198,9 +290,29 @@ class ShardEngine:
         _lib.check(self.dev.lib.pmx_adaprox_more_subs(self.dev.h, int(t0), int(n)))
 
 
+class _DevArray:
+    """zero-copy view of a device buffer of the C library for torch (the __cuda_array_interface__ protocol)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def _device_tensor(ptr, n, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", device))
+
+
+def projection_type(seq):
+    """True if every operator of a device sequence is a coordinate-wise projection whose result does not depend on the
+    proximal pass count (plus / id / zero / absolute min, max, hard): what S-split (and a sharded A) require."""
+    box = {_lib.PROX[n] for n in ("id", "zero", "plus")}
+    maybe = {_lib.PROX[n] for n in ("min", "max", "hard", "hard_plus") if n in _lib.PROX}
+    return all(seq.seq[i].op in box or (seq.seq[i].op in maybe and not seq.seq[i].relative) for i in range(seq.n))
+
+
 def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, scheme="adam", b1=0.9, b2=0.999,
                         eps=1e-8, p=0.25, check_convergence=True, e_rel=1e-3, max_iter=1000, prox_max_iter=1000,
-                        group=None, device=None, Y_is_device_ptr=None):
+                        group=None, device=None, Y_is_device_ptr=None, s_split="auto"):
     """Row-sharded counterpart of `nmf(Y, A, S, algorithm=adaprox, ...)` for one rank.
 
     Y_local: this rank's rows of Y (ndarray, M_local x N); A_local: the matching rows of A (updated in
@@ -231,7 +343,12 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
                                                stream=tstream.cuda_stream) as dev:
         dev.set_Y(Y_local)
         dev.set_factors(A_local, S)
-        eng = ShardEngine(dev, world, rank, M_global)
+        # S-split ("auto": whenever it applies): the S update sharded over the ranks between a reduce-scatter and an
+        # all-gather instead of replicated behind an all-reduce -- projection-type prox_S, N divisible by the rank count
+        can_split = world > 1 and S.shape[1] % world == 0 and projection_type(seqs[1])
+        if s_split is True and not can_split:
+            raise NotImplementedError("S-split needs a projection-type prox_S and N divisible by the number of ranks")
+        eng = ShardEngine(dev, world, rank, M_global, s_split=bool(s_split) and can_split)
         dev.adaprox_begin(seqs, scheme=scheme, b2=b2, eps=eps, p=p, check_convergence=check_convergence,
                           prox_max_iter=prox_max_iter, e_rel=e)
         drv = ShardedAdaproxDriver(eng, group, check_convergence, seqs[0].n > 0 or seqs[1].n > 0, prox_max_iter)
@@ -349,7 +466,12 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream, mode=getattr(args, "mode", None))
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
-    eng = ShardEngine(dev, world, rank, M, backend)
+    # PMX_BENCH_FAKE_WORLD=W (single process): this GPU plays rank 0 of W -- M is the rank's share, the collectives are local
+    fake = int(os.environ.get("PMX_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
+    eff_world = fake if fake > 1 else world
+    # S-split whenever it applies: adaprox with a projection-type prox_S (cfg4), N divisible by the rank count
+    s_split = backend == "adaprox" and not unity and eff_world > 1 and N % eff_world == 0 and os.environ.get("PMX_S_SPLIT", "1") != "0"
+    eng = ShardEngine(dev, eff_world, 0 if fake > 1 else rank, M * fake if fake > 1 else M, backend, s_split=s_split)
     pA = ops.device_proxseq(ops.prox_plus, 0)
     pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
     # adaprox: the untimed warm-up continues until the proximal loops are past their start-up transient (as in the
@@ -358,7 +480,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     total = warm + args.steps
     if backend == "adaprox":
         dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
-        drv = ShardedAdaproxDriver(eng, None, False, True, 1000)
+        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, dist_module=OneRankOfMany() if fake > 1 else None)
         b1 = np.full(total, 0.9)
         run = lambda n: drv.run(n, b1)
     elif backend == "pgm":
@@ -399,7 +521,9 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         "vs_baseline": None, "dtype": getattr(args, "mode_dtype", {}).get(eff_mode, eff_mode), "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
                    "mode": getattr(args, "mode_desc", {}).get(eff_mode, eff_mode),
-                   "parallelism": "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration" % (world, eng.layout.count)},
+                   "parallelism": ("rows of Y/A sharded over %d GPUs; S update sharded as well: one RCCL reduce-scatter of gS (%d floats) + one all-gather of S per iteration" if s_split else
+                                   "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration") % (eff_world, eng.layout.count)
+                                  + ("; ONE process playing rank 0 of %d (local collectives)" % fake if fake > 1 else "")},
         "gflops": flop_per_it * its / 1e9,
         "roofline": ({"kernel": info["kernel"], "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                       "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,

@@ -14,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import nmf_oracle as orc
-from proxmin_amd.distributed import CommLayout, ShardedAdaproxDriver, ShardedLoop, shard_rows, HALT_CONVERGED
+from proxmin_amd.distributed import CommLayout, SplitLayout, ShardedAdaproxDriver, ShardedLoop, shard_rows, HALT_CONVERGED
 
 
 class NumpyShardEngine:
@@ -93,6 +93,88 @@ class NumpyShardEngine:
 
     def more_subs(self, t0, n):
         raise AssertionError("the stand-in engine never runs out of sub-iteration passes")
+
+
+class NumpySplitShardEngine(NumpyShardEngine):
+    """S-split protocol (pmx_set_s_split): the comm buffer is `world` chunks [gSt rows of rank q | Gram | colsum(A) | colsum(S) |
+    scalars]; after the driver's reduce-scatter this rank updates A's local rows and ITS columns of S (moments included), the
+    driver all-gathers S^T.  Same phase semantics as the HIP engine's (fp64 NumPy)."""
+
+    s_split = True
+
+    def __init__(self, rank, world, *args, **kw):
+        super().__init__(*args, **kw)
+        self.rank, self.world = rank, world
+        self.lay = SplitLayout(self.N, self.K, world)
+        self.comm = torch.zeros(self.lay.count, dtype=torch.float64)
+        self.comm_out = torch.zeros(self.lay.chunk, dtype=torch.float64)
+        self.c0 = rank * self.lay.sncol
+        self.c1 = self.c0 + self.lay.sncol
+        self.st_full = torch.from_numpy(np.ascontiguousarray(self.S.T))      # S^T (N x K), what the driver all-gathers
+        self.St = self.st_full.numpy()
+        self.MmS = np.zeros((self.K, self.lay.sncol))
+        self.VvS = np.zeros((self.K, self.lay.sncol))
+        self.sumsS = (0.0, 0.0)
+        self.first = True
+
+    def _extras_split(self):
+        L, c = self.lay, self.comm.numpy()
+        Sloc = self.St[self.c0:self.c1].T                          # K x sncol
+        for q in range(self.world):
+            b = q * L.chunk
+            c[b + L.gram:b + L.colsum_A] = 0
+            c[b + L.colsum_A:b + L.colsum_A + self.K] = self.A.sum(0)
+            c[b + L.colsum_S:b + L.colsum_S + self.K] = Sloc.sum(1)
+            c[b + L.scalars:b + L.scalars + 4] = (*self.sums[0], *self.sumsS)
+
+    def _post_split(self, have_prev):
+        L, o = self.lay, self.comm_out.numpy()
+        self.alpha = [o[L.colsum_A:L.colsum_A + self.K] / self.Mg / 10, (o[L.colsum_S:L.colsum_S + self.K] / self.N / 10)[:, None]]
+        if self.check and have_prev:
+            dA, nA, dS, nS = o[L.scalars:L.scalars + 4]
+            if dA <= self.e ** 2 * nA and dS <= self.e ** 2 * nS:
+                self.halted, self.reason = 1, HALT_CONVERGED
+
+    def phase(self, phase, it, b1_it, b1_prev, nsub):
+        if self.halted:
+            return
+        L, c = self.lay, self.comm.numpy()
+        if phase == 0:
+            S = np.ascontiguousarray(self.St.T)                    # the all-gathered S
+            self.gA, gS = orc.residual_gradients(self.A, S, self.Y)
+            gSt = gS.T
+            for q in range(self.world):
+                c[q * L.chunk:q * L.chunk + L.gram] = gSt[q * L.sncol:(q + 1) * L.sncol].ravel()
+            self._extras_split()
+        elif phase == 1:
+            self._post_split(it > 0)
+            if self.halted:
+                return
+            o = self.comm_out.numpy()
+            b1 = np.full(it + 1, b1_it)
+            b1[it - 1] = b1_prev
+            Sloc = np.ascontiguousarray(self.St[self.c0:self.c1].T)
+            G = [self.gA, o[:L.gram].reshape(L.sncol, self.K).T.copy()]
+            X = [self.A, Sloc]
+            Mm, Vv = [self.Mm[0], self.MmS], [self.Vv[0], self.VvS]
+            for j in range(2):
+                prev = X[j].copy()
+                Phi, Psi = orc.moment_update(self.scheme, it, G[j], Mm[j], Vv[j], None, b1, self.b2, self.eps, self.p)
+                X[j][:] -= self.alpha[j] * Phi / Psi
+                if self.spec[j] is not None:                       # projection-type operators only: one pass is the fixed point
+                    X[j][:] = orc.apply_prox(X[j], self.alpha[j], self.spec[j])
+                    self.tau[j] = 2
+                sums = (float(((X[j] - prev) ** 2).sum()), float((X[j] ** 2).sum()))
+                if j == 0:
+                    self.sums[0] = sums
+                else:
+                    self.sumsS = sums
+            self.St[self.c0:self.c1] = Sloc.T
+            self.it_done += 1
+        elif phase == 2:
+            self._extras_split()
+        elif phase == 3:
+            self._post_split(True)
 
 
 class NumpyPgmShardEngine:
@@ -252,13 +334,21 @@ def _worker(rank, world, port, case, ret):
             n = loop.run(its)
             ret[rank] = (r0, r1, A_l, S, n, loop.stopped)
             return
+        split = case[0] == "split"
+        if split:
+            case = case[1:]
         M, N, K, unity, scheme, pS, check, e_rel, its = case
         Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=unity, seed=3)
         r0, r1 = shard_rows(M, world)[rank]
         A_l, S = A0[r0:r1].copy(), S0.copy()
-        eng = NumpyShardEngine(Y[r0:r1], A_l, S, M, ("plus",), pS, scheme, check, e_rel)
+        if split:
+            eng = NumpySplitShardEngine(rank, world, Y[r0:r1], A_l, S, M, ("plus",), pS, scheme, check, e_rel)
+        else:
+            eng = NumpyShardEngine(Y[r0:r1], A_l, S, M, ("plus",), pS, scheme, check, e_rel)
         drv = ShardedAdaproxDriver(eng, None, check, True, 1000, chunk=3)
         n = drv.run(its, np.full(its, 0.9))
+        if split:
+            S = np.ascontiguousarray(eng.St.T)
         ret[rank] = (r0, r1, A_l, S, n, drv.stopped)
     finally:
         dist.destroy_process_group()
@@ -268,6 +358,10 @@ CASES = [
     (61, 90, 4, True, "amsgrad", ("unity_plus", 0), False, 1e-3, 7),
     (50, 64, 3, False, "adam", ("plus",), True, 1e-9, 6),
     (48, 70, 3, False, "amsgrad", ("plus",), True, 8e-2, 60),      # converges early: deferred test must stop at the same iterate
+    # S-split: reduce-scatter -> each rank updates its N / 2 columns of S -> all-gather (driver's gloo fall-backs included)
+    ("split", 50, 64, 3, False, "adam", ("plus",), True, 1e-9, 6),
+    ("split", 48, 70, 3, False, "amsgrad", ("plus",), True, 8e-2, 60),
+    ("split", 61, 90, 4, False, "amsgrad", ("plus",), False, 1e-3, 7),
 ]
 
 
@@ -277,6 +371,8 @@ def test_sharded_protocol_matches_unsharded_oracle(case):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    if case[0] == "split":
+        case = case[1:]
     M, N, K, unity, scheme, pS, check, e_rel, its = case
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=unity, seed=3)
     Ao, So = A0.copy(), S0.copy()
@@ -298,6 +394,8 @@ def test_shard_rows_and_layout():
     assert shard_rows(16384, 8)[-1] == (14336, 16384)
     L = CommLayout(1000, 5)
     assert (L.gram, L.colsum, L.scalars, L.count) == (5000, 5000 + 32 * 32, 5000 + 1024 + 128, 5000 + 1024 + 128 + 32)
+    P = SplitLayout(1000, 5, 4)
+    assert (P.sncol, P.gram, P.colsum_A, P.colsum_S, P.scalars, P.chunk, P.count) == (250, 1250, 1250 + 1024, 1250 + 1152, 1250 + 1280, 1250 + 1312, 4 * (1250 + 1312))
 
 
 PB_CASES = [

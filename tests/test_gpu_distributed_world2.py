@@ -15,6 +15,10 @@ CASES = {
     "adaprox_unity": dict(M=768, N=900, K=24, unity=True, its=9),
     "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512, N % 256 = 0: the fast 16-bit-split kernels / the f32 whole-block kernel
     "adaprox_k128": dict(M=512, N=640, K=128, unity=False, its=5, modes=("f32", "f16x2")),   # 256 rows per rank: k_grad_f16_k128 in mode f16x2
+    # S-split: the S update sharded too (reduce-scatter -> each rank updates N / 2 columns and their moments -> all-gather);
+    # the cases above keep S replicated behind an all-reduce (s_split=False), these run the other mode on the same problems
+    "adaprox_k64_split": dict(M=1024, N=1280, K=64, unity=False, its=6, s_split=True),
+    "adaprox_k128_split": dict(M=512, N=640, K=128, unity=False, its=5, modes=("f32", "f16x2"), s_split=True),
     "pgm": dict(M=520, N=700, K=12, its=7),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
@@ -35,9 +39,9 @@ def _free_port():
 def _worker(rank, world, port, name, mode, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    # two processes share the GPU here: the fused adaprox tail needs all of it to itself (its census barrier would abort,
-    # which a row-sharded run cannot repair) -- one process per GPU is the product configuration
-    os.environ["PMX_TAIL_FUSED"] = "0"
+    # two processes share the GPU here: the fused adaprox tail (the product configuration's) needs all of it to itself, so
+    # the ranks' tails take turns under an inter-process lock (test-only: one process per GPU never sets it)
+    os.environ["PMX_TAIL_LOCKFILE"] = os.path.join(out_dir, "tail.lock")
     if rank in CASES[name].get("inject", {}):
         os.environ["PMX_INJECT_K1_FAULT"] = CASES[name]["inject"][rank]
     import torch
@@ -58,7 +62,7 @@ def _worker(rank, world, port, name, mode, out_dir):
         if name.startswith("adaprox"):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
             conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme="amsgrad",
-                                                check_convergence=False, e_rel=1e-3, max_iter=c["its"])
+                                                check_convergence=False, e_rel=1e-3, max_iter=c["its"], s_split=c.get("s_split", False))
         elif name == "pgm":
             conv, n = pdist.nmf_pgm_sharded(Y[r0:r1], A_l, S, M, e_rel=1e-9, max_iter=c["its"])
         else:
