@@ -2142,7 +2142,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a
 #pragma unroll
             for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
             load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
-            float* dst = a.comm + (r / a.sncol) * a.chunk + (r % a.sncol) * K;
+            const int q = (int)r / (int)a.sncol;             // (32-bit: a 64-bit division per row made this kernel twice as long)
+            float* dst = a.comm + (int64_t)q * a.chunk + (int64_t)((int)r - q * (int)a.sncol) * K;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 if (ok[c]) dst[l32 + 32 * c] = g[c];

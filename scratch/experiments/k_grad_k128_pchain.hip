@@ -1,0 +1,671 @@
+// K1 for K = 128 in the two-term fp16 arithmetic of k_grad_f16_v8 (included by pmx_api.hip after k_grad_bf16.hip, whose
+// image layouts, swizzles, transposing reads and operand scales it shares).
+//
+// Same pass, same roles as k_grad_f16_v8 -- four producer waves (P = A S, R = P - Y, R split and parked as two fp16
+// [n][m] images), four consumer waves two blocks behind (gA = R S^T, gSt = R^T A from those images), one barrier per
+// 128 x 32 block -- re-blocked for twice the contraction length:
+//   * a region is 128 columns (4 blocks): the two fp16 terms of its S rows for all 128 k are 64 KB of LDS, kept as two
+//     "k halves" per block, each laid out exactly like v8's 32 x 64 image, so every read pattern of v8 (b128 rows for the
+//     P contraction, transposing reads for gA) applies to a half unchanged;
+//   * the producers' A operand (32 rows x 128 k x two terms = 64 VGPRs per lane) stays in registers for a panel as in
+//     v8, but there is no room to prefetch the next panel beside it, and a panel is over after 4 blocks, not 8.  So A is
+//     split into its two fp16 terms ONCE per launch by k_split_a_f16 (8 bytes per element of A: noise next to Y), and in
+//     the last block of a panel each 16-k fragment is re-loaded with the next panel's rows right behind the three MFMAs
+//     that were its last readers: the loads land during that block's epilogue and barrier, no conversion in the loop;
+//   * the consumers hold gA for the panel (32 rows x 128 k per wave: 64 accumulator registers) and their two gSt tiles
+//     of each of the 4 blocks (128 registers): everything in ONE pass over Y.  (A variant doing one 64-wide half of the
+//     gradients per launch, the residual computed twice, was measured at 0.56 ms against 0.40 ms and removed.)
+// LDS: S 64 KB + A images 64 KB (both halves, for gSt) + R 32 KB = the CU's 160 KB.
+// MFMAs per block: 24 per producer wave, 48 per consumer wave (24 + 24 at K = 64): the consumers bound the slot here.
+// gA: one slab per column region (N / 128 of them), gSt: two per row region -- or, <CHAIN> (round 3):
+//
+// gA summed in place along chains, by the PRODUCERS.  One slab per column region is as many bytes as Y itself at K = 128
+// (cfg4's 8192-row share: 128 x 4 MB written here, read back by the update kernel: 100 of its 144 us).  The K = 64 kernels
+// let each consumer wave fetch the previous sum into spare registers and add its tile before storing (k_grad_f16_v8<.., CHAIN>);
+// the consumers here hold 192 accumulators and have none.  So a consumer parks its finished 32 x 128 tile in a small
+// workgroup-private scratch (2 x 64 KB, plain stores: it stays in the XCD's L2), and the producer wave of the same rows --
+// which has registers and issue slots to spare: this kernel is bound by the consumers' 48 MFMAs per block -- folds it into
+// the chain's slab during the next four slots, a quarter (8 rows) per slot: scratch + previous sum (sc1 loads, requested at
+// the top of the slot) -> add -> plain stores (behind the slot's epilogue), after the fourth quarter s_waitcnt vmcnt(0) +
+// arrival word, right where the only load in flight is a Y tile requested a whole slot earlier.  Chain order, panel
+// rotation, arrival words with the writer's XCC_ID, timeouts and the fault -> slabs fall-back are k_grad_f16_v8's.
+// ------------------------------------------------------------------------------------------------
+constexpr int W8_NCB = 4;
+// <CHAIN>: member c of a chain visits its panels rotated by W8_CHAIN_STRIDE c.  A tile reaches the chain's slab ten slots after
+// its panel began (4 blocks + 2 slots of consumer lag + 4 fold slots): with a stride of ONE panel the successor would want the
+// sum the moment it appears, and every hop would wait (measured: 1.05 ms per launch against 0.42); three panels leave two
+// slots of slack.  Needs W8_CHAIN_STRIDE x chain length <= panels per region.
+constexpr int W8_CHAIN_STRIDE = 3;
+constexpr int W8_S_HALF = 2 * V5_S_TERM;            // [h][l] images of one k half of a 32-column block
+constexpr int W8_SL_BYTES = 2 * W8_S_HALF;          // both halves: 16 KB per block
+constexpr int W8_A_HALF = V5_AIMG_BYTES;            // [h][l] images of one k half of the 128-row panel: 32 KB
+constexpr int W8_OFF_A = W8_NCB * W8_SL_BYTES;
+constexpr int W8_NKT = 2;                           // 64-wide k halves
+constexpr int W8_OFF_R = W8_OFF_A + W8_NKT * W8_A_HALF, W8_LDS_BYTES = W8_OFF_R + 2 * V5_R_BYTES;
+static_assert(W8_LDS_BYTES <= 160 * 1024, "");
+static_assert(W8_OFF_R % 256 == 0, "R images must start on a bank row");
+
+struct GradK128Args {
+    const float* Y;
+    int64_t ldY;
+    const _Float16* Ah;      // [M][128] high / low fp16 terms of 2^eA A (k_split_a_f16)
+    const _Float16* Al;
+    const float* St;         // [N][128]
+    float* slabA;
+    float* slabS;
+    double* lossPart;
+    const DevStatus* status;
+    int M, N;
+    int RP;
+    int doA, doS;
+    int gridX, gridY;
+    const float* absmax;     // [2][V8_NPART] partial maxima of |A|, |St|
+    float ymax;
+    // <CHAIN>: see GradV4Args
+    int chainL;
+    unsigned* chainFlags;    // [chains][RP][4] arrival words
+    unsigned chainBase;
+    DevStatus* wstatus;
+    int chainInject;
+    float* gaScratch;        // [workgroups][2][128][128]: the consumers' finished tiles on their way to the chain's slab
+};
+
+struct SplitAArgs {
+    const float* X;          // [count] fp32
+    int64_t count;           // multiple of 8
+    const float* absmax;     // [V8_NPART] partial maxima of |X|
+    _Float16* H;
+    _Float16* L;
+    const DevStatus* status;
+};
+// 2^e with max|X| 2^e in [2^13, 2^14) from the partial maxima (the same expression k_grad_f16_k128 evaluates)
+__device__ __forceinline__ float w8_scale_from_partials(const float* part, float* red, int tid, int nthreads) {
+    float m = 0.f;
+    for (int i = tid; i < V8_NPART; i += nthreads) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    float mx = red[0];
+    for (int i = 1; i < nthreads / 64; ++i) mx = fmaxf(mx, red[i]);
+    __syncthreads();
+    int q = 0;
+    (void)frexpf(mx, &q);
+    return ldexpf(1.f, mx > 0.f ? 14 - q : 0);
+}
+__global__ __launch_bounds__(256) void k_split_a_f16(SplitAArgs a) {
+    __shared__ float red[4];
+    if (chain_halted(a.status)) return;
+    const float sc = w8_scale_from_partials(a.absmax, red, threadIdx.x, 256);
+    const int64_t n8 = a.count >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 x0 = reinterpret_cast<const float4*>(a.X)[2 * i], x1 = reinterpret_cast<const float4*>(a.X)[2 * i + 1];
+        f16x4 h0, l0, h1, l1;
+        v8_split2(x0, sc, h0, l0);
+        v8_split2(x1, sc, h1, l1);
+        f16x8 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = h0[q]; h[4 + q] = h1[q]; l[q] = l0[q]; l[4 + q] = l1[q]; }
+        reinterpret_cast<f16x8*>(a.H)[i] = h;
+        reinterpret_cast<f16x8*>(a.L)[i] = l;
+    }
+}
+void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
+    int64_t blocks = (a.count / 8 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_split_a_f16, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+template <bool CHAIN>
+__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
+    constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
+    constexpr int OFF_R = W8_OFF_R;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    if (chain_halted(a.status)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lq = lane >> 4;
+    const int M = a.M, N = a.N;
+    int rowRegion, colRegion;
+    int chainId = 0, chainPos = 0;
+    {
+        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
+        if constexpr (CHAIN) {               // the members of a chain: same row region, consecutive column regions, ONE XCD (checked at run time)
+            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
+            chainPos = idx % L;
+            chainId = (idx / L) * 8 + xcd;
+            rowRegion = chainId % gx;
+            colRegion = (chainId / gx) * L + chainPos;
+        } else if (gy % 8 == 0) {            // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
+            const int xcd = lin & 7, idx = lin >> 3;
+            rowRegion = idx % gx;
+            colRegion = xcd * (gy >> 3) + idx / gx;
+        } else {
+            rowRegion = lin % gx;
+            colRegion = lin / gx;
+        }
+    }
+    const int row0 = rowRegion * a.RP * V5_BM;
+    const int col0 = colRegion * NCB * V5_BN;
+    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
+    if (nrp > a.RP) nrp = a.RP;
+    if (nrp < 0) nrp = 0;
+    const int T = nrp * NCB;                 // blocks of this region; slots = T + 2
+    const bool producer = w < 4;
+    const int j = w & 3;
+    float lossAcc = 0.f;
+    // CHAIN: panels are visited rotated by the place in the chain (every region has all RP panels in this mode)
+    auto panel_at = [&](int t) {
+        if constexpr (CHAIN) { const int q = t - W8_CHAIN_STRIDE * chainPos; return q < 0 ? q + nrp : q; }
+        else return t;
+    };
+
+    if (T <= 0) {                            // region outside the matrix: its gSt slab parts and loss partial are zero
+        if (!producer) {
+            const int mh = j >> 1, kt = j & 1;
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            for (int h = 0; h < NKT; ++h)
+                for (int c = 0; c < NCB; ++c)
+                    for (int i = 0; i < 16; ++i) {
+                        const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                        if (gn < N && a.doS) dst[(int64_t)gn * K + h * 64 + kt * 32 + l31] = 0.f;
+                    }
+        }
+        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
+        return;
+    }
+
+    // ---- power-of-two operand scales (see k_grad_f16_v8); uniform --------------------------------------------------
+    float scS, scR, unP, unA, unS;
+    {
+        float* red = reinterpret_cast<float*>(smem);
+        float m0 = 0.f, m1 = 0.f;
+        for (int i = tid; i < V8_NPART; i += V5_THREADS) { m0 = fmaxf(m0, a.absmax[i]); m1 = fmaxf(m1, a.absmax[V8_NPART + i]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+        if (lane == 0) { red[w] = m0; red[8 + w] = m1; }
+        __syncthreads();
+        float mA = red[0], mS = red[8];
+        for (int i = 1; i < 8; ++i) { mA = fmaxf(mA, red[i]); mS = fmaxf(mS, red[8 + i]); }
+        __syncthreads();                     // red aliases the S images
+        int qA = 0, qS = 0, qR = 0;
+        (void)frexpf(mA, &qA);
+        (void)frexpf(mS, &qS);
+        (void)frexpf(a.ymax + (float)K * mA * mS, &qR);
+        const int eA = mA > 0.f ? 14 - qA : 0, eS = mS > 0.f ? 14 - qS : 0, eR = 14 - qR;
+        scS = ldexpf(1.f, eS); scR = ldexpf(1.f, eR);
+        unP = ldexpf(1.f, -(eA + eS)); unA = ldexpf(1.f, -(eR + eS)); unS = ldexpf(1.f, -(eR + eA));
+    }
+    {   // ---- both fp16 terms of the region's 128 S rows, once: block c, k half (k >> 6) -> its v8-style image ----------
+        const float4* ssrc = reinterpret_cast<const float4*>(a.St + (int64_t)col0 * K) + tid;
+        float4 sr[NCB][2];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) { sr[c][0] = ssrc[c * 1024]; sr[c][1] = ssrc[c * 1024 + 512]; }
+        const int c4 = tid & 31, half = c4 >> 4, cc = c4 & 15;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = (tid >> 5) + 16 * u;
+                f16x4 t0, t1;
+                v8_split2(sr[c][u], scS, t0, t1);
+                unsigned char* d = smem + c * W8_SL_BYTES + half * W8_S_HALF + row * ROWB + ((((cc >> 1) ^ v3_swz(row)) & 7) << 4) + 8 * (cc & 1);
+                *reinterpret_cast<f16x4*>(d) = t0;
+                *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+            }
+    }
+
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    if (producer) {
+        // ================================ producers: P = A S and R ================================================
+        f32x16 p0, p1;
+        float yE[16], yO[16];
+        f16x8 afr[8][2];
+        const int jw = __builtin_amdgcn_readfirstlane(j);
+        const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
+        const unsigned ylane = (unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31;
+        auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
+            int brp = b >> 2;
+            if (brp >= nrp) brp = nrp - 1;
+            brp = panel_at(brp);
+            const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 3) * V5_BN;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
+        };
+        // fragment ks of this lane: k = 16 ks + 8 hi .. + 7 of row (panel row 32 j + l31)
+        const int64_t afrag0 = (int64_t)(row0 + j * 32 + l31) * K + hi * 8;
+        auto load_afr = [&](int rp, int ks) {      // (past the region's last panel: that panel again, so that every panel ends alike)
+            if (rp >= nrp) rp = nrp - 1;
+            const int64_t o = afrag0 + (int64_t)panel_at(rp) * V5_BM * K + ks * 16;
+            afr[ks][0] = *reinterpret_cast<const f16x8*>(a.Ah + o);
+            afr[ks][1] = *reinterpret_cast<const f16x8*>(a.Al + o);
+        };
+        auto publish_A = [&]() {             // the current panel's terms -> A images, for the consumers' gSt contraction
+            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 k4 + hi: ^ (k4 << 5)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                unsigned char* d = smem + W8_OFF_A + (ks >> 2) * W8_A_HALF + (pa ^ ((ks & 3) << 5));
+                *reinterpret_cast<f16x8*>(d) = afr[ks][0];
+                *reinterpret_cast<f16x8*>(d + V5_A_TERM) = afr[ks][1];
+            }
+        };
+        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // P contraction's B operand: row l31, chunk 2 k4 + hi
+        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) load_afr(0, ks);
+        load_Y(0, yE);
+        // slot 0 runs the same code as every other slot (no peeled copy: the loop head then sees the same requests in flight
+        // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
+        // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests Y(1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yO[i] = 0.f; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();        // S images published
+
+        // One slot (block s = (rp, cb)).  GEMM: block s into pc.  EPI: block s-1 from pp and its Y tile -> R[(s-1) & 1].
+        // RELOAD: the panel's last block: each A fragment is re-loaded with the next panel's rows behind its MFMAs (one
+        // code path for every panel: two variants would meet at the loop head with different numbers of requests in
+        // flight, and the compiler's merged wait counts then drain the Y tiles requested a slot ago).
+        // ---- CHAIN: this wave folds the tile its consumer parked (rows 32 j .. of a panel, 128 k) into the chain's slab ----
+        unsigned* cflags = nullptr;
+        unsigned myxcc = 0;
+        const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+        if constexpr (CHAIN) {
+            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
+            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        }
+        bool cadd = false, cdead = false;
+        unsigned cwant = 0;
+        unsigned* curFlag = nullptr;
+        const float* fsrc = nullptr;         // scratch tile of the panel being folded (this lane's 64 bytes of row 8 q + lane / 8)
+        float* fdst = nullptr;               // the same place in the chain's slab
+        float4 fs[4], fp[4];
+        auto chain_fault = [&](int code) {
+            if (lane == 0 && code > 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            cadd = false;
+            cdead = true;
+        };
+        if constexpr (CHAIN) {
+            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+        }
+        // quarter q of the fold of the panel visited ft-th: requests (top of a slot) ...
+        auto fold_issue = [&](int ft, int q) {
+            if constexpr (CHAIN) {
+                if (ft < 0 || ft >= nrp || !(a.doA & 1) || ((a.doA >> 8) & 1)) return;
+                if (q == 0) {
+                    const int pnl = panel_at(ft);
+                    // place of this workgroup among the members' visits of panel pnl, in time (k_grad_f16_v8)
+                    // place of this workgroup among the members' visits of panel pnl, in time: member c comes at
+                    // (pnl + D c) mod nrp; the ones that wrap around (c >= c0) come first, in the order of c
+                    const int c = chainPos, L = a.chainL, D = W8_CHAIN_STRIDE;
+                    const int c0 = (nrp - pnl + D - 1) / D;
+                    const int nw = L - c0 > 0 ? L - c0 : 0;
+                    const int k = c >= c0 ? c - (L - nw) : c + nw;
+                    cadd = k > 0 && !cdead && !((a.doA >> 9) & 1);
+                    cwant = a.chainBase + (unsigned)k;
+                    curFlag = cflags + pnl * 4;
+                    // request u of a quarter = rows 2 u, 2 u + 1 of its eight, a whole 512-byte row per 32 lanes: every wave
+                    // instruction moves full cache lines (a lane-strided 64 bytes per lane touched every line four times)
+                    const int lr = lane >> 5, lc = (lane & 31) * 4;
+                    fsrc = a.gaScratch + ((int64_t)blockIdx.x * 2 + (ft & 1)) * (V5_BM * K) + (int64_t)(j * 32 + lr) * K + lc;
+                    fdst = a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(row0 + pnl * V5_BM + j * 32 + lr) * K + lc;
+                    if (cadd) {              // the predecessor finished this panel about a panel-time ago: normally no spin
+                        unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if ((v >> 4) != cwant) {
+                            const long long t0 = wall_clock64();          // 100 MHz
+                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
+                                if ((spins & 63) == 0) {
+                                    if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
+                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            }
+                        }
+                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                        asm volatile("" ::: "memory");    // the loads of the previous sum stay behind the arrival check
+                    }
+                }
+                const float* s = fsrc + (int64_t)q * 8 * K;
+                const float* p = fdst + (int64_t)q * 8 * K;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {    // 16-byte nontemporal loads: served by L2, never by this CU's L1 (the tile was stored by
+                                                 // another wave / another CU; per-dword sc1 loads of this lane-strided pattern made the launch 2.4 x longer)
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t sv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(s + 2 * u * K));
+                    fs[u] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                    if (cadd) {
+                        const f32x4_t pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + 2 * u * K));
+                        fp[u] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    } else fp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        // ... and the add + stores (behind the slot's epilogue); after the fourth quarter the arrival word
+        auto fold_finish = [&](int ft, int q) {
+            if constexpr (CHAIN) {
+                if (ft < 0 || ft >= nrp || !(a.doA & 1) || ((a.doA >> 8) & 1)) return;
+                float* p = fdst + (int64_t)q * 8 * K;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<float4*>(p + 2 * u * K) = make_float4(fs[u].x + fp[u].x, fs[u].y + fp[u].y, fs[u].z + fp[u].z, fs[u].w + fp[u].w);
+                if (q == 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are in L2 (in flight besides: a Y tile requested a slot ago)
+                    if (lane == 0) __hip_atomic_store(curFlag, ((cwant + 1u) << 4) | myxcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        auto slot = [&](int s, int rp, auto cb_c, f32x16& pc, f32x16& pp, float (&y)[16], auto gemm_c, auto epi_c, auto reload_c) {
+            constexpr int cb = decltype(cb_c)::value;
+            constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value, RELOAD = decltype(reload_c)::value;
+            if constexpr (cb == 2 && GEMM) {         // block s-2 opened this row panel: the consumers start on it in this slot
+                publish_A();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
+            // CHAIN: the tile of the panel visited (rp - 1)-th (slots 2, 3) / (rp - 2)-th (slots 0, 1) was parked by the end of
+            // slot 1 of the panel after it; its four quarters are folded in the four slots that follow
+            constexpr int fq = (cb + 2) & 3;
+            const int ft = cb >= 2 ? rp - 1 : rp - 2;
+            fold_issue(ft, fq);
+            if constexpr (CHAIN) __builtin_amdgcn_sched_barrier(0);    // the requests stay at the top of the slot ...
+            if constexpr (GEMM) {
+                const unsigned char* Slb = smem + cb * W8_SL_BYTES;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pc[i] = 0.f;
+                f16x8 sh[8], sl[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int so = (ks >> 2) * W8_S_HALF + (s_g1 ^ ((ks & 3) << 5));
+                    sh[ks] = *reinterpret_cast<const f16x8*>(Slb + so);
+                    sl[ks] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][1], sh[ks], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sl[ks], pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sh[ks], pc, 0, 0, 0);
+                    if constexpr (RELOAD) {
+                        // pinned in program order (only VALU / SALU / LDS instructions may move across): behind the MFMAs
+                        // that read the old fragment (else both live: spills), and AHEAD of this slot's Y requests -- the
+                        // next slot opens by waiting for these fragments (L2 hits), and vmcnt counts in order: it must
+                        // not wait for the Y tiles (HBM latency) requested a moment ago
+                        __builtin_amdgcn_sched_barrier(0x86);
+                        load_afr(rp + 1, ks);
+                        __builtin_amdgcn_sched_barrier(0x86);
+                    }
+                }
+                if constexpr (!RELOAD) {
+                    // The 24 MFMAs are one dependent chain; left alone the scheduler (the kernel as a whole sits at the
+                    // register limit) reads one S fragment pair, waits for it, issues its three MFMAs, reads the next pair
+                    // into the same registers ... : eight exposed LDS latencies per slot.  Order imposed here: the reads
+                    // run two fragment pairs (24 VGPRs) ahead of the MFMAs that use them.
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        if (ks + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // the epilogue of block s-1 in the MFMAs' shadow
+                    }
+                }
+            }
+            if constexpr (EPI) {
+                unsigned char* Rb = smem + OFF_R + ((s - 1) & 1) * V5_R_BYTES;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 h, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float r = pp[4 * g + q] * unP - y[4 * g + q];
+                        lossAcc += r * r;
+                        const float rs = r * scR;
+                        const _Float16 hh = (_Float16)rs;
+                        h[q] = hh;
+                        l[q] = (_Float16)(rs - (float)hh);
+                    }
+                    const int o = r_w ^ (g << 4);
+                    *reinterpret_cast<f16x4*>(Rb + o) = h;
+                    *reinterpret_cast<f16x4*>(Rb + V5_R_TERM + o) = l;
+                }
+            }
+            if constexpr (CHAIN) __builtin_amdgcn_sched_barrier(0);    // ... and their first use behind the slot's MFMAs and epilogue
+            fold_finish(ft, fq);
+            if constexpr (EPI) load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
+            __builtin_amdgcn_s_barrier();
+            // The four slots of a panel are ONE basic block (compile-time cb).  Without a fence the scheduler pulls the head
+            // of the next slot's epilogue up here -- and with it a wait for the Y tile requested one slot ago.
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
+        using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
+        // even blocks: accumulator p0, Y set yE; odd blocks: p1, yO.  Slot s requests Y(s + 1) into the set block s - 1 has left.
+#pragma nounroll
+        for (int rp = 0; rp < nrp; ++rp) {
+            const int s = rp * NCB;
+            slot(s, rp, c0{}, p0, p1, yO, yes{}, yes{}, no{});
+            slot(s + 1, rp, c1{}, p1, p0, yE, yes{}, yes{}, no{});
+            slot(s + 2, rp, c2{}, p0, p1, yO, yes{}, yes{}, no{});
+            slot(s + 3, rp, c3{}, p1, p0, yE, yes{}, yes{}, yes{});
+        }
+        slot(T, nrp, c0{}, p0, p1, yO, no{}, yes{}, no{});
+        slot(T + 1, nrp, c1{}, p1, p0, yE, no{}, no{}, no{});
+        if constexpr (CHAIN) {                   // the last panel's tile was parked during the slot that has just ended
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fold_issue(nrp - 1, q); fold_finish(nrp - 1, q); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ================================ consumers: gA and gSt of block s-2 ======================================
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();              // S images published
+
+        f32x16 accS[NCB][NKT];
+        f32x16 accA[NKT][2];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int h = 0; h < NKT; ++h)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accS[c][h][i] = 0.f;
+#pragma unroll
+        for (int h = 0; h < NKT; ++h)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
+        const int kt = j & 1, mh = j >> 1;   // gSt tile (per k half); gA: rows 32 j .., both 32-wide k tiles of each half
+        int r_t0, r_t1;                      // gA's A operand (R, transposing read)
+        {
+            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
+            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+        }
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // gA's B operand; k tile 1: ^ 64
+        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // gSt's A operand, ^ (ks << 5)
+        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // gSt's B operand
+        auto flush_gA = [&](int prow, int rp) {
+#pragma unroll
+            for (int h = 0; h < NKT; ++h) {
+                // CHAIN: into the workgroup's scratch (the producers fold it into the chain's slab), else this region's own slab
+                float* p0_ = CHAIN ? a.gaScratch + ((int64_t)blockIdx.x * 2 + (rp & 1)) * (V5_BM * K) + (int64_t)(j * 32 + 4 * hi) * K + h * 64 + l31
+                                   : a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + h * 64 + l31;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float* ph_ = p0_ + half * 16 * K;
+                    asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
+                        const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                        ph_[ro] = accA[h][0][i] * unA;
+                        ph_[ro + 32] = accA[h][1][i] * unA;
+                    }
+                }
+            }
+        };
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto consume = [&](int b, int prow, int rp, auto cb_c) {     // block b: column block cb of the panel at row prow (visited rp-th)
+            constexpr int cb = decltype(cb_c)::value;
+            const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + cb * W8_SL_BYTES;
+            const unsigned char* Ab = smem + W8_OFF_A;
+            if (a.doA & 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 r0 = v8_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const f16x8 r1 = v8_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
+                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h) {
+                        const unsigned char* Sh = Slb + h * W8_S_HALF;
+                        const f16x8 s00 = v8_tr_pair(Sh, so0, so1);
+                        const f16x8 s01 = v8_tr_pair(Sh + V5_S_TERM, so0, so1);
+                        const f16x8 s10 = v8_tr_pair(Sh, so0 ^ 64, so1 ^ 64);
+                        const f16x8 s11 = v8_tr_pair(Sh + V5_S_TERM, so0 ^ 64, so1 ^ 64);
+                        accA[h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s00, accA[h][0], 0, 0, 0);
+                        accA[h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s10, accA[h][1], 0, 0, 0);
+                        accA[h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s01, accA[h][0], 0, 0, 0);
+                        accA[h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s11, accA[h][1], 0, 0, 0);
+                        accA[h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s00, accA[h][0], 0, 0, 0);
+                        accA[h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s10, accA[h][1], 0, 0, 0);
+                    }
+                }
+            }
+            if (a.doS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ro = r_g3 ^ (ks << 5);
+                    const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
+                    const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
+                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h) {
+                        const unsigned char* Ahh = Ab + h * W8_A_HALF;
+                        const f16x8 a0 = v8_tr_pair(Ahh, ao0, ao1);
+                        const f16x8 a1 = v8_tr_pair(Ahh + V5_A_TERM, ao0, ao1);
+                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, accS[cb][h], 0, 0, 0);
+                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accS[cb][h], 0, 0, 0);
+                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accS[cb][h], 0, 0, 0);
+                    }
+                }
+            }
+            if constexpr (cb + 1 == NCB) {
+                if (a.doA & 1) {
+                    flush_gA(prow, rp);
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
+                    if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile is in L2 before the barrier lets the producers at it
+                }
+            }
+        };
+        using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
+        using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
+        sync();
+        sync();
+        int s = 2;
+#pragma nounroll
+        for (int rp = 0; rp < nrp; ++rp) {
+            const int prow = row0 + panel_at(rp) * V5_BM;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();          // block s-2 opens a row panel: the producers have published its A terms
+            consume(s - 2, prow, rp, c0{}); sync(); ++s;
+            consume(s - 2, prow, rp, c1{}); sync(); ++s;
+            consume(s - 2, prow, rp, c2{}); sync(); ++s;
+            consume(s - 2, prow, rp, c3{}); sync(); ++s;
+        }
+        if (a.doS) {
+            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+#pragma unroll
+            for (int h = 0; h < NKT; ++h) {
+                const int kk = h * 64 + kt * 32 + l31;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    const int bcol = col0 + c * V5_BN;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int gn = bcol + tile_row(i, lane);
+                        dst[(int64_t)gn * K + kk] = accS[c][h][i] * unS;
+                    }
+                }
+            }
+        }
+    }
+    {
+        float v = lossAcc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 4; ++i) s += (double)red[i];
+            a.lossPart[blockIdx.x] = s;
+        }
+    }
+}
+
+// host side -----------------------------------------------------------------------------------------
+// shapes the kernel takes (PMX_K1_K128=0: off, the exact-fp32 kernel instead -- tuning A/B)
+bool grad_k128_applies(int64_t M, int64_t N, int64_t K) {
+    if (K != 128 || M % V5_BM != 0 || N % (W8_NCB * V5_BN) != 0) return false;
+    return !(getenv("PMX_K1_K128") && atoi(getenv("PMX_K1_K128")) == 0);
+}
+GradPlan grad_plan_k128(int64_t M, int64_t N) {
+    GradPlan p{};
+    p.KP = 128;
+    p.BN = V5_BN;
+    const int64_t panels = M / V5_BM;
+    p.gridY = (int)(N / (W8_NCB * V5_BN));
+    const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : 256;   // one resident workgroup per CU
+    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
+    if (wantX < 1) wantX = 1;
+    if (wantX > panels) wantX = panels;
+    p.RP = (int)((panels + wantX - 1) / wantX);
+    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    p.nSlabA = p.gridY;
+    p.nSlabS = p.gridX * 2;
+    p.ldsBytes = W8_LDS_BYTES;
+    return p;
+}
+template <bool CHAIN>
+static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_grad_f16_k128<CHAIN>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
+    return a.chainL > 0 && (a.doA & 1) ? grad_launch_k128_t<true>(a, stream) : grad_launch_k128_t<false>(a, stream);
+}
+// chain length of the K = 128 kernel (0: one gA slab per column region): as grad_chain_length, with this kernel's plan
+int grad_chain_length_k128(const GradPlan& p, int64_t M, int num_cus) {
+    const int cap = getenv("PMX_K1_CHAIN") ? atoi(getenv("PMX_K1_CHAIN")) : 32;
+    if (cap < 2) return 0;
+    const int64_t panels = M / V5_BM;
+    if (M % V5_BM != 0 || panels % p.RP != 0) return 0;
+    if (p.gridX * p.gridY > num_cus || (p.gridX * p.gridY) % 8 != 0) return 0;
+    for (int L = std::min(std::min(std::min(p.RP / W8_CHAIN_STRIDE, p.gridY), 32), cap); L >= 2; --L)
+        if (p.gridY % L == 0 && ((p.gridX * p.gridY / L) % 8) == 0) return L;
+    return 0;
+}
