@@ -126,10 +126,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PmxError("libpmx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). proxmin_amd has no CPU fallback." % LIB_PATH)
-    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If it is loaded AFTER this library
-    # (which resolves the system one), the process ends up with two runtimes and the second sees no device; loaded
-    # first, libpmx binds to the copy already in the process.  So bring torch in first when it is installed.
-    if "torch" not in sys.modules:
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64: if torch is imported AFTER this library (which
+    # resolves the system runtime) the process ends up with two runtimes and the second sees no device; imported first,
+    # libpmx binds to the copy already in the process.  So torch -- an OPTIONAL companion: this package itself needs only
+    # NumPy and libamdhip64; torch is used by bench.py, the tests and proxmin_amd.distributed -- is brought in first when it
+    # is installed.  PMX_TORCH_PRELOAD=0 switches that off (a torch-free deployment, or one that imports torch itself
+    # before proxmin_amd).
+    if "torch" not in sys.modules and os.environ.get("PMX_TORCH_PRELOAD", "1") != "0":
         try:
             import torch  # noqa: F401
         except Exception:

@@ -5,11 +5,22 @@ entry points.  Pure plumbing -- every number is produced by the HIP kernels behi
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 
 import numpy as np
 
 from . import _lib
+
+logger = logging.getLogger("proxmin")
+_noticed = set()
+
+
+def _notice(key, msg):
+    """one line per distinct situation on logger "proxmin" (INFO): which K1 a context really got"""
+    if key not in _noticed:
+        _noticed.add(key)
+        logger.info(msg)
 
 
 # Arithmetic of the three contractions inside the fused residual-gradient kernel:
@@ -56,6 +67,16 @@ class DeviceNMF:
                                            C.c_void_p(stream) if stream else None))
         self.h = h
         self._keep = []
+        # a split-precision context that fell off its fast kernel says so once (pmx_k1_info knows): ragged shapes and
+        # K outside {64, 128} run the generic split-bf16 kernels or the exact-fp32 one, 1.5-3 x slower per pass
+        if mode != "f32":
+            k = self.k1_info()["kernel"]
+            fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small")}[mode]
+            generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
+            if k not in fast or generic_bf16 or (mode == "f16x2" and k == "k_grad_bf16"):
+                _notice((mode, k, self.K, self.M % 128 == 0, self.N % 256 == 0),
+                        "proxmin_amd: mode %s at %d x %d x %d runs %s, not the tuned kernel (those take K = 64 with M %% 128 = 0 and "
+                        "N %% 256 = 0, or K = 128 with M %% 128 = 0 and N %% 128 = 0)" % (mode, self.M, self.N, self.K, k))
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -296,7 +317,10 @@ def open_weighted(M, N, K, W, **kw):
         dev.set_W(W)
         return dev
     except NotImplementedError:
+        mode = dev.mode
         dev.close()
+    _notice(("weighted", mode, K), "proxmin_amd: a weighted likelihood at %d x %d x %d has no kernel in mode %s (its weighted kernels take "
+            "K = 64, M %% 128 = 0, N %% 256 = 0): this context computes in exact fp32 (k_grad_f32)" % (M, N, K, mode))
     dev = DeviceNMF(M, N, K, **dict(kw, mode="f32"))
     dev.set_W(W)
     return dev
