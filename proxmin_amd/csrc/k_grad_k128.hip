@@ -45,6 +45,9 @@ struct GradK128Args {
     int gridX, gridY;
     const float* absmax;     // [2][V8_NPART] partial maxima of |A|, |St|
     float ymax;
+    const float* W;          // <HASW>: weights of the likelihood (nmf.py:13-41), M x N, row pitch ldW; nullptr: W == 1
+    int64_t ldW;
+    float wmax;              // max(1, max |W|): enters the bound that scales R
 };
 
 struct SplitAArgs {
@@ -94,6 +97,9 @@ void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_split_a_f16, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
+// HASW: weighted likelihood -- D = W (A S - Y), loss 1/2 sum W (Y - A S)^2: the producers fetch the W tile next to the Y tile
+// (they have the registers: the consumers bound this kernel) and scale R in the epilogue, as in k_grad_f16_v8<.., HASW>.
+template <bool HASW>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
     constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
     constexpr int OFF_R = W8_OFF_R;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         int qA = 0, qS = 0, qR = 0;
         (void)frexpf(mA, &qA);
         (void)frexpf(mS, &qS);
-        (void)frexpf(a.ymax + (float)K * mA * mS, &qR);
+        (void)frexpf((a.ymax + (float)K * mA * mS) * (HASW ? a.wmax : 1.f), &qR);
         const int eA = mA > 0.f ? 14 - qA : 0, eS = mS > 0.f ? 14 - qS : 0, eR = 14 - qR;
         scS = ldexpf(1.f, eS); scR = ldexpf(1.f, eR);
         unP = ldexpf(1.f, -(eA + eS)); unA = ldexpf(1.f, -(eR + eS)); unS = ldexpf(1.f, -(eR + eA));
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         // ================================ producers: P = A S and R ================================================
         f32x16 p0, p1;
         float yE[16], yO[16];
+        float wv1[HASW ? 16 : 1];            // weights of ONE block, requested a slot ahead of their use (a slot is ~3 us here)
         f16x8 afr[8][2];
         const int jw = __builtin_amdgcn_readfirstlane(j);
         const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
@@ -197,6 +204,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 3) * V5_BN;
 #pragma unroll
             for (int i = 0; i < 16; ++i) y[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY + ylane]);
+        };
+        const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
+        const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
+        auto load_W = [&](int b, float (&wv)[HASW ? 16 : 1]) {
+            if constexpr (HASW) {
+                int brp = b >> 2;
+                if (brp >= nrp) brp = nrp - 1;
+                const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 3) * V5_BN;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
+            }
         };
         // fragment ks of this lane: k = 16 ks + 8 hi .. + 7 of row (panel row 32 j + l31)
         const int64_t afrag0 = (int64_t)(row0 + j * 32 + l31) * K + hi * 8;
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
         // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests Y(1)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yO[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yO[i] = 0.f; if constexpr (HASW) wv1[i] = 0.f; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // S images published
 
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         // RELOAD: the panel's last block: each A fragment is re-loaded with the next panel's rows behind its MFMAs (one
         // code path for every panel: two variants would meet at the loop head with different numbers of requests in
         // flight, and the compiler's merged wait counts then drain the Y tiles requested a slot ago).
-        auto slot = [&](int s, int rp, auto cb_c, f32x16& pc, f32x16& pp, float (&y)[16], auto gemm_c, auto epi_c, auto reload_c) {
+        auto slot = [&](int s, int rp, auto cb_c, f32x16& pc, f32x16& pp, float (&y)[16], float (&wv)[HASW ? 16 : 1], auto gemm_c, auto epi_c, auto reload_c) {
             constexpr int cb = decltype(cb_c)::value;
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value, RELOAD = decltype(reload_c)::value;
             if constexpr (cb == 2 && GEMM) {         // block s-2 opened this row panel: the consumers start on it in this slot
@@ -288,8 +306,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     f16x4 h, l;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float r = pp[4 * g + q] * unP - y[4 * g + q];
-                        lossAcc += r * r;
+                        float r = pp[4 * g + q] * unP - y[4 * g + q];
+                        if constexpr (HASW) {
+                            const float ww = wv[4 * g + q];
+                            lossAcc += ww * (r * r);
+                            r *= ww;
+                        } else {
+                            lossAcc += r * r;
+                        }
                         const float rs = r * scR;
                         const _Float16 hh = (_Float16)rs;
                         h[q] = hh;
@@ -300,6 +324,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     *reinterpret_cast<f16x4*>(Rb + V5_R_TERM + o) = l;
                 }
                 load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+                load_W(s, wv);               // weights of block s: the next slot's epilogue
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
             __builtin_amdgcn_s_barrier();
@@ -313,13 +338,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
             const int s = rp * NCB;
-            slot(s, rp, c0{}, p0, p1, yO, yes{}, yes{}, no{});
-            slot(s + 1, rp, c1{}, p1, p0, yE, yes{}, yes{}, no{});
-            slot(s + 2, rp, c2{}, p0, p1, yO, yes{}, yes{}, no{});
-            slot(s + 3, rp, c3{}, p1, p0, yE, yes{}, yes{}, yes{});
+            slot(s, rp, c0{}, p0, p1, yO, wv1, yes{}, yes{}, no{});
+            slot(s + 1, rp, c1{}, p1, p0, yE, wv1, yes{}, yes{}, no{});
+            slot(s + 2, rp, c2{}, p0, p1, yO, wv1, yes{}, yes{}, no{});
+            slot(s + 3, rp, c3{}, p1, p0, yE, wv1, yes{}, yes{}, yes{});
         }
-        slot(T, nrp, c0{}, p0, p1, yO, no{}, yes{}, no{});
-        slot(T + 1, nrp, c1{}, p1, p0, yE, no{}, no{}, no{});
+        slot(T, nrp, c0{}, p0, p1, yO, wv1, no{}, yes{}, no{});
+        slot(T + 1, nrp, c1{}, p1, p0, yE, wv1, no{}, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
@@ -501,9 +526,13 @@ GradPlan grad_plan_k128(int64_t M, int64_t N) {
     p.ldsBytes = W8_LDS_BYTES;
     return p;
 }
-hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+template <bool HASW>
+static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_f16_k128, dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(k_grad_f16_k128<HASW>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
+    return a.W != nullptr ? grad_launch_k128_t<true>(a, stream) : grad_launch_k128_t<false>(a, stream);
 }

@@ -445,7 +445,7 @@ extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int cop
 // max(1, max |W|) for the fp16 path's residual scale
 static int measure_wmax(pmx_ctx* c) {
     c->wmax = 1.f;
-    if (!c->use_f16 || !c->W) return PMX_OK;
+    if (!c->f16_scales || !c->W) return PMX_OK;      // (the two-term fp16 kernels, K = 64 and K = 128: max |W| enters R's scale)
     launch_absmax_pitched(c->W, c->ldW, c->M, c->N, c->absmax + 512, c->stream);
     HIP_CHECK(hipGetLastError());
     float h[256];
@@ -462,8 +462,8 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
-    if ((c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K)) || c->k128)
-        FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64, M %% 128 = 0, N %% 256 = 0; create the context with PMX_MODE_F32");
+    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
+        FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64 with M %% 128 = 0, N %% 256 = 0 or K = 128 with M %% 128 = 0, N %% 128 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     HIP_CHECK(hipSetDevice(c->device));
     if (from_host || copy) {
@@ -698,6 +698,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.doA = doA; g.doS = doS;
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
         g.absmax = c->absmax; g.ymax = c->ymax;
+        g.W = c->W; g.ldW = c->ldW; g.wmax = c->wmax;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;

@@ -463,7 +463,7 @@ def test_k128_two_term_fp16_kernel(eng, orc, M, N):
     """K = 128 in mode f16x2 (k_grad_f16_k128: BASELINE's 8-GPU case, 8192-row shards of 65536 x 16384): one region, many
     regions, row regions whose last one is short (3200 rows = 25 panels over 13 regions of 2; 8320 = 65 panels), more
     workgroups than CUs; gradients and loss against the fp64 oracle at the tolerance of the fp32 kernel.  Shapes it does
-    not take (ragged M or N) run the exact-fp32 kernel, and a weighted likelihood is refused loudly."""
+    not take (ragged M or N) run the exact-fp32 kernel; a weighted likelihood runs the kernel's <HASW> instance."""
     Y, A, S = orc.synthetic_problem(M, N, 128, np.float32, seed=M + N)
     with eng.DeviceNMF(M, N, 128, mode="f16x2") as dev:
         info = dev.k1_info()
@@ -473,9 +473,22 @@ def test_k128_two_term_fp16_kernel(eng, orc, M, N):
         gA, gS = dev.grad()
         loss = dev.loglike()
         gA2, gS2 = dev.grad()
-        with pytest.raises(NotImplementedError):
-            dev.set_W(np.ones((M, N), np.float32))
+        # weighted likelihood (round 3: k_grad_f16_k128<HASW>; zeros included), then back to W == 1
+        rng = np.random.default_rng(8)
+        W = (0.1 + 2.0 * rng.random((M, N))).astype(np.float32)
+        W[rng.random((M, N)) < 0.15] = 0
+        dev.set_W(W)
+        gAw, gSw = dev.grad()
+        lossw = dev.loglike()
+        dev.set_W(None)
+        gA3, gS3 = dev.grad()
     assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)          # fixed summation order: bitwise repeatable
+    assert np.array_equal(gA, gA3) and np.array_equal(gS, gS3)
+    A64, S64, Y64 = (x.astype(np.float64) for x in (A, S, Y))
+    rAw, rSw = orc.residual_gradients(A64, S64, Y64, W.astype(np.float64))
+    np.testing.assert_allclose(gAw, rAw, rtol=2e-5, atol=2e-5 * np.abs(rAw).max())
+    np.testing.assert_allclose(gSw, rSw, rtol=2e-5, atol=2e-5 * np.abs(rSw).max())
+    assert lossw == pytest.approx(orc.half_sq_residual(A64, S64, Y64, W.astype(np.float64)), rel=2e-5)
     A64, S64, Y64 = (x.astype(np.float64) for x in (A, S, Y))
     rA, rS = orc.residual_gradients(A64, S64, Y64)
     np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
