@@ -42,6 +42,11 @@ def _worker(rank, world, port, name, mode, out_dir):
     # two processes share the GPU here: the fused adaprox tail (the product configuration's) needs all of it to itself, so
     # the ranks' tails take turns under an inter-process lock (test-only: one process per GPU never sets it)
     os.environ["PMX_TAIL_LOCKFILE"] = os.path.join(out_dir, "tail.lock")
+    if CASES[name].get("inject"):
+        # the chained-K1 fault case: two processes' chained K1s on ONE GPU are not co-resident either, a member may wait its
+        # full 20 ms for a predecessor while it holds its CU -- ten times the tail's census patience.  That fight is the
+        # point of the case (K1 falls back to slabs); the tail runs as separate kernels here.
+        os.environ["PMX_TAIL_FUSED"] = "0"
     if rank in CASES[name].get("inject", {}):
         os.environ["PMX_INJECT_K1_FAULT"] = CASES[name]["inject"][rank]
     import torch
