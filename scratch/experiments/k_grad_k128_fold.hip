@@ -18,7 +18,28 @@
 // LDS: S 64 KB + A images 64 KB (both halves, for gSt) + R 32 KB = the CU's 160 KB.
 // MFMAs per block: 24 per producer wave, 48 per consumer wave (24 + 24 at K = 64): the consumers bound the slot here.
 // gA: one slab per column region (N / 128 of them), gSt: two per row region, as v8 without chaining.
+//
+// <FOLD>: the gA slabs are as many bytes as Y, and the update kernel that sums them afterwards spends ~100 us of a 0.54 ms
+// rank-iteration (cfg4's 8192-row share) streaming them back in.  In this instance the PRODUCER waves (they have registers
+// and issue slots to spare: the consumers bound the slot) sum the tiles while K1 is still running, a few panels behind their
+// writers: workgroup (row region r, column region c) folds row c of every 128-row panel of r (for 128 column regions; rows
+// c, c + G, .. for G = 64, 32), producer wave w the tiles of column regions [w G/4, (w+1) G/4), 8 loads of 8 bytes per lane
+// and slot, requested behind the slot's Y requests and added one slot later, at the very end of the slot -- nothing on the critical path waits for them.  The consumers'
+// flush stores are agent-scope (write-through: the reader sits on another XCD), and one slot after a flush each consumer
+// wave stores the launch number into its arrival word; a producer wave polls the 32 words it depends on with ONE load per
+// slot (same latency) and only requests tiles of panels it has seen complete; requests of a wave that has nothing
+// ready go to a page of zeros, so the instruction stream -- and with it every vmcnt the compiler counts -- is the same in
+// every slot.  What is left after the last panel (two or three panels) is folded in a polling loop with a 20 ms bound:
+// workgroups that are not co-resident make it expire -> DevStatus::k1_fault, the chain of kernels stops before anything is
+// updated and the host repeats the iteration without FOLD (pmx_api.hip, as for the chained K1 of K = 64).  The update kernels
+// then sum FOUR slabs (one per producer wave) instead of N / 128: deterministic, fixed order.
 // ------------------------------------------------------------------------------------------------
+#ifndef PMX_FOLD_ORDER
+#define PMX_FOLD_ORDER 1
+#endif
+#ifndef PMX_FOLD_ABL
+#define PMX_FOLD_ABL 0
+#endif
 constexpr int W8_NCB = 4;
 constexpr int W8_S_HALF = 2 * V5_S_TERM;            // [h][l] images of one k half of a 32-column block
 constexpr int W8_SL_BYTES = 2 * W8_S_HALF;          // both halves: 16 KB per block
@@ -48,6 +69,12 @@ struct GradK128Args {
     const float* W;          // <HASW>: weights of the likelihood (nmf.py:13-41), M x N, row pitch ldW; nullptr: W == 1
     int64_t ldW;
     float wmax;              // max(1, max |W|): enters the bound that scales R
+    float* foldA;            // <FOLD>: [4][M][128] gA summed over column regions [w G/4, (w+1) G/4) by producer wave w, then gridX gridY 4 dummy rows
+    unsigned* foldFlags;     // <FOLD>: [gridX][RP][4][gridY]: launch number of the last flush by (row region, panel, consumer wave, column region)
+    const float* foldZero;   // <FOLD>: 512 bytes of zeros
+    unsigned foldSeq;        // <FOLD>: this launch's number (> 0)
+    int foldInject;          // tests: report a fault
+    DevStatus* wstatus;
 };
 
 struct SplitAArgs {
@@ -99,7 +126,7 @@ void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
 
 // HASW: weighted likelihood -- D = W (A S - Y), loss 1/2 sum W (Y - A S)^2: the producers fetch the W tile next to the Y tile
 // (they have the registers: the consumers bound this kernel) and scale R in the epilogue, as in k_grad_f16_v8<.., HASW>.
-template <bool HASW>
+template <bool HASW, bool FOLD>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
     constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
     constexpr int OFF_R = W8_OFF_R;
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         const float* ybase0 = a.Y + (int64_t)(row0 + jw * 32) * a.ldY + col0;
         // saddr-form requests: the row's address is scalar (block base + row pitch), the lane's part ONE 32-bit byte offset
         // held for the whole launch -- no 64-bit address pairs in VGPRs (16 of them were live around every batch of requests)
-        const unsigned ylane = ((unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31) * 4u;
+        unsigned ylane = ((unsigned)(4 * hi) * (unsigned)a.ldY + (unsigned)l31) * 4u;
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 2;
             if (brp >= nrp) brp = nrp - 1;
@@ -213,19 +240,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             }
         };
         const float* wbase0 = HASW ? a.W + (int64_t)(row0 + jw * 32) * a.ldW + col0 : nullptr;
-        const unsigned wlane = HASW ? ((unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31) * 4u : 0u;
+        const unsigned wlane = HASW ? (unsigned)(4 * hi) * (unsigned)a.ldW + (unsigned)l31 : 0u;
         auto load_W = [&](int b, float (&wv)[HASW ? 16 : 1]) {
             if constexpr (HASW) {
                 int brp = b >> 2;
                 if (brp >= nrp) brp = nrp - 1;
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 3) * V5_BN;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    unsigned vo = wlane;
-                    asm volatile("" : "+v"(vo));
-                    const unsigned char* rb = reinterpret_cast<const unsigned char*>(base + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW);
-                    wv[i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(rb + vo));
-                }
+                for (int i = 0; i < 16; ++i) wv[i] = __builtin_nontemporal_load(&base[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldW + wlane]);
             }
         };
         // fragment ks of this lane: k = 16 ks + 8 hi .. + 7 of row (panel row 32 j + l31)
@@ -249,14 +271,99 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) load_afr(0, ks);
-        load_W(0, wv1);                      // (stands in for the weights of "block -1": R = 0 there; the loop head sees the
-                                             // same requests in flight from here as from the end of a panel)
+        // ---- <FOLD>: this wave's share of the in-kernel gA sum (see the head of the file) ----------------------------
+        // One "quarter" per slot: 8 tiles' worth of ONE row (512 B each: 8 B per lane).  G = gridY column regions, G / 4 of
+        // them per wave, 128 / G rows per workgroup and panel, G / 32 quarters per row, four quarters per panel.
+        const int G = a.gridY, qs = G == 128 ? 2 : (G == 64 ? 1 : 0), qpr = 1 << qs;
+        int f_panel = 0, f_q = 0;                // next request: quarter f_q of panel f_panel
+        int f_ready = 0;                         // panels whose tiles (this wave's column regions) are known to have landed
+        float f_acc0 = 0.f, f_acc1 = 0.f;        // running sum of the row in progress
+        unsigned long long fset[2][8];
+        unsigned fpoll[2] = {0u, 0u};
+        int fpoll_panel[2] = {-1, -1};
+        float f_keep[2] = {1.f, 1.f};
+        int64_t f_dst[2] = {0, 0};
+        const int64_t f_dummy = FOLD ? ((int64_t)4 * M + (int64_t)blockIdx.x * 4 + jw) * K : 0;
+        const int64_t f_zoff = FOLD ? a.foldZero - a.slabA : 0;
+        const unsigned f_voff = (unsigned)lane * 8u;   // byte offset of this lane's two floats in a 512-byte row
+        // arrival words this wave depends on: lane l & 31 <-> (row c + G ri, column region jw G/4 + cr): written by consumer wave (row >> 5)
+        int f_flagoff = 0;
+        if constexpr (FOLD) {
+            const int l = lane & 31, per = G >> 2, ri = l / per, cr = l % per;
+            f_flagoff = ((colRegion + G * ri) >> 5) * G + jw * per + cr;
+        }
+        bool f_dead = false;
+        auto fold_fault = [&](int code) {
+            if (lane == 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            f_dead = true;
+        };
+        auto fold_consume = [&](auto ic) {       // the set requested a slot ago
+            constexpr int i = decltype(ic)::value;
+            float s0 = f_acc0, s1 = f_acc1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += __builtin_bit_cast(float, (unsigned)(fset[i][u] & 0xffffffffull));
+                s1 += __builtin_bit_cast(float, (unsigned)(fset[i][u] >> 32));
+            }
+            float2 out = {s0, s1};
+            {
+                unsigned vo = f_voff;
+                asm volatile("" : "+v"(vo));
+                *reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(a.foldA + f_dst[i]) + vo) = out;   // a finished row, or the dummy row
+            }
+            const float keep = f_keep[i];
+            f_acc0 = s0 * keep; f_acc1 = s1 * keep;
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64((int)(fpoll[i] - a.foldSeq) >= 0);
+            f_ready += (int)(okm == ~0ull) & (int)(fpoll_panel[i] == f_ready);
+        };
+        auto fold_request = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            // selections by mask arithmetic: a conditional expression here becomes a branch, and a branch ends the basic block
+            // the slot's hand-laid schedule (and the compiler's exact wait counts) live in
+            const int64_t vmask = (PMX_FOLD_ABL & 2) ? 0 : -(int64_t)(f_panel < f_ready);             // all ones: this quarter's tiles have landed
+            const int ri = f_q >> qs, qq = f_q & (qpr - 1);
+            const int fp = min(f_panel, nrp - 1);
+            const int row = row0 + fp * V5_BM + colRegion + G * ri;
+            const int64_t realoff = ((int64_t)(jw * (G >> 2) + qq * 8) * M + row) * K;
+            const int64_t off = f_zoff + ((realoff - f_zoff) & vmask);       // the page of zeros, as an offset from slabA
+            const int64_t stride = ((int64_t)M * K) & vmask;
+            const float* p = a.slabA + off;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned vo = f_voff;
+                asm volatile("" : "+v"(vo));
+                const unsigned char* pu = reinterpret_cast<const unsigned char*>(p + u * stride) + vo;
+                fset[i][u] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int64_t emask = vmask & -(int64_t)(qq == qpr - 1);         // this quarter completes a row
+            f_keep[i] = __builtin_bit_cast(float, (unsigned)(~emask) & 0x3f800000u);   // 0.f after a finished row, else 1.f
+            f_dst[i] = f_dummy + ((((int64_t)jw * M + row) * K - f_dummy) & emask);
+            const int adv = (int)(vmask & 1);
+            f_panel += (f_q + adv) >> 2;
+            f_q = (f_q + adv) & 3;
+            const int pp = min(f_ready, nrp - 1);
+            fpoll[i] = __hip_atomic_load(a.foldFlags + ((int64_t)(rowRegion * a.RP + pp) * 4) * G + f_flagoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fpoll_panel[i] = pp;
+        };
+        if constexpr (FOLD) {
+            // the loop head must see the same requests in flight from the prologue as from the end of a panel (the compiler
+            // merges the two and its wait counts stay exact only then): a first request -- nothing is ready, it goes to the
+            // page of zeros -- in front of Y(0), as every slot has one in front of its Y requests
+            f_dst[0] = f_dst[1] = f_dummy;
+            if (a.foldInject && blockIdx.x == 0 && jw == 0) fold_fault(3);
+            fold_request(std::integral_constant<int, 0>{});
+        }
         load_Y(0, yE);
         // slot 0 runs the same code as every other slot (no peeled copy: the loop head then sees the same requests in flight
         // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
         // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests Y(1)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yO[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yO[i] = 0.f; if constexpr (HASW) wv1[i] = 0.f; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // S images published
 
@@ -267,6 +374,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         auto slot = [&](int s, int rp, auto cb_c, f32x16& pc, f32x16& pp, float (&y)[16], float (&wv)[HASW ? 16 : 1], auto gemm_c, auto epi_c, auto reload_c) {
             constexpr int cb = decltype(cb_c)::value;
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value, RELOAD = decltype(reload_c)::value;
+            if constexpr (FOLD && EPI) {
+                // the epilogue's arithmetic is pure: nothing but this keeps instruction selection from starting it at the end of
+                // the PREVIOUS slot (behind the sums' code) -- and with it a wait for the Y tile requested a slot ago
+                asm volatile("" : "+v"(pp));
+            }
             if constexpr (cb == 2 && GEMM) {         // block s-2 opened this row panel: the consumers start on it in this slot
                 publish_A();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -277,11 +389,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pc[i] = 0.f;
                 f16x8 sh[8], sl[8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                auto read_S = [&](int ks) {
                     const int so = (ks >> 2) * W8_S_HALF + (s_g1 ^ ((ks & 3) << 5));
                     sh[ks] = *reinterpret_cast<const f16x8*>(Slb + so);
                     sl[ks] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                };
+                if constexpr (RELOAD && FOLD) {
+                    read_S(0); read_S(1);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) read_S(ks);
                 }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -292,10 +409,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                         // pinned in program order (only VALU / SALU / LDS instructions may move across): behind the MFMAs
                         // that read the old fragment (else both live: spills), and AHEAD of this slot's Y requests -- the
                         // next slot opens by waiting for these fragments (L2 hits), and vmcnt counts in order: it must
-                        // not wait for the Y tiles (HBM latency) requested a moment ago
-                        __builtin_amdgcn_sched_barrier(0x86);
+                        // not wait for the Y tiles (HBM latency) requested a moment ago.
+                        // <FOLD> (a kernel at the register limit): the S fragments are pinned as well, two pairs ahead of
+                        // their MFMAs -- left free, all sixteen are read up front (64 VGPRs) and the loop spills
+                        __builtin_amdgcn_sched_barrier(FOLD ? 0x06 : 0x86);
                         load_afr(rp + 1, ks);
-                        __builtin_amdgcn_sched_barrier(0x86);
+                        if constexpr (FOLD) { if (ks + 2 < 8) read_S(ks + 2); }
+                        __builtin_amdgcn_sched_barrier(FOLD ? 0x06 : 0x86);
                     }
                 }
                 if constexpr (!RELOAD) {
@@ -337,9 +457,20 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     *reinterpret_cast<f16x4*>(Rb + o) = h;
                     *reinterpret_cast<f16x4*>(Rb + V5_R_TERM + o) = l;
                 }
-                load_W(s, wv);               // weights of block s: the next slot's epilogue.  AHEAD of the Y requests: vmcnt counts
-                                             // in order, and waiting for these must not mean waiting for a Y tile with a slot to spare
+#if PMX_FOLD_ORDER == 1
+                if constexpr (FOLD) {        // AHEAD of the Y requests: vmcnt counts in order, and the sums' requests must not be
+                    __builtin_amdgcn_sched_barrier(0);      // younger than a Y tile that has two slots to arrive
+                    fold_consume(std::integral_constant<int, 0>{});     // ONE set in flight: requested a slot ago
+                    fold_request(std::integral_constant<int, 0>{});
+                }
+#endif
                 load_Y(s + 1, y);            // the set is free again: Y of the block two slots on
+                load_W(s, wv);               // weights of block s: the next slot's epilogue
+            }
+            if constexpr (FOLD && (!EPI || PMX_FOLD_ORDER == 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+                fold_consume(std::integral_constant<int, 0>{});
+                fold_request(std::integral_constant<int, 0>{});
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
             __builtin_amdgcn_s_barrier();
@@ -361,6 +492,21 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         slot(T, nrp, c0{}, p0, p1, yO, wv1, no{}, yes{}, no{});
         slot(T + 1, nrp, c1{}, p1, p0, yE, wv1, no{}, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (FOLD) {
+            // the two sets still in flight, then whatever is left (the last two or three panels), polling: every workgroup of
+            // the row region must get there -- 20 ms bound, like the chained K1's hand-off
+            fold_consume(std::integral_constant<int, 0>{});
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (f_panel < nrp && !f_dead && !(PMX_FOLD_ABL & 2)) {
+                const int before = f_panel * 4 + f_q;
+                fold_request(std::integral_constant<int, 0>{});
+                fold_consume(std::integral_constant<int, 0>{});
+                if (f_panel * 4 + f_q == before && f_ready <= f_panel) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) fold_fault(1);
+                }
+            }
+        }
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -405,8 +551,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     for (int q = 0; q < 8; ++q) {
                         const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
                         const int ro = ((q & 3) + 8 * (q >> 2)) * K;
-                        ph_[ro] = accA[h][0][i] * unA;
-                        ph_[ro + 32] = accA[h][1][i] * unA;
+                        if constexpr (FOLD && !(PMX_FOLD_ABL & 1)) {              // agent scope: written through to where a reader on another XCD finds it
+                            __hip_atomic_store(reinterpret_cast<unsigned*>(ph_ + ro), __builtin_bit_cast(unsigned, accA[h][0][i] * unA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(reinterpret_cast<unsigned*>(ph_ + ro + 32), __builtin_bit_cast(unsigned, accA[h][1][i] * unA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            ph_[ro] = accA[h][0][i] * unA;
+                            ph_[ro + 32] = accA[h][1][i] * unA;
+                        }
                     }
                 }
             }
@@ -414,6 +565,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         auto sync = [&]() {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
+        };
+        unsigned* pendFlag = nullptr;           // <FOLD>: arrival word to write once this wave's flush stores have been acknowledged
+        auto fold_publish = [&]() {
+            if constexpr (FOLD) {
+                if (pendFlag != nullptr) {
+                    if (!(PMX_FOLD_ABL & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pendFlag, a.foldSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");
+                    pendFlag = nullptr;
+                }
+            }
         };
         auto consume = [&](int b, int prow, auto cb_c) {     // block b: column block cb of the panel at row prow
             constexpr int cb = decltype(cb_c)::value;
@@ -460,9 +622,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     }
                 }
             }
+            if constexpr (cb == 0) fold_publish();          // the previous panel's flush is one slot old: its stores have landed
             if constexpr (cb + 1 == NCB) {
                 if (a.doA & 1) {
                     flush_gA(prow);
+                    if constexpr (FOLD) pendFlag = a.foldFlags + ((int64_t)(rowRegion * a.RP + (prow - row0) / V5_BM) * 4 + j) * a.gridY + colRegion;
 #pragma unroll
                     for (int h = 0; h < NKT; ++h)
 #pragma unroll
@@ -485,6 +649,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             consume(s - 2, prow, c2{}); sync(); ++s;
             consume(s - 2, prow, c3{}); sync(); ++s;
         }
+        fold_publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
 #pragma unroll
@@ -541,13 +706,24 @@ GradPlan grad_plan_k128(int64_t M, int64_t N) {
     p.ldsBytes = W8_LDS_BYTES;
     return p;
 }
-template <bool HASW>
+template <bool HASW, bool FOLD>
 static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_f16_k128<HASW>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_k128<HASW, FOLD>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
+// the in-kernel gA sum (<FOLD>): every workgroup has all its panels, 32 / 64 / 128 column regions, one resident workgroup per CU
+bool grad_k128_fold_applies(const GradPlan& p, int64_t M, int ncu) {
+    if (getenv("PMX_K1_K128_FOLD") && atoi(getenv("PMX_K1_K128_FOLD")) == 0) return false;
+    if (p.gridY != 32 && p.gridY != 64 && p.gridY != 128) return false;
+    if (M % ((int64_t)p.RP * V5_BM) != 0 || (int64_t)p.gridX * p.RP * V5_BM != M) return false;
+    return ncu > 0 && p.gridX * p.gridY <= ncu;
+}
 hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
-    return a.W != nullptr ? grad_launch_k128_t<true>(a, stream) : grad_launch_k128_t<false>(a, stream);
+    // (no weighted <FOLD> instance: the weights' 16 registers on top of the sums' 20 make the producers' loop spill, and a
+    // spill reload drains the Y requests in flight; pmx_api.hip leaves the sum to the update kernels for a weighted context)
+    if (a.W != nullptr) return grad_launch_k128_t<true, false>(a, stream);
+    const bool fold = a.foldA != nullptr && (a.doA & 1);
+    return fold ? grad_launch_k128_t<false, true>(a, stream) : grad_launch_k128_t<false, false>(a, stream);
 }

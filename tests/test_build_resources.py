@@ -20,8 +20,8 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb1ELb1E": 8,    # 3   weighted, chained
     "15k_grad_f16_k128ILb0E": 32,         # 29  two-term fp16 K1 at K = 128: 192 accumulator registers in the consumers
                                           #     (a handful of reloads per panel in their loop, the rest in the final flush)
-    "15k_grad_f16_k128ILb1E": 128,        # 113 its weighted instance (the W tile's 16 registers and addresses on top of a kernel at
-                                          #     the limit: 0.67 ms against 0.45 unweighted and 1.51 for the exact-fp32 kernel it replaces)
+    "15k_grad_f16_k128ILb1E": 32,         # 29  its weighted instance (saddr-form W and Y requests: 113 before, with reloads inside the
+                                          #     producers' loop; 0.458 ms against 0.43 unweighted and 1.51 for the exact-fp32 kernel)
     "13k_grad_f32_pc": 4,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (eight instances: 2 in the
                                           #     weighted, chained K = 64 one, 0 in the others)
     "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)
