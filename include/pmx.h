@@ -323,6 +323,24 @@ int pmx_chain_status(pmx_ctx* ctx, int* halted, int* reason, int* it_done, int l
 int pmx_adaprox_more_subs(pmx_ctx* ctx, int t0, int n);
 int pmx_iter_result(pmx_ctx* ctx, pmx_result* res);
 
+/* ---- the collectives themselves, for a caller without torch.distributed -------------------------------------------------
+ * No reference counterpart (the reference is single-process).  The phase protocol above leaves its one all-reduce -- or, with
+ * the S-split, its reduce-scatter and all-gather -- per iteration to the caller; these entry points are RCCL behind the C ABI:
+ * looked up at run time (the RCCL a process has loaded already, else librccl.so.1; PMX_RCCL_LIB overrides), one communicator
+ * per context, float32 sums, every call enqueued on the CONTEXT'S STREAM: ordered with the kernels of the phases, no host
+ * synchronisation.  Bootstrap: rank 0 calls pmx_comm_unique_id and hands the 128 bytes to the other ranks by its own means
+ * (MPI_Bcast, a file, a socket); then every rank calls pmx_comm_init (collective: returns when all `world` ranks have).
+ *   iteration, replicated S:   pmx_adaprox_phase(0) ; pmx_comm_all_reduce(comm buffer, pmx_comm_layout count) ; pmx_adaprox_phase(1)
+ *   iteration, S-split:        phase(0) ; pmx_comm_reduce_scatter(comm buffer -> comm_out, chunk) ; phase(1) ;
+ *                              pmx_comm_all_gather(S^T + rank * N/world * K  ->  S^T, N/world * K)        (in place)
+ * pmx_ctx_destroy destroys the communicator. */
+int pmx_comm_unique_id(unsigned char id[128]);
+int pmx_comm_init(pmx_ctx* ctx, const unsigned char id[128], int rank, int world);
+int pmx_comm_all_reduce(pmx_ctx* ctx, float* dptr, int64_t count);                                     /* in place */
+int pmx_comm_reduce_scatter(pmx_ctx* ctx, const float* dsend, float* drecv, int64_t recvcount);         /* dsend: world x recvcount */
+int pmx_comm_all_gather(pmx_ctx* ctx, const float* dsend, float* drecv, int64_t sendcount);             /* drecv: world x sendcount */
+int pmx_comm_destroy(pmx_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

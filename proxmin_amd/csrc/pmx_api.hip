@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include "pmx_common.h"
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
@@ -155,6 +156,8 @@ struct pmx_ctx {
     bool ssplit = false;
     int64_t scol0 = 0, sncol = 0;
     float* comm_out = nullptr;             // caller-owned: this rank's chunk after the reduce-scatter
+    void* rccl_comm = nullptr;             // pmx_comm_init: an RCCL communicator of this context's device (collectives run on its stream)
+    int rccl_rank = 0, rccl_world = 0;
 };
 
 static int dalloc(pmx_ctx* c, void** p, size_t bytes, bool zero = true) {
@@ -331,6 +334,7 @@ extern "C" int pmx_ctx_destroy(pmx_ctx* c) {
     if (!c) return PMX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)pmx_comm_destroy(c);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->hstatus) (void)hipHostFree(c->hstatus);
@@ -2380,5 +2384,116 @@ extern "C" int pmx_iter_result(pmx_ctx* c, pmx_result* res) {
     int rc = read_status(c);
     if (rc != PMX_OK) return rc;
     fill_result(c, res, 0);
+    return PMX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Collectives through the C ABI (missing 7): the row-sharded protocol (pmx_*_phase) leaves its one
+// all-reduce (or reduce-scatter + all-gather) per iteration to the caller; a caller without torch.distributed gets them
+// here: RCCL itself, looked up at run time (dlopen: the library a process has loaded already -- torch ships its own -- or
+// librccl.so.1 of the ROCm installation; PMX_RCCL_LIB overrides), one communicator per context, every collective on the
+// context's stream, i.e. ordered with its kernels without a single host synchronisation.  The 128-byte id of rank 0
+// reaches the other ranks by whatever the caller bootstraps with (MPI, a file, torch.distributed's store).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[128]; };                    // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0;             // ncclFloat32, ncclSum
+RcclApi g_rccl;
+int rccl_load() {
+    if (g_rccl.handle) return PMX_OK;
+    const char* names[] = {getenv("PMX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (int pass = 0; pass < 2 && !h; ++pass)            // first what the process has loaded already (one RCCL per process)
+        for (const char* n : names)
+            if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+    if (!h) FAIL(PMX_E_UNSUPPORTED, "RCCL not found (librccl.so.1; set PMX_RCCL_LIB): %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.ReduceScatter || !a.AllGather || !a.GetErrorString)
+        FAIL(PMX_E_UNSUPPORTED, "the RCCL library found lacks an entry point this layer needs");
+    g_rccl = a;
+    return PMX_OK;
+}
+}  // namespace
+#define RCCL_CHECK(expr)                                                                              \
+    do {                                                                                              \
+        const int r_ = (expr);                                                                        \
+        if (r_ != 0) FAIL(PMX_E_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));                     \
+    } while (0)
+
+extern "C" int pmx_comm_unique_id(unsigned char id[128]) {
+    if (!id) FAIL(PMX_E_INVALID, "NULL argument");
+    int rc = rccl_load();
+    if (rc != PMX_OK) return rc;
+    RcclId u;
+    RCCL_CHECK(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, 128);
+    return PMX_OK;
+}
+extern "C" int pmx_comm_init(pmx_ctx* c, const unsigned char id[128], int rank, int world) {
+    if (!c || !id) FAIL(PMX_E_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) FAIL(PMX_E_INVALID, "bad rank/world");
+    if (c->rccl_comm) FAIL(PMX_E_STATE, "this context has a communicator already");
+    int rc = rccl_load();
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipSetDevice(c->device));
+    RcclId u;
+    memcpy(u.internal, id, 128);
+    RCCL_CHECK(g_rccl.CommInitRank(&c->rccl_comm, world, u, rank));
+    c->rccl_rank = rank; c->rccl_world = world;
+    return PMX_OK;
+}
+extern "C" int pmx_comm_destroy(pmx_ctx* c) {
+    if (!c || !c->rccl_comm) return PMX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    const int r = g_rccl.CommDestroy(c->rccl_comm);
+    c->rccl_comm = nullptr;
+    if (r != 0) FAIL(PMX_E_HIP, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));
+    return PMX_OK;
+}
+static int comm_ready(pmx_ctx* c) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (!c->rccl_comm) FAIL(PMX_E_STATE, "pmx_comm_init has not been called");
+    HIP_CHECK(hipSetDevice(c->device));
+    return PMX_OK;
+}
+extern "C" int pmx_comm_all_reduce(pmx_ctx* c, float* dptr, int64_t count) {
+    int rc = comm_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!dptr || count < 0) FAIL(PMX_E_INVALID, "bad argument");
+    RCCL_CHECK(g_rccl.AllReduce(dptr, dptr, (size_t)count, RCCL_FLOAT32, RCCL_SUM, c->rccl_comm, c->stream));
+    return PMX_OK;
+}
+extern "C" int pmx_comm_reduce_scatter(pmx_ctx* c, const float* dsend, float* drecv, int64_t recvcount) {
+    int rc = comm_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!dsend || !drecv || recvcount < 0) FAIL(PMX_E_INVALID, "bad argument");
+    RCCL_CHECK(g_rccl.ReduceScatter(dsend, drecv, (size_t)recvcount, RCCL_FLOAT32, RCCL_SUM, c->rccl_comm, c->stream));
+    return PMX_OK;
+}
+extern "C" int pmx_comm_all_gather(pmx_ctx* c, const float* dsend, float* drecv, int64_t sendcount) {
+    int rc = comm_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!dsend || !drecv || sendcount < 0) FAIL(PMX_E_INVALID, "bad argument");
+    RCCL_CHECK(g_rccl.AllGather(dsend, drecv, (size_t)sendcount, RCCL_FLOAT32, c->rccl_comm, c->stream));
     return PMX_OK;
 }

@@ -119,6 +119,66 @@ class OneRankOfMany:
         return 1
 
 
+class NativeRccl:
+    """torch.distributed's three collectives of the sharded drivers, on RCCL through the C ABI instead (include/pmx.h:
+    pmx_comm_*): one communicator per context, every call enqueued on the context's own stream -- no Python-side stream
+    juggling, nothing of torch in the data path.  The drivers only need this interface (all_reduce, reduce_scatter_tensor,
+    all_gather_into_tensor, get_rank, get_world_size, ReduceOp.SUM), so an instance goes where `torch.distributed` went.
+    `bootstrap(dev, rank, world, broadcast)`: rank 0 draws the 128-byte id, `broadcast(bytes_or_None) -> bytes` hands it to
+    every rank (torch.distributed's broadcast_object_list, MPI, a file ...), every rank joins."""
+
+    class ReduceOp:
+        SUM = None
+
+    def __init__(self, dev, rank, world):
+        self.dev, self.rank, self.world = dev, int(rank), int(world)
+
+    @classmethod
+    def bootstrap(cls, dev, rank, world, broadcast):
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(dev.lib.pmx_comm_unique_id(uid))
+        raw = broadcast(bytes(uid.raw) if rank == 0 else None)
+        assert len(raw) == 128
+        _lib.check(dev.lib.pmx_comm_init(dev.h, raw, int(rank), int(world)))
+        return cls(dev, rank, world)
+
+    def all_reduce(self, t, op=None, group=None):
+        _lib.check(self.dev.lib.pmx_comm_all_reduce(self.dev.h, C.c_void_p(t.data_ptr()), t.numel()))
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None):
+        assert inp.numel() == out.numel() * self.world
+        _lib.check(self.dev.lib.pmx_comm_reduce_scatter(self.dev.h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), out.numel()))
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        assert out.numel() == inp.numel() * self.world
+        _lib.check(self.dev.lib.pmx_comm_all_gather(self.dev.h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), inp.numel()))
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+
+def _collectives(comm, dev, rank, world, group):
+    """`comm`: "torch" (torch.distributed on the current stream) | "native" (RCCL through the C ABI, bootstrapped over the
+    process group that is there anyway) | None: $PMX_COMM, default "torch"."""
+    import torch.distributed as dist
+    comm = comm or os.environ.get("PMX_COMM", "torch")
+    if comm == "torch":
+        return dist
+    if comm != "native":
+        raise ValueError("comm must be 'torch' or 'native'")
+
+    def broadcast(raw):
+        box = [raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return box[0]
+    return NativeRccl.bootstrap(dev, rank, world, broadcast)
+
+
 class ShardedAdaproxDriver:
     """Iteration loop of the row-sharded adaprox back-end (algorithms.py:365-413 with one all-reduce
     per iteration).  `engine` provides phase(), chain_status(), more_subs() and the `comm` tensor."""
@@ -201,9 +261,10 @@ class ShardedLoop:
     and flushes it after the last iteration; bsdmm's all-reduce sits between its A step and its S step, so its
     test is exact without deferral."""
 
-    def __init__(self, engine, group=None, deferred_test=True, chunk=16):
-        import torch.distributed as dist
-        self.dist, self.eng, self.group = dist, engine, group
+    def __init__(self, engine, group=None, deferred_test=True, chunk=16, dist_module=None):
+        if dist_module is None:
+            import torch.distributed as dist_module
+        self.dist, self.eng, self.group = dist_module, engine, group
         self.deferred = bool(deferred_test)
         self.chunk = int(chunk)
         self.it = 0
@@ -312,13 +373,14 @@ def projection_type(seq):
 
 def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, scheme="adam", b1=0.9, b2=0.999,
                         eps=1e-8, p=0.25, check_convergence=True, e_rel=1e-3, max_iter=1000, prox_max_iter=1000,
-                        group=None, device=None, Y_is_device_ptr=None, s_split="auto"):
+                        group=None, device=None, Y_is_device_ptr=None, s_split="auto", comm=None):
     """Row-sharded counterpart of `nmf(Y, A, S, algorithm=adaprox, ...)` for one rank.
 
     Y_local: this rank's rows of Y (ndarray, M_local x N); A_local: the matching rows of A (updated in
     place); S: full K x N (replicated, updated in place, identical on every rank).
     Requires an initialised torch.distributed process group whose backend can reduce CUDA tensors
-    (nccl = RCCL).  Returns (converged, iterations)."""
+    (nccl = RCCL).  comm: "torch" (default) issues the collectives through torch.distributed, "native" through the C ABI's own
+    RCCL entry points (pmx_comm_*; the process group only hands the communicator id around).  Returns (converged, iterations)."""
     import torch
     import torch.distributed as dist
     from . import operators
@@ -351,7 +413,8 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
         eng = ShardEngine(dev, world, rank, M_global, s_split=bool(s_split) and can_split)
         dev.adaprox_begin(seqs, scheme=scheme, b2=b2, eps=eps, p=p, check_convergence=check_convergence,
                           prox_max_iter=prox_max_iter, e_rel=e)
-        drv = ShardedAdaproxDriver(eng, group, check_convergence, seqs[0].n > 0 or seqs[1].n > 0, prox_max_iter)
+        drv = ShardedAdaproxDriver(eng, group, check_convergence, seqs[0].n > 0 or seqs[1].n > 0, prox_max_iter,
+                                   dist_module=_collectives(comm, dev, rank, world, group))
         its = drv.run(max_iter, b1)
         dA, dS = dev.get_factors()
         A_local[...] = dA
@@ -363,7 +426,7 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
 
 
 def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, accelerated=False, step_scale=1.0,
-                    fixed_steps=None, e_rel=1e-3, max_iter=1000, group=None, device=None):
+                    fixed_steps=None, e_rel=1e-3, max_iter=1000, group=None, device=None, comm=None):
     """Row-sharded `nmf(Y, A, S, algorithm=pgm, ...)` for one rank (Lipschitz steps x step_scale, or fixed steps).
     Returns (converged, iterations)."""
     import torch
@@ -383,7 +446,7 @@ def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, acc
         dev.set_factors(A_local, S)
         eng = ShardEngine(dev, world, rank, M_global, "pgm")
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=step_scale, fixed_steps=fixed_steps, e_rel=e)
-        loop = ShardedLoop(eng, group, deferred_test=True)
+        loop = ShardedLoop(eng, group, deferred_test=True, dist_module=_collectives(comm, dev, rank, world, group))
         its = loop.run(max_iter)
         dA, dS = dev.get_factors()
         A_local[...] = dA
@@ -394,7 +457,7 @@ def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, acc
 
 
 def nmf_bsdmm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, proxs_g=None, e_rel=1e-3, e_abs=0.0,
-                      max_iter=1000, group=None, device=None):
+                      max_iter=1000, group=None, device=None, comm=None):
     """Row-sharded `nmf(Y, A, S, algorithm=bsdmm, proxs_g=...)` for one rank.  Returns (converged, iterations)."""
     import torch
     import torch.distributed as dist
@@ -416,7 +479,7 @@ def nmf_bsdmm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, p
         dev.set_factors(A_local, S)
         eng = ShardEngine(dev, world, rank, M_global, "bsdmm")
         dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea)
-        loop = ShardedLoop(eng, group, deferred_test=False)
+        loop = ShardedLoop(eng, group, deferred_test=False, dist_module=_collectives(comm, dev, rank, world, group))
         its = loop.run(max_iter)
         dA, dS = dev.get_factors()
         A_local[...] = dA
@@ -478,19 +541,22 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     # single-GPU leg of bench.py), at least 20 iterations
     warm = max(args.warmup, 20) if backend == "adaprox" else args.warmup
     total = warm + args.steps
+    # the collectives: local stand-ins when one process plays rank 0 of W, else torch.distributed or ($PMX_COMM=native) RCCL
+    # through the C ABI
+    coll = OneRankOfMany() if fake > 1 else _collectives(None, dev, rank, world, None)
     if backend == "adaprox":
         dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
-        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, dist_module=OneRankOfMany() if fake > 1 else None)
+        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, dist_module=coll)
         b1 = np.full(total, 0.9)
         run = lambda n: drv.run(n, b1)
     elif backend == "pgm":
         dev.pgm_begin([pA, pS], accelerated=False, e_rel=(1e-12, 1e-12))
-        loop = ShardedLoop(eng, None, deferred_test=True)
+        loop = ShardedLoop(eng, None, deferred_test=True, dist_module=coll)
         run = loop.run
     else:
         pg = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=1e-3), 0)]
         dev.bsdmm_begin([pA, pS], [pg, pg], e_rel=(1e-12, 1e-12), e_abs=(0.0, 0.0))
-        loop = ShardedLoop(eng, None, deferred_test=False)
+        loop = ShardedLoop(eng, None, deferred_test=False, dist_module=coll)
         run = loop.run
     run(warm)
     dev.set_timing(True, every=4)   # HIP events around every 4th K1 launch of the timed region
