@@ -104,7 +104,8 @@ enum {
     PMX_BUF_PSI_A = 14, PMX_BUF_PSI_ST = 15,   /* adaprox Psi of the current iteration (algorithms.py:375-377)                */
     PMX_BUF_Z0 = 16, /* + block*PMX_MAX_G + i : bsdmm Z_i of block (utils.py:244-254)     */
     PMX_BUF_U0 = 32, /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
-    PMX_BUF_TG0 = 48 /* + block*PMX_MAX_G + i : host round trip of a user-defined proxs_g member: its argument, then its result */
+    PMX_BUF_TG0 = 48, /* + block*PMX_MAX_G + i : host round trip of a user-defined proxs_g member: its argument, then its result */
+    PMX_BUF_STEP_A = 64, PMX_BUF_STEP_ST = 65  /* pgm: per-element steps of a user `step` that returned arrays (pmx_pgm_step_arrays) */
 };
 
 typedef struct pmx_ctx pmx_ctx;
@@ -226,6 +227,11 @@ int pmx_pgm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
  * `steps` (phases 1, 2): the two step sizes a user `step` returned, or NULL to keep the device's.  Lipschitz / fixed /
  * user steps; not with Barzilai-Borwein steps or backtracking. */
 int pmx_pgm_split(pmx_ctx* ctx, int phase, const double* steps, pmx_result* res);
+/* A user `step` may return ARRAYS that broadcast against the blocks (algorithms.py:106-108: `_X[j] - S[j] * G[j]`,
+ * `prox[j](.., S[j])`): the caller broadcasts block j's to rows x K (S: N x K, transposed like everything of S), uploads it
+ * into PMX_BUF_STEP_A / _ST and sets bit j of `mask`; phases 1 and 2 of pmx_pgm_split then take that block's step from the
+ * buffer, element by element (the proximal operators get it per element as well), until the mask is cleared. */
+int pmx_pgm_step_arrays(pmx_ctx* ctx, int mask);
 
 typedef struct pmx_adaprox_params { /* algorithms.adaprox arguments, algorithms.py:248-265 */
     pmx_proxseq prox[2];

@@ -26,6 +26,7 @@ SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 
 BUF_A, BUF_ST, BUF_GA, BUF_GST, BUF_MA, BUF_MST, BUF_VA, BUF_VST, BUF_VHA, BUF_VHST = range(10)
 BUF_EVAL_A, BUF_EVAL_ST, BUF_TMP_A, BUF_TMP_ST, BUF_PSI_A, BUF_PSI_ST = 10, 11, 12, 13, 14, 15
 BUF_Z0, BUF_U0, BUF_TG0 = 16, 32, 48
+BUF_STEP_A = 64                       # + block: per-element steps of a user `step` that returned arrays (pgm)
 
 
 class Prox(C.Structure):
@@ -107,6 +108,7 @@ _SIGNATURES = {
     "pmx_set_comm_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pmx_bsdmm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_double, C.POINTER(Result)]),
+    "pmx_pgm_step_arrays": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pmx_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "pmx_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -138,18 +138,29 @@ def _split_prox(prox, none_is_id):
     return seqs, host
 
 
-def _scalar_steps(s, what):
+def _user_steps(s, what, shapes):
+    """What a user `step` returned for pgm -> (one scalar per block for the device -- 1.0 stands in where the block's step is
+    an array --, [None or the array per block], the values as the caller gets them back / as a host prox is handed them).
+    Arrays must broadcast against their block (algorithms.py:106-108 multiplies them into the gradient)."""
     s = utils._as_tuple(s)
     if len(s) == 1:
         s = s * 2
     assert len(s) == 2, "%s must return one step per block" % what
-    out = []
-    for v in s:
-        v = np.asarray(v)
-        if v.size != 1:
-            raise NotImplementedError("array-valued step sizes from a user `step` are not supported in pgm (scalars per block only)")
-        out.append(float(v.reshape(())))
-    return tuple(out)
+    scal, arrs, orig = [], [], []
+    for j, v in enumerate(s):
+        a = np.asarray(v)
+        if a.size == 1:
+            scal.append(float(a.reshape(())))
+            arrs.append(None)
+            orig.append(float(a.reshape(())))
+        else:
+            np.broadcast_shapes(a.shape, shapes[j])      # raises ValueError like NumPy would inside the reference
+            if np.broadcast_shapes(a.shape, shapes[j]) != tuple(shapes[j]):
+                raise ValueError("step of block %d has shape %r: it does not broadcast against %r" % (j, a.shape, tuple(shapes[j])))
+            scal.append(1.0)
+            arrs.append(a)
+            orig.append(v)
+    return tuple(scal), arrs, orig
 
 
 def _component_steps(alpha, K, j):
@@ -226,6 +237,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
             # device, the user's step / prox on the host with exactly the arguments the reference passes, the update,
             # extrapolation and stopping test on the device again.
             takes_grads = False
+            arrays_on, steps_user, step_arrays = False, None, [None, None]
             if user_step is not None:                           # the reference's signature probe (algorithms.py:73-77)
                 try:
                     user_step(A, S, it=0, grads=(A, S))
@@ -246,16 +258,24 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
                     Xe = (dev.get(_lib.BUF_EVAL_A, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_EVAL_A, 1)).astype(dt))
                     if takes_grads:
                         Gh = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
-                        steps = _scalar_steps(user_step(*Xe, it=it, grads=Gh), "step")
+                        ret = user_step(*Xe, it=it, grads=Gh)
                     else:
-                        steps = _scalar_steps(user_step(*Xe, it=it), "step")
+                        ret = user_step(*Xe, it=it)
+                    # scalars per block, or arrays that broadcast against the blocks (uploaded element by element)
+                    steps, step_arrays, steps_user = _user_steps(ret, "step", (A.shape, S.shape))
+                    if any(a is not None for a in step_arrays) or arrays_on:
+                        dev.pgm_step_arrays(step_arrays)
+                        arrays_on = any(a is not None for a in step_arrays)
                 if any(h is not None for h in host_prox):
                     dev.pgm_split(1, steps)
                     for j, h in enumerate(host_prox):
                         if h is None:
                             continue
                         T = np.ascontiguousarray(dev.get(_lib.BUF_TMP_A, j)).astype(dt)
-                        sj = dt.type(steps[j] if steps is not None else r0.steps[j])
+                        if steps is not None and step_arrays[j] is not None:
+                            sj = np.asarray(steps_user[j]).astype(dt)        # the array, as the reference hands it on
+                        else:
+                            sj = dt.type(steps[j] if steps is not None else r0.steps[j])
                         out = h(T, sj)                           # prox(X, step) -> X' (algorithms.py:37-39, :108)
                         dev.put(_lib.BUF_TMP_A, j, np.asarray(out))
                 res = dev.pgm_split(2, steps)
@@ -281,6 +301,8 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         G = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
     converged = tuple(bool(c) for c in res.converged) if res is not None else (False, False)
     steps = (dt.type(res.steps[0]), dt.type(res.steps[1])) if res is not None else (None, None)
+    if res is not None and slow and user_step is not None and steps_user is not None:
+        steps = tuple(steps_user[j] if step_arrays[j] is not None else steps[j] for j in range(2))   # arrays go back as returned
     logger.info("Completed {0} iterations".format(it_done))
     if not all(converged):
         logger.warning("Solution did not converge")

@@ -352,6 +352,10 @@ struct PgmArgs {
     //   mode 2  "post": the update with prox(...) := T_j as the host left it;      mode 3: block not touched by this launch
     int mode[2];
     float* T[2];
+    // a user `step` that returned ARRAYS (algorithms.py:106-108: `_X[j] - S[j] * G[j]`, `prox[j](.., S[j])` broadcast like NumPy):
+    // block j's step of every element, rows x K like the block itself (the host broadcasts what the callable returned); nullptr: the
+    // scalar of DevStatus::step
+    const float* stepArr[2];
     // stopping test by the LAST workgroup to finish (algorithms.py:130-135) instead of a separate single-workgroup launch:
     // every workgroup publishes its partial sums (release), takes a ticket, and the one that draws the last ticket of
     // this launch folds all partials in the usual fixed order and decides.  tickets == nullptr: the caller launches
@@ -394,8 +398,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
             const int64_t e = r * K + l32 + 32 * c;
             xo[c] = ok[c] ? X[e] : 0.f;
             const float xe = a.accelerated ? (ok[c] ? Xe[e] : 0.f) : xo[c];
-            v[c] = mode == 2 ? (ok[c] ? a.T[j][e] : 0.f) : xe - s * g[c];
-            sk[c] = s;
+            const float se = a.stepArr[j] != nullptr ? (ok[c] ? a.stepArr[j][e] : 0.f) : s;
+            v[c] = mode == 2 ? (ok[c] ? a.T[j][e] : 0.f) : xe - se * g[c];
+            sk[c] = se;
         }
         if (mode == 1) {
 #pragma unroll

@@ -156,6 +156,8 @@ struct pmx_ctx {
     bool ssplit = false;
     int64_t scol0 = 0, sncol = 0;
     float* comm_out = nullptr;             // caller-owned: this rank's chunk after the reduce-scatter
+    float* stepArr[2] = {nullptr, nullptr};   // pgm, split iterations: per-element steps of a user `step` that returned arrays (PMX_BUF_STEP_*)
+    int step_arr_mask = 0;                   // bit j: block j's step comes from stepArr[j] in the split phases that follow
     void* rccl_comm = nullptr;             // pmx_comm_init: an RCCL communicator of this context's device (collectives run on its stream)
     int rccl_rank = 0, rccl_world = 0;
 };
@@ -513,6 +515,9 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
     } else if (buf >= PMX_BUF_TG0 && buf < PMX_BUF_TG0 + 2 * PMX_MAX_G) {
         j = (buf - PMX_BUF_TG0) / PMX_MAX_G;
         p = &c->Tg[j][(buf - PMX_BUF_TG0) % PMX_MAX_G];
+    } else if (buf == PMX_BUF_STEP_A || buf == PMX_BUF_STEP_ST) {
+        j = buf - PMX_BUF_STEP_A;
+        p = &c->stepArr[j];
     } else FAIL(PMX_E_INVALID, "unknown buffer id %d", buf);
     *count = c->rows[j] * c->K;
     if (!*p) {
@@ -1320,6 +1325,15 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     return PMX_OK;
 }
 
+extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (mask < 0 || mask > 3) FAIL(PMX_E_INVALID, "mask must be 0..3");
+    for (int j = 0; j < 2; ++j)
+        if (((mask >> j) & 1) && !c->stepArr[j]) FAIL(PMX_E_STATE, "block %d: upload the steps into PMX_BUF_STEP_%s first", j, j ? "ST" : "A");
+    c->step_arr_mask = mask;
+    return PMX_OK;
+}
+
 extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_result* res) {
     if (c) c->absmax_by_finish = false;
     int rc = require_ready(c);
@@ -1341,6 +1355,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
             u.rows[j] = c->rows[j];
             u.prox[j] = to_dev(p.prox[j]);
             u.T[j] = c->Xp[j];
+            u.stepArr[j] = (c->step_arr_mask >> j) & 1 ? c->stepArr[j] : nullptr;
             u.mode[j] = stage == 1 ? (p.host_prox[j] ? 1 : 3) : (p.host_prox[j] ? 2 : 0);
         }
         u.K = (int)c->K;

@@ -227,6 +227,18 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_pgm_split(self.h, int(phase), st, C.byref(r)))
         return r
 
+    def pgm_step_arrays(self, arrays):
+        """arrays[j]: None (block j keeps its scalar step) or an array that broadcasts against block j (A: M x K, S: K x N) --
+        uploaded element by element for the split phases that follow (include/pmx.h: pmx_pgm_step_arrays)."""
+        mask = 0
+        for j, a in enumerate(arrays):
+            if a is None:
+                continue
+            shape = (self.M, self.K) if j == 0 else (self.K, self.N)
+            self.put(_lib.BUF_STEP_A, j, np.broadcast_to(np.asarray(a, dtype=np.float32), shape))
+            mask |= 1 << j
+        _lib.check(self.lib.pmx_pgm_step_arrays(self.h, mask))
+
     def pgm_run(self, n_iter):
         r = _lib.Result()
         _lib.check(self.lib.pmx_pgm_run(self.h, int(n_iter), C.byref(r)))

@@ -344,7 +344,50 @@ def write_weighted_fixture():
     print("wrote weighted.npz", meta["cases"])
 
 
+def write_array_step_fixture():
+    """algorithms.pgm called directly with a user `step` that returns ARRAYS (they broadcast against the blocks:
+    algorithms.py:106-108 multiplies S[j] into G[j] and hands S[j] to prox[j]): per-component vectors, full-shape and row
+    arrays with an operator whose threshold scales with the step (prox_soft), plain and accelerated."""
+    blob, meta = {}, {"cases": {}, "numpy": np.__version__, "reference": "proxmin 0.6.12"}
+    for tag, (M, N, K, dtype) in {"f64": (33, 47, 3, np.float64), "f32": (64, 96, 8, np.float32)}.items():
+        Y, A0, S0 = problem(M, N, K, dtype, False, 2468)
+        rng = np.random.default_rng(1357)
+        sA, sS = rnmf.step_pgm(A0, S0)
+        vecA = (0.5 * sA * (1.0 + 0.1 * np.arange(K))).astype(dtype)                    # (K,)   against A (M, K)
+        vecS = (0.5 * sS * (1.0 + 0.1 * np.arange(K)))[:, None].astype(dtype)           # (K, 1) against S (K, N)
+        fullA = (0.5 * sA * (0.5 + rng.random((M, K)))).astype(dtype)                   # (M, K)
+        rowS = (0.5 * sS * (0.5 + rng.random((1, N)))).astype(dtype)                    # (1, N)
+        blob[tag + "/Y"], blob[tag + "/A0"], blob[tag + "/S0"] = Y, A0, S0
+        blob[tag + "/vecA"], blob[tag + "/vecS"], blob[tag + "/fullA"], blob[tag + "/rowS"] = vecA, vecS, fullA, rowS
+        soft = partial(rops.prox_soft_plus, thresh=0.05, type="relative")
+        runs = {
+            "vectors_plus": dict(step=(vecA, vecS), prox=[rops.prox_plus, rops.prox_plus], accelerated=False),
+            "vectors_plus_fista": dict(step=(vecA, vecS), prox=[rops.prox_plus, rops.prox_plus], accelerated=True),
+            "full_row_soft": dict(step=(fullA, rowS), prox=[soft, soft], accelerated=False),
+            "scalar_and_vector": dict(step=(float(0.5 * sA), vecS), prox=[rops.prox_plus, soft], accelerated=True),
+        }
+        grad = partial(rnmf.grad_likelihood, Y=Y)
+        for name, kw in runs.items():
+            A, S = A0.copy(), S0.copy()
+            tb = rutils.Traceback()
+            st = kw["step"]
+            conv, G, steps = ralg.pgm([A, S], grad, lambda *X, it=None, st=st: st, prox=kw["prox"], accelerated=kw["accelerated"],
+                                      e_rel=1e-6, max_iter=10, callback=tb)
+            key = "%s/%s" % (tag, name)
+            blob[key + "/A"], blob[key + "/S"] = A, S
+            blob[key + "/gA"], blob[key + "/gS"] = G
+            blob[key + "/n_callbacks"] = len(tb.trace)
+            print("  array steps %-4s %-20s its=%d  |A| %.6g |S| %.6g" % (tag, name, len(tb.trace), np.abs(A).sum(), np.abs(S).sum()))
+        meta["cases"][tag] = {"M": M, "N": N, "K": K, "runs": sorted(runs)}
+    blob["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "array_steps.npz"), **blob)
+    print("wrote array_steps.npz")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "array_steps":      # one fixture only (the others are unchanged)
+        write_array_step_fixture()
+        sys.exit(0)
     all_names = list(CASES)
     print("nmf 200x1000 K=5 fp64 (SURVEY section 4 table; inputs regenerated from seed by the tests)")
     write_nmf_fixture("nmf_200x1000_k5_f64.npz", 200, 1000, 5, np.float64, 25, 1e-6, False,
@@ -358,3 +401,4 @@ if __name__ == "__main__":
     write_helper_fixture()
     write_unmixing_fixture()
     write_weighted_fixture()
+    write_array_step_fixture()

@@ -368,3 +368,51 @@ def test_bsdmm_with_generic_closures(pm, orc):
     assert np.abs(A - A0).max() > 1e-3
     np.testing.assert_allclose(A, A2, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(S, S2, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_pgm_with_array_valued_user_steps(pm, tag):
+    """A user `step` may return ARRAYS that broadcast against the blocks (algorithms.py:106-108 multiplies S[j] into G[j]
+    and hands S[j] to prox[j]) -- round 3: uploaded element by element (pmx_pgm_step_arrays), the operators get their step
+    per element too (prox_soft_plus with a relative threshold).  Fixture tests/golden/array_steps.npz, generated from the
+    reference: per-component vectors, a full-shape array with a row array, a scalar next to a vector, plain and FISTA; a
+    user-written prox is handed the array as it was returned; the arrays come back as pgm's third return value."""
+    from test_gpu_nmf import assert_factors_close
+    z, meta = load_golden("array_steps.npz")
+    Y, A0, S0 = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"]
+    vecA, vecS, fullA, rowS = (z["%s/%s" % (tag, k)] for k in ("vecA", "vecS", "fullA", "rowS"))
+    dtype = "float64" if tag == "f64" else "float32"
+    soft = partial(pm.operators.prox_soft_plus, thresh=0.05, type="relative")
+    sA_scalar = float(vecA[0])           # = 0.5 * step_pgm's value for A, as the generator used
+    runs = {
+        "vectors_plus": ((vecA, vecS), [pm.operators.prox_plus] * 2, False),
+        "vectors_plus_fista": ((vecA, vecS), [pm.operators.prox_plus] * 2, True),
+        "full_row_soft": ((fullA, rowS), [soft, soft], False),
+        "scalar_and_vector": ((sA_scalar, vecS), [pm.operators.prox_plus, soft], True),
+    }
+    assert sorted(runs) == meta["cases"][tag]["runs"]
+    grad = partial(pm.nmf.grad_likelihood, Y=Y)
+    for name, (st, prox, accel) in runs.items():
+        A, S = A0.copy(), S0.copy()
+        conv, G, steps = pm.pgm([A, S], grad, lambda *X, it=None, st=st: st, prox=prox, accelerated=accel, e_rel=1e-6, max_iter=10)
+        assert_factors_close(A, z["%s/%s/A" % (tag, name)], dtype, "%s %s A" % (tag, name))
+        assert_factors_close(S, z["%s/%s/S" % (tag, name)], dtype, "%s %s S" % (tag, name))
+        for j in range(2):
+            if np.ndim(st[j]):
+                assert steps[j] is st[j]
+            else:
+                assert float(steps[j]) == pytest.approx(float(st[j]), rel=1e-6)
+    # a user-written prox next to array steps: it receives the array itself (its shape says so), result as with the operator
+    seen = []
+
+    def my_plus_logged(X, step):
+        seen.append(np.shape(step))
+        return np.maximum(X, 0)
+    A, S = A0.copy(), S0.copy()
+    pm.pgm([A, S], grad, lambda *X, it=None: (vecA, vecS), prox=[my_plus_logged, pm.operators.prox_plus], e_rel=1e-6, max_iter=10)
+    assert seen and all(s == vecA.shape for s in seen)
+    assert_factors_close(A, z[tag + "/vectors_plus/A"], dtype, tag + " user prox A")
+    assert_factors_close(S, z[tag + "/vectors_plus/S"], dtype, tag + " user prox S")
+    # what NumPy would refuse, this refuses the same way
+    with pytest.raises(ValueError):
+        pm.pgm([A0.copy(), S0.copy()], grad, lambda *X, it=None: (np.ones(A0.shape[1] + 1), 1e-3), prox=[pm.operators.prox_plus] * 2, max_iter=2)

@@ -200,3 +200,29 @@ def test_weighted_likelihood_matches_reference(tag):
     assert meta["default_step_error"] == "ValueError"
     with pytest.raises(ValueError):
         orc.pgm_nmf(Y, A0.copy(), S0.copy(), max_iter=2, W=W)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_array_valued_steps_match_reference(tag):
+    """algorithms.pgm with a user `step` that returns arrays (they broadcast against the blocks, algorithms.py:106-108;
+    prox_soft_plus scales its threshold with them): fixture array_steps.npz, generated from the reference."""
+    z, meta = load_golden("array_steps.npz")
+    Y, A0, S0 = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"]
+    vecA, vecS, fullA, rowS = (z["%s/%s" % (tag, k)] for k in ("vecA", "vecS", "fullA", "rowS"))
+    soft = ("soft_plus", 0.05, "relative")
+    runs = {
+        "vectors_plus": ((vecA, vecS), ("plus",), ("plus",), False),
+        "vectors_plus_fista": ((vecA, vecS), ("plus",), ("plus",), True),
+        "full_row_soft": ((fullA, rowS), soft, soft, False),
+        "scalar_and_vector": ((float(vecA[0]), vecS), ("plus",), soft, True),
+    }
+    assert sorted(runs) == meta["cases"][tag]["runs"]
+    tol = TOL[str(Y.dtype)] if tag == "f64" else dict(rtol=5e-3, atol=5e-4)       # fp32 trajectories: see DESIGN.md section 2
+    for name, (st, pA, pS, accel) in runs.items():
+        A, S = A0.copy(), S0.copy()
+        ret = orc.pgm_nmf(Y, A, S, pA, pS, step=lambda a, s, it, g, st=st: st, accelerated=accel, max_iter=10, e_rel=1e-6)
+        key = "%s/%s" % (tag, name)
+        np.testing.assert_allclose(A, z[key + "/A"], err_msg=key, **tol)
+        np.testing.assert_allclose(S, z[key + "/S"], err_msg=key, **tol)
+        np.testing.assert_allclose(ret[1][0], z[key + "/gA"], err_msg=key, rtol=max(tol["rtol"], 1e-8), atol=1e-3 if tag == "f32" else 1e-9)
+        assert ret[3] == int(z[key + "/n_callbacks"])
