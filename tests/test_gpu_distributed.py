@@ -107,10 +107,12 @@ def test_native_rccl_collectives_through_the_c_abi(pg):
         assert dev.lib.pmx_comm_init(dev.h, uid.raw, 0, 1) != 0                    # one communicator per context
         x = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.5 - 7.0
         want = x.clone()
-        _lib.check(dev.lib.pmx_comm_all_reduce(dev.h, C.c_void_p(x.data_ptr()), x.numel()))
         out = torch.empty(4096, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        _lib.check(dev.lib.pmx_comm_all_reduce(dev.h, C.c_void_p(x.data_ptr()), x.numel()))
         _lib.check(dev.lib.pmx_comm_reduce_scatter(dev.h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), out.numel()))
         g = torch.zeros(4096, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()       # (torch filled these on ITS stream; the collectives run on the context's)
         _lib.check(dev.lib.pmx_comm_all_gather(dev.h, C.c_void_p(out.data_ptr()), C.c_void_p(g.data_ptr()), out.numel()))
         dev.sync()
         assert torch.equal(x, want) and torch.equal(out, want) and torch.equal(g, want)
