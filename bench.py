@@ -208,6 +208,52 @@ def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6, transient=0):
     return rec, sub_timed
 
 
+RCCL_LOG = "/tmp/pmx_bench_rccl_%d.log"
+
+
+def rccl_debug_on(rank, world):
+    """Multi-GPU runs: have RCCL write what it decided at communicator set-up (topology, rings / trees, transports, the
+    algorithm / protocol tuning table) to a per-rank file -- INIT, GRAPH and TUNING only, nothing per collective -- so that the
+    JSON line can say over WHAT the whole-job number was measured.  An NCCL_DEBUG level the caller chose (INFO, TRACE) is left alone;
+    VERSION / WARN (this image exports VERSION) are raised to INFO, into the file."""
+    if (world <= 1 and not os.environ.get("PMX_FORCE_SHARDED")) or os.environ.get("NCCL_DEBUG", "VERSION").upper() not in ("VERSION", "WARN") or os.environ.get("PMX_DIST_BACKEND", "nccl") != "nccl":
+        return None
+    path = RCCL_LOG % rank
+    try:
+        if os.path.exists(path):
+            os.remove(path)
+    except OSError:
+        return None
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def rccl_debug_excerpt(path, limit=16):
+    """A few lines of rank 0's RCCL set-up log: version, ranks, channels, transports, algorithm / protocol table."""
+    import re
+    if not path:
+        return None
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError:
+        return None
+    pat = re.compile(r"(RCCL version|NCCL version|nranks|Channel \d+/\d+ *:|Ring \d+ *:|Trees? |via P2P|via SHM|via NET|[Cc]onnected all|Algorithm|Protocol|AllReduce|ReduceScatter|AllGather|xGMI|XGMI|nChannels)")
+    keep, seen = [], set()
+    for ln in lines:
+        if pat.search(ln):
+            body = ln.split("NCCL INFO", 1)[-1].strip()[:200]
+            key = re.sub(r"\d+", "#", body)[:60]
+            if key in seen:
+                continue
+            seen.add(key)
+            keep.append(body)
+            if len(keep) >= limit:
+                break
+    return {"log_lines": len(lines), "excerpt": keep}
+
+
 def emit(out):
     """The ONE JSON line, as the LAST line of stdout: libraries that write through C stdio (RCCL's version banner) have
     their buffer flushed first, and the process leaves without running exit-time destructors that could print more."""
@@ -286,11 +332,12 @@ def main():
     if args.mode is None:
         args.mode = "f32" if args.config == "cfg2" else "f16x2"
 
-    import torch
-    import __graft_entry__ as g
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    rccl_log = rccl_debug_on(rank, world)     # before torch (and with it RCCL) is loaded: the library reads its environment once
+    import torch
+    import __graft_entry__ as g
     if "PMX_BENCH_DEVICE" in os.environ:      # test-only: several ranks on one GPU (see proxmin_amd/distributed.py)
         local = int(os.environ["PMX_BENCH_DEVICE"])
     torch.cuda.set_device(local)              # before any collective: RCCL binds a rank to the current device
@@ -313,6 +360,8 @@ def main():
         args.mode_dtype, args.mode_desc = MODE_DTYPE, MODE_DESC
         out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
         if rank == 0:
+            if rccl_log:
+                out["rccl"] = rccl_debug_excerpt(rccl_log)
             emit(out)
         return
 
