@@ -232,6 +232,10 @@ int pmx_pgm_split(pmx_ctx* ctx, int phase, const double* steps, pmx_result* res)
  * into PMX_BUF_STEP_A / _ST and sets bit j of `mask`; phases 1 and 2 of pmx_pgm_split then take that block's step from the
  * buffer, element by element (the proximal operators get it per element as well), until the mask is cleared. */
 int pmx_pgm_step_arrays(pmx_ctx* ctx, int mask);
+/* a context begun with use_fixed_steps: new constants for the iterations that follow -- a user `step` evaluated on the host
+ * once per iteration next to the device's backtracking line search (algorithms.py:106 with :110-127), which pmx_pgm_split
+ * does not do: the caller sets the steps, then runs pmx_pgm_run(ctx, 1, ..) */
+int pmx_pgm_set_fixed_steps(pmx_ctx* ctx, const double steps[2]);
 
 typedef struct pmx_adaprox_params { /* algorithms.adaprox arguments, algorithms.py:248-265 */
     pmx_proxseq prox[2];

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "pmx_buffer_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pmx_bsdmm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_double, C.POINTER(Result)]),
     "pmx_pgm_step_arrays": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_pgm_set_fixed_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "pmx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pmx_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "pmx_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

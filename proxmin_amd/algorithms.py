@@ -220,8 +220,11 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     else:
         raise TypeError("step must be callable")
     slow = user_step is not None or any(h is not None for h in host_prox) or user_grad
-    if slow and (bb is not None or backtracking):
-        raise NotImplementedError("a user-defined grad / prox / step together with Barzilai-Borwein steps or backtracking is not implemented")
+    # a user `step` next to the line search: the callable on the host once per iteration, the Beck-Teboulle loop on the device
+    bt_user_step = backtracking and user_step is not None and not any(h is not None for h in host_prox) and not user_grad
+    if slow and (bb is not None or backtracking) and not bt_user_step:
+        raise NotImplementedError("a user-defined grad / prox together with Barzilai-Borwein steps or backtracking, or a user `step` "
+                                  "together with Barzilai-Borwein steps, is not implemented")
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
@@ -232,7 +235,40 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         res = None
         it_done = 0
         dt = A.dtype
-        if slow:
+        steps_user, step_arrays = None, [None, None]
+        if bt_user_step:
+            # algorithms.py:105-127 with a Python `step`: its scalars become the constants of ONE device iteration with the
+            # line search (T[j] S[j] in the reference: T lives on the device, S comes from here)
+            takes_grads = False
+            try:                                                # the reference's signature probe (algorithms.py:73-77)
+                user_step(A, S, it=0, grads=(A, S))
+                takes_grads = True
+            except TypeError:
+                takes_grads = False
+            for it in range(max_iter):
+                if _wants_iterates(callback):
+                    try:
+                        callback(A, S, it=it)
+                    except StopIteration:
+                        break
+                if takes_grads:
+                    dev.pgm_split(0)                            # the gradient at the evaluation point, for the callable only
+                Xe = (dev.get(_lib.BUF_EVAL_A, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_EVAL_A, 1)).astype(dt))
+                if takes_grads:
+                    Gh = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
+                    ret = user_step(*Xe, it=it, grads=Gh)
+                else:
+                    ret = user_step(*Xe, it=it)
+                steps, step_arrays, _ = _user_steps(ret, "step", (A.shape, S.shape))
+                if any(a is not None for a in step_arrays):
+                    raise NotImplementedError("array-valued steps from a user `step` together with backtracking are not implemented")
+                dev.pgm_set_fixed_steps(steps)
+                res = dev.pgm_run(1)
+                _write_back(dev, A, S)
+                it_done = res.total_iterations
+                if res.stopped:
+                    break
+        elif slow:
             # One iteration per pass, in pieces (algorithms.py:87-135): the gradient at the (extrapolated) point on the
             # device, the user's step / prox on the host with exactly the arguments the reference passes, the update,
             # extrapolation and stopping test on the device again.

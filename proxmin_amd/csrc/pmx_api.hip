@@ -1325,6 +1325,16 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     return PMX_OK;
 }
 
+extern "C" int pmx_pgm_set_fixed_steps(pmx_ctx* c, const double steps[2]) {
+    if (!c || !steps) FAIL(PMX_E_INVALID, "NULL argument");
+    if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
+    if (!c->pgm.use_fixed_steps) FAIL(PMX_E_STATE, "the context was not begun with fixed steps");
+    HIP_CHECK(hipSetDevice(c->device));
+    c->pgm.fixed_steps[0] = steps[0];
+    c->pgm.fixed_steps[1] = steps[1];
+    return set_fixed_steps(c, steps);
+}
+
 extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (mask < 0 || mask > 3) FAIL(PMX_E_INVALID, "mask must be 0..3");
@@ -1340,7 +1350,9 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
     const pmx_pgm_params& p = c->pgm;
-    if (p.bb_type || p.backtracking) FAIL(PMX_E_UNSUPPORTED, "pmx_pgm_split: not with Barzilai-Borwein steps or backtracking");
+    // (phase 0 alone -- the gradient at the evaluation point, for a user `step` that wants `grads` -- is harmless next to
+    //  the line search: the iteration itself then runs through pmx_pgm_run(ctx, 1) with the steps of pmx_pgm_set_fixed_steps)
+    if (p.bb_type || (p.backtracking && phase != 0)) FAIL(PMX_E_UNSUPPORTED, "pmx_pgm_split: not with Barzilai-Borwein steps or backtracking");
     const float* A = p.accelerated ? c->Xe[0] : c->X[0];
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     const bool any_host = p.host_prox[0] || p.host_prox[1];

@@ -227,6 +227,10 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_pgm_split(self.h, int(phase), st, C.byref(r)))
         return r
 
+    def pgm_set_fixed_steps(self, steps):
+        """new step constants of a context begun with fixed steps (include/pmx.h: pmx_pgm_set_fixed_steps)"""
+        _lib.check(self.lib.pmx_pgm_set_fixed_steps(self.h, (C.c_double * 2)(float(steps[0]), float(steps[1]))))
+
     def pgm_step_arrays(self, arrays):
         """arrays[j]: None (block j keeps its scalar step) or an array that broadcasts against block j (A: M x K, S: K x N) --
         uploaded element by element for the split phases that follow (include/pmx.h: pmx_pgm_step_arrays)."""

@@ -384,7 +384,49 @@ def write_array_step_fixture():
     print("wrote array_steps.npz")
 
 
+def write_bt_user_step_fixture():
+    """algorithms.pgm with backtracking=True AND a user `step` (algorithms.py:106 with :110-127): multiples of the Lipschitz
+    steps, so that the line search has to halve; with and without `grads` in the callable's signature, plain and accelerated."""
+    blob, meta = {}, {"cases": {}, "numpy": np.__version__, "reference": "proxmin 0.6.12"}
+    for tag, (M, N, K, dtype) in {"f64": (33, 47, 3, np.float64), "f32": (64, 96, 8, np.float32)}.items():
+        Y, A0, S0 = problem(M, N, K, dtype, False, 9753)
+        blob[tag + "/Y"], blob[tag + "/A0"], blob[tag + "/S0"] = Y, A0, S0
+        grad = partial(rnmf.grad_likelihood, Y=Y)
+        f = partial(rnmf.log_likelihood, Y=Y)
+        seen = {"grads": 0}
+
+        def scaled(fac):
+            def st(*X, it=None):
+                return tuple(fac * s for s in rnmf.step_pgm(*X))
+            return st
+
+        def step2_grads(*X, it=None, grads=None):
+            seen["grads"] += int(grads is not None)
+            return tuple(2.0 * s for s in rnmf.step_pgm(*X))
+        # 1.5 x and 2 x the Lipschitz steps: the search halves T and the runs stay monotone; larger factors (and any factor > 1
+        # with acceleration) send the reference's own iteration off to 1e5 .. 1e8 -- nothing to compare trajectories on
+        runs = {"x1.5": (scaled(1.5), False), "x2_with_grads": (step2_grads, False), "x1_fista": (scaled(1.0), True)}
+        for name, (st, accel) in runs.items():
+            A, S = A0.copy(), S0.copy()
+            tb = rutils.Traceback()
+            conv, G, steps = ralg.pgm([A, S], grad, st, prox=[rops.prox_plus, rops.prox_plus], accelerated=accel, backtracking=True, f=f,
+                                      e_rel=1e-6, max_iter=15, callback=tb)
+            key = "%s/%s" % (tag, name)
+            blob[key + "/A"], blob[key + "/S"] = A, S
+            blob[key + "/steps"] = np.array([float(steps[0]), float(steps[1])])
+            blob[key + "/loss"] = rnmf.log_likelihood(A, S, Y=Y)
+            blob[key + "/n_callbacks"] = len(tb.trace)
+            print("  bt + user step %-4s %-10s its=%d loss=%.9g" % (tag, name, len(tb.trace), blob[key + "/loss"]))
+        meta["cases"][tag] = {"M": M, "N": N, "K": K, "runs": sorted(runs)}
+    blob["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "bt_user_step.npz"), **blob)
+    print("wrote bt_user_step.npz")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bt_user_step":
+        write_bt_user_step_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "array_steps":      # one fixture only (the others are unchanged)
         write_array_step_fixture()
         sys.exit(0)
@@ -402,3 +444,4 @@ if __name__ == "__main__":
     write_unmixing_fixture()
     write_weighted_fixture()
     write_array_step_fixture()
+    write_bt_user_step_fixture()

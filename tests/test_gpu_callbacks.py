@@ -416,3 +416,42 @@ def test_pgm_with_array_valued_user_steps(pm, tag):
     # what NumPy would refuse, this refuses the same way
     with pytest.raises(ValueError):
         pm.pgm([A0.copy(), S0.copy()], grad, lambda *X, it=None: (np.ones(A0.shape[1] + 1), 1e-3), prox=[pm.operators.prox_plus] * 2, max_iter=2)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_backtracking_with_a_user_step(pm, tag):
+    """algorithms.pgm(backtracking=True, f=...) with a user `step` (round 3): the callable on the host once per iteration,
+    the Beck-Teboulle line search on the device (pmx_pgm_set_fixed_steps + pmx_pgm_run(ctx, 1)).  Fixture bt_user_step.npz,
+    generated from the reference with 1.5 x / 2 x the Lipschitz steps (the search halves T) and, accelerated, 1 x."""
+    from test_gpu_nmf import assert_factors_close
+    z, meta = load_golden("bt_user_step.npz")
+    Y, A0, S0 = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"]
+    dtype = "float64" if tag == "f64" else "float32"
+    grad = partial(pm.nmf.grad_likelihood, Y=Y)
+    f = partial(pm.nmf.log_likelihood, Y=Y)
+    seen = {"grads": 0}
+
+    def scaled(fac):
+        def st(*X, it=None):
+            return tuple(fac * s for s in pm.nmf.step_pgm(*X))
+        return st
+
+    def step2_grads(*X, it=None, grads=None):
+        seen["grads"] += int(grads is not None and grads[0].shape == X[0].shape)
+        return tuple(2.0 * s for s in pm.nmf.step_pgm(*X))
+    runs = {"x1.5": (scaled(1.5), False), "x2_with_grads": (step2_grads, False), "x1_fista": (scaled(1.0), True)}
+    assert sorted(runs) == meta["cases"][tag]["runs"]
+    for name, (st, accel) in runs.items():
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        conv, G, steps = pm.pgm([A, S], grad, st, prox=[pm.operators.prox_plus] * 2, accelerated=accel, backtracking=True, f=f,
+                                e_rel=1e-6, max_iter=15, callback=tb)
+        key = "%s/%s" % (tag, name)
+        assert len(tb.trace) == int(z[key + "/n_callbacks"])
+        assert_factors_close(A, z[key + "/A"], dtype, key + " A")
+        assert_factors_close(S, z[key + "/S"], dtype, key + " S")
+        assert pm.nmf.log_likelihood(A, S, Y=Y) == pytest.approx(float(z[key + "/loss"]), rel=2e-3)
+    assert seen["grads"] >= 15
+    # what stays out: a user prox next to the line search
+    with pytest.raises(NotImplementedError):
+        pm.pgm([A0.copy(), S0.copy()], grad, scaled(1.0), prox=[lambda X, step: np.maximum(X, 0), pm.operators.prox_plus], backtracking=True, f=f, max_iter=2)

@@ -226,3 +226,22 @@ def test_array_valued_steps_match_reference(tag):
         np.testing.assert_allclose(S, z[key + "/S"], err_msg=key, **tol)
         np.testing.assert_allclose(ret[1][0], z[key + "/gA"], err_msg=key, rtol=max(tol["rtol"], 1e-8), atol=1e-3 if tag == "f32" else 1e-9)
         assert ret[3] == int(z[key + "/n_callbacks"])
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_backtracking_with_a_user_step_matches_reference(tag):
+    """algorithms.pgm(backtracking=True) with a user `step` (multiples of the Lipschitz steps: the line search has to halve T):
+    fixture bt_user_step.npz, generated from the reference."""
+    z, meta = load_golden("bt_user_step.npz")
+    Y, A0, S0 = z[tag + "/Y"], z[tag + "/A0"], z[tag + "/S0"]
+    runs = {"x1.5": (1.5, False), "x2_with_grads": (2.0, False), "x1_fista": (1.0, True)}
+    assert sorted(runs) == meta["cases"][tag]["runs"]
+    tol = TOL[str(Y.dtype)] if tag == "f64" else dict(rtol=5e-3, atol=5e-4)
+    for name, (fac, accel) in runs.items():
+        A, S = A0.copy(), S0.copy()
+        ret = orc.pgm_nmf(Y, A, S, step=lambda a, s, it, g, fac=fac: tuple(fac * v for v in orc.lipschitz_steps(a, s)), accelerated=accel,
+                          backtracking=True, max_iter=15, e_rel=1e-6)
+        key = "%s/%s" % (tag, name)
+        np.testing.assert_allclose(A, z[key + "/A"], err_msg=key, **tol)
+        np.testing.assert_allclose(S, z[key + "/S"], err_msg=key, **tol)
+        assert ret[3] == int(z[key + "/n_callbacks"])
