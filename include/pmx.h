@@ -225,7 +225,8 @@ int pmx_pgm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
  *            downloads it, applies `prox(T_j, s_j)`, uploads the result into the same buffer;
  *   phase 2  the update (built-in operators fused as always), extrapolation, stopping test; fills *res.
  * `steps` (phases 1, 2): the two step sizes a user `step` returned, or NULL to keep the device's.  Lipschitz / fixed /
- * user steps; not with Barzilai-Borwein steps or backtracking. */
+ * user / Barzilai-Borwein steps (the latter evaluated on the device in phase 0, as in a fused iteration); not with
+ * backtracking (phase 0 alone is allowed there: see pmx_pgm_set_fixed_steps). */
 int pmx_pgm_split(pmx_ctx* ctx, int phase, const double* steps, pmx_result* res);
 /* A user `step` may return ARRAYS that broadcast against the blocks (algorithms.py:106-108: `_X[j] - S[j] * G[j]`,
  * `prox[j](.., S[j])`): the caller broadcasts block j's to rows x K (S: N x K, transposed like everything of S), uploads it

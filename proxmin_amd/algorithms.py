@@ -222,9 +222,10 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     slow = user_step is not None or any(h is not None for h in host_prox) or user_grad
     # a user `step` next to the line search: the callable on the host once per iteration, the Beck-Teboulle loop on the device
     bt_user_step = backtracking and user_step is not None and not any(h is not None for h in host_prox) and not user_grad
-    if slow and (bb is not None or backtracking) and not bt_user_step:
-        raise NotImplementedError("a user-defined grad / prox together with Barzilai-Borwein steps or backtracking, or a user `step` "
-                                  "together with Barzilai-Borwein steps, is not implemented")
+    # Barzilai-Borwein steps next to a user-defined prox / grad: the rule stays on the device (it is the step), the callable
+    # takes its round trip as with any other rule
+    if slow and backtracking and not bt_user_step:
+        raise NotImplementedError("a user-defined grad / prox together with backtracking is not implemented")
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm

@@ -1087,8 +1087,8 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
             if (rc == PMX_OK) rc = dallocT(c, &c->bbG[j], (size_t)c->rows[j] * c->K, false);
             if (rc != PMX_OK) return rc;
         }
-    if ((p->host_prox[0] || p->host_prox[1]) && (p->bb_type || p->backtracking))
-        FAIL(PMX_E_UNSUPPORTED, "a user-defined prox together with Barzilai-Borwein steps or backtracking is not implemented");
+    if ((p->host_prox[0] || p->host_prox[1]) && p->backtracking)     // (every trial of the line search would go through the host)
+        FAIL(PMX_E_UNSUPPORTED, "a user-defined prox together with backtracking is not implemented");
     for (int j = 0; j < 2; ++j)
         if (p->host_prox[j]) {
             rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
@@ -1352,7 +1352,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
     const pmx_pgm_params& p = c->pgm;
     // (phase 0 alone -- the gradient at the evaluation point, for a user `step` that wants `grads` -- is harmless next to
     //  the line search: the iteration itself then runs through pmx_pgm_run(ctx, 1) with the steps of pmx_pgm_set_fixed_steps)
-    if (p.bb_type || (p.backtracking && phase != 0)) FAIL(PMX_E_UNSUPPORTED, "pmx_pgm_split: not with Barzilai-Borwein steps or backtracking");
+    if (p.backtracking && phase != 0) FAIL(PMX_E_UNSUPPORTED, "pmx_pgm_split: not with backtracking");
     const float* A = p.accelerated ? c->Xe[0] : c->X[0];
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     const bool any_host = p.host_prox[0] || p.host_prox[1];
@@ -1380,10 +1380,10 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
     switch (phase) {
         case 0: {
             if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }   // (one iteration per call: nothing to repeat into)
-            if (!p.use_fixed_steps) {
+            if (!p.use_fixed_steps && !p.bb_type) {
                 rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);
                 if (rc != PMX_OK) return rc;
-            } else if (!steps) {
+            } else if (p.use_fixed_steps && !steps) {
                 // nmf.constant_step with a host-side prox: reset_status left DevStatus::step at 0 and only pmx_pgm_run
                 // uploads the constants -- without them the host prox would be handed T = Xe - 0 G
                 rc = set_fixed_steps(c, p.fixed_steps);
@@ -1391,11 +1391,27 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
             }
             rc = enqueue_grad(c, A, St, 1, 1);
             if (rc != PMX_OK) return rc;
-            FoldArgs f{};
-            for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
-            f.K = (int)c->K;
-            f.status = c->dstatus;
-            launch_fold(f, 2, c->stream);
+            if (p.bb_type) {             // the Barzilai-Borwein rule on the device (utils.py:216-241), exactly as a fused iteration
+                BBArgs b{};              // does it: k_bb_reduce folds the gradient as well
+                b.X[0] = A; b.X[1] = St;
+                for (int j = 0; j < 2; ++j) {
+                    b.slab[j] = slab_ref(c, j);
+                    b.G[j] = c->G[j]; b.Xprev[j] = c->bbX[j]; b.Gprev[j] = c->bbG[j];
+                    b.rows[j] = c->rows[j];
+                }
+                b.K = (int)c->K; b.status = c->dstatus; b.partials = c->partials;
+                b.first = c->it == 0;
+                launch_bb_reduce(b, c->stream);
+                BBStepArgs bs{};
+                bs.status = c->dstatus; bs.partials = c->partials; bs.it = c->it; bs.type = p.bb_type; bs.init_r = p.bb_init_r;
+                launch_bb_step(bs, c->stream);
+            } else {
+                FoldArgs f{};
+                for (int j = 0; j < 2; ++j) { f.slab[j] = slab_ref(c, j); f.G[j] = c->G[j]; f.rows[j] = c->rows[j]; }
+                f.K = (int)c->K;
+                f.status = c->dstatus;
+                launch_fold(f, 2, c->stream);
+            }
             HIP_CHECK(hipGetLastError());
             rc = read_status(c);
             if (rc != PMX_OK) return rc;

@@ -455,3 +455,32 @@ def test_backtracking_with_a_user_step(pm, tag):
     # what stays out: a user prox next to the line search
     with pytest.raises(NotImplementedError):
         pm.pgm([A0.copy(), S0.copy()], grad, scaled(1.0), prox=[lambda X, step: np.maximum(X, 0), pm.operators.prox_plus], backtracking=True, f=f, max_iter=2)
+
+
+@pytest.mark.parametrize("bbtype,accel", [(1, False), (2, True)])
+def test_barzilai_borwein_steps_with_a_user_prox_or_gradient(pm, orc, bbtype, accel):
+    """utils.BarzilaiBorweinStepper next to a user-written prox / gradient (round 3): the rule stays on the device -- it is the
+    step, evaluated by the same kernels as in a fused iteration -- and the callable takes its host round trip.  A user-written
+    projection and a NumPy gradient that compute what the library computes must give what the fused path gives."""
+    Y, A0, S0 = orc.synthetic_problem(220, 310, 7, np.float32, seed=13)
+
+    def run(prox, grad):
+        A, S = A0.copy(), S0.copy()
+        bb = pm.utils.BarzilaiBorweinStepper(type=bbtype, init_r=0.1)
+        conv, G, steps = pm.pgm([A, S], grad, bb.step, prox=prox, accelerated=accel, max_iter=8, e_rel=1e-12)
+        return A, S, steps
+    lib_grad = partial(pm.nmf.grad_likelihood, Y=Y)
+    A1, S1, st1 = run([pm.operators.prox_plus] * 2, lib_grad)                     # fused
+    A2, S2, st2 = run([my_plus, pm.operators.prox_plus], lib_grad)                # block A's prox on the host
+    assert np.array_equal(A1, A2) and np.array_equal(S1, S2)
+    assert tuple(st1) == tuple(st2)
+    A3, S3, st3 = run([pm.operators.prox_plus] * 2, _numpy_grad(Y))               # the gradient from the host (fp32 NumPy)
+    np.testing.assert_allclose(A3, A1, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(S3, S1, rtol=2e-4, atol=2e-5)
+    # and against the oracle's restatement of the stepper
+    Ao, So = A0.copy(), S0.copy()
+    obb = orc.BBStepper(kind=bbtype, init_r=0.1)
+    orc.pgm_nmf(Y, Ao, So, step=lambda a, s, it, g: obb.step((a, s), it, g), accelerated=accel, max_iter=8, e_rel=1e-12)
+    from test_gpu_nmf import assert_factors_close
+    assert_factors_close(A2, Ao, np.float32, "bb + user prox A")
+    assert_factors_close(S2, So, np.float32, "bb + user prox S")
