@@ -55,7 +55,7 @@ def test_traffic_record_matches_the_committed_sources():
     assert "cfg3/f16x2" in rec
     for v in rec.values():
         assert set(("source_hash", "fetch_bytes", "write_bytes", "bytes_per_launch", "how")) <= set(v)
-        assert v["bytes_per_launch"] == v["fetch_bytes"] + v["write_bytes"]
+        assert abs(v["bytes_per_launch"] - v["fetch_bytes"] - v["write_bytes"]) <= 2        # (each rounded separately)
     e = bench.pmc_traffic("cfg3", "f16x2")
     if rec["cfg3/f16x2"]["source_hash"] != h:
         assert e is None                    # a measurement of another build is not printed
