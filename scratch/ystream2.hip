@@ -9,6 +9,7 @@
 //   mode 4  dwordx4, 64-column blocks (4 rows x 256 B per wave-instruction; 128 x 64 blocks, half as many slots)
 // hipcc --offload-arch=gfx950 -O3 -o ystream2 ystream2.hip
 #include <hip/hip_runtime.h>
+#include <string>
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -140,7 +141,39 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t
     if (blockIdx.x == 0 && tid == 0) { out[4] = (float)(__builtin_readcyclecounter() - tc0); out[5] = (float)(wall_clock64() - tw0); }
 }
 
+// "hold" mode: ystream2 hold <variant> <seconds> -- one variant back to back for a while (random data, pitch N), so that a
+// sampler of the package power / clock (scratch/r3_skeleton_power.py) sees a steady state; prints the average launch time
+static int hold(const char* which, double secs) {
+    const int M = 16384, N = 16384, RP = 16, gridX = 8;
+    const int64_t ld = N;
+    float* out; CHECK(hipMalloc(&out, 64)); CHECK(hipMemset(out, 0, 64));
+    float* Y; CHECK(hipMalloc(&Y, (size_t)M * ld * 4));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Y, (size_t)M * ld, 1234u); CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto go = [&](auto kern) {
+        CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 1024));
+        double total_ms = 0; long launches = 0;
+        while (total_ms < secs * 1e3) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, dim3(gridX * (N / 256)), dim3(512), 1024, 0, Y, ld, M, N, RP, gridX, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            total_ms += ms; launches += 200;
+        }
+        printf("hold %s: %.4f ms per launch over %ld launches\n", which, total_ms / launches, launches);
+    };
+    const std::string w(which);
+    if (w == "stream4") go(k<1, 4, false, true>);                 // Y alone, 16-byte requests, four blocks in flight
+    else if (w == "stream_v8") go(k<0, 2, false, true>);          // Y alone, v8's request shape
+    else if (w == "mfma") go(k<3, 1, true, true>);                // K1's MFMAs alone (36 per SIMD and slot, constant operands)
+    else if (w == "both4") go(k<1, 4, true, true>);               // both
+    else if (w == "both_v8") go(k<0, 2, true, true>);
+    else { printf("unknown variant %s\n", which); return 1; }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 4 && std::string(argv[1]) == "hold") return hold(argv[2], atof(argv[3]));
     const int M = 16384, N = 16384, RP = 16, gridX = 8;
     const int pads[3] = {0, 64, 2048 + 64};
     float* out;
