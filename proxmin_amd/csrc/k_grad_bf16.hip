@@ -2140,9 +2140,13 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
 // Chained in-place accumulation of gA (k_grad_f16_v8<.., CHAIN>): members per chain for this plan, or 0 when the mode
 // does not apply.  Needs: every row region with all its RP panels (the rotation), chains that are whole multiples of 8
 // in number (one XCD each under round-robin dispatch), all workgroups co-resident (one per CU).
-int grad_chain_length(const GradPlan& p, int64_t M, int num_cus) {
-    // PMX_K1_CHAIN: 0 switches the mode off, n >= 2 caps the chain length (tests)
-    const int cap = getenv("PMX_K1_CHAIN") ? atoi(getenv("PMX_K1_CHAIN")) : 32;
+int grad_chain_length(const GradPlan& p, int64_t M, int num_cus, int longest) {
+    // longest: 32 -- the whole XCD in one chain at 16384 x 16384 -- for the split-bf16 and exact-fp32 kernels; 16 for
+    // k_grad_f16_v8 (round 3, PMC per chain length in profiles/r03_d_chain_length_traffic.txt: K1 writes 82 MB instead of 140 and
+    // moves 1.13 x instead of 1.17 x its algorithmic bytes at the same speed -- 2486 against 2480 it/s, alternating on one box;
+    // split-bf16 loses 1 % at 16, exact fp32 is indifferent).
+    // PMX_K1_CHAIN: 0 switches the mode off, n >= 2 caps the chain length (tests, A/B)
+    const int cap = getenv("PMX_K1_CHAIN") ? atoi(getenv("PMX_K1_CHAIN")) : longest;
     if (cap < 2) return 0;
     const int64_t panels = (M + V5_BM - 1) / V5_BM;
     if (M % V5_BM != 0 || panels % p.RP != 0) return 0;

@@ -296,7 +296,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (v7_shape || c->f32pc) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
-        c->chainL = grad_chain_length(c->plan, M, ncu);
+        c->chainL = grad_chain_length(c->plan, M, ncu, c->use_f16 ? 16 : 32);
         if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
     }
     int rc = PMX_OK;

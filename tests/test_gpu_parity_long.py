@@ -114,7 +114,7 @@ def test_cfg3_twenty_iterations_bench_mode_against_default_mode(eng):
     Af, Sf, subf, _ = _run_device(eng, "f32", M, N, K, backend, unity, Yd, A0, S0, 20)
     Ah, Sh, subh, info = _run_device(eng, "f16x2", M, N, K, backend, unity, Yd, A0, S0, 20)
     Ah2, Sh2, _, _ = _run_device(eng, "f16x2", M, N, K, backend, unity, Yd, A0, S0, 20)
-    assert info["chain"] == 32 and info["tail_fused"] and info["chain_faults"] == 0
+    assert info["chain"] == 16 and info["tail_fused"] and info["chain_faults"] == 0
     assert np.array_equal(Ah, Ah2) and np.array_equal(Sh, Sh2), "f16x2 run is not repeatable bit for bit"
     assert subf == subh, (subf, subh)
     fA, wA = frac_within(Ah, Af)

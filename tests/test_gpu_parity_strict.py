@@ -197,7 +197,7 @@ def test_full_size_cfg3_against_the_oracle(orc, mode):
         A, S = dev.get_factors()
         sub = [int(r.sub_iterations[0]), int(r.sub_iterations[1])]
         if mode == "f16x2":
-            assert dev.k1_info()["chain"] == 32 and dev.k1_info()["tail_fused"]
+            assert dev.k1_info()["chain"] == 16 and dev.k1_info()["tail_fused"]
     Y64 = Yd.cpu().numpy().astype(np.float64)
     del Yd
     Ao, So = A0.astype(np.float64), S0.astype(np.float64)
