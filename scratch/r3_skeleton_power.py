@@ -23,7 +23,8 @@ def rd(f):
 
 
 lines = ["HIP device 0 = PCI %s; hwmon %s; cap %.0f W" % (BDF, hw, rd("power1_cap") / 1e6)]
-for variant, secs in (("idle", 3), ("stream4", 5), ("stream_v8", 5), ("mfma", 5), ("both4", 5), ("both_v8", 5)):
+for variant, secs in (("idle", 3), ("stream4", 5), ("stream_v8", 5), ("mfma", 5), ("mfma_ldsrand", 5), ("both4", 5), ("both_v8", 5),
+                      ("both_v8_ldsconst", 5), ("both_v8_ldsrand", 5), ("both_v8_ldsrand_epi", 5)):
     samples = []
     stop = threading.Event()
 
@@ -45,8 +46,8 @@ for variant, secs in (("idle", 3), ("stream4", 5), ("stream_v8", 5), ("mfma", 5)
     mid = samples[len(samples) // 4: -max(1, len(samples) // 10)] or samples      # drop the ramp and the tail
     pw = [s[0] for s in mid]; fq = [s[1] for s in mid]
     ms = float(msg.split(":")[1].split("ms")[0]) if "ms per launch" in msg else float("nan")
-    line = "%-10s %-58s power W mean %.0f (min %.0f, max %.0f)  sclk MHz mean %.0f   energy per launch %.3f J (dynamic, above 298 W: %.3f J)" % (
-        variant, msg, sum(pw) / len(pw), min(pw), max(pw), sum(fq) / len(fq), sum(pw) / len(pw) * ms * 1e-3, (sum(pw) / len(pw) - 298.0) * ms * 1e-3)
+    line = "%-20s %-64s power W mean %.0f (min %.0f, max %.0f)  sclk MHz mean %.0f   energy per launch %.3f J (dynamic, above 298 W: %.3f J)" % (
+        variant, msg[:64], sum(pw) / len(pw), min(pw), max(pw), sum(fq) / len(fq), sum(pw) / len(pw) * ms * 1e-3, (sum(pw) / len(pw) - 298.0) * ms * 1e-3)
     print(line, flush=True)
     lines.append(line)
 open(os.path.join(OUT, "skeleton.txt"), "w").write("\n".join(lines) + "\n")

@@ -17,6 +17,7 @@ __device__ __forceinline__ unsigned long long wall_clock64_() { return __builtin
 #define wall_clock64 wall_clock64_
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -36,7 +37,11 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
-template <int MODE, int DEPTH, bool MFMA, bool NT, int MF = 12, bool BAR = true>
+// OPS: where the MFMA operands come from -- 0 two constant registers (the sweep above); 1 one fresh 16-byte fragment per MFMA
+// read from LDS, every fragment holding the SAME values (the reads without the switching); 2 the same reads of pseudo-random
+// fp16 data (reads + operand switching, as in the real kernel: ~1 fragment per MFMA).  EPI: the producers also run an
+// epilogue's worth of work on the Y tile (66 dependent-free VALU, 8 ds_write_b64 per wave and block).
+template <int MODE, int DEPTH, bool MFMA, bool NT, int MF = 12, bool BAR = true, int OPS = 0, bool EPI = false>
 __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t ld, int M, int N, int RP, int gridX, float* out) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int BN = MODE == 4 ? 64 : 32, NCB = 256 / BN;
@@ -51,6 +56,20 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t
     const int T = RP * NCB;
     const bool producer = w < 4;
     float acc = out[2];          // opaque: keeps the no-load variants' MFMAs alive
+    if constexpr (OPS != 0) {    // 64 KB of operand fragments at smem + 65536 (the LDS-DMA ring, when used, sits below)
+        f16x8* frag = reinterpret_cast<f16x8*>(smem + 65536);
+        for (int e = tid; e < 4096; e += 512) {
+            f16x8 v;
+            for (int i = 0; i < 8; ++i) {
+                const unsigned h = (OPS == 2 ? (unsigned)(e * 8 + i) * 2654435761u : (unsigned)((tid & 63) * 8 + i) * 40503u) >> 16;
+                v[i] = (_Float16)(((float)(h & 1023) - 512.f) * (OPS == 2 ? 16.f : 0.002f));
+            }
+            if (OPS == 1) v = (e & 1) ? fb : fa;
+            frag[e] = v;
+        }
+        __syncthreads();
+    }
+    const f16x8* fragw = reinterpret_cast<const f16x8*>(smem + 65536) + lane;     // + 64 * n: conflict-free 16-byte reads
     const unsigned long long tc0 = __builtin_readcyclecounter(), tw0 = wall_clock64();
     float y[MODE == 2 || MODE == 3 ? 1 : DEPTH][NY] = {};
     const unsigned ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -118,15 +137,38 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ Y, int64_t
             }
             use(d);
             issue(d, t + d + DEPTH);
-            if constexpr (MFMA) {
-                if (producer) {
+            if constexpr (EPI) {
+                if (producer) {      // an epilogue's worth: ~4 VALU per value of the tile, two fp16 images written
+                    float r[16];
 #pragma unroll
-                    for (int q = 0; q < MF * NM; ++q) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
-                } else {
+                    for (int i = 0; i < 16; ++i) { const float x = y[d % (MODE == 2 || MODE == 3 ? 1 : DEPTH)][i & (NY - 1)] * 1.0001f - acc; r[i] = x * 0.5f + (float)(_Float16)x; }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 h, l;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)r[4 * g + q]; l[q] = (_Float16)(r[4 * g + q] - (float)h[q]); }
+                        *reinterpret_cast<f16x4*>(smem + 32768 + w * 4096 + g * 1024 + lane * 8) = h;
+                        *reinterpret_cast<f16x4*>(smem + 49152 + w * 4096 + g * 1024 + lane * 8) = l;
+                    }
+                }
+            }
+            if constexpr (MFMA) {
+                const int t0 = (t + d) * 7;
+                if (producer) {
+                    f16x8 b = fb;
 #pragma unroll
                     for (int q = 0; q < MF * NM; ++q) {
-                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, c1, 0, 0, 0);
+                        if constexpr (OPS != 0) { if ((q % 3) != 2) b = fragw[64 * ((t0 + q) & 63)]; }      // 8 of 12: the S fragments
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, b, c0, 0, 0, 0);
+                    }
+                } else {
+                    f16x8 x = fa, z = fb;
+#pragma unroll
+                    for (int q = 0; q < MF * NM; ++q) {
+                        if constexpr (OPS != 0) { if (q & 1) x = fragw[64 * ((t0 + q) & 63)]; else z = fragw[64 * ((t0 + q + 31) & 63)]; }   // one fresh fragment per MFMA pair member
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, z, c0, 0, 0, 0);
+                        if constexpr (OPS != 0) { if (q & 1) z = fragw[64 * ((t0 + q + 17) & 63)]; else x = fragw[64 * ((t0 + q + 5) & 63)]; }
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, x, c1, 0, 0, 0);
                     }
                 }
             }
@@ -163,6 +205,23 @@ static int hold(const char* which, double secs) {
         printf("hold %s: %.4f ms per launch over %ld launches\n", which, total_ms / launches, launches);
     };
     const std::string w(which);
+    const int big = 131072;
+    auto go_lds = [&](auto kern) {
+        CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        double total_ms = 0; long launches = 0;
+        while (total_ms < secs * 1e3) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, dim3(gridX * (N / 256)), dim3(512), big, 0, Y, ld, M, N, RP, gridX, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            total_ms += ms; launches += 200;
+        }
+        printf("hold %s: %.4f ms per launch over %ld launches\n", which, total_ms / launches, launches);
+    };
+    if (w == "both_v8_ldsconst") { go_lds(k<0, 2, true, true, 12, true, 1, false>); return 0; }     // + operand fragments read from LDS, always the same values
+    if (w == "both_v8_ldsrand") { go_lds(k<0, 2, true, true, 12, true, 2, false>); return 0; }       // + pseudo-random operand data
+    if (w == "both_v8_ldsrand_epi") { go_lds(k<0, 2, true, true, 12, true, 2, true>); return 0; }    // + an epilogue's VALU and LDS stores
+    if (w == "mfma_ldsrand") { go_lds(k<3, 1, true, true, 12, true, 2, false>); return 0; }          // the MFMAs alone, random operands
     if (w == "stream4") go(k<1, 4, false, true>);                 // Y alone, 16-byte requests, four blocks in flight
     else if (w == "stream_v8") go(k<0, 2, false, true>);          // Y alone, v8's request shape
     else if (w == "mfma") go(k<3, 1, true, true>);                // K1's MFMAs alone (36 per SIMD and slot, constant operands)
