@@ -17,7 +17,16 @@
 //     gradients per launch, the residual computed twice, was measured at 0.56 ms against 0.40 ms and removed.)
 // LDS: S 64 KB + A images 64 KB (both halves, for gSt) + R 32 KB = the CU's 160 KB.
 // MFMAs per block: 24 per producer wave, 48 per consumer wave (24 + 24 at K = 64): the consumers bound the slot here.
-// gA: one slab per column region (N / 128 of them), gSt: two per row region, as v8 without chaining.
+// [r4] gSt: consumer wave j owns ONE 32-wide k tile (k = 32 j ..) of every block and contracts over all 128 rows of the
+// panel (eight 16-row steps) -- round 2/3 gave a wave two k tiles and half the rows, i.e. 128 accumulator registers for the
+// region's four blocks and two partial gSt slabs per row region; now 64 registers and ONE slab per row region.  With gA's 64
+// that is 128 accumulator registers per consumer (k_grad_f16_v8 holds 160), which is what makes room for
+// <CHAIN>: gA summed in place along XCD-local chains of workgroups -- k_grad_f16_v8<.., CHAIN>'s protocol (arrival words
+// carrying the writer's XCC_ID, sc1 fetch-and-add in the consumers' registers, fault -> slabs), re-timed for a panel of
+// four blocks: arrival looked at in the panel's second block, the previous sum fetched in two halves of 32 registers during
+// the third and fourth, published one slot into the next panel.  A member's panels are rotated by `chainStride` panels per
+// place in the chain (2 where the region has the panels for it: the predecessor's sum is then a whole panel-time old when it
+// is asked for).  gA: one slab per CHAIN (N / 128 / chainL of them) instead of one per column region.
 // ------------------------------------------------------------------------------------------------
 constexpr int W8_NCB = 4;
 constexpr int W8_S_HALF = 2 * V5_S_TERM;            // [h][l] images of one k half of a 32-column block
@@ -48,6 +57,13 @@ struct GradK128Args {
     const float* W;          // <HASW>: weights of the likelihood (nmf.py:13-41), M x N, row pitch ldW; nullptr: W == 1
     int64_t ldW;
     float wmax;              // max(1, max |W|): enters the bound that scales R
+    // <CHAIN> (see k_grad_f16_v8<.., CHAIN>, GradV4Args)
+    int chainL;              // workgroups per chain (0: one gA slab per column region)
+    int chainStride;         // panels between the rotations of neighbouring members (chainStride * chainL <= RP)
+    unsigned* chainFlags;    // [chains][RP][4] arrival words, monotonic over launches
+    unsigned chainBase;      // launch sequence number * 64
+    DevStatus* wstatus;      // writable view of `status` (fault report)
+    int chainInject;         // tests: report a fault from this launch
 };
 
 struct SplitAArgs {
@@ -99,7 +115,7 @@ void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
 
 // HASW: weighted likelihood -- D = W (A S - Y), loss 1/2 sum W (Y - A S)^2: the producers fetch the W tile next to the Y tile
 // (they have the registers: the consumers bound this kernel) and scale R in the epilogue, as in k_grad_f16_v8<.., HASW>.
-template <bool HASW>
+template <bool HASW, bool CHAIN>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
     constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
     constexpr int OFF_R = W8_OFF_R;
@@ -111,9 +127,16 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
     const int li = lane & 15, lq = lane >> 4;
     const int M = a.M, N = a.N;
     int rowRegion, colRegion;
+    int chainId = 0, chainPos = 0;           // CHAIN: which chain, and this workgroup's place in its rotation
     {
         const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {                   // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
+        if constexpr (CHAIN) {               // the members of a chain are multiples of 8 apart in dispatch order: ONE XCD (checked at run time)
+            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
+            chainPos = idx % L;
+            chainId = (idx / L) * 8 + xcd;
+            rowRegion = chainId % gx;
+            colRegion = (chainId / gx) * L + chainPos;
+        } else if (gy % 8 == 0) {            // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
             colRegion = xcd * (gy >> 3) + idx / gx;
@@ -131,17 +154,23 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
     const bool producer = w < 4;
     const int j = w & 3;
     float lossAcc = 0.f;
+    // CHAIN: the t-th panel this workgroup visits is panel (t - chainStride * chainPos) mod RP (every region has all RP panels
+    // in this mode): the members of a chain are on different panels at any time, and member c reaches a panel chainStride
+    // panel-times after member c - 1 did
+    const int rot = CHAIN ? a.chainStride * chainPos : 0;
+    auto panel_at = [&](int t) {
+        if constexpr (CHAIN) { const int p = t - rot; return p < 0 ? p + nrp : p; }
+        else return t;
+    };
 
     if (T <= 0) {                            // region outside the matrix: its gSt slab parts and loss partial are zero
         if (!producer) {
-            const int mh = j >> 1, kt = j & 1;
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            for (int h = 0; h < NKT; ++h)
-                for (int c = 0; c < NCB; ++c)
-                    for (int i = 0; i < 16; ++i) {
-                        const int gn = col0 + c * V5_BN + tile_row(i, lane);
-                        if (gn < N && a.doS) dst[(int64_t)gn * K + h * 64 + kt * 32 + l31] = 0.f;
-                    }
+            float* dst = a.slabS + (int64_t)rowRegion * N * K;
+            for (int c = 0; c < NCB; ++c)
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
+                    if (gn < N && a.doS) dst[(int64_t)gn * K + j * 32 + l31] = 0.f;
+                }
         }
         if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
         return;
@@ -203,6 +232,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         auto load_Y = [&](int b, float (&y)[16]) {     // block b, clamped past the end of the region
             int brp = b >> 2;
             if (brp >= nrp) brp = nrp - 1;
+            brp = panel_at(brp);
             const float* base = ybase0 + (int64_t)brp * V5_BM * a.ldY + (b & 3) * V5_BN;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -218,6 +248,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             if constexpr (HASW) {
                 int brp = b >> 2;
                 if (brp >= nrp) brp = nrp - 1;
+                brp = panel_at(brp);
                 const float* base = wbase0 + (int64_t)brp * V5_BM * a.ldW + (b & 3) * V5_BN;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -232,6 +263,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         const int64_t afrag0 = (int64_t)(row0 + j * 32 + l31) * K + hi * 8;
         auto load_afr = [&](int rp, int ks) {      // (past the region's last panel: that panel again, so that every panel ends alike)
             if (rp >= nrp) rp = nrp - 1;
+            rp = panel_at(rp);
             const int64_t o = afrag0 + (int64_t)rp * V5_BM * K + ks * 16;
             afr[ks][0] = *reinterpret_cast<const f16x8*>(a.Ah + o);
             afr[ks][1] = *reinterpret_cast<const f16x8*>(a.Al + o);
@@ -366,19 +398,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // S images published
 
-        f32x16 accS[NCB][NKT];
-        f32x16 accA[NKT][2];
+        f32x16 accS[NCB];                    // gSt: k tile 32 j .. of each of the region's four blocks, all 128 rows of every panel
+        f32x16 accA[NKT][2];                 // gA: rows 32 j .. of the panel, k tiles h * 64 + t * 32
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
-            for (int h = 0; h < NKT; ++h)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) accS[c][h][i] = 0.f;
+            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
 #pragma unroll
         for (int h = 0; h < NKT; ++h)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
-        const int kt = j & 1, mh = j >> 1;   // gSt tile (per k half); gA: rows 32 j .., both 32-wide k tiles of each half
+        const int kt = j & 1, kh = j >> 1;   // gSt's k tile: half kh of the A images, 32-wide tile kt within it
         int r_t0, r_t1;                      // gA's A operand (R, transposing read)
         {
             const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
@@ -391,12 +421,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
         };
         const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // gA's B operand; k tile 1: ^ 64
-        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // gSt's A operand, ^ (ks << 5)
-        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // gSt's B operand
+        const int r_g3 = l31 * 256 + ((hi ^ v4_swz(l31)) << 4);                                // gSt's A operand (R^T rows n), rows 16 ks ..: ^ (ks << 5)
+        const int a_t0 = tr_src(8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(8 * hi + 4 + (li >> 2), kt * 32);   // gSt's B operand, rows 16 ks ..: + ks * 16 * ROWB
+        // gA slab this workgroup contributes to: its own (one per column region), or its chain's (accumulated in place)
+        const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+        auto gA_tile = [&](int prow) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31; };
         auto flush_gA = [&](int prow) {
 #pragma unroll
             for (int h = 0; h < NKT; ++h) {
-                float* p0_ = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + h * 64 + l31;
+                float* p0_ = gA_tile(prow) + h * 64;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     float* ph_ = p0_ + half * 16 * K;
@@ -415,11 +448,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
         };
-        auto consume = [&](int b, int prow, auto cb_c) {     // block b: column block cb of the panel at row prow
+        auto consumeA = [&](int b, auto cb_c) {    // gA of block b: column block cb of the current panel
             constexpr int cb = decltype(cb_c)::value;
             const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
             const unsigned char* Slb = smem + cb * W8_SL_BYTES;
-            const unsigned char* Ab = smem + W8_OFF_A;
             if (a.doA & 1) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -442,34 +474,118 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     }
                 }
             }
+        };
+        auto consumeS = [&](int b, auto cb_c) {    // gSt of block b
+            constexpr int cb = decltype(cb_c)::value;
+            const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Ab = smem + W8_OFF_A + kh * W8_A_HALF;
             if (a.doS) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < 8; ++ks) {       // rows 16 ks .. of the panel
                     const int ro = r_g3 ^ (ks << 5);
                     const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
                     const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
                     const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
-#pragma unroll
-                    for (int h = 0; h < NKT; ++h) {
-                        const unsigned char* Ahh = Ab + h * W8_A_HALF;
-                        const f16x8 a0 = v8_tr_pair(Ahh, ao0, ao1);
-                        const f16x8 a1 = v8_tr_pair(Ahh + V5_A_TERM, ao0, ao1);
-                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, accS[cb][h], 0, 0, 0);
-                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accS[cb][h], 0, 0, 0);
-                        accS[cb][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accS[cb][h], 0, 0, 0);
-                    }
-                }
-            }
-            if constexpr (cb + 1 == NCB) {
-                if (a.doA & 1) {
-                    flush_gA(prow);
-#pragma unroll
-                    for (int h = 0; h < NKT; ++h)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
+                    const f16x8 a0 = v8_tr_pair(Ab, ao0, ao1);
+                    const f16x8 a1 = v8_tr_pair(Ab + V5_A_TERM, ao0, ao1);
+                    accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, accS[cb], 0, 0, 0);
+                    accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accS[cb], 0, 0, 0);
+                    accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accS[cb], 0, 0, 0);
                 }
             }
         };
+        auto consume = [&](int b, auto cb_c) { consumeA(b, cb_c); consumeS(b, cb_c); };
+        // ---- CHAIN: gA summed in place through the XCD's L2 (protocol and fault handling: k_grad_f16_v8<.., CHAIN>) ----------
+        const float invUnA = scR * scS;              // 2^(eR+eS): previous sums enter the accumulators in their scale
+        unsigned* cflags = nullptr;
+        unsigned myxcc = 0;
+        if constexpr (CHAIN) {
+            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
+            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        }
+        unsigned* pendFlag = nullptr;                // arrival to publish once this wave's stores of the panel have landed
+        unsigned pendVal = 0;
+        unsigned* curFlag = nullptr;
+        unsigned cwant = 0, cseen = 0;
+        bool cadd = false;                           // this panel has a previous sum to add (not the first visitor of the panel)
+        bool cdead = false;                          // a fault was seen: no more waiting, the launch's gA is discarded anyway
+        auto chain_fault = [&](int code) {
+            if (lane == 0 && code > 0) {
+                a.wstatus->k1_fault = code;
+                a.wstatus->reason = HALT_ERROR;
+                __threadfence();
+                a.wstatus->halt = 1;
+            }
+            cadd = false;
+            cdead = true;
+        };
+        auto chain_publish = [&]() {
+            if constexpr (CHAIN) {
+                if (pendFlag != nullptr) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
+                    pendFlag = nullptr;
+                }
+            }
+        };
+        auto chain_open = [&](int pnl) {             // this workgroup's place among the visitors of panel pnl, in time
+            if constexpr (CHAIN) {
+                chain_publish();                     // the previous panel's arrival (its stores have had a slot to land)
+                const int c = chainPos, L = a.chainL, sg = a.chainStride;
+                const int c0 = (nrp - pnl + sg - 1) / sg;          // first member that reaches pnl after wrapping around: those come first
+                const int nw = L - c0 > 0 ? L - c0 : 0;
+                const int k = pnl + sg * c >= nrp ? c - c0 : c + nw;
+                cadd = (a.doA & 1) && k > 0 && !cdead;
+                cwant = a.chainBase + (unsigned)k;
+                curFlag = cflags + pnl * 4;
+            }
+        };
+        auto chain_look = [&]() {                    // request the arrival word (looked at after this block's MFMAs)
+            if constexpr (CHAIN) {
+                if (cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        auto chain_wait = [&]() {
+            if constexpr (CHAIN) {
+                if (cadd) {                          // the predecessor finished this panel a panel-time or more ago: normally no spin
+                    unsigned v = __builtin_amdgcn_readfirstlane(cseen);
+                    if ((v >> 4) != cwant) {
+                        const long long t0 = wall_clock64();          // 100 MHz
+                        for (int spins = 1; (v >> 4) != cwant; ++spins) {
+                            if ((spins & 63) == 0) {
+                                if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
+                                if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    }
+                    if (cadd && (v & 15u) != myxcc) chain_fault(2);
+                    asm volatile("" ::: "memory");   // the sc1 loads of the previous sum stay behind the arrival check
+                }
+            }
+        };
+        // k half h of the previous sum of this wave's tile (32 registers): requested in front of a block's MFMAs, added behind them
+        auto chain_fetch = [&](int prow, int h, float (&pv)[32]) {
+            const float* pb = gA_tile(prow) + h * 64;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float* q = pb + ((i & 3) + 8 * (i >> 2)) * K;
+                pv[i] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                pv[16 + i] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(q + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        };
+        auto chain_add = [&](int h, const float (&pv)[32]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                accA[h][0][i] += pv[i] * invUnA;
+                accA[h][1][i] += pv[16 + i] * invUnA;
+            }
+        };
+        if constexpr (CHAIN) {
+            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+        }
         using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
         using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
         sync();
@@ -477,27 +593,58 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         int s = 2;
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
-            const int prow = row0 + rp * V5_BM;
+            const int pnl = panel_at(rp);
+            const int prow = row0 + pnl * V5_BM;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();          // block s-2 opens a row panel: the producers have published its A terms
-            consume(s - 2, prow, c0{}); sync(); ++s;
-            consume(s - 2, prow, c1{}); sync(); ++s;
-            consume(s - 2, prow, c2{}); sync(); ++s;
-            consume(s - 2, prow, c3{}); sync(); ++s;
+            chain_open(pnl);
+            consume(s - 2, c0{}); sync(); ++s;
+            chain_look();
+            consume(s - 2, c1{});
+            chain_wait();
+            sync(); ++s;
+            // The panel's last block: gA first, so that its flush (64 stores per lane) has the block's gSt contraction and the
+            // barrier to land behind -- the arrival word is published at the top of the next panel behind a vmcnt(0) that then
+            // costs nothing.  CHAIN: the previous sum arrives in two halves of 32 registers, each requested in front of MFMAs.
+            if constexpr (CHAIN) {
+                float pv[32];
+                if (cadd) chain_fetch(prow, 0, pv);
+                consume(s - 2, c2{});
+                if (cadd) chain_add(0, pv);
+                sync(); ++s;
+                if (cadd) chain_fetch(prow, 1, pv);
+                consumeA(s - 2, c3{});
+                if (cadd) chain_add(1, pv);
+            } else {
+                consume(s - 2, c2{}); sync(); ++s;
+                consumeA(s - 2, c3{});
+            }
+            if (a.doA & 1) {
+                flush_gA(prow);
+#pragma unroll
+                for (int h = 0; h < NKT; ++h)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
+                if constexpr (CHAIN) {
+                    pendFlag = curFlag;
+                    pendVal = ((cwant + 1u) << 4) | myxcc;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);     // (the stores stay in front of the gSt contraction)
+            consumeS(s - 2, c3{});
+            sync(); ++s;
         }
+        chain_publish();
         if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+            float* dst = a.slabS + (int64_t)rowRegion * N * K;
+            const int kk = j * 32 + l31;
 #pragma unroll
-            for (int h = 0; h < NKT; ++h) {
-                const int kk = h * 64 + kt * 32 + l31;
+            for (int c = 0; c < NCB; ++c) {
+                const int bcol = col0 + c * V5_BN;
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) {
-                    const int bcol = col0 + c * V5_BN;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int gn = bcol + tile_row(i, lane);
-                        dst[(int64_t)gn * K + kk] = accS[c][h][i] * unS;
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int gn = bcol + tile_row(i, lane);
+                    dst[(int64_t)gn * K + kk] = accS[c][i] * unS;
                 }
             }
         }
@@ -537,17 +684,27 @@ GradPlan grad_plan_k128(int64_t M, int64_t N) {
     p.RP = (int)((panels + wantX - 1) / wantX);
     p.gridX = (int)((panels + p.RP - 1) / p.RP);
     p.nSlabA = p.gridY;
-    p.nSlabS = p.gridX * 2;
+    p.nSlabS = p.gridX;
     p.ldsBytes = W8_LDS_BYTES;
     return p;
 }
-template <bool HASW>
+// panels between the rotations of neighbouring chain members (PMX_K128_STRIDE: A/B)
+int grad_k128_chain_stride(const GradPlan& p, int chainL) {
+    if (chainL <= 0) return 1;
+    const int want = getenv("PMX_K128_STRIDE") ? atoi(getenv("PMX_K128_STRIDE")) : 1;   // measured (profiles/r04_a_k128_chain_ab.txt): 1 beats 2 -- the predecessor's sum is still in L2
+    int sg = p.RP / chainL;
+    if (sg > want) sg = want;
+    return sg < 1 ? 1 : sg;
+}
+template <bool HASW, bool CHAIN>
 static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_f16_k128<HASW>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_k128<HASW, CHAIN>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
-    return a.W != nullptr ? grad_launch_k128_t<true>(a, stream) : grad_launch_k128_t<false>(a, stream);
+    if (a.chainL > 0 && (a.doA & 1))
+        return a.W != nullptr ? grad_launch_k128_t<true, true>(a, stream) : grad_launch_k128_t<false, true>(a, stream);
+    return a.W != nullptr ? grad_launch_k128_t<true, false>(a, stream) : grad_launch_k128_t<false, false>(a, stream);
 }

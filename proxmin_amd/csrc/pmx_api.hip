@@ -293,10 +293,10 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
     const bool v7_shape = c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);     // k_grad_bf16_v7 / k_grad_f16_v8: the chained frame
-    if (v7_shape || c->f32pc) {
+    if (v7_shape || c->f32pc || c->k128) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
-        c->chainL = grad_chain_length(c->plan, M, ncu, c->use_f16 ? 16 : 32);
+        c->chainL = grad_chain_length(c->plan, M, ncu, (c->use_f16 || c->k128) ? 16 : 32);
         if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
     }
     int rc = PMX_OK;
@@ -708,6 +708,15 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
         g.absmax = c->absmax; g.ymax = c->ymax;
         g.W = c->W; g.ldW = c->ldW; g.wmax = c->wmax;
+        if (c->chainL > 0 && (doA & 1)) {    // k_grad_f16_k128<.., CHAIN>
+            if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
+                HIP_CHECK(hipMemsetAsync(c->chainFlags, 0, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4 * sizeof(unsigned), c->stream));
+                c->chainSeq = 0;
+            }
+            g.chainL = c->chainL; g.chainStride = grad_k128_chain_stride(c->plan, c->chainL);
+            g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
+            g.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
+        }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;

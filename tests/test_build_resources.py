@@ -18,10 +18,13 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb0ELb0E": 8,    # 0   the same with one gA slab per column region (6 in its loss-only instance)
     "13k_grad_f16_v8ILb0ELb1ELb0E": 8,    # 0   weighted (5 in its loss-only instance)
     "13k_grad_f16_v8ILb0ELb1ELb1E": 8,    # 3   weighted, chained
-    "15k_grad_f16_k128ILb0E": 32,         # 29  two-term fp16 K1 at K = 128: 192 accumulator registers in the consumers
-                                          #     (a handful of reloads per panel in their loop, the rest in the final flush)
-    "15k_grad_f16_k128ILb1E": 32,         # 29  its weighted instance (saddr-form W and Y requests: 113 before, with reloads inside the
-                                          #     producers' loop; 0.458 ms against 0.43 unweighted and 1.51 for the exact-fp32 kernel)
+    # two-term fp16 K1 at K = 128.  [r4] gSt re-split (one k tile per consumer wave, all 128 rows): 128 accumulator registers
+    # in the consumers instead of 192 -- round 3's instances spilled 29 each, with reloads in the consumers' loop
+    "15k_grad_f16_k128ILb0ELb0E": 4,      # 0   one gA slab per column region
+    "15k_grad_f16_k128ILb1ELb0E": 8,      # 2   weighted
+    "15k_grad_f16_k128ILb0ELb1E": 12,     # 10  chained gA (the previous sum arrives in two halves of 32 registers); every spill store
+                                          #     sits in the prologue, every reload behind the loops (checked in the ISA: none inside)
+    "15k_grad_f16_k128ILb1ELb1E": 16,     # 12  weighted, chained
     "13k_grad_f32_pc": 4,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (eight instances: 2 in the
                                           #     weighted, chained K = 64 one, 0 in the others)
     "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)

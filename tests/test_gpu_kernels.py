@@ -291,8 +291,6 @@ def test_fp16_two_term_kernel_operand_scaling(eng, orc, case, K):
     an all-zero factor, |Y| ~ 1e4, weights up to 50) must still give fp32-class gradients -- no overflow to inf, no flush
     to zero."""
     M, N = 384, 768
-    if K == 128 and case == "big_weights":
-        pytest.skip("k_grad_f16_k128 takes no weights (set_W raises: test_k128_two_term_fp16_kernel)")
     rng = np.random.default_rng(hash(case) % 1000)
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=5)
     W = None
@@ -376,10 +374,13 @@ def test_weighted_gradient_matches_oracle(eng, orc, M, N, K):
                                                  (8192, 8192, 64, "f16x2", 32, 8), (16384, 4096, 64, "f16x2", 32, 8), (2048, 16384, 64, "f16x2", 32, 4),
                                                  (4096, 4096, 64, "f32", 32, 2), (4096, 16384, 64, "f32", 32, 8), (8192, 8192, 32, "f32", 32, 8),
                                                  (2048, 16384, 32, "f32", 4, 4),
-                                                 (4096, 4096, 64, "bf16x3", 32, 2), (4096, 16384, 64, "bf16x3", 32, 8), (8192, 8192, 64, "bf16x3", 4, 4)])
+                                                 (4096, 4096, 64, "bf16x3", 32, 2), (4096, 16384, 64, "bf16x3", 32, 8), (8192, 8192, 64, "bf16x3", 4, 4),
+                                                 # [r4] K = 128 (k_grad_f16_k128<.., CHAIN>): chains of 4 / 8 / 16, panel rotation stride 1 and 2
+                                                 (4096, 4096, 128, "f16x2", 32, 4), (4096, 8192, 128, "f16x2", 32, 8), (8192, 4096, 128, "f16x2", 32, 8),
+                                                 (16384, 2048, 128, "f16x2", 32, 8), (8192, 16384, 128, "f16x2", 32, 32), (8192, 16384, 128, "f16x2", 16, 16), (8192, 16384, 128, "f16x2", 4, 4)])
 def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, cap, want):
-    """Shapes whose region plan gives chains of 2 .. 16 workgroups, in the three kernels that carry the protocol
-    (k_grad_f16_v8 in mode f16x2, k_grad_f32_pc in mode f32, k_grad_bf16_v7 in mode bf16x3): gradients and loss against the fp64 oracle, the same
+    """Shapes whose region plan gives chains of 2 .. 16 workgroups, in the kernels that carry the protocol
+    (k_grad_f16_v8 in mode f16x2 -- k_grad_f16_k128 at K = 128 --, k_grad_f32_pc in mode f32, k_grad_bf16_v7 in mode bf16x3): gradients and loss against the fp64 oracle, the same
     tolerance as every other K1; the chained launch must be the one that ran (no fault, no silent fall-back), twice in a
     row bit-identically (fixed order of the in-place sums), and equal to the slab path up to summation order."""
     monkeypatch.setenv("PMX_K1_CHAIN", str(cap))
@@ -388,7 +389,8 @@ def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, c
     S[K - 1, :] += np.linspace(1.0, 0.0, N, dtype=np.float32)
     with eng.DeviceNMF(M, N, K, mode=mode) as dev:
         info = dev.k1_info()
-        assert info["kernel"] == {"f16x2": "k_grad_f16_v8", "f32": "k_grad_f32_pc", "bf16x3": "k_grad_bf16"}[mode] and info["chain"] == want, info
+        kernel = "k_grad_f16_k128" if K == 128 else {"f16x2": "k_grad_f16_v8", "f32": "k_grad_f32_pc", "bf16x3": "k_grad_bf16"}[mode]
+        assert info["kernel"] == kernel and info["chain"] == want, info
         assert info["slabs_A"] == info["col_regions"] // want
         dev.set_Y(Y)
         dev.set_factors(A, S)
@@ -396,6 +398,17 @@ def test_chained_gradient_matches_oracle(eng, orc, monkeypatch, M, N, K, mode, c
         gA2, gS2 = dev.grad()
         loss = dev.loglike()
         assert dev.k1_info()["chain_faults"] == 0 and dev.k1_info()["chain"] == want
+        if K == 128:                     # the weighted chained instance (<HASW, CHAIN>)
+            rng = np.random.default_rng(3)
+            W = (0.1 + 2.0 * rng.random((M, N), dtype=np.float32)).astype(np.float32)
+            W[rng.random((M, N), dtype=np.float32) < 0.15] = 0
+            dev.set_W(W)
+            wA, wS = dev.grad()
+            assert dev.k1_info()["chain_faults"] == 0 and dev.k1_info()["chain"] == want
+            idx = np.sort(np.random.default_rng(4).choice(M, 256, replace=False))
+            D = W[idx].astype(np.float64) * (A[idx].astype(np.float64) @ S.astype(np.float64) - Y[idx].astype(np.float64))
+            rAw = D @ S.astype(np.float64).T
+            np.testing.assert_allclose(wA[idx], rAw, rtol=2e-5, atol=2e-5 * np.abs(rAw).max())
     assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)
     A64, S64, Y64 = A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64)
     rA, rS = orc.residual_gradients(A64, S64, Y64)

@@ -508,7 +508,7 @@ def test_fused_adaprox_tail_equals_the_chain_of_kernels(pm, orc, monkeypatch, M,
         assert info["tail_fused"] and info["tail_faults"] == 0, info
 
 
-@pytest.mark.parametrize("kmode", ["f16x2", "f32", "bf16x3"])
+@pytest.mark.parametrize("kmode", ["f16x2", "f32", "bf16x3", "f16x2-k128"])
 @pytest.mark.parametrize("backend", ["adaprox", "fista", "bsdmm"])
 def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
     """The chained gA accumulation reports a fault (here injected into the 3rd chained launch; for real: a predecessor
@@ -518,6 +518,9 @@ def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
     carry the protocol: k_grad_f16_v8 (mode f16x2), k_grad_f32_pc (mode f32), k_grad_bf16_v7 (mode bf16x3)."""
     import proxmin_amd as pm
     M, N, K = 4096, 4096, 64
+    want_chain = 2
+    if kmode == "f16x2-k128":            # [r4] k_grad_f16_k128<.., CHAIN>: chains of 4 at this shape
+        kmode, K, want_chain = "f16x2", 128, 4
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=(backend == "adaprox"), seed=8)
     pm.set_default_mode(kmode)
     try:
@@ -544,7 +547,7 @@ def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
         from proxmin_amd import engine, operators as ops
         monkeypatch.setenv("PMX_INJECT_K1_FAULT", "3")
         with engine.DeviceNMF(M, N, K, mode=kmode) as dev:
-            assert dev.k1_info()["chain"] == 2
+            assert dev.k1_info()["chain"] == want_chain
             dev.set_Y(Y)
             dev.set_factors(A0, S0)
             dev.adaprox_begin([ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(ops.prox_plus, 1)], scheme="adam", e_rel=(1e-3, 1e-3))
