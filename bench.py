@@ -307,9 +307,14 @@ def other_configs(Y3, local):
             k1_avg = k1_ms / max(k1_n, 1)
             info = dev.k1_info()
             roof = roofline_entry(effective_mode(dev), M, N, K, flop_launch, k1_avg, k1_n, k1_avg * nk1 * steps / (1e3 * dt), info["kernel"])
+            tr = pmc_traffic({"cfg4_share8192": "cfg4_rows8192"}.get(name, name), effective_mode(dev))
             res[name] = {"value": steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
-                         "mode": mode, "backend": backend, "shape": [M, N, K], "k1_kernel": roof["kernel"], "k1_ms": k1_avg,
-                         "roofline_bound": roof["bound"], "roofline_frac": roof["frac"], "k1_share_of_step": roof["k1_share_of_step"]}
+                         "mode": mode, "backend": backend, "shape": [M, N, K], "k1_kernel": roof["kernel"] + ("<chain %d>" % info["chain"] if info["chain"] else ""),
+                         "k1_ms": k1_avg, "tail_ms": 1e3 * dt / steps - nk1 * k1_avg,      # the step minus its K1 launches: update kernels, step rule, gaps
+                         "roofline_bound": roof["bound"], "roofline_frac": roof["frac"], "k1_share_of_step": roof["k1_share_of_step"],
+                         # HBM bytes per K1 launch from rocprofv3 PMC passes over THIS build (profiles/k1_traffic.json, hash-checked), else null
+                         "traffic": tr["bytes_per_launch"] if tr else None, "algorithmic_bytes": M * N * 4,
+                         "traffic_over_algorithmic": (tr["bytes_per_launch"] / float(M * N * 4)) if tr else None}
             dev.close()
             del dev
         except Exception as exc:                                   # a side measurement must never take the headline down
@@ -356,9 +361,9 @@ def main():
         M = args.rows
 
     if world > 1 or os.environ.get("PMX_FORCE_SHARDED"):
-        from proxmin_amd import distributed as pdist
+        import bench_multi
         args.mode_dtype, args.mode_desc = MODE_DTYPE, MODE_DESC
-        out = pdist.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
+        out = bench_multi.bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local)
         if rank == 0:
             if rccl_log:
                 out["rccl"] = rccl_debug_excerpt(rccl_log)
@@ -417,6 +422,7 @@ def main():
         "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
         "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
                                    k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"]),
+        "tail_ms": 1e3 * dt / args.steps - (2 if backend == "bsdmm" else 1) * k1_avg_ms,     # the step minus its K1 launches
     }
     info = dev.k1_info()
     if info["chain"]:

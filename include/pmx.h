@@ -157,6 +157,18 @@ int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
  * from it. */
 int pmx_set_timing(pmx_ctx* ctx, int on);
 int pmx_get_timing(pmx_ctx* ctx, double* total_ms, int* launches);
+/* Row-sharded runs (pmx_*_phase): a per-phase timeline of a rank's iteration from HIP events on the context's stream, every
+ * `every`-th iteration (0: off).  pmx_get_phase_timing returns the mean duration in ms of
+ *   [0] phase 0 up to and including K1 (operand maxima / fp16 split of A / Gram launches that precede it included)
+ *   [1] the rest of phase 0 (k_shard_pack*: gS slabs folded into the collective's buffer)
+ *   [2] end of phase 0 -> start of phase 1: the collective the caller enqueued in between (all-reduce / reduce-scatter)
+ *   [3] phase 1 up to the update (k_shard_post*, the step rule of the sharded pgm / bsdmm)
+ *   [4] the update (fused adaprox tail, or the kernels it stands for; pgm / bsdmm block updates)
+ *   [5] end of phase 1 -> start of the next phase 0 (S-split: the all-gather of S; else ~0)
+ * and the number of iterations averaged (synchronises the stream).  bench.py --gpus N prints it as "phases_ms" so that a
+ * multi-GPU line explains itself. */
+int pmx_set_phase_timing(pmx_ctx* ctx, int every);
+int pmx_get_phase_timing(pmx_ctx* ctx, double ms[6], int* iterations);
 /* average duration (ms, HIP events) of `reps` back-to-back launches of K1 at the current factors with
  * only the requested outputs (do_A / do_S; 0,0 = residual + loss only): kernel ablation for tuning. */
 int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "pmx_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "pmx_set_phase_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "pmx_get_phase_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pmx_time_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmx_k1_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pmx_grad": (C.c_int, [C.c_void_p]),

@@ -536,7 +536,10 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
     if closures is not None:
         _warn_host_path("proxs_f / steps_f_cb (%r, %r)" % closures)
         Xt = utils._as_tuple(X)
-        assert len(Xt) == 2, "X must be [A, S]"
+        if (len(Xt) != 2 or np.ndim(Xt[0]) != 2 or np.ndim(Xt[1]) != 2 or np.shape(Xt[0])[1] != np.shape(Xt[1])[0]):
+            raise NotImplementedError("bsdmm with generic proxs_f / steps_f_cb closures runs on the device only for a two-block problem "
+                                      "X = [A (M x K), S (K x N)] (got blocks of shapes %s); other block structures are outside the "
+                                      "NMF/CMF path this library implements" % ([np.shape(x) for x in Xt],))
         Y, A, S, W = None, Xt[0], Xt[1], None
     else:
         Y, A, S, W = _problem_from_grad(X, grad)
@@ -621,6 +624,8 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
                     hf = host_f[j] is not None or closures is not None
                     mask = sum(1 << i for i, h in enumerate(host_g[j]) if h is not None)
                     user_sf = float(closures[1]((A, S), j=j)) if closures is not None else 0.0   # steps_f_cb(X, j=j) (algorithms.py:807)
+                    if closures is not None and not user_sf > 0.0:
+                        raise ValueError("steps_f_cb returned %r for block %d: a positive step is required" % (user_sf, j))
                     r0 = dev.bsdmm_split(j, 0, hf, mask, step_f=user_sf)
                     step_f = dt.type(r0.steps[j])
                     rows = A.shape[0] if j == 0 else S.shape[1]

@@ -2173,7 +2173,9 @@ bool grad_bf16_reads_fp32(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
 bool grad_bf16_takes_weights(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
     return grad_bf16_reads_fp32(p, M, N, K) && p.variant >= 7 && (N % (V5_NB * V5_BN)) == 0;
 }
-hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float* A, const float* St, hipStream_t stream, int* nloss) {
+// took_f16 (optional): whether the two-term fp16 kernel is what runs -- a context in mode f16x2 drops to the split-bf16 kernel of
+// the same frame at launch time when Y (or W) cannot be fetched eight bytes at a time (odd pitch, misaligned base, ldW != ldY)
+hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float* A, const float* St, hipStream_t stream, int* nloss, bool* took_f16 = nullptr) {
     GradBfArgs a = a_;
     a.gridX = p.gridX;
     a.gridY = p.gridY;
@@ -2194,7 +2196,9 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
         const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)
-        if (a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0 && pairs_ok) return grad_launch_f16_v8(g, stream);
+        const bool f16 = a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0 && pairs_ok;
+        if (took_f16) *took_f16 = f16;
+        if (f16) return grad_launch_f16_v8(g, stream);
         if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
         return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
     }

@@ -13,12 +13,14 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <string>
 #include <algorithm>
 
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
 #include <dlfcn.h>
+#include <link.h>
 #include "pmx_common.h"
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
@@ -81,6 +83,7 @@ struct pmx_ctx {
     bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
     bool k128 = false;                     // mode F16X2, K = 128 at a shape k_grad_f16_k128 takes
     bool f32pc = false;                    // exact-fp32 arithmetic at a shape the producer / consumer kernel k_grad_f32_pc takes
+    bool f16_fell_back = false;            // use_f16, but the last launch ran the split-bf16 kernel (Y / W not fetchable in 8-byte pairs)
     bool f16_scales = false;               // use_f16 || k128: the K1 kernel needs the factor maxima (absmax) and max|Y|
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
@@ -99,6 +102,9 @@ struct pmx_ctx {
     int nSlabA = 0;                        // gA slabs the update kernels fold (plan.nSlabA, or one per chain group)
     int nSlabS = 0;                        // gSt slabs
     int chainFaults = 0;                   // times the chained mode was left after a fault
+    // test hooks, read from the environment ONCE when the context is created (never on a launch path):
+    int hook_inject_k1 = 0;                //   PMX_INJECT_K1_FAULT=n: the n-th chained K1 launch reports a fault
+    std::string hook_tail_lockfile;        //   PMX_TAIL_LOCKFILE: several processes on ONE GPU take turns with the persistent tail
     bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
     GridBar* gridbar = nullptr;            // its barrier state
     long long* tailprof = nullptr;         // PMX_TAIL_PROF=1: phase time stamps of the last fused tail
@@ -145,6 +151,13 @@ struct pmx_ctx {
     unsigned timing_seq = 0;
     std::vector<hipEvent_t> ev;            // pairs
     size_t ev_used = 0;
+
+    // per-phase timeline of the row-sharded iteration (pmx_set_phase_timing): events + their marks (0..6), in record order
+    int ph_every = 0;
+    unsigned ph_seq = 0;
+    bool ph_cur = false, ph_prev = false;   // this / the previous iteration is a timed one
+    std::vector<hipEvent_t> ph_ev;
+    std::vector<int> ph_mark;
 
     // multi-GPU
     int rank = 0, world = 1;
@@ -281,6 +294,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         if (e != hipSuccess) { delete c; FAIL(PMX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
+    if (const char* e = getenv("PMX_INJECT_K1_FAULT")) c->hook_inject_k1 = atoi(e);
+    if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     c->use_small = grad_small_applies(M, N, K);
     c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
     c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K));
@@ -339,6 +354,7 @@ extern "C" int pmx_ctx_destroy(pmx_ctx* c) {
     (void)pmx_comm_destroy(c);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ph_ev) (void)hipEventDestroy(e);
     if (c->hstatus) (void)hipHostFree(c->hstatus);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -382,9 +398,59 @@ extern "C" int pmx_get_timing(pmx_ctx* c, double* total_ms, int* launches) {
     return PMX_OK;
 }
 
+// mark m of the sharded iteration's timeline: 0 phase-0 start, 1 K1 done, 2 phase-0 end, 3 phase-1 start, 4 post done,
+// 5 phase-1 end, 6 next phase-0 start (recorded for the iteration BEFORE the one mark 0 opens)
+static int phase_mark(pmx_ctx* c, int m) {
+    if (c->ph_every <= 0) return PMX_OK;
+    if (m == 0) {
+        if (c->ph_prev && c->ph_mark.size() < c->ph_ev.size()) {
+            HIP_CHECK(hipEventRecord(c->ph_ev[c->ph_mark.size()], c->stream));
+            c->ph_mark.push_back(6);
+        }
+        c->ph_cur = (c->ph_seq++ % (unsigned)c->ph_every) == 0 && c->ph_mark.size() + 8 <= c->ph_ev.size();
+        c->ph_prev = c->ph_cur;
+    }
+    if (!c->ph_cur) return PMX_OK;
+    HIP_CHECK(hipEventRecord(c->ph_ev[c->ph_mark.size()], c->stream));
+    c->ph_mark.push_back(m);
+    return PMX_OK;
+}
+extern "C" int pmx_set_phase_timing(pmx_ctx* c, int every) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (every > 0 && c->ph_ev.empty()) {
+        c->ph_ev.resize(4096);
+        for (auto& e : c->ph_ev) HIP_CHECK(hipEventCreate(&e));
+    }
+    c->ph_every = every > 0 ? every : 0;
+    c->ph_seq = 0;
+    c->ph_cur = c->ph_prev = false;
+    c->ph_mark.clear();
+    return PMX_OK;
+}
+extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
+    if (!c || !ms || !iterations) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i + 1 < c->ph_mark.size(); ++i) {
+        const int a = c->ph_mark[i], b = c->ph_mark[i + 1];
+        if (b != a + 1 || a > 5) continue;               // (a mark-6 event closes an iteration; 0 opens the next)
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, c->ph_ev[i], c->ph_ev[i + 1]));
+        sum[a] += t;
+        cnt[a] += 1;
+    }
+    for (int a = 0; a < 6; ++a) ms[a] = cnt[a] ? sum[a] / cnt[a] : 0.0;
+    *iterations = cnt[0];
+    return PMX_OK;
+}
+
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -715,7 +781,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
             }
             g.chainL = c->chainL; g.chainStride = grad_k128_chain_stride(c->plan, c->chainL);
             g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
-            g.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
+            g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
@@ -754,10 +820,12 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
                 c->chainSeq = 0;
             }
             g.chainL = c->chainL; g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
-            g.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
+            g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
-        HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss));
+        bool took_f16 = false;
+        HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss, &took_f16));
+        c->f16_fell_back = c->use_f16 && !took_f16;      // (pmx_k1_info reports the kernel that ran)
     } else {
         const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -768,7 +836,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
             }
             GradArgs gc = g;
             gc.chainL = c->chainL; gc.chainFlags = c->chainFlags; gc.chainBase = (++c->chainSeq) * 64u; gc.wstatus = c->dstatus;
-            gc.chainInject = getenv("PMX_INJECT_K1_FAULT") && (int)c->chainSeq == atoi(getenv("PMX_INJECT_K1_FAULT"));   // tests
+            gc.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
             HIP_CHECK(grad_launch_f32pc(c->plan, gc, c->stream));
         } else
         HIP_CHECK(c->use_small ? grad_launch_small(c->plan, g, c->stream) : (c->f32pc ? grad_launch_f32pc(c->plan, g, c->stream) : grad_launch_f32(c->plan, g, c->stream)));
@@ -952,6 +1020,7 @@ extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!out) FAIL(PMX_E_INVALID, "out is NULL");
+    if (c->host_grad) FAIL(PMX_E_UNSUPPORTED, "pmx_loglike: this context runs on a caller-supplied gradient (pmx_set_host_grad) and has no Y to evaluate the likelihood on");
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
     rc = enqueue_grad(c, c->X[0], c->X[1], 0, 0);
     if (rc != PMX_OK) return rc;
@@ -1341,7 +1410,7 @@ extern "C" int pmx_pgm_set_fixed_steps(pmx_ctx* c, const double steps[2]) {
     HIP_CHECK(hipSetDevice(c->device));
     c->pgm.fixed_steps[0] = steps[0];
     c->pgm.fixed_steps[1] = steps[1];
-    return set_fixed_steps(c, steps);
+    return set_fixed_steps(c, c->pgm.fixed_steps);    // (the context's own copy: the asynchronous upload outlives the caller's array)
 }
 
 extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
@@ -1653,9 +1722,9 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
     // PMX_TAIL_LOCKFILE (tests only): several processes share ONE GPU -- their persistent tails (one workgroup per CU each,
     // a census barrier at the top) cannot be resident together, so each is run to completion under an inter-process lock.
     // The product configuration is one process per GPU and never sets it.
-    static const char* lockfile = getenv("PMX_TAIL_LOCKFILE");
+    const char* lockfile = c->hook_tail_lockfile.empty() ? nullptr : c->hook_tail_lockfile.c_str();   // (read once, at pmx_ctx_create)
     int lockfd = -1;
-    if (lockfile && *lockfile) {
+    if (lockfile) {
         lockfd = open(lockfile, O_CREAT | O_RDWR, 0600);
         if (lockfd < 0) FAIL(PMX_E_STATE, "PMX_TAIL_LOCKFILE: cannot open %s", lockfile);
         HIP_CHECK(hipStreamSynchronize(c->stream));          // everything this rank enqueued before the tail has left the GPU
@@ -1922,6 +1991,9 @@ extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigne
     if (j != 0 && j != 1) FAIL(PMX_E_INVALID, "block %d out of range", j);
     const pmx_bsdmm_params& p = c->bsd;
     if (host_g >> p.n_g[j]) FAIL(PMX_E_INVALID, "host_g names a constraint that does not exist");
+    // step_f_host: 0 = "no user step" (the device's Lipschitz rule); anything else must be a usable step -- a negative or NaN
+    // value from a user steps_f_cb must not fall through to the NMF rule of a context that may have no NMF gradient at all
+    if (phase == 0 && !(step_f_host >= 0.0)) FAIL(PMX_E_INVALID, "block %d: the user step %g is not a positive number", j, step_f_host);
     auto args = [&](int stage) {
         BsdmmArgs u{};
         u.X = c->X[j];
@@ -2199,11 +2271,16 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
     }
     switch (phase) {
         case 0:
-            rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, c->absmax_by_finish);
+            rc = phase_mark(c, 0);
+            if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1, c->absmax_by_finish);
+            if (rc == PMX_OK) rc = phase_mark(c, 1);
             if (rc != PMX_OK) return rc;
-            return c->ssplit ? shard_pack_split(c, 1) : shard_pack(c, 1);
+            rc = c->ssplit ? shard_pack_split(c, 1) : shard_pack(c, 1);
+            return rc == PMX_OK ? phase_mark(c, 2) : rc;
         case 1: {
-            rc = c->ssplit ? shard_post_split(c, it > 0) : shard_post(c, it > 0);
+            rc = phase_mark(c, 3);
+            if (rc == PMX_OK) rc = c->ssplit ? shard_post_split(c, it > 0) : shard_post(c, it > 0);
+            if (rc == PMX_OK) rc = phase_mark(c, 4);
             if (rc != PMX_OK) return rc;
             if (c->tail_fused) {
                 c->shard_grad_from_comm = true;
@@ -2211,7 +2288,7 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
                 c->shard_grad_from_comm = false;
                 // S-split: the tail saw this rank's columns of S only; the next K1 measures the operand maxima itself
                 c->absmax_by_finish = rc == PMX_OK && !c->ssplit;
-                return rc;
+                return rc == PMX_OK ? phase_mark(c, 5) : rc;
             }
             c->shard_grad_from_comm = true;
             rc = ada_enqueue_moment(c, it, b1_it, b1_prev);
@@ -2225,7 +2302,7 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
             r.enq = ada_enqueue_subs(c, 0, ns);
             rc = ada_enqueue_tail(c, r.enq);
             c->absmax_by_finish = rc == PMX_OK && !c->ssplit;
-            return rc;
+            return rc == PMX_OK ? phase_mark(c, 5) : rc;
         }
         case 2: return c->ssplit ? shard_pack_split(c, 0) : shard_pack(c, 0);
         case 3: return c->ssplit ? shard_post_split(c, 1) : shard_post(c, 1);
@@ -2273,24 +2350,31 @@ extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     switch (phase) {
         case 0:
+            rc = phase_mark(c, 0);
+            if (rc != PMX_OK) return rc;
             if (!p.use_fixed_steps) {
                 rc = enqueue_gram_only(c, A, St, true, true);
                 if (rc != PMX_OK) return rc;
             }
             rc = enqueue_grad(c, A, St, 1, 1);
+            if (rc == PMX_OK) rc = phase_mark(c, 1);
             if (rc != PMX_OK) return rc;
-            return shard_pack(c, 1, !p.use_fixed_steps, 0);
+            rc = shard_pack(c, 1, !p.use_fixed_steps, 0);
+            return rc == PMX_OK ? phase_mark(c, 2) : rc;
         case 1:
-            rc = shard_post(c, it > 0);
+            rc = phase_mark(c, 3);
+            if (rc == PMX_OK) rc = shard_post(c, it > 0);
             if (rc != PMX_OK) return rc;
             if (p.use_fixed_steps) rc = set_fixed_steps(c, p.fixed_steps);
             else {
                 rc = shard_gram_in(c);
                 if (rc == PMX_OK) rc = enqueue_eig_only(c, true, true, (double)p.step_scale);
             }
+            if (rc == PMX_OK) rc = phase_mark(c, 4);
             if (rc != PMX_OK) return rc;
             c->it += 1;
-            return pgm_enqueue_update(c, true, 0);
+            rc = pgm_enqueue_update(c, true, 0);
+            return rc == PMX_OK ? phase_mark(c, 5) : rc;
         case 2: return shard_pack(c, 0, false, 0);
         case 3: return shard_post(c, 1);
         default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
@@ -2349,22 +2433,26 @@ extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
         FAIL(PMX_E_UNSUPPORTED, "row-sharded bsdmm runs the default update order (A, then S) only");
     if (phase == 0) {
         // A step: everything is local (step_A comes from the replicated S)
-        rc = enqueue_steps(c, c->X[0], c->X[1], true, false, 1.0);
+        rc = phase_mark(c, 0);
+        if (rc == PMX_OK) rc = enqueue_steps(c, c->X[0], c->X[1], true, false, 1.0);
         if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], 1, 0);
         if (rc == PMX_OK) rc = bsdmm_enqueue_block(c, 0, false, nullptr, 0);
         // S step, local part: Gram of the UPDATED A, gS with the updated A, pack
         if (rc == PMX_OK) rc = enqueue_gram_only(c, c->X[0], c->X[1], true, false);
         if (rc == PMX_OK) rc = enqueue_grad(c, c->X[0], c->X[1], 0, 1);
+        if (rc == PMX_OK) rc = phase_mark(c, 1);            // (both K1 launches and the A step between them)
         if (rc == PMX_OK) rc = shard_pack(c, 1, true, 4 * p.n_g[0]);
-        return rc;
+        return rc == PMX_OK ? phase_mark(c, 2) : rc;
     }
     if (phase == 1) {
-        rc = shard_gram_in(c);
+        rc = phase_mark(c, 3);
+        if (rc == PMX_OK) rc = shard_gram_in(c);
         if (rc == PMX_OK) rc = enqueue_eig_only(c, true, false, 1.0);                   // lmax(A^T A) -> step_S
         if (rc == PMX_OK) rc = bsdmm_enqueue_decide(c, 0, scal, c->M_global * c->K);    // block A on the global norms
+        if (rc == PMX_OK) rc = phase_mark(c, 4);
         if (rc == PMX_OK) rc = bsdmm_enqueue_block(c, 1, true, nullptr, 0);
         if (rc == PMX_OK) rc = bsdmm_enqueue_decide(c, 1, nullptr, c->N * c->K);
-        return rc;
+        return rc == PMX_OK ? phase_mark(c, 5) : rc;
     }
     FAIL(PMX_E_INVALID, "bad phase %d", phase);
 }
@@ -2466,10 +2554,28 @@ int rccl_load() {
     if (g_rccl.handle) return PMX_OK;
     const char* names[] = {getenv("PMX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (int pass = 0; pass < 2 && !h; ++pass)            // first what the process has loaded already (one RCCL per process)
-        for (const char* n : names)
-            if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-    if (!h) FAIL(PMX_E_UNSUPPORTED, "RCCL not found (librccl.so.1; set PMX_RCCL_LIB): %s", dlerror());
+    for (const char* n : names)                            // first what the process has loaded already (one RCCL per process)
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h && !getenv("PMX_RCCL_LIB")) {
+        // An RCCL under another name may be mapped already (torch ships its own): loading the system library beside it would
+        // bring a second HIP runtime into the process (_lib.py).  Look through the loaded objects before loading anything.
+        struct Probe { char path[512]; } probe{};
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) {
+            const char* nm = info->dlpi_name;
+            if (nm && strstr(nm, "librccl") != nullptr) { snprintf(static_cast<Probe*>(data)->path, sizeof(Probe::path), "%s", nm); return 1; }
+            return 0;
+        }, &probe);
+        if (probe.path[0]) {
+            h = dlopen(probe.path, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (!h) FAIL(PMX_E_UNSUPPORTED, "an RCCL is mapped already (%s) but cannot be opened; set PMX_RCCL_LIB to the library to use", probe.path);
+        }
+    }
+    for (const char* n : names)
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        const char* why = dlerror();
+        FAIL(PMX_E_UNSUPPORTED, "RCCL not found (librccl.so.1; set PMX_RCCL_LIB): %s", why ? why : "no further detail from the loader");
+    }
     RcclApi a;
     a.handle = h;
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));

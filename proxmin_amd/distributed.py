@@ -161,22 +161,59 @@ class NativeRccl:
         return self.world
 
 
+def default_comm(backend):
+    """Who issues the per-iteration collectives when the caller does not say: RCCL through the C ABI ("native": every call
+    enqueued on the context's own stream by the library, no per-iteration stream bookkeeping in Python) whenever the process
+    group itself runs on RCCL (backend "nccl": one GPU per rank, the library loadable by construction); torch.distributed for
+    anything else (gloo: the CPU protocol tests and several ranks on one GPU, where RCCL refuses to run)."""
+    return "native" if "nccl" in str(backend).lower() else "torch"
+
+
 def _collectives(comm, dev, rank, world, group):
     """`comm`: "torch" (torch.distributed on the current stream) | "native" (RCCL through the C ABI, bootstrapped over the
-    process group that is there anyway) | None: $PMX_COMM, default "torch"."""
+    process group that is there anyway) | None: $PMX_COMM, else default_comm(backend of the group) -- [r4] native on RCCL."""
     import torch.distributed as dist
-    comm = comm or os.environ.get("PMX_COMM", "torch")
+    comm_arg = comm
+    comm = comm or os.environ.get("PMX_COMM") or default_comm(dist.get_backend(group))
     if comm == "torch":
         return dist
     if comm != "native":
         raise ValueError("comm must be 'torch' or 'native'")
+    explicit = comm_arg is not None or bool(os.environ.get("PMX_COMM"))
 
     def broadcast(raw):
         box = [raw]
         if world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return box[0]
-    return NativeRccl.bootstrap(dev, rank, world, broadcast)
+    # Join the communicator and prove it on a known answer before the solver depends on it; the ranks then AGREE (over the
+    # process group that is there anyway) on whether every one of them succeeded.  Asked for explicitly, a failure raises;
+    # chosen by default, the run goes on with torch.distributed's collectives and says so.
+    import torch
+    err, nat = None, None
+    try:
+        nat = NativeRccl.bootstrap(dev, rank, world, broadcast)
+        probe = torch.full((256,), float(rank + 1), dtype=torch.float32, device=torch.device("cuda", dev.device))
+        torch.cuda.synchronize(dev.device)
+        nat.all_reduce(probe)
+        dev.sync()
+        if not bool((probe == float(world * (world + 1) // 2)).all().item()):
+            err = _lib.PmxError("native RCCL all-reduce self-test: wrong sum")
+    except Exception as exc:           # noqa: BLE001 -- whatever went wrong, the ranks must still agree below
+        err = exc
+    if world > 1:
+        okf = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float32, device=torch.device("cuda", dev.device))
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN, group=group)
+        all_ok = bool(okf.item() >= 1.0)
+    else:
+        all_ok = err is None
+    if all_ok:
+        return nat
+    if explicit:
+        raise err if err is not None else _lib.PmxError("native RCCL collectives failed on another rank")
+    import logging
+    logging.getLogger("proxmin").warning("native RCCL collectives unavailable (%s): using torch.distributed's", err if err is not None else "failed on another rank")
+    return dist
 
 
 class ShardedAdaproxDriver:
@@ -223,7 +260,12 @@ class ShardedAdaproxDriver:
             t_enq = self.nsub
             while halted and reason == HALT_NEED_SUB:
                 # iteration `it_done` ran out of proximal sub-iteration passes (same on every rank: the
-                # S block is replicated and A's projection-type prox never needs more than two passes)
+                # S block is replicated and A's projection-type prox never needs more than two passes).
+                # Under S-split every rank owns other columns of S: a rank-local shortage would re-enqueue collectives on
+                # one rank only -- S-split is restricted to projection-type prox_S so that this cannot happen.
+                if getattr(self.eng, "s_split", False):
+                    raise _lib.PmxError("S-split: a rank-local proximal loop ran out of passes (HALT_NEED_SUB); projection-type "
+                                        "operators never do -- refusing to re-enqueue collectives on one rank only")
                 more = min(max(4, t_enq), 64)
                 self.eng.more_subs(t_enq, more)
                 t_enq += more
@@ -323,6 +365,10 @@ class ShardEngine:
             ptr, n = C.c_void_p(), C.c_int64()
             _lib.check(lib.pmx_buffer_ptr(dev.h, _lib.BUF_ST, C.byref(ptr), C.byref(n)))
             self.st_full = _device_tensor(ptr.value, n.value, dev.device)      # S^T (N x K) as the library holds it
+            # the all-gather must land in the library's own buffer: a tensor that COPIED it would leave K1 reading stale columns
+            if self.st_full.data_ptr() != ptr.value or self.st_full.numel() != n.value:
+                raise _lib.PmxError("S-split: torch did not alias the library's S^T buffer (%#x, %d floats) but made a copy"
+                                    % (ptr.value, n.value))
             return
         cnt = C.c_int64()
         offs = (C.c_int64 * 3)()
@@ -487,124 +533,3 @@ def nmf_bsdmm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, p
         r = _lib.Result()
         _lib.check(dev.lib.pmx_iter_result(dev.h, C.byref(r)))
     return [bool(r.converged[0]), bool(r.converged[1])], its
-
-
-def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
-    """bench.py leg for --gpus N > 1: rows of Y / A sharded over the ranks (strong scaling)."""
-    import torch
-    import torch.distributed as dist
-    from functools import partial
-    from . import operators as ops
-    from .engine import DeviceNMF
-
-    # PMX_DIST_BACKEND / PMX_BENCH_DEVICE: test-only overrides (two ranks on one GPU over gloo; RCCL needs a GPU per rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")      # (PMX_FORCE_SHARDED=1 without a launcher: a world of one)
-    os.environ.setdefault("MASTER_PORT", "29531")
-    if not dist.is_initialized():
-        dist.init_process_group(backend=os.environ.get("PMX_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    if "PMX_BENCH_DEVICE" in os.environ:
-        local = int(os.environ["PMX_BENCH_DEVICE"])
-        torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    r0, r1 = shard_rows(M, world)[rank]
-    Ml = r1 - r0
-    g = torch.Generator(device=device)
-    g.manual_seed(1234)
-    At = torch.rand((M, K), generator=g, device=device, dtype=torch.float32)
-    St = torch.rand((K, N), generator=g, device=device, dtype=torch.float32)
-    if unity:
-        St /= St.sum(0, keepdim=True)
-    g.manual_seed(1234 + 7919 * (rank + 1))
-    Y = At[r0:r1] @ St
-    Y += 0.01 * torch.randn((Ml, N), generator=g, device=device, dtype=torch.float32)
-    del At, St
-    rng = np.random.default_rng(1234)
-    A0 = rng.random((M, K), dtype=np.float32)[r0:r1].copy()
-    S0 = rng.random((K, N), dtype=np.float32)
-    if unity:
-        S0 /= S0.sum(0, keepdims=True)
-    torch.cuda.synchronize()
-    tstream = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(tstream)          # collectives order against the current stream
-    dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream, mode=getattr(args, "mode", None))
-    dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
-    dev.set_factors(A0, S0)
-    # PMX_BENCH_FAKE_WORLD=W (single process): this GPU plays rank 0 of W -- M is the rank's share, the collectives are local
-    fake = int(os.environ.get("PMX_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
-    eff_world = fake if fake > 1 else world
-    # S-split whenever it applies: adaprox with a projection-type prox_S (cfg4), N divisible by the rank count
-    s_split = backend == "adaprox" and not unity and eff_world > 1 and N % eff_world == 0 and os.environ.get("PMX_S_SPLIT", "1") != "0"
-    eng = ShardEngine(dev, eff_world, 0 if fake > 1 else rank, M * fake if fake > 1 else M, backend, s_split=s_split)
-    pA = ops.device_proxseq(ops.prox_plus, 0)
-    pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
-    # adaprox: the untimed warm-up continues until the proximal loops are past their start-up transient (as in the
-    # single-GPU leg of bench.py), at least 20 iterations
-    warm = max(args.warmup, 20) if backend == "adaprox" else args.warmup
-    total = warm + args.steps
-    # the collectives: local stand-ins when one process plays rank 0 of W, else torch.distributed or ($PMX_COMM=native) RCCL
-    # through the C ABI
-    coll = OneRankOfMany() if fake > 1 else _collectives(None, dev, rank, world, None)
-    if backend == "adaprox":
-        dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
-        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, dist_module=coll)
-        b1 = np.full(total, 0.9)
-        run = lambda n: drv.run(n, b1)
-    elif backend == "pgm":
-        dev.pgm_begin([pA, pS], accelerated=False, e_rel=(1e-12, 1e-12))
-        loop = ShardedLoop(eng, None, deferred_test=True, dist_module=coll)
-        run = loop.run
-    else:
-        pg = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=1e-3), 0)]
-        dev.bsdmm_begin([pA, pS], [pg, pg], e_rel=(1e-12, 1e-12), e_abs=(0.0, 0.0))
-        loop = ShardedLoop(eng, None, deferred_test=False, dist_module=coll)
-        run = loop.run
-    run(warm)
-    dev.set_timing(True, every=4)   # HIP events around every 4th K1 launch of the timed region
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t1 = time.perf_counter()
-    k1_ms, k1_n = dev.get_timing()
-    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    k1 = torch.tensor([k1_ms / max(k1_n, 1)], dtype=torch.float64, device=device)
-    dist.all_reduce(k1, op=dist.ReduceOp.MAX)
-    k1_avg_ms = float(k1.item())
-    nk1 = 2 if backend == "bsdmm" else 1            # bsdmm: two K1 launches of 4 MNK each per iteration
-    flop_per_it = (8.0 if backend == "bsdmm" else 6.0) * M * N * K
-    info = dev.k1_info()
-    eff_mode = "f32" if info["kernel"] in ("k_grad_f32", "k_grad_f32_pc") else dev.mode      # a split mode falls back to fp32 where it has no kernel
-    its = args.steps / dt
-    ach = (flop_per_it / nk1 * Ml / M) / (k1_avg_ms * 1e-3) / 1e12
-    out = {
-        "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
-        "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": getattr(args, "mode_dtype", {}).get(eff_mode, eff_mode), "data": "synthetic",
-        "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": getattr(args, "mode_desc", {}).get(eff_mode, eff_mode),
-                   "parallelism": ("rows of Y/A sharded over %d GPUs; S update sharded as well: one RCCL reduce-scatter of gS (%d floats) + one all-gather of S per iteration" if s_split else
-                                   "rows of Y/A sharded over %d GPUs, one RCCL all-reduce of gS (%d floats) per iteration") % (eff_world, eng.layout.count)
-                                  + ("; ONE process playing rank 0 of %d (local collectives)" % fake if fake > 1 else "")},
-        "gflops": flop_per_it * its / 1e9,
-        "roofline": ({"kernel": info["kernel"], "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
-                      "frac": ach / 157.3, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info} if eff_mode == "f32" else
-                     {"kernel": "k_grad_f16_k128", "bound": "mfma", "achieved": 3.0 * ach, "peak": 2500.0, "unit": "TFLOP/s",
-                      "frac": 3.0 * ach / 2500.0, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
-                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info,
-                      "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC)"} if info["kernel"] == "k_grad_f16_k128" else
-                     {"kernel": ((("k_grad_f16_v8" + ("<chain %d>" % info["chain"] if info["chain"] else "") if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
-                                 else "k_grad_bf16"), "bound": "hbm", "k1_layout": info,
-                      "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,
-                      "unit": "GB/s", "frac": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                      "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
-                      "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt)}),
-    }
-    dev.close()
-    dist.destroy_process_group()
-    return out

@@ -165,6 +165,18 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_get_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    PHASES = ("k1_with_prologue", "pack", "collective", "post", "update", "after_update_to_next_k1")
+
+    def set_phase_timing(self, every=4):
+        """Row-sharded runs: HIP-event timeline of every `every`-th iteration's phases (include/pmx.h: pmx_set_phase_timing); 0: off."""
+        _lib.check(self.lib.pmx_set_phase_timing(self.h, int(every)))
+
+    def get_phase_timing(self):
+        """({phase: mean ms}, iterations averaged) since set_phase_timing."""
+        ms, n = (C.c_double * 6)(), C.c_int()
+        _lib.check(self.lib.pmx_get_phase_timing(self.h, ms, C.byref(n)))
+        return {k: ms[i] for i, k in enumerate(self.PHASES)}, n.value
+
     def time_grad(self, do_A=True, do_S=True, reps=10):
         """average K1 duration in ms (kernel ablation helper, includes the presplit kernel in bf16x3 mode)"""
         ms = C.c_double()
