@@ -2003,6 +2003,27 @@ struct PackArgs {
 // stop EVERY rank before the update of that iteration -- ranks can never disagree about which iterations were applied,
 // so they always issue the same number of collectives (a rank-local decision there would be a hang, not an error).
 constexpr int SHARD_HALT_SLOT = 31;
+// [r4] Grid = PACK_XWG "extras" workgroups in FRONT of the EW_BLOCKS that fold the gS slabs: the small sums are chains of dependent
+// round trips (column-sum fold, stopping sums, Gram copy) that workgroup 0 used to run BEHIND its share of the rows -- the whole
+// launch waited on that one workgroup (25 us for 25 MB of traffic); now they run beside the fold, one piece per workgroup.
+constexpr int PACK_XWG = 3;
+// four (or fewer) partial-sum folds with every load in flight before the first add; each sum in fold_partials' own order
+template <int NS>
+__device__ __forceinline__ void fold_partials_many(const double* const (&part)[NS], double (&out)[NS]) {
+    const int lane = threadIdx.x & 63;
+    double v[NS][EW_BLOCKS / 64];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < EW_BLOCKS / 64; ++i) v[q][i] = part[q][i * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < EW_BLOCKS / 64; ++i) t += v[q][i];
+        out[q] = wave_sum(t);
+    }
+}
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
     __shared__ double scratch[EW_WAVES];
@@ -2011,26 +2032,34 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
         return;
     }
     const int K = a.K;
-    if (a.fold_grad) {
-        ROW_LOOP_BEGIN(a.N)
-            bool ok[NC];
-            float g[NC];
+    if (blockIdx.x >= PACK_XWG) {
+        if (a.fold_grad) {
+            const int l32 = threadIdx.x & 31;
+            const int64_t hw_ = ((int64_t)(blockIdx.x - PACK_XWG) * EW_THREADS + threadIdx.x) >> 5;
+            const int64_t nhw_ = ((int64_t)EW_BLOCKS * EW_THREADS) >> 5;
+            for (int64_t r = hw_; r < a.N; r += nhw_) {
+                bool ok[NC];
+                float g[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
-            load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
+                for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+                load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (ok[c]) a.comm[r * K + l32 + 32 * c] = g[c];
-        ROW_LOOP_END
+                for (int c = 0; c < NC; ++c)
+                    if (ok[c]) a.comm[r * K + l32 + 32 * c] = g[c];
+            }
+        }
+        return;
     }
-    if (blockIdx.x == 0) {
-        float* ex = a.comm + a.N * K;
-        const int t = threadIdx.x;
+    float* ex = a.comm + a.N * K;
+    float* cs = ex + a.KP * a.KP;
+    float* sc = cs + MAXK;
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {               // Gram(A) (pgm / bsdmm) or zeros
         if (a.gramA != nullptr)
             for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = (float)a.gramA[e];
         else
             for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
-        float* cs = ex + a.KP * a.KP;
+    } else if (blockIdx.x == 1) {        // column sums of the local rows of A
         __shared__ double asum[ALPHA_NG][MAXK];
         colsum_fold(a.colpart, K, false, asum);   // block 0
         if (t < MAXK) {
@@ -2038,10 +2067,11 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack(PackArgs a) {
             for (int q = 0; q < ALPHA_NG; ++q) s += asum[q][t];
             cs[t] = (float)s;
         }
-        float* sc = cs + MAXK;
-        const double d = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, scratch);
-        const double n = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS, scratch);
-        if (t < 32) sc[t] = t == 0 ? (float)d : (t == 1 ? (float)n : 0.f);
+    } else {                             // stopping sums of block 0 (+ bsdmm's extra slots); [31] = the halt flag: 0 here
+        const double* const two[2] = {a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS};
+        double dn[2];
+        fold_partials_many<2>(two, dn);
+        if (t < 32) sc[t] = t == 0 ? (float)dn[0] : (t == 1 ? (float)dn[1] : 0.f);
         for (int i = 0; i < a.n_extra; ++i) {
             const double q = fold_partials(a.partials + ((int64_t)(SL_G0 + i) * 2 + 0) * EW_BLOCKS, scratch);
             if (t == 0) sc[2 + i] = (float)q;
@@ -2129,10 +2159,10 @@ struct PackSplitArgs {
     int fold_grad;
     int world;
     int64_t sncol, chunk;
+    int zero_gram;           // write zeros into every chunk's (unused) Gram section: the first pack into a buffer only
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a) {
-    __shared__ double scratch[EW_WAVES];
     const int64_t ex0 = a.sncol * a.K;                   // offset of the extras inside a chunk
     const int64_t sc0 = ex0 + (int64_t)a.KP * a.KP + 2 * MAXK;
     if (chain_halted(a.status)) {
@@ -2140,45 +2170,51 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a
         return;
     }
     const int K = a.K;
-    if (a.fold_grad) {
-        ROW_LOOP_BEGIN(a.N)
-            bool ok[NC];
-            float g[NC];
+    if (blockIdx.x >= PACK_XWG) {            // the fold of the gS slabs into the ranks' chunks (extras: the workgroups in front)
+        if (a.fold_grad) {
+            const int l32 = threadIdx.x & 31;
+            const int64_t hw_ = ((int64_t)(blockIdx.x - PACK_XWG) * EW_THREADS + threadIdx.x) >> 5;
+            const int64_t nhw_ = ((int64_t)EW_BLOCKS * EW_THREADS) >> 5;
+            for (int64_t r = hw_; r < a.N; r += nhw_) {
+                bool ok[NC];
+                float g[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
-            load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
-            const int q = (int)r / (int)a.sncol;             // (32-bit: a 64-bit division per row made this kernel twice as long)
-            float* dst = a.comm + (int64_t)q * a.chunk + (int64_t)((int)r - q * (int)a.sncol) * K;
+                for (int c = 0; c < NC; ++c) ok[c] = l32 + 32 * c < K;
+                load_grad<NC>(g, ok, a.slabS, a.N, K, r, l32);
+                const int q = (int)r / (int)a.sncol;             // (32-bit: a 64-bit division per row made this kernel twice as long)
+                float* dst = a.comm + (int64_t)q * a.chunk + (int64_t)((int)r - q * (int)a.sncol) * K;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (ok[c]) dst[l32 + 32 * c] = g[c];
-        ROW_LOOP_END
-    }
-    if (blockIdx.x == 0) {
-        const int t = threadIdx.x;
-        __shared__ double asum[ALPHA_NG][MAXK];
-        __shared__ float cs[2][MAXK];
-        for (int j = 0; j < 2; ++j) {
-            colsum_fold(a.colpart + (int64_t)j * EW_BLOCKS * MAXK, K, false, asum);
-            if (t < MAXK) {
-                double s = 0.0;
-                for (int q = 0; q < ALPHA_NG; ++q) s += asum[q][t];
-                cs[j][t] = (float)s;
+                for (int c = 0; c < NC; ++c)
+                    if (ok[c]) dst[l32 + 32 * c] = g[c];
             }
-            __syncthreads();
         }
-        double sums[4];
-        sums[0] = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, scratch);
-        sums[1] = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS, scratch);
-        sums[2] = fold_partials(a.partials + ((int64_t)SL_DIFF2 * 2 + 1) * EW_BLOCKS, scratch);
-        sums[3] = fold_partials(a.partials + ((int64_t)SL_NORM2 * 2 + 1) * EW_BLOCKS, scratch);
-        for (int q = 0; q < a.world; ++q) {
-            float* ex = a.comm + q * a.chunk + ex0;
+        return;
+    }
+    const int t = threadIdx.x;
+    if (blockIdx.x < 2) {                    // column sums of block j = blockIdx.x (local rows of A / own columns of S), into every chunk
+        const int j = blockIdx.x;
+        __shared__ double asum[ALPHA_NG][MAXK];
+        colsum_fold(a.colpart + (int64_t)j * EW_BLOCKS * MAXK, K, false, asum);
+        if (t < MAXK) {
+            double s = 0.0;
+            for (int q = 0; q < ALPHA_NG; ++q) s += asum[q][t];
+            const float v = (float)s;
+            for (int q = 0; q < a.world; ++q) a.comm[q * a.chunk + ex0 + (int64_t)a.KP * a.KP + j * MAXK + t] = v;
+        }
+        return;
+    }
+    // stopping sums of both blocks (+ the halt flag's zero), into every chunk.  The Gram section of a chunk (KP^2 floats: the
+    // layout's, unused by adaprox) is zeroed when the host says so (first pack after pmx_set_comm_buffer): nothing writes it
+    // afterwards, and one workgroup storing world x 64 KB of zeros per iteration was a third of this launch
+    const double* const four[4] = {a.partials + ((int64_t)SL_DIFF2 * 2 + 0) * EW_BLOCKS, a.partials + ((int64_t)SL_NORM2 * 2 + 0) * EW_BLOCKS,
+                                   a.partials + ((int64_t)SL_DIFF2 * 2 + 1) * EW_BLOCKS, a.partials + ((int64_t)SL_NORM2 * 2 + 1) * EW_BLOCKS};
+    double sums[4];
+    fold_partials_many<4>(four, sums);
+    for (int q = 0; q < a.world; ++q) {
+        float* ex = a.comm + q * a.chunk + ex0;
+        if (a.zero_gram)
             for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
-            float* c0 = ex + a.KP * a.KP;
-            if (t < MAXK) { c0[t] = cs[0][t]; c0[MAXK + t] = cs[1][t]; }
-            if (t < 32) c0[2 * MAXK + t] = t < 4 ? (float)sums[t] : 0.f;
-        }
+        if (t < 32) ex[a.KP * a.KP + 2 * MAXK + t] = t < 4 ? (float)sums[t] : 0.f;
     }
 }
 // after the reduce-scatter: global step sizes of BOTH blocks and the deferred outer test of the previous iteration
@@ -2283,9 +2319,9 @@ hipError_t launch_ada_tail(const TailArgs& a, hipStream_t s) {
     return launch_ada_tail_t<4>(a, s);
 }
 void launch_bsdmm_update(const BsdmmArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_bsdmm_update, dim3(EW_BLOCKS), s, a); }
-void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS), s, a); }
+void launch_shard_pack(const PackArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack, dim3(EW_BLOCKS + PACK_XWG), s, a); }
 void launch_shard_gram_in(const GramInArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_gram_in, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 void launch_shard_post(const ShardPostArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post, dim3(1), dim3(EW_THREADS), 0, s, a); }
-void launch_shard_pack_split(const PackSplitArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack_split, dim3(EW_BLOCKS), s, a); }
+void launch_shard_pack_split(const PackSplitArgs& a, hipStream_t s) { DISPATCH_NC(a.K, k_shard_pack_split, dim3(EW_BLOCKS + PACK_XWG), s, a); }
 void launch_shard_post_split(const ShardPostSplitArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_shard_post_split, dim3(1), dim3(EW_THREADS), 0, s, a); }
 void launch_bsdmm_decide(const BsdmmDecideArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bsdmm_decide, dim3(1), dim3(EW_THREADS), 0, s, a); }

@@ -163,6 +163,7 @@ struct pmx_ctx {
     int rank = 0, world = 1;
     int64_t M_global = 0;
     float* comm = nullptr;                 // caller-owned all-reduce buffer
+    bool comm_gram_dirty = true;           // S-split: the chunks' (unused) Gram sections have not been zeroed in this buffer yet
     bool shard_grad_from_comm = false;
     // S-split (pmx_set_s_split): the UPDATE of S is sharded too -- this rank owns the sncol columns of S from scol0 (rows of
     // S^T), their moments and proximal loop; gS arrives by reduce-scatter into comm_out, the updated columns leave by all-gather
@@ -2130,6 +2131,7 @@ extern "C" int pmx_set_comm_buffer(pmx_ctx* c, float* dptr, int64_t count) {
     if (count < comm_count(c)) FAIL(PMX_E_INVALID, "comm buffer too small: %lld < %lld", (long long)count, (long long)comm_count(c));
     if (c->W) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     c->comm = dptr;
+    c->comm_gram_dirty = true;
     return PMX_OK;
 }
 
@@ -2223,6 +2225,8 @@ static int shard_pack_split(pmx_ctx* c, int fold_grad) {
     p.world = c->world;
     p.sncol = c->sncol;
     p.chunk = split_chunk(c);
+    p.zero_gram = c->comm_gram_dirty ? 1 : 0;
+    c->comm_gram_dirty = false;
     launch_shard_pack_split(p, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
