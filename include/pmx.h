@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 2
+#define PMX_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------------------- */
 enum {
@@ -43,9 +43,15 @@ enum {
     /* (1 was a plain-bf16 mode -- Y rounded to bf16 in HBM -- that was never built: 2^-9 relative error on Y cannot meet
        the path's rtol 1e-4; the split modes below keep Y in fp32)                                                       */
     PMX_MODE_BF16X3 = 2, /* Y fp32 in HBM, operands split into bf16 terms (3 for A@S, 2 for the gradients), fp32 accumulate */
-    PMX_MODE_F16X2 = 3   /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes and K = 128 / M % 128 = 0 / N % 128 = 0
+    PMX_MODE_F16X2 = 3,  /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes and K = 128 / M % 128 = 0 / N % 128 = 0
                             shapes (the latter without weights) run the two-term fp16 kernels (power-of-two operand
                             scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
+    PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
+                            (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
+                            M, N <= 8192: the reference's own examples and BASELINE cfg1) and the pgm / FISTA back-end with
+                            this library's operators: pmx_set_Y_host_f64, pmx_upload_f64 / pmx_download_f64, pmx_pgm_begin,
+                            pmx_pgm_run, pmx_grad, pmx_loglike, pmx_iter_result; every other entry point returns
+                            PMX_E_UNSUPPORTED in such a context (the host wrappers compute those cases in fp32 as before) */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */
@@ -72,8 +78,10 @@ enum {
 typedef struct pmx_prox {
     int32_t op;
     int32_t unit;
-    float thresh;
+    double thresh;      /* [ABI v3] fp64 (was float): the fp64 contexts threshold with the caller's own value -- 0.01f differs from
+                           0.01 by 2e-8 relative; the fp32 kernels use (float)thresh exactly as before */
     int32_t relative;
+    int32_t reserved;   /* 0 */
 } pmx_prox;
 
 #define PMX_MAX_SEQ 4 /* AlternatingProjections of up to 4 built-ins (operators.py:187-211) */
@@ -145,6 +153,11 @@ int pmx_set_W_device(pmx_ctx* ctx, const float* dW, int64_t ld, int copy);
 /* raw float32 transfers host <-> one of the PMX_BUF_* arrays (count = number of floats) */
 int pmx_upload(pmx_ctx* ctx, int buf, const float* host, int64_t count);
 int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
+/* PMX_MODE_F64 contexts: Y (M x N, row pitch ld, copied) and the raw fp64 transfers of PMX_BUF_A / _ST (both directions)
+ * and PMX_BUF_GA / _GST (download: the gradient pgm returns, algorithms.py:144) */
+int pmx_set_Y_host_f64(pmx_ctx* ctx, const double* Y, int64_t ld);
+int pmx_upload_f64(pmx_ctx* ctx, int buf, const double* host, int64_t count);
+int pmx_download_f64(pmx_ctx* ctx, int buf, double* host, int64_t count);
 /* device address of a buffer (for zero-copy interop, e.g. torch.distributed on the comm buffer) */
 int pmx_buffer_ptr(pmx_ctx* ctx, int buf, void** dptr, int64_t* count);
 

@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "libpmx.so")   # PMX
 MAX_SEQ = 4
 MAX_G = 4
 MAXK = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums (include/pmx.h)
-MODE_F32, MODE_BF16X3, MODE_F16X2 = 0, 2, 3
+MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64 = 0, 2, 3, 4
 PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "max": 6,
         "hard": 7, "hard_plus": 8, "soft": 9, "soft_plus": 10}
 SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}
@@ -30,7 +30,7 @@ BUF_STEP_A = 64                       # + block: per-element steps of a user `st
 
 
 class Prox(C.Structure):
-    _fields_ = [("op", C.c_int32), ("unit", C.c_int32), ("thresh", C.c_float), ("relative", C.c_int32)]
+    _fields_ = [("op", C.c_int32), ("unit", C.c_int32), ("thresh", C.c_double), ("relative", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ProxSeq(C.Structure):
@@ -76,6 +76,9 @@ _SIGNATURES = {
     "pmx_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "pmx_set_Y_host_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_upload_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "pmx_download_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_set_phase_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_get_phase_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pmx_time_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -66,8 +66,15 @@ def _host_gradient(dev, grad, dt, accelerated_eval=True):
     return Xe
 
 
-def _open_device(Y, A, S, W):
-    """Context for one solver call; weights (nmf.py:13-41): engine.open_weighted picks the kernel."""
+def _open_device(Y, A, S, W, f64=False):
+    """Context for one solver call; weights (nmf.py:13-41): engine.open_weighted picks the kernel.  f64: the caller's
+    arrays are fp64 and the call is one the fp64 kernels cover (pgm / FISTA, small problem): compute in fp64 like the
+    reference does for fp64 inputs (nmf.py:39-41)."""
+    if f64:
+        dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64")
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        return dev
     if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
         dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
         dev.set_host_grad(True)
@@ -229,7 +236,11 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
-    with _open_device(Y, A, S, W) as dev:
+    # [r4] fp64 inputs of a small problem, everything of the iteration on the device: fp64 arithmetic (PMX_MODE_F64)
+    from .engine import f64_applies
+    f64 = (not slow and not backtracking and bb is None and W is None and Y is not None
+           and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+    with _open_device(Y, A, S, W, f64=f64) as dev:
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
                       e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
                       host_prox=[h is not None for h in host_prox])
@@ -579,11 +590,19 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
         """device sequence of an operator of this library; (prox_id, callable) for anything else (host round trip)"""
         q = q if q is not None else operators.prox_id
         try:
-            return operators.device_proxseq(q, j), None
-        except NotImplementedError:
+            return operators.device_proxseq(q, j, for_solver=True), None
+        except NotImplementedError as exc:
             if not callable(q):
                 raise
-            _warn_host_path("%s of block %d (%r)" % (what, j, q))
+            if isinstance(exc, operators.NotFusable):
+                # [r4] this library's prox_unity* along the block's LONG axis: its grid-wide sum exists as a stand-alone device
+                # kernel only, so the operator takes the same between-launches path a user callable takes (pmx_bsdmm_split) --
+                # calling it on the host copy runs that kernel; no host arithmetic
+                if "unity-long-bsdmm-%d" % j not in _warned:
+                    _warned.add("unity-long-bsdmm-%d" % j)
+                    logger.warning("proxmin_amd: %s: one iteration per call, its argument goes through the host" % exc)
+            else:
+                _warn_host_path("%s of block %d (%r)" % (what, j, q))
             return operators.device_proxseq(operators.prox_id, j), q
 
     seq_f, host_f = [], []

@@ -126,6 +126,10 @@ struct EigArgs {
     const float* X[2];
     int64_t rows[2];
     double* Gw;            // writable view of G
+    int force_exact;       // fp64 contexts: always finish with the exact solver (Lanczos + Sturm multisection: lambda to fp64
+                           // round-off).  The power iteration runs on the fp32 copy of G and is accepted at a residual of 1e-6
+                           // lambda, i.e. lambda to ~1e-12 / (relative gap) -- plenty for fp32 factors, 8e-10 in fp64 ones after
+                           // 25 iterations (measured against the reference's fixture)
 };
 // one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
@@ -248,7 +252,7 @@ __device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, c
     }
     const bool not_dominant = probe > l * (1.0 + 1e-5);
     int used_exact = 0;
-    if (l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant)) {
+    if (l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant || a.force_exact)) {
         // ---- Lanczos tridiagonalisation with full re-orthogonalisation (fp64), K steps = exact ---------
         __shared__ double al[MAXK], be[MAXK + 1], cdot[MAXK];
         __shared__ int nT;
@@ -436,7 +440,7 @@ __device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, co
     }
     if (ud > 0.0) probe = fmax(probe, un / ud);
     const bool not_dominant = probe > l * (1.0 + 1e-5);
-    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant);
+    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant || a.force_exact);
     if (!need_exact) {
         if (t == 0) {
             st->lam[f] = l;

@@ -186,7 +186,8 @@ __device__ __forceinline__ void prox_one(float (&v)[NC], const bool (&ok)[NC], c
         default: {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float t = p.relative ? p.thresh * sk[c] : p.thresh;   // operators.py:4-14
+                const float th = (float)p.thresh;                           // (fp32 arithmetic: the threshold as the fp32 value it always was)
+                const float t = p.relative ? th * sk[c] : th;               // operators.py:4-14
                 float x = v[c];
                 switch (p.op) {
                     case PMX_PROX_MIN: x = (x - t < 0.f) ? t : x; break;             // operators.py:66-68

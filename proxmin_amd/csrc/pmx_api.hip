@@ -28,6 +28,7 @@
 #include "k_grad_f32pc.hip"
 #include "k_update.hip"
 #include "k_gram.hip"
+#include "k_small_f64.hip"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -72,6 +73,15 @@ struct pmx_ctx {
     float* Ug[2][PMX_MAX_G] = {};
     float* bbX[2] = {nullptr, nullptr};    // Barzilai-Borwein X_prev
     float* bbG[2] = {nullptr, nullptr};    // Barzilai-Borwein G_prev
+
+    // PMX_MODE_F64 (small problems, pgm / FISTA: k_small_f64.hip): the context's arrays in fp64; none of the float arrays above exist
+    bool f64 = false;
+    double* Yd = nullptr;
+    double* Xd[2] = {nullptr, nullptr};
+    double* Xed[2] = {nullptr, nullptr};
+    double* Gd[2] = {nullptr, nullptr};
+    double* slabd[2] = {nullptr, nullptr};
+    int t64x = 0, t64y = 0;                // K1 tiles: column tiles (-> gA slabs), row tiles (-> gSt slabs)
 
     // K1
     bool host_grad = false;                // pmx_set_host_grad: the gradient is whatever the caller uploaded into PMX_BUF_GA / GST (user `grad` callable)
@@ -277,7 +287,10 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     if (K > MAXK) FAIL(PMX_E_UNSUPPORTED, "K=%lld > %d components is not supported", (long long)K, MAXK);
     if (M > (1ll << 30) || N > (1ll << 30)) FAIL(PMX_E_UNSUPPORTED, "dimension too large");
-    if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
+    if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2 && mode != PMX_MODE_F64) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
+    if (mode == PMX_MODE_F64 && !(grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192))
+        FAIL(PMX_E_UNSUPPORTED, "fp64 arithmetic is implemented for small problems only (K <= 16, M N <= 2^20, M, N <= 8192); %lld x %lld x %lld runs in fp32",
+             (long long)M, (long long)N, (long long)K);
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) FAIL(PMX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -314,6 +327,35 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
         c->chainL = grad_chain_length(c->plan, M, ncu, (c->use_f16 || c->k128) ? 16 : 32);
         if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
+    }
+    if (mode == PMX_MODE_F64) {              // fp64 context: its own arrays and kernels (k_small_f64.hip), nothing of the fp32 state
+        c->f64 = true;
+        c->use_small = true;
+        c->use_bf16 = c->use_f16 = c->k128 = c->f32pc = c->f16_scales = false;
+        c->chainL = 0;
+        c->t64x = (int)((N + SG_COLS - 1) / SG_COLS);
+        c->t64y = (int)((M + S64_ROWS - 1) / S64_ROWS);
+        c->nSlabA = c->t64x; c->nSlabS = c->t64y;
+        c->plan.gridX = c->t64y; c->plan.gridY = c->t64x; c->plan.RP = 1;
+        int rc64 = dallocT(c, &c->Yd, (size_t)M * N, false);
+        for (int j = 0; j < 2 && rc64 == PMX_OK; ++j) {
+            rc64 = dallocT(c, &c->Xd[j], (size_t)c->rows[j] * K);
+            if (rc64 == PMX_OK) rc64 = dallocT(c, &c->Gd[j], (size_t)c->rows[j] * K);
+        }
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->slabd[0], (size_t)c->nSlabA * M * K, false);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->slabd[1], (size_t)c->nSlabS * N * K, false);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->lossPart, (size_t)c->t64x * c->t64y);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->gramG, (size_t)2 * c->KP * c->KP);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->eigQ, (size_t)2 * c->KP * c->KP);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->dstatus, 1);
+        if (rc64 == PMX_OK) {
+            hipError_t e = hipHostMalloc((void**)&c->hstatus, sizeof(DevStatus), hipHostMallocDefault);
+            if (e != hipSuccess) { pmx_set_error("hipHostMalloc: %s", hipGetErrorString(e)); rc64 = PMX_E_NOMEM; }
+        }
+        if (rc64 != PMX_OK) { pmx_ctx_destroy(c); return rc64; }
+        *out = c;
+        return PMX_OK;
     }
     int rc = PMX_OK;
     if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
@@ -451,7 +493,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64 ? 7 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -485,6 +527,7 @@ static int measure_ymax(pmx_ctx* c) {
 
 extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
     if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
+    if (c->f64) FAIL(PMX_E_UNSUPPORTED, "an fp64 context takes Y through pmx_set_Y_host_f64");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
     int rc = dallocT(c, &c->Yown, (size_t)c->M * c->N, false);
@@ -499,6 +542,7 @@ extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
 
 extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int copy) {
     if (!c || !dY) FAIL(PMX_E_INVALID, "NULL argument");
+    if (c->f64) FAIL(PMX_E_UNSUPPORTED, "an fp64 context takes Y through pmx_set_Y_host_f64");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
     if (copy) {
@@ -532,6 +576,7 @@ static int measure_wmax(pmx_ctx* c) {
 }
 
 static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, int copy) {
+    if (c && c->f64 && W) FAIL(PMX_E_UNSUPPORTED, "weights are not implemented in fp64 contexts");
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
@@ -559,6 +604,7 @@ extern "C" int pmx_set_W_host(pmx_ctx* c, const float* W, int64_t ld) { return s
 extern "C" int pmx_set_W_device(pmx_ctx* c, const float* dW, int64_t ld, int copy) { return set_W_common(c, dW, ld, 0, copy); }
 
 static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool create) {
+    if (c->f64) FAIL(PMX_E_UNSUPPORTED, "an fp64 context has no float arrays: pmx_upload_f64 / pmx_download_f64");
     int j;
     float** p = nullptr;
     if (buf >= PMX_BUF_A && buf <= PMX_BUF_PSI_ST) {
@@ -629,6 +675,55 @@ extern "C" int pmx_buffer_ptr(pmx_ctx* c, int buf, void** dptr, int64_t* count) 
     if (rc != PMX_OK) return rc;
     *dptr = *slot;
     if (count) *count = n;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PMX_MODE_F64: transfers of an fp64 context (k_small_f64.hip)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pmx_set_Y_host_f64(pmx_ctx* c, const double* Y, int64_t ld) {
+    if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
+    if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_Y_host_f64 needs a PMX_MODE_F64 context");
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpy2DAsync(c->Yd, c->N * sizeof(double), Y, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->haveY = true;
+    return PMX_OK;
+}
+static int buf_lookup_f64(pmx_ctx* c, int buf, bool writable, double** p, int64_t* count) {
+    if (!c->f64) FAIL(PMX_E_STATE, "not a PMX_MODE_F64 context");
+    const int j = buf & 1;
+    switch (buf) {
+        case PMX_BUF_A: case PMX_BUF_ST: *p = c->Xd[j]; break;
+        case PMX_BUF_GA: case PMX_BUF_GST: if (writable) FAIL(PMX_E_INVALID, "the gradient buffers of an fp64 context are read-only"); *p = c->Gd[j]; break;
+        case PMX_BUF_EVAL_A: case PMX_BUF_EVAL_ST: if (writable) FAIL(PMX_E_INVALID, "buffer %d is read-only", buf);
+            *p = (c->algo == ALG_PGM && c->pgm.accelerated && c->Xed[j]) ? c->Xed[j] : c->Xd[j]; break;
+        default: FAIL(PMX_E_UNSUPPORTED, "buffer %d does not exist in an fp64 context", buf);
+    }
+    *count = c->rows[j] * c->K;
+    return PMX_OK;
+}
+extern "C" int pmx_upload_f64(pmx_ctx* c, int buf, const double* host, int64_t count) {
+    if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    double* d; int64_t n;
+    int rc = buf_lookup_f64(c, buf, true, &d, &n);
+    if (rc != PMX_OK) return rc;
+    if (count != n) FAIL(PMX_E_INVALID, "buffer %d holds %lld doubles, got %lld", buf, (long long)n, (long long)count);
+    HIP_CHECK(hipMemcpyAsync(d, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+extern "C" int pmx_download_f64(pmx_ctx* c, int buf, double* host, int64_t count) {
+    if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    double* d; int64_t n;
+    int rc = buf_lookup_f64(c, buf, false, &d, &n);
+    if (rc != PMX_OK) return rc;
+    if (count != n) FAIL(PMX_E_INVALID, "buffer %d holds %lld doubles, got %lld", buf, (long long)n, (long long)count);
+    HIP_CHECK(hipMemcpyAsync(host, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     return PMX_OK;
 }
 
@@ -931,8 +1026,11 @@ static int shard_gram_in(pmx_ctx* c) {
     return PMX_OK;
 }
 
-static int require_ready(pmx_ctx* c) {
+// f64_ok: the entry point has an fp64 implementation (include/pmx.h: PMX_MODE_F64 lists them); every other one refuses an
+// fp64 context instead of touching float arrays it does not have
+static int require_ready(pmx_ctx* c, bool f64_ok = false) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (c->f64 && !f64_ok) FAIL(PMX_E_UNSUPPORTED, "this entry point has no fp64 implementation (PMX_MODE_F64 covers pgm / FISTA on small problems)");
     if (!c->haveY) FAIL(PMX_E_STATE, "Y has not been set");
     HIP_CHECK(hipSetDevice(c->device));
     return PMX_OK;
@@ -953,11 +1051,89 @@ static void fill_result(pmx_ctx* c, pmx_result* r, int it_before) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PMX_MODE_F64: K1 (+ the step rule) and the pgm iteration of an fp64 context
+// ------------------------------------------------------------------------------------------------
+static int enqueue_front64(pmx_ctx* c, const double* A, const double* St, int doA, int doS, bool tiles, bool steps, double scale) {
+    Grad64Args g{};
+    g.Y = c->Yd; g.ldY = c->N;
+    g.A = A; g.St = St;
+    g.slabA = c->slabd[0]; g.slabS = c->slabd[1];
+    g.lossPart = c->lossPart;
+    g.status = c->dstatus;
+    g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
+    g.doA = doA; g.doS = doS;
+    EigArgs e{};
+    e.G = c->gramG; e.Gw = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+    e.want[0] = steps; e.want[1] = steps;        // factor 0 (A) -> step of block 1 (S), factor 1 (St) -> step of block 0 (A)
+    e.scale = scale;
+    e.max_iter = 200;
+    e.Q = c->eigQ;
+    e.X[0] = nullptr; e.X[1] = nullptr;          // (the fp64 rows travel as their own arguments)
+    e.force_exact = 1;                           // lambda_max to fp64 round-off (k_gram.hip: EigArgs::force_exact)
+    e.rows[0] = c->M; e.rows[1] = c->N;
+    HIP_CHECK(launch_front64(g, e, A, St, tiles ? c->t64x : 0, tiles ? c->t64y : 0, steps, c->stream));
+    if (tiles) c->nloss = c->t64x * c->t64y;
+    return PMX_OK;
+}
+static int pgm64_enqueue_iteration(pmx_ctx* c) {
+    const pmx_pgm_params& p = c->pgm;
+    const double* A = p.accelerated ? c->Xed[0] : c->Xd[0];
+    const double* St = p.accelerated ? c->Xed[1] : c->Xd[1];
+    int rc = enqueue_front64(c, A, St, 1, 1, true, !p.use_fixed_steps, (double)p.step_scale);   // algorithms.py:105-106
+    if (rc != PMX_OK) return rc;
+    Pgm64Args u{};
+    for (int j = 0; j < 2; ++j) {
+        u.X[j] = c->Xd[j];
+        u.Xe[j] = p.accelerated ? c->Xed[j] : c->Xd[j];
+        u.G[j] = c->Gd[j];
+        u.slab[j] = c->slabd[j];
+        u.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS;
+        u.rows[j] = c->rows[j];
+        u.prox[j] = to_dev(p.prox[j]);
+    }
+    u.K = (int)c->K;
+    u.status = c->dstatus;
+    u.partials = c->partials;
+    u.accelerated = p.accelerated;
+    {   // omega the NEXT iteration reads (utils.py:198-206), in fp64
+        double om = 0.0;
+        if (p.accelerated) {
+            const double t = c->nest_t, t1 = 0.5 * (1.0 + sqrt(4.0 * t * t + 1.0));
+            om = (t - 1.0) / t1;
+            c->nest_t = t1;
+        }
+        u.omega_next = om;
+    }
+    const int64_t rmax = c->rows[0] > c->rows[1] ? c->rows[0] : c->rows[1];
+    const int nbx = (int)((rmax + EW_THREADS / 32 - 1) / (EW_THREADS / 32));      // <= 256: M, N <= 8192
+    launch_pgm64_update(u, nbx, c->stream);                                        // algorithms.py:107-108
+    DecideArgs d{};
+    d.status = c->dstatus; d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check = 1;
+    launch_pgm_decide(d, c->stream);                                               // algorithms.py:130-135
+    HIP_CHECK(hipGetLastError());
+    c->it += 1;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // single operations
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_grad(pmx_ctx* c) {
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
+    if (c->f64) {
+        HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+        rc = enqueue_front64(c, c->Xd[0], c->Xd[1], 1, 1, true, false, 1.0);
+        if (rc != PMX_OK) return rc;
+        Fold64Args f{};
+        for (int j = 0; j < 2; ++j) { f.slab[j] = c->slabd[j]; f.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS; f.G[j] = c->Gd[j]; f.count[j] = c->rows[j] * c->K; }
+        launch_fold64(f, c->stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PMX_OK;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
         rc = enqueue_grad(c, c->X[0], c->X[1], 1, 1);
@@ -1018,9 +1194,21 @@ extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* a
 }
 
 extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!out) FAIL(PMX_E_INVALID, "out is NULL");
+    if (c->f64) {
+        HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
+        rc = enqueue_front64(c, c->Xd[0], c->Xd[1], 0, 0, true, false, 1.0);
+        if (rc != PMX_OK) return rc;
+        std::vector<double> h(c->nloss);
+        HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, c->nloss * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        double s = 0.0;
+        for (double v : h) s += v;
+        *out = 0.5 * s;
+        return PMX_OK;
+    }
     if (c->host_grad) FAIL(PMX_E_UNSUPPORTED, "pmx_loglike: this context runs on a caller-supplied gradient (pmx_set_host_grad) and has no Y to evaluate the likelihood on");
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
     rc = enqueue_grad(c, c->X[0], c->X[1], 0, 0);
@@ -1039,7 +1227,7 @@ extern "C" int pmx_step_pgm(pmx_ctx* c, double out[2]) {
     if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
-    int rc = enqueue_steps(c, c->X[0], c->X[1], true, true, 1.0);
+    int rc = c->f64 ? enqueue_front64(c, c->Xd[0], c->Xd[1], 0, 0, false, true, 1.0) : enqueue_steps(c, c->X[0], c->X[1], true, true, 1.0);
     if (rc != PMX_OK) return rc;
     rc = read_status(c);
     if (rc != PMX_OK) return rc;
@@ -1077,7 +1265,11 @@ static int enqueue_alpha_from_factors(pmx_ctx* c, const AlphaArgs& al) {
     return PMX_OK;
 }
 
+// entry points without an fp64 implementation that do not pass through require_ready()
+#define REJECT_F64(c) do { if ((c) && (c)->f64) FAIL(PMX_E_UNSUPPORTED, "%s has no fp64 implementation (PMX_MODE_F64 covers pgm / FISTA on small problems)", __func__); } while (0)
+
 extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
+    REJECT_F64(c);
     if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
@@ -1138,12 +1330,31 @@ extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const p
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     if (c) c->absmax_by_finish = false;
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
     for (int j = 0; j < 2; ++j) {
         rc = check_prox(p->prox[j], j ? "prox_S" : "prox_A");
         if (rc != PMX_OK) return rc;
+    }
+    if (c->f64) {                                // PMX_MODE_F64: plain pgm / FISTA with device operators and a device or fixed step
+        if (p->backtracking || p->bb_type || p->host_prox[0] || p->host_prox[1])
+            FAIL(PMX_E_UNSUPPORTED, "fp64 contexts run pgm / FISTA with this library's operators and step rules (no line search, Barzilai-Borwein or user prox)");
+        c->pgm = *p;
+        c->algo = ALG_PGM;
+        c->it = 0;
+        c->nest_t = 1.0;
+        rc = reset_status(c);
+        if (rc != PMX_OK) return rc;
+        if (p->accelerated) {
+            for (int j = 0; j < 2; ++j) {
+                rc = dallocT(c, &c->Xed[j], (size_t)c->rows[j] * c->K, false);
+                if (rc != PMX_OK) return rc;
+                HIP_CHECK(hipMemcpyAsync(c->Xed[j], c->Xd[j], c->rows[j] * c->K * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            }
+            c->nest_t = 0.5 * (1.0 + sqrt(4.0 * c->nest_t * c->nest_t + 1.0));       // the first omega (== 0) is consumed at it = 0
+        }
+        return PMX_OK;
     }
     if (c->W && !p->use_fixed_steps && !p->bb_type)   // nmf.step_pgm with an array W raises (nmf.py:63)
         FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
@@ -1368,7 +1579,7 @@ static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
 
 extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c) c->absmax_by_finish = false;
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
     if (n_iter < 0) FAIL(PMX_E_INVALID, "n_iter < 0");
@@ -1376,6 +1587,19 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c->pgm.use_fixed_steps) {
         rc = set_fixed_steps(c, c->pgm.fixed_steps);
         if (rc != PMX_OK) return rc;
+    }
+    if (c->f64) {
+        for (int left = n_iter; left > 0 && !c->hstatus->stopped; left -= 32) {
+            for (int i = 0; i < std::min(left, 32); ++i) {
+                rc = pgm64_enqueue_iteration(c);
+                if (rc != PMX_OK) return rc;
+            }
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+        }
+        fill_result(c, res, it0);
+        return PMX_OK;
     }
     int left = n_iter;
     while (left > 0 && !c->hstatus->stopped) {
@@ -1415,6 +1639,7 @@ extern "C" int pmx_pgm_set_fixed_steps(pmx_ctx* c, const double steps[2]) {
 }
 
 extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
+    REJECT_F64(c);
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (mask < 0 || mask > 3) FAIL(PMX_E_INVALID, "mask must be 0..3");
     for (int j = 0; j < 2; ++j)
@@ -1833,6 +2058,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
 }
 
 extern "C" int pmx_adaprox_set_alpha(pmx_ctx* c, const float* alpha) {
+    REJECT_F64(c);
     if (!c || !alpha) FAIL(PMX_E_INVALID, "NULL argument");
     if (c->algo != ALG_ADAPROX || c->ada.use_fixed_steps != 2) FAIL(PMX_E_STATE, "pmx_adaprox_begin with use_fixed_steps = 2 has not been called");
     HIP_CHECK(hipSetDevice(c->device));
@@ -2098,6 +2324,7 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
 static int64_t comm_count(const pmx_ctx* c) { return c->N * c->K + (int64_t)c->KP * c->KP + MAXK + 32; }
 
 extern "C" int pmx_set_world(pmx_ctx* c, int rank, int world, int64_t M_global) {
+    REJECT_F64(c);
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (world < 1 || rank < 0 || rank >= world) FAIL(PMX_E_INVALID, "bad rank/world");
     if (M_global < c->M) FAIL(PMX_E_INVALID, "M_global < local M");
@@ -2106,6 +2333,7 @@ extern "C" int pmx_set_world(pmx_ctx* c, int rank, int world, int64_t M_global) 
 }
 
 extern "C" int pmx_set_host_grad(pmx_ctx* c, int on) {
+    REJECT_F64(c);
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     HIP_CHECK(hipSetDevice(c->device));
     if (on) {
@@ -2127,6 +2355,7 @@ extern "C" int pmx_comm_layout(pmx_ctx* c, int64_t* count, int64_t offsets[3]) {
 }
 
 extern "C" int pmx_set_comm_buffer(pmx_ctx* c, float* dptr, int64_t count) {
+    REJECT_F64(c);
     if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
     if (count < comm_count(c)) FAIL(PMX_E_INVALID, "comm buffer too small: %lld < %lld", (long long)count, (long long)comm_count(c));
     if (c->W) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
@@ -2185,6 +2414,7 @@ static int shard_post(pmx_ctx* c, int have_prev) {
 //   comm buffer = world chunks of [ gSt rows of rank q (N/world x K) | Gram (KP^2) | colsum(A) | colsum(S) | scalars ]
 //   (the small sums are copied into every chunk: each rank finds them, summed, in the chunk the reduce-scatter hands it)
 extern "C" int pmx_set_s_split(pmx_ctx* c, int on) {
+    REJECT_F64(c);
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!on) { c->ssplit = false; c->scol0 = 0; c->sncol = 0; return PMX_OK; }
     if (c->world < 1) FAIL(PMX_E_STATE, "pmx_set_world has not been called");

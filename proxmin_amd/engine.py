@@ -48,6 +48,14 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def f64_applies(M, N, K):
+    """Shapes the fp64 kernels take (include/pmx.h: PMX_MODE_F64 -- the small-problem path: the reference's own examples
+    and BASELINE cfg1); PMX_F64=0 switches the mode off (fp64 inputs are then computed in fp32 and cast back, as before)."""
+    if os.environ.get("PMX_F64", "1") == "0" or os.environ.get("PMX_K1_SMALL", "1") == "0":
+        return False
+    return K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -61,7 +69,8 @@ class DeviceNMF:
         self.device = device
         mode = mode or _DEFAULT_MODE
         self.mode = mode
-        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2}[mode]
+        self.f64 = mode == "f64"          # fp64 operands, products and sums (small problems, pgm / FISTA: k_small_f64.hip)
+        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f64": _lib.MODE_F64}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
                                            C.c_void_p(stream) if stream else None))
@@ -69,7 +78,7 @@ class DeviceNMF:
         self._keep = []
         # a split-precision context that fell off its fast kernel says so once (pmx_k1_info knows): ragged shapes and
         # K outside {64, 128} run the generic split-bf16 kernels or the exact-fp32 one, 1.5-3 x slower per pass
-        if mode != "f32":
+        if mode not in ("f32", "f64"):
             k = self.k1_info()["kernel"]
             fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small")}[mode]
             generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
@@ -103,6 +112,10 @@ class DeviceNMF:
     def set_Y(self, Y):
         Y = np.asarray(Y)
         assert Y.shape == (self.M, self.N), "Y must be M x N"
+        if self.f64:
+            Yd = np.ascontiguousarray(Y, dtype=np.float64)
+            _lib.check(self.lib.pmx_set_Y_host_f64(self.h, _vp(Yd), self.N))
+            return
         Yf = _f32(Y)
         _lib.check(self.lib.pmx_set_Y_host(self.h, _vp(Yf), self.N))
 
@@ -130,10 +143,18 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_set_W_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
 
     def _upload(self, buf, arr2d):
+        if self.f64:
+            a = np.ascontiguousarray(arr2d, dtype=np.float64)
+            _lib.check(self.lib.pmx_upload_f64(self.h, buf, _vp(a), a.size))
+            return
         a = _f32(arr2d)
         _lib.check(self.lib.pmx_upload(self.h, buf, _vp(a), a.size))
 
     def _download(self, buf, rows):
+        if self.f64:
+            out = np.empty((rows, self.K), dtype=np.float64)
+            _lib.check(self.lib.pmx_download_f64(self.h, buf, _vp(out), out.size))
+            return out
         out = np.empty((rows, self.K), dtype=np.float32)
         _lib.check(self.lib.pmx_download(self.h, buf, _vp(out), out.size))
         return out
@@ -189,7 +210,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
         return d

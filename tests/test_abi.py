@@ -39,8 +39,8 @@ def test_binding_covers_header(lib):
 def test_struct_layouts_match_header():
     """sizes implied by include/pmx.h (checked against the ctypes mirrors)."""
     from proxmin_amd import _lib
-    assert ctypes.sizeof(_lib.Prox) == 16
-    assert ctypes.sizeof(_lib.ProxSeq) == 8 + 16 * _lib.MAX_SEQ
+    assert ctypes.sizeof(_lib.Prox) == 24
+    assert ctypes.sizeof(_lib.ProxSeq) == 8 + 24 * _lib.MAX_SEQ
     assert ctypes.sizeof(_lib.Result) == 4 * 5 + 4 + 16 + 16   # 5 ints + pad, 2 doubles, 2 int64
     # and every parameter struct against the compiled library's own sizeof
     sizes = (ctypes.c_int * 5)()

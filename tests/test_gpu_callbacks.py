@@ -192,6 +192,16 @@ def test_prox_unity_along_the_long_axis(pm, orc):
         np.testing.assert_allclose(A, Ao, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(S, So, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(A.sum(0), 1.0, rtol=1e-5)
+    # [r4] bsdmm with the LIBRARY's long-axis operator, as prox_f of A and as a constraint of S (rows of S: axis=1): the
+    # operator runs as the stand-alone device kernel between the stages of pmx_bsdmm_split (round 3: NotImplementedError)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, prox_A=partial(pm.operators.prox_unity_plus, axis=0),
+               proxs_g=[[pm.operators.prox_plus], [partial(pm.operators.prox_unity_plus, axis=1)]], max_iter=5, e_rel=1e-9)
+    Ao, So = A0.astype(np.float64), S0.astype(np.float64)
+    orc.bsdmm_nmf(Y.astype(np.float64), Ao, So, prox_A=("unity_plus", 0), proxs_g=[[("plus",)], [("unity_plus", 1)]], max_iter=5, e_rel=1e-9)
+    np.testing.assert_allclose(A, Ao, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(S, So, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(A.sum(0), 1.0, rtol=1e-5)
 
 
 def test_bsdmm_update_order_and_direct_entry(pm, orc):
