@@ -1612,11 +1612,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     {
         const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
         if constexpr (CHAIN) {
-            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
-            chainPos = idx % L;
-            chainId = (idx / L) * 8 + xcd;
-            rowRegion = chainId % gx;
-            colRegion = (chainId / gx) * L + chainPos;
+            chain_region_map(lin, a.chainL, gx, chainId, chainPos, rowRegion, colRegion);
         } else if (gy % 8 == 0) {
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
@@ -1887,39 +1883,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
             PH(9)
         };
-        unsigned* cflags = nullptr;
-        unsigned myxcc = 0;
+        ChainLink link;                      // chain_link.h: the hand-off protocol
+        if constexpr (CHAIN) link.init(a.chainFlags, chainId, nrp, j, a.status, a.wstatus, lane);
         if constexpr (CHAIN) {
-            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
-            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-        }
-        unsigned* pendFlag = nullptr;
-        unsigned pendVal = 0;
-        unsigned* curFlag = nullptr;
-        unsigned cwant = 0, cseen = 0;
-        bool cadd = false, cdead = false;
-        auto chain_fault = [&](int code) {
-            if (lane == 0 && code > 0) {
-                a.wstatus->k1_fault = code;
-                a.wstatus->reason = HALT_ERROR;
-                __threadfence();
-                a.wstatus->halt = 1;
-            }
-            cadd = false;
-            cdead = true;
-        };
-        auto chain_publish = [&]() {
-            if constexpr (CHAIN) {
-                if (pendFlag != nullptr) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
-                    pendFlag = nullptr;
-                }
-            }
-        };
-        if constexpr (CHAIN) {
-            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+            if (a.chainInject && blockIdx.x == 0 && j == 0) link.fault(3);
         }
         auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
             const unsigned char* Rb = smem + V7_OFF_R + (b & 1) * V5_R_BYTES;
@@ -1976,20 +1943,12 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                 if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
-                    if constexpr (CHAIN) {
-                        chain_publish();     // the previous panel's arrival
-                        const int c = chainPos, L = a.chainL;
-                        const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
-                        const int kq = pnl + c >= nrp ? pnl + c - nrp : c + nw;     // place of this workgroup among the visits of panel pnl
-                        cadd = (a.doA & 1) && kq > 0 && !cdead;
-                        cwant = a.chainBase + (unsigned)kq;
-                        curFlag = cflags + pnl * 4;
-                    }
+                    if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, 1, nrp, a.chainBase, (a.doA & 1) != 0);
                 }
                 float pv0[4], pv1[4];
                 if constexpr (CHAIN) {
-                    if (cb == 3 && cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cb >= 4 && cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
+                    if (cb == 3) link.look();
+                    if (cb >= 4 && link.cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
                         const float* pb = gA_tile(prow) + 8 * (cb - 4) * K;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -2000,24 +1959,8 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                 }
                 consume(s - 2, prow, cb, accS[cb]);
                 if constexpr (CHAIN) {
-                    if (cb == 3 && cadd) {
-                        unsigned v = __builtin_amdgcn_readfirstlane(cseen);
-                        if ((v >> 4) != cwant) {
-                            const long long t0 = wall_clock64();          // 100 MHz
-                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
-                                if ((spins & 63) == 0) {
-                                    if (chain_halted(a.status)) { chain_fault(0); break; }
-                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
-                                }
-                                __builtin_amdgcn_s_sleep(8);
-                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            }
-                        }
-                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
-                        // compiler fence: the sc1 loads of the previous sum (next column blocks) stay behind the arrival check
-                        asm volatile("" ::: "memory");
-                    }
-                    if (cb >= 4 && cadd) {
+                    if (cb == 3) link.wait();   // the predecessor finished this panel about a panel-time ago: normally no spin
+                    if (cb >= 4 && link.cadd) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             accA0[4 * (cb - 4) + q] += pv0[q];
@@ -2028,8 +1971,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                         flush_gA(prow);
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-                        pendFlag = curFlag;
-                        pendVal = ((cwant + 1u) << 4) | myxcc;
+                        link.flushed();
                     }
                 }
                 PH(7)
@@ -2037,7 +1979,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
                 ++s;
             }
         }
-        chain_publish();
+        if constexpr (CHAIN) link.publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
             const int kk = kt * 32 + l31;

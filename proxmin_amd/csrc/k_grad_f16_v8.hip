@@ -118,11 +118,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         if constexpr (CHAIN) {
             // The chainL workgroups of a chain (same row region, consecutive column regions) are consecutive multiples of 8
             // apart in dispatch order, i.e. on ONE XCD where workgroup b runs on XCD b % 8 (checked at run time, below).
-            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
-            chainPos = idx % L;
-            chainId = (idx / L) * 8 + xcd;
-            rowRegion = chainId % gx;
-            colRegion = (chainId / gx) * L + chainPos;
+            chain_region_map(lin, a.chainL, gx, chainId, chainPos, rowRegion, colRegion);
         } else if (gy % 8 == 0) {
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
@@ -522,54 +518,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
             }
         };
-        // ---- CHAIN: gA summed in place, through the XCD's L2 ------------------------------------------------------
-        // The chainL workgroups of a chain own the same rows and consecutive column regions; their contributions to a
-        // panel of gA are added IN PLACE in one slab, one member after the other in a fixed order (deterministic), each
-        // of the four consumer waves handing its 32 x 64 tile to the same wave of the next member through an arrival word:
-        //     wait for arrival k  ->  tile += previous sum (sc1 loads: served by L2, never by this CU's L1)  ->  plain
-        //     stores  ->  s_waitcnt vmcnt(0) (the stores are in L2)  ->  arrival word = k + 1 (relaxed agent-scope store).
-        // No release fence, no write-back: the lines stay dirty in the L2 the members share and reach HBM once.  That is
-        // only a hand-off if both workgroups really sit on the same XCD, which HIP does not promise: every arrival word
-        // carries its writer's XCC_ID, a reader on another XCD (or one whose predecessor never shows up: workgroups not
-        // co-resident) reports a fault through DevStatus instead of using the data, the chain of kernels stops, and the
-        // host repeats the iteration with one slab per column region (pmx_api.hip).  The previous sum is fetched in four
-        // pieces during the panel's last four column blocks (requested before a block's MFMAs, added after them), the
-        // arrival word of a finished panel is published one slot later: no wait of the protocol sits in front of work.
+        // ---- CHAIN: gA summed in place, through the XCD's L2 (chain_link.h: protocol, fault handling) --------------------
+        // The previous sum is fetched in four pieces during the panel's last four column blocks (requested before a block's
+        // MFMAs, added after them), the arrival word of a finished panel is published one slot later: no wait of the
+        // protocol sits in front of work.
         const float invUnA = scR * scS;              // 2^(eR+eS): previous sums enter the accumulators in their scale
-        unsigned* cflags = nullptr;
-        unsigned myxcc = 0;
+        ChainLink link;
+        if constexpr (CHAIN) link.init(a.chainFlags, chainId, nrp, j, a.status, a.wstatus, lane);
         if constexpr (CHAIN) {
-            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
-            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-        }
-        unsigned* pendFlag = nullptr;                // arrival to publish once this wave's stores of the panel have landed
-        unsigned pendVal = 0;
-        unsigned* curFlag = nullptr;
-        unsigned cwant = 0, cseen = 0;
-        bool cadd = false;                           // this panel has a previous sum to add (not the first of its chain)
-        bool cdead = false;                          // a fault was seen: no more waiting, the launch's gA is discarded anyway
-        auto chain_fault = [&](int code) {
-            if (lane == 0 && code > 0) {
-                a.wstatus->k1_fault = code;
-                a.wstatus->reason = HALT_ERROR;
-                __threadfence();
-                a.wstatus->halt = 1;
-            }
-            cadd = false;
-            cdead = true;
-        };
-        auto chain_publish = [&]() {
-            if constexpr (CHAIN) {
-                if (pendFlag != nullptr) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
-                    pendFlag = nullptr;
-                }
-            }
-        };
-        if constexpr (CHAIN) {
-            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+            if (a.chainInject && blockIdx.x == 0 && j == 0) link.fault(3);
         }
         sync();
         sync();
@@ -583,22 +540,12 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 if (cb == 0) {               // block s-2 opens a row panel: the producers publish its A terms now
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
-                    if constexpr (CHAIN) {
-                        chain_publish();     // the previous panel's arrival
-                        // place of this workgroup among the members' visits of panel pnl, in time: members that reach
-                        // it after wrapping around (pnl + c >= RP) come first
-                        const int c = chainPos, L = a.chainL;
-                        const int nw = pnl + L - nrp > 0 ? pnl + L - nrp : 0;
-                        const int k = pnl + c >= nrp ? pnl + c - nrp : c + nw;
-                        cadd = (a.doA & 1) && k > 0 && !cdead;
-                        cwant = a.chainBase + (unsigned)k;
-                        curFlag = cflags + pnl * 4;
-                    }
+                    if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, 1, nrp, a.chainBase, (a.doA & 1) != 0);
                 }
                 float pv0[4], pv1[4];
                 if constexpr (CHAIN) {
-                    if (cb == 3 && cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cb >= 4 && cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
+                    if (cb == 3) link.look();
+                    if (cb >= 4 && link.cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) ..
                         const float* pb = gA_tile(prow) + (8 * ((cb - 4) & 1) + 16 * ((cb - 4) >> 1)) * K;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -609,24 +556,8 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 }
                 consume(s - 2, prow, cb, accS[cb]);
                 if constexpr (CHAIN) {
-                    if (cb == 3 && cadd) {   // the predecessor finished this panel about a panel-time ago: normally no spin
-                        unsigned v = __builtin_amdgcn_readfirstlane(cseen);
-                        if ((v >> 4) != cwant) {
-                            const long long t0 = wall_clock64();          // 100 MHz
-                            for (int spins = 1; (v >> 4) != cwant; ++spins) {
-                                if ((spins & 63) == 0) {
-                                    if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
-                                    if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
-                                }
-                                __builtin_amdgcn_s_sleep(8);
-                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            }
-                        }
-                        if (cadd && (v & 15u) != myxcc) chain_fault(2);
-                        // compiler fence: the sc1 loads of the previous sum (next column blocks) stay behind the arrival check
-                        asm volatile("" ::: "memory");
-                    }
-                    if (cb >= 4 && cadd) {
+                    if (cb == 3) link.wait();   // the predecessor finished this panel about a panel-time ago: normally no spin
+                    if (cb >= 4 && link.cadd) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             accA0[4 * (cb - 4) + q] += pv0[q] * invUnA;
@@ -637,8 +568,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         flush_gA(prow);
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-                        pendFlag = curFlag;
-                        pendVal = ((cwant + 1u) << 4) | myxcc;
+                        link.flushed();
                     }
                 }
                 PH(7)
@@ -646,7 +576,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 ++s;
             }
         }
-        chain_publish();
+        if constexpr (CHAIN) link.publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
             const int kk = kt * 32 + l31;

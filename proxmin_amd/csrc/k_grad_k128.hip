@@ -131,11 +131,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
     {
         const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
         if constexpr (CHAIN) {               // the members of a chain are multiples of 8 apart in dispatch order: ONE XCD (checked at run time)
-            const int L = a.chainL, xcd = lin & 7, idx = lin >> 3;
-            chainPos = idx % L;
-            chainId = (idx / L) * 8 + xcd;
-            rowRegion = chainId % gx;
-            colRegion = (chainId / gx) * L + chainPos;
+            chain_region_map(lin, a.chainL, gx, chainId, chainPos, rowRegion, colRegion);
         } else if (gy % 8 == 0) {            // consecutive workgroups land on consecutive XCDs: an XCD takes a band of column regions
             const int xcd = lin & 7, idx = lin >> 3;
             rowRegion = idx % gx;
@@ -495,77 +491,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             }
         };
         auto consume = [&](int b, auto cb_c) { consumeA(b, cb_c); consumeS(b, cb_c); };
-        // ---- CHAIN: gA summed in place through the XCD's L2 (protocol and fault handling: k_grad_f16_v8<.., CHAIN>) ----------
+        // ---- CHAIN: gA summed in place through the XCD's L2 (protocol and fault handling: chain_link.h) --------------------
         const float invUnA = scR * scS;              // 2^(eR+eS): previous sums enter the accumulators in their scale
-        unsigned* cflags = nullptr;
-        unsigned myxcc = 0;
-        if constexpr (CHAIN) {
-            cflags = a.chainFlags + (size_t)chainId * nrp * 4 + j;
-            myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-        }
-        unsigned* pendFlag = nullptr;                // arrival to publish once this wave's stores of the panel have landed
-        unsigned pendVal = 0;
-        unsigned* curFlag = nullptr;
-        unsigned cwant = 0, cseen = 0;
-        bool cadd = false;                           // this panel has a previous sum to add (not the first visitor of the panel)
-        bool cdead = false;                          // a fault was seen: no more waiting, the launch's gA is discarded anyway
-        auto chain_fault = [&](int code) {
-            if (lane == 0 && code > 0) {
-                a.wstatus->k1_fault = code;
-                a.wstatus->reason = HALT_ERROR;
-                __threadfence();
-                a.wstatus->halt = 1;
-            }
-            cadd = false;
-            cdead = true;
-        };
-        auto chain_publish = [&]() {
-            if constexpr (CHAIN) {
-                if (pendFlag != nullptr) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(pendFlag, pendVal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("" ::: "memory");   // nothing of the next panel moves in front of the arrival store
-                    pendFlag = nullptr;
-                }
-            }
-        };
-        auto chain_open = [&](int pnl) {             // this workgroup's place among the visitors of panel pnl, in time
-            if constexpr (CHAIN) {
-                chain_publish();                     // the previous panel's arrival (its stores have had a slot to land)
-                const int c = chainPos, L = a.chainL, sg = a.chainStride;
-                const int c0 = (nrp - pnl + sg - 1) / sg;          // first member that reaches pnl after wrapping around: those come first
-                const int nw = L - c0 > 0 ? L - c0 : 0;
-                const int k = pnl + sg * c >= nrp ? c - c0 : c + nw;
-                cadd = (a.doA & 1) && k > 0 && !cdead;
-                cwant = a.chainBase + (unsigned)k;
-                curFlag = cflags + pnl * 4;
-            }
-        };
-        auto chain_look = [&]() {                    // request the arrival word (looked at after this block's MFMAs)
-            if constexpr (CHAIN) {
-                if (cadd) cseen = __hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        auto chain_wait = [&]() {
-            if constexpr (CHAIN) {
-                if (cadd) {                          // the predecessor finished this panel a panel-time or more ago: normally no spin
-                    unsigned v = __builtin_amdgcn_readfirstlane(cseen);
-                    if ((v >> 4) != cwant) {
-                        const long long t0 = wall_clock64();          // 100 MHz
-                        for (int spins = 1; (v >> 4) != cwant; ++spins) {
-                            if ((spins & 63) == 0) {
-                                if (chain_halted(a.status)) { chain_fault(0); break; }              // somebody else gave up
-                                if (wall_clock64() - t0 > 2000000) { chain_fault(1); break; }        // 20 ms
-                            }
-                            __builtin_amdgcn_s_sleep(8);
-                            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(curFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        }
-                    }
-                    if (cadd && (v & 15u) != myxcc) chain_fault(2);
-                    asm volatile("" ::: "memory");   // the sc1 loads of the previous sum stay behind the arrival check
-                }
-            }
-        };
+        ChainLink link;
+        if constexpr (CHAIN) link.init(a.chainFlags, chainId, nrp, j, a.status, a.wstatus, lane);
         // k half h of the previous sum of this wave's tile (32 registers): requested in front of a block's MFMAs, added behind them
         auto chain_fetch = [&](int prow, int h, float (&pv)[32]) {
             const float* pb = gA_tile(prow) + h * 64;
@@ -584,7 +513,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             }
         };
         if constexpr (CHAIN) {
-            if (a.chainInject && blockIdx.x == 0 && j == 0) chain_fault(3);
+            if (a.chainInject && blockIdx.x == 0 && j == 0) link.fault(3);
         }
         using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
         using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
@@ -597,24 +526,24 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
             const int prow = row0 + pnl * V5_BM;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();          // block s-2 opens a row panel: the producers have published its A terms
-            chain_open(pnl);
+            if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, a.chainStride, nrp, a.chainBase, (a.doA & 1) != 0);
             consume(s - 2, c0{}); sync(); ++s;
-            chain_look();
+            if constexpr (CHAIN) link.look();
             consume(s - 2, c1{});
-            chain_wait();
+            if constexpr (CHAIN) link.wait();
             sync(); ++s;
             // The panel's last block: gA first, so that its flush (64 stores per lane) has the block's gSt contraction and the
             // barrier to land behind -- the arrival word is published at the top of the next panel behind a vmcnt(0) that then
             // costs nothing.  CHAIN: the previous sum arrives in two halves of 32 registers, each requested in front of MFMAs.
             if constexpr (CHAIN) {
                 float pv[32];
-                if (cadd) chain_fetch(prow, 0, pv);
+                if (link.cadd) chain_fetch(prow, 0, pv);
                 consume(s - 2, c2{});
-                if (cadd) chain_add(0, pv);
+                if (link.cadd) chain_add(0, pv);
                 sync(); ++s;
-                if (cadd) chain_fetch(prow, 1, pv);
+                if (link.cadd) chain_fetch(prow, 1, pv);
                 consumeA(s - 2, c3{});
-                if (cadd) chain_add(1, pv);
+                if (link.cadd) chain_add(1, pv);
             } else {
                 consume(s - 2, c2{}); sync(); ++s;
                 consumeA(s - 2, c3{});
@@ -625,16 +554,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                 for (int h = 0; h < NKT; ++h)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { accA[h][0][i] = 0.f; accA[h][1][i] = 0.f; }
-                if constexpr (CHAIN) {
-                    pendFlag = curFlag;
-                    pendVal = ((cwant + 1u) << 4) | myxcc;
-                }
+                if constexpr (CHAIN) link.flushed();
             }
             __builtin_amdgcn_sched_barrier(0);     // (the stores stay in front of the gSt contraction)
             consumeS(s - 2, c3{});
             sync(); ++s;
         }
-        chain_publish();
+        if constexpr (CHAIN) link.publish();
         if (a.doS) {
             float* dst = a.slabS + (int64_t)rowRegion * N * K;
             const int kk = j * 32 + l31;

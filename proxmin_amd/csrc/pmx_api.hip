@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 #include <link.h>
 #include "pmx_common.h"
+#include "chain_link.h"
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
 #include "k_grad_k128.hip"
