@@ -113,7 +113,8 @@ enum {
     PMX_BUF_Z0 = 16, /* + block*PMX_MAX_G + i : bsdmm Z_i of block (utils.py:244-254)     */
     PMX_BUF_U0 = 32, /* + block*PMX_MAX_G + i : bsdmm U_i                                 */
     PMX_BUF_TG0 = 48, /* + block*PMX_MAX_G + i : host round trip of a user-defined proxs_g member: its argument, then its result */
-    PMX_BUF_STEP_A = 64, PMX_BUF_STEP_ST = 65  /* pgm: per-element steps of a user `step` that returned arrays (pmx_pgm_step_arrays) */
+    PMX_BUF_STEP_A = 64, PMX_BUF_STEP_ST = 65, /* pgm: per-element steps of a user `step` that returned arrays (pmx_pgm_step_arrays) */
+    PMX_BUF_BT_A = 66, PMX_BUF_BT_ST = 67      /* pgm line search with a user-defined prox: its argument, then its result (pmx_pgm_bt_split) */
 };
 
 typedef struct pmx_ctx pmx_ctx;
@@ -253,6 +254,16 @@ int pmx_pgm_run(pmx_ctx* ctx, int n_iter, pmx_result* res);
  * user / Barzilai-Borwein steps (the latter evaluated on the device in phase 0, as in a fused iteration); not with
  * backtracking (phase 0 alone is allowed there: see pmx_pgm_set_fixed_steps). */
 int pmx_pgm_split(pmx_ctx* ctx, int phase, const double* steps, pmx_result* res);
+/* [ABI v3] ONE iteration of pgm WITH the Beck-Teboulle line search (algorithms.py:110-127) when a block's prox is a user callable
+ * (pmx_pgm_params::host_prox): every trial of that block takes a host round trip, everything else stays on the device.
+ *   phase 0  start the iteration.  Returns with *need = bit mask of the blocks whose prox the caller now owes: their arguments
+ *            _X_j - T_j s_j G_j are in PMX_BUF_BT_A / _ST, eff_steps[j] = T_j s_j is the step the reference passes the callable
+ *            (:108, :125); the caller applies it, uploads the result into the same buffer and calls
+ *   phase 1  adopt the results, evaluate the sufficient-decrease test; a failed test halves T of the block with the largest
+ *            relative update and -- if that block's prox is the caller's -- returns with *need set again.
+ * *need == 0: the iteration is complete and *res is filled.  Steps: the device's Lipschitz rule, or constants
+ * (pmx_pgm_set_fixed_steps before phase 0: a user `step`). */
+int pmx_pgm_bt_split(pmx_ctx* ctx, int phase, int* need, double eff_steps[2], pmx_result* res);
 /* A user `step` may return ARRAYS that broadcast against the blocks (algorithms.py:106-108: `_X[j] - S[j] * G[j]`,
  * `prox[j](.., S[j])`): the caller broadcasts block j's to rows x K (S: N x K, transposed like everything of S), uploads it
  * into PMX_BUF_STEP_A / _ST and sets bit j of `mask`; phases 1 and 2 of pmx_pgm_split then take that block's step from the

@@ -26,6 +26,7 @@ SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 
 BUF_A, BUF_ST, BUF_GA, BUF_GST, BUF_MA, BUF_MST, BUF_VA, BUF_VST, BUF_VHA, BUF_VHST = range(10)
 BUF_EVAL_A, BUF_EVAL_ST, BUF_TMP_A, BUF_TMP_ST, BUF_PSI_A, BUF_PSI_ST = 10, 11, 12, 13, 14, 15
 BUF_Z0, BUF_U0, BUF_TG0 = 16, 32, 48
+BUF_BT_A = 66                         # + block: argument / result of a user prox inside the line search (pmx_pgm_bt_split)
 BUF_STEP_A = 64                       # + block: per-element steps of a user `step` that returned arrays (pgm)
 
 
@@ -92,6 +93,7 @@ _SIGNATURES = {
     "pmx_pgm_begin": (C.c_int, [C.c_void_p, C.POINTER(PgmParams)]),
     "pmx_pgm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
     "pmx_pgm_split": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Result)]),
+    "pmx_pgm_bt_split": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(Result)]),
     "pmx_adaprox_set_alpha": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pmx_adaprox_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(Result)]),
     "pmx_adaprox_begin": (C.c_int, [C.c_void_p, C.POINTER(AdaproxParams), C.c_int]),

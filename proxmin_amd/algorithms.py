@@ -229,10 +229,13 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     slow = user_step is not None or any(h is not None for h in host_prox) or user_grad
     # a user `step` next to the line search: the callable on the host once per iteration, the Beck-Teboulle loop on the device
     bt_user_step = backtracking and user_step is not None and not any(h is not None for h in host_prox) and not user_grad
+    # [r4] a user `prox` inside the line search: every trial of THAT block takes a host round trip (pmx_pgm_bt_split), the
+    # test itself, the other block and the likelihood evaluations stay on the device; a user `step` may come with it
+    bt_user_prox = backtracking and any(h is not None for h in host_prox) and not user_grad and bb is None
     # Barzilai-Borwein steps next to a user-defined prox / grad: the rule stays on the device (it is the step), the callable
     # takes its round trip as with any other rule
-    if slow and backtracking and not bt_user_step:
-        raise NotImplementedError("a user-defined grad / prox together with backtracking is not implemented")
+    if slow and backtracking and not (bt_user_step or bt_user_prox):
+        raise NotImplementedError("a user-defined grad (or Barzilai-Borwein steps with a user prox) together with backtracking is not implemented")
 
     if W is not None and isinstance(step, _nmf.scaled_step_pgm):
         raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
@@ -248,7 +251,45 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
         it_done = 0
         dt = A.dtype
         steps_user, step_arrays = None, [None, None]
-        if bt_user_step:
+        if bt_user_prox:
+            takes_grads = False
+            if user_step is not None:                            # the reference's signature probe (algorithms.py:73-77)
+                try:
+                    user_step(A, S, it=0, grads=(A, S))
+                    takes_grads = True
+                except TypeError:
+                    takes_grads = False
+            for it in range(max_iter):
+                if _wants_iterates(callback):
+                    try:
+                        callback(A, S, it=it)
+                    except StopIteration:
+                        break
+                if user_step is not None:
+                    if takes_grads:
+                        dev.pgm_split(0)                         # the gradient at the evaluation point, for the callable only
+                    Xe = (dev.get(_lib.BUF_EVAL_A, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_EVAL_A, 1)).astype(dt))
+                    if takes_grads:
+                        Gh = (dev.get(_lib.BUF_GA, 0).astype(dt), np.ascontiguousarray(dev.get(_lib.BUF_GA, 1)).astype(dt))
+                        ret = user_step(*Xe, it=it, grads=Gh)
+                    else:
+                        ret = user_step(*Xe, it=it)
+                    steps, step_arrays, _ = _user_steps(ret, "step", (A.shape, S.shape))
+                    if any(a is not None for a in step_arrays):
+                        raise NotImplementedError("array-valued steps from a user `step` together with backtracking are not implemented")
+                    dev.pgm_set_fixed_steps(steps)
+                need, eff, res = dev.pgm_bt_split(0)
+                while need:                                      # prox[j](_X[j] - T[j] S[j] G[j], T[j] S[j]) (algorithms.py:108, :125)
+                    for j in range(2):
+                        if (need >> j) & 1:
+                            T = np.ascontiguousarray(dev.get(_lib.BUF_BT_A, j)).astype(dt)
+                            dev.put(_lib.BUF_BT_A, j, np.asarray(host_prox[j](T, dt.type(eff[j]))))
+                    need, eff, res = dev.pgm_bt_split(1)
+                _write_back(dev, A, S)
+                it_done = res.total_iterations
+                if res.stopped:
+                    break
+        elif bt_user_step:
             # algorithms.py:105-127 with a Python `step`: its scalars become the constants of ONE device iteration with the
             # line search (T[j] S[j] in the reference: T lives on the device, S comes from here)
             takes_grads = False

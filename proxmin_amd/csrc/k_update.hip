@@ -480,6 +480,12 @@ struct BtArgs {
     float T[2];
     int do_block[2];
     int first;           // first application in this iteration: X still holds X_, fold slabs, store Xp and G
+    // [r4] a user-defined prox of block j inside the line search (one host round trip per TRIAL of that block):
+    //   mode 0  the operator of this library, on the device;
+    //   mode 1  "pre":  Tb_j = Xe_j - T_j s_j G_j for the host's callable (first: Xp and G stored as in mode 0); X_j untouched, no sums;
+    //   mode 2  "post": X_j <- Tb_j as the host left it, and the sums of the trial (reads Xp and G: `first` must be 0)
+    int mode[2];
+    float* Tb[2];
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_bt_update(BtArgs a) {
@@ -503,10 +509,20 @@ __global__ __launch_bounds__(EW_THREADS) void k_bt_update(BtArgs a) {
             if (!a.first) g[c] = ok[c] ? a.G[j][e] : 0.f;
             xo[c] = ok[c] ? (a.first ? a.X[j][e] : a.Xp[j][e]) : 0.f;
             const float xe = ok[c] ? a.Xe[j][e] : 0.f;
-            v[c] = xe - s * g[c];
+            v[c] = a.mode[j] == 2 ? (ok[c] ? a.Tb[j][e] : 0.f) : xe - s * g[c];
             sk[c] = s;
         }
-        prox_row<NC>(v, ok, a.prox[j], sk);
+        if (a.mode[j] == 1) {                // the argument of the user's prox; X_ and G kept for the trials that follow
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ok[c]) {
+                    const int64_t e = r * K + l32 + 32 * c;
+                    a.Tb[j][e] = v[c];
+                    if (a.first) { a.Xp[j][e] = xo[c]; a.G[j][e] = g[c]; }
+                }
+            continue;
+        }
+        if (a.mode[j] == 0) prox_row<NC>(v, ok, a.prox[j], sk);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             if (ok[c]) {
@@ -521,6 +537,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bt_update(BtArgs a) {
                 mx = fmaxf(mx, fabsf(xo[c]));
             }
     ROW_LOOP_END
+    if (a.mode[j] == 1) return;              // (uniform per block: nothing to reduce yet)
     double red[2] = {(double)d2, (double)n2};
     block_sum_store<2>(red, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
     double r1[1] = {(double)d1};

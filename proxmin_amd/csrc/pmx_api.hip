@@ -147,7 +147,10 @@ struct pmx_ctx {
     int it = 0;                            // iterations enqueued AND completed (host view)
     double nest_t = 1.0;                   // NesterovAccelerator.t (utils.py:195)
     double btT[2] = {1.0, 1.0};            // backtracking step multipliers T (algorithms.py:85), never reset inside a run
-    double bt_fprev = 0.0;
+    double bt_fprev = 0.0, bt_fnow = 0.0;
+    int bt_pending = 0;                    // line search: blocks (bit j) whose user prox the caller owes (pmx_pgm_bt_split)
+    int bt_trial = 3;                      // blocks whose sums the current trial renews
+    float* btBuf[2] = {nullptr, nullptr};  // argument / result of a user prox inside the line search (PMX_BUF_BT_A / _ST)
     float omega_cur = 0.f;
     int nsub_guess = 2;
     int sub_nt = SUB_NT_MAX;               // proximal sub-iteration passes per launch (PMX_SUB_BATCH=1: one launch per pass)
@@ -632,6 +635,9 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
     } else if (buf == PMX_BUF_STEP_A || buf == PMX_BUF_STEP_ST) {
         j = buf - PMX_BUF_STEP_A;
         p = &c->stepArr[j];
+    } else if (buf == PMX_BUF_BT_A || buf == PMX_BUF_BT_ST) {
+        j = buf - PMX_BUF_BT_A;
+        p = &c->btBuf[j];
     } else FAIL(PMX_E_INVALID, "unknown buffer id %d", buf);
     *count = c->rows[j] * c->K;
     if (!*p) {
@@ -1378,8 +1384,13 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
             if (rc == PMX_OK) rc = dallocT(c, &c->bbG[j], (size_t)c->rows[j] * c->K, false);
             if (rc != PMX_OK) return rc;
         }
-    if ((p->host_prox[0] || p->host_prox[1]) && p->backtracking)     // (every trial of the line search would go through the host)
-        FAIL(PMX_E_UNSUPPORTED, "a user-defined prox together with backtracking is not implemented");
+    c->bt_pending = 0;
+    if (p->backtracking)
+        for (int j = 0; j < 2; ++j)
+            if (p->host_prox[j]) {               // [r4] every trial of that block takes a host round trip (pmx_pgm_bt_split)
+                rc = dallocT(c, &c->btBuf[j], (size_t)c->rows[j] * c->K, false);
+                if (rc != PMX_OK) return rc;
+            }
     for (int j = 0; j < 2; ++j)
         if (p->host_prox[j]) {
             rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
@@ -1502,22 +1513,14 @@ static int loss_now(pmx_ctx* c, const float* A, const float* St, double* out) {
     return PMX_OK;
 }
 
-// one PGM iteration with the Beck-Teboulle line search (algorithms.py:93-135); host-driven, synchronous
-static int pgm_bt_iteration(pmx_ctx* c) {
+// one PGM iteration with the Beck-Teboulle line search (algorithms.py:93-135); host-driven, synchronous.
+// [r4] Resumable: a block whose prox is a user callable (pmx_pgm_params::host_prox) has every TRIAL of the search take a host
+// round trip -- the device forms the callable's argument T_j = _X_j - T_j s_j G_j (k_bt_update mode 1, PMX_BUF_BT_A / _ST),
+// returns with *need = the blocks waiting for their prox (and eff[j] = T_j s_j, the step the reference passes it, :108,125),
+// and the next call (phase 1) adopts what the caller left there (mode 2) and goes on with the test.  *need == 0: the
+// iteration is complete.  Blocks with this library's operators never leave the device.
+static BtArgs bt_args(pmx_ctx* c) {
     const pmx_pgm_params& p = c->pgm;
-    int rc;
-    // _X is a separate buffer in this mode (algorithms.py:96-97): Xe already holds it (copy of X, or the
-    // extrapolated point written by k_bt_finish at the end of the previous iteration)
-    if (c->it == 0) {                                        // f_prev = f(*X_) on the first iteration (:113-114)
-        rc = loss_now(c, c->X[0], c->X[1], &c->bt_fprev);
-        if (rc != PMX_OK) return rc;
-    }
-    if (!p.use_fixed_steps && !p.bb_type) {
-        rc = enqueue_steps(c, c->Xe[0], c->Xe[1], true, true, (double)p.step_scale);
-        if (rc != PMX_OK) return rc;
-    }
-    rc = enqueue_grad(c, c->Xe[0], c->Xe[1], 1, 1);
-    if (rc != PMX_OK) return rc;
     BtArgs u{};
     for (int j = 0; j < 2; ++j) {
         u.X[j] = c->X[j]; u.Xe[j] = c->Xe[j]; u.Xp[j] = c->Xp[j]; u.G[j] = c->G[j];
@@ -1525,39 +1528,83 @@ static int pgm_bt_iteration(pmx_ctx* c) {
         u.rows[j] = c->rows[j];
         u.prox[j] = to_dev(p.prox[j]);
         u.T[j] = (float)c->btT[j];
-        u.do_block[j] = 1;
+        u.Tb[j] = c->btBuf[j];
     }
-    u.K = (int)c->K; u.status = c->dstatus; u.partials = c->partials; u.first = 1;
-    launch_bt_update(u, c->stream);
+    u.K = (int)c->K; u.status = c->dstatus; u.partials = c->partials;
+    return u;
+}
+static int bt_step(pmx_ctx* c, int phase, int* need, double eff[2]) {
+    const pmx_pgm_params& p = c->pgm;
+    int rc;
+    *need = 0;
     BtCollectArgs col{};
-    col.status = c->dstatus; col.partials = c->partials; col.do_block[0] = col.do_block[1] = 1;
-    launch_bt_collect(col, c->stream);
-    double f_now;
-    rc = loss_now(c, c->X[0], c->X[1], &f_now);
-    if (rc != PMX_OK) return rc;
-    rc = read_status(c);
-    if (rc != PMX_OK) return rc;
-    for (int guard = 0; guard < 200; ++guard) {
-        const DevStatus* s = c->hstatus;
-        double q = 0.0;
-        for (int j = 0; j < 2; ++j) q += s->bt[j][0] + 0.5 / (c->btT[j] * s->step[j]) * s->bt[j][1];
-        if (!(f_now > c->bt_fprev + q)) break;               // algorithms.py:117-118
-        // block with the largest relative update direction (algorithms.py:121)
-        const double r0 = s->step[0] * s->bt[0][2] / s->bt[0][3], r1 = s->step[1] * s->bt[1][2] / s->bt[1][3];
-        const int jm = r1 > r0 ? 1 : 0;                      // np.argmax: first maximum
-        c->btT[jm] *= 0.5;
-        u.first = 0;
-        u.do_block[0] = jm == 0; u.do_block[1] = jm == 1;
-        u.T[jm] = (float)c->btT[jm];
+    col.status = c->dstatus; col.partials = c->partials;
+    if (phase == 0) {
+        if (c->bt_pending) FAIL(PMX_E_STATE, "the line search is waiting for the prox of block mask %d (phase 1)", c->bt_pending);
+        // _X is a separate buffer in this mode (algorithms.py:96-97): Xe already holds it (copy of X, or the
+        // extrapolated point written by k_bt_finish at the end of the previous iteration)
+        if (c->it == 0) {                                        // f_prev = f(*X_) on the first iteration (:113-114)
+            rc = loss_now(c, c->X[0], c->X[1], &c->bt_fprev);
+            if (rc != PMX_OK) return rc;
+        }
+        if (!p.use_fixed_steps && !p.bb_type) {
+            rc = enqueue_steps(c, c->Xe[0], c->Xe[1], true, true, (double)p.step_scale);
+            if (rc != PMX_OK) return rc;
+        }
+        rc = enqueue_grad(c, c->Xe[0], c->Xe[1], 1, 1);
+        if (rc != PMX_OK) return rc;
+        BtArgs u = bt_args(c);
+        u.first = 1;
+        for (int j = 0; j < 2; ++j) { u.do_block[j] = 1; u.mode[j] = p.host_prox[j] ? 1 : 0; }
         launch_bt_update(u, c->stream);
-        col.do_block[0] = u.do_block[0]; col.do_block[1] = u.do_block[1];
+        c->bt_pending = (p.host_prox[0] ? 1 : 0) | (p.host_prox[1] ? 2 : 0);
+        c->bt_trial = 3;                                         // blocks whose sums this trial renews: both
+        if (c->bt_pending) {
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            for (int j = 0; j < 2; ++j) eff[j] = c->btT[j] * c->hstatus->step[j];
+            *need = c->bt_pending;
+            return PMX_OK;
+        }
+    } else {
+        if (!c->bt_pending) FAIL(PMX_E_STATE, "no block of the line search is waiting for its prox");
+        BtArgs u = bt_args(c);
+        u.first = 0;
+        for (int j = 0; j < 2; ++j) { u.do_block[j] = (c->bt_pending >> j) & 1; u.mode[j] = 2; }
+        launch_bt_update(u, c->stream);
+        c->bt_pending = 0;
+    }
+    for (int guard = 0; guard < 200; ++guard) {
+        col.do_block[0] = c->bt_trial & 1; col.do_block[1] = (c->bt_trial >> 1) & 1;
         launch_bt_collect(col, c->stream);
+        double f_now;
         rc = loss_now(c, c->X[0], c->X[1], &f_now);
         if (rc != PMX_OK) return rc;
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
+        const DevStatus* s = c->hstatus;
+        double q = 0.0;
+        for (int j = 0; j < 2; ++j) q += s->bt[j][0] + 0.5 / (c->btT[j] * s->step[j]) * s->bt[j][1];
+        if (!(f_now > c->bt_fprev + q)) { c->bt_fnow = f_now; break; }   // algorithms.py:117-118
+        // block with the largest relative update direction (algorithms.py:121)
+        const double r0 = s->step[0] * s->bt[0][2] / s->bt[0][3], r1 = s->step[1] * s->bt[1][2] / s->bt[1][3];
+        const int jm = r1 > r0 ? 1 : 0;                          // np.argmax: first maximum
+        c->btT[jm] *= 0.5;
+        BtArgs u = bt_args(c);
+        u.first = 0;
+        u.do_block[0] = jm == 0; u.do_block[1] = jm == 1;
+        u.mode[jm] = p.host_prox[jm] ? 1 : 0;
+        launch_bt_update(u, c->stream);
+        c->bt_trial = 1 << jm;
+        c->bt_fnow = f_now;
+        if (p.host_prox[jm]) {
+            c->bt_pending = 1 << jm;
+            for (int j = 0; j < 2; ++j) eff[j] = c->btT[j] * s->step[j];
+            *need = c->bt_pending;
+            return PMX_OK;
+        }
     }
-    c->bt_fprev = f_now;                                      // :127
+    c->bt_fprev = c->bt_fnow;                                    // :127
     BtFinishArgs fin{};
     for (int j = 0; j < 2; ++j) { fin.X[j] = c->X[j]; fin.Xp[j] = c->Xp[j]; fin.Xe[j] = c->Xe[j]; fin.rows[j] = c->rows[j]; }
     fin.K = (int)c->K; fin.status = c->dstatus;
@@ -1571,6 +1618,13 @@ static int pgm_bt_iteration(pmx_ctx* c) {
     HIP_CHECK(hipGetLastError());
     c->it += 1;
     return PMX_OK;
+}
+static int pgm_bt_iteration(pmx_ctx* c) {                        // every operator on the device: never waits for the caller
+    int need = 0;
+    double eff[2];
+    int rc = bt_step(c, 0, &need, eff);
+    if (rc == PMX_OK && need) FAIL(PMX_E_STATE, "a user-defined prox inside the line search runs through pmx_pgm_bt_split");
+    return rc;
 }
 
 static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
@@ -1646,6 +1700,29 @@ extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
     for (int j = 0; j < 2; ++j)
         if (((mask >> j) & 1) && !c->stepArr[j]) FAIL(PMX_E_STATE, "block %d: upload the steps into PMX_BUF_STEP_%s first", j, j ? "ST" : "A");
     c->step_arr_mask = mask;
+    return PMX_OK;
+}
+
+extern "C" int pmx_pgm_bt_split(pmx_ctx* c, int phase, int* need, double eff_steps[2], pmx_result* res) {
+    if (c) c->absmax_by_finish = false;
+    int rc = require_ready(c);
+    if (rc != PMX_OK) return rc;
+    if (!need || !eff_steps) FAIL(PMX_E_INVALID, "NULL argument");
+    if (c->algo != ALG_PGM || !c->pgm.backtracking) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called with backtracking");
+    if (phase != 0 && phase != 1) FAIL(PMX_E_INVALID, "bad phase %d", phase);
+    const int it0 = c->hstatus->it_done;
+    if (phase == 0 && c->pgm.use_fixed_steps) {
+        rc = set_fixed_steps(c, c->pgm.fixed_steps);
+        if (rc != PMX_OK) return rc;
+    }
+    if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }       // (one iteration per call: nothing to repeat into)
+    rc = bt_step(c, phase, need, eff_steps);
+    if (rc != PMX_OK) return rc;
+    if (*need == 0) {
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        fill_result(c, res, it0);
+    }
     return PMX_OK;
 }
 

@@ -260,6 +260,14 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_pgm_split(self.h, int(phase), st, C.byref(r)))
         return r
 
+    def pgm_bt_split(self, phase):
+        """One piece of ONE pgm iteration with the line search when a block's prox is a user callable (include/pmx.h:
+        pmx_pgm_bt_split) -> (mask of the blocks whose prox is owed, (T_A s_A, T_S s_S), result)."""
+        r = _lib.Result()
+        need, eff = C.c_int(), (C.c_double * 2)()
+        _lib.check(self.lib.pmx_pgm_bt_split(self.h, int(phase), C.byref(need), eff, C.byref(r)))
+        return need.value, (eff[0], eff[1]), r
+
     def pgm_set_fixed_steps(self, steps):
         """new step constants of a context begun with fixed steps (include/pmx.h: pmx_pgm_set_fixed_steps)"""
         _lib.check(self.lib.pmx_pgm_set_fixed_steps(self.h, (C.c_double * 2)(float(steps[0]), float(steps[1]))))

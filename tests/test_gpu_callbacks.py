@@ -462,9 +462,10 @@ def test_backtracking_with_a_user_step(pm, tag):
         assert_factors_close(S, z[key + "/S"], dtype, key + " S")
         assert pm.nmf.log_likelihood(A, S, Y=Y) == pytest.approx(float(z[key + "/loss"]), rel=2e-3)
     assert seen["grads"] >= 15
-    # what stays out: a user prox next to the line search
+    # [r4] a user prox next to the line search runs too (test_backtracking_with_a_user_prox); what stays out: a user GRADIENT there
     with pytest.raises(NotImplementedError):
-        pm.pgm([A0.copy(), S0.copy()], grad, scaled(1.0), prox=[lambda X, step: np.maximum(X, 0), pm.operators.prox_plus], backtracking=True, f=f, max_iter=2)
+        pm.pgm([A0.copy(), S0.copy()], lambda A, S: pm.nmf.grad_likelihood(A, S, Y=Y), scaled(1.0), prox=[pm.operators.prox_plus] * 2,
+               backtracking=True, f=f, max_iter=2)
 
 
 @pytest.mark.parametrize("bbtype,accel", [(1, False), (2, True)])
@@ -494,3 +495,56 @@ def test_barzilai_borwein_steps_with_a_user_prox_or_gradient(pm, orc, bbtype, ac
     from test_gpu_nmf import assert_factors_close
     assert_factors_close(A2, Ao, np.float32, "bb + user prox A")
     assert_factors_close(S2, So, np.float32, "bb + user prox S")
+
+
+@pytest.mark.parametrize("accel", [False, True])
+def test_backtracking_with_a_user_prox(pm, orc, accel):
+    """[r4] algorithms.py:110-127 with a user-written prox (round 3: NotImplementedError): every trial of that block takes a
+    host round trip (pmx_pgm_bt_split), the sufficient-decrease test, the other block and f stay on the device.  A 4 x too
+    long fixed step forces halvings.  A user-written projection must give the library operator's factors BIT FOR BIT (same
+    device arithmetic on either side of an exact host operation); a user-written soft threshold is checked against the oracle;
+    and the callable is handed T[j] S[j], the halved step, like the reference's (:125)."""
+    from test_gpu_nmf import assert_factors_close
+    Y, A0, S0 = orc.synthetic_problem(150, 210, 5, np.float32, seed=17)
+    sA, sS = orc.lipschitz_steps(A0.astype(np.float64), S0.astype(np.float64))
+    fixed = (4 * sA, 4 * sS)
+    f = partial(pm.nmf.log_likelihood, Y=Y)
+    seen = []
+
+    def my_plus(X, step):
+        seen.append(float(step))
+        return np.maximum(X, 0)
+    runs = {}
+    for name, prox_A in (("library", pm.operators.prox_plus), ("user", my_plus)):
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A, S, prox_A=prox_A, step=pm.nmf.constant_step(*fixed), accelerated=accel, backtracking=True, f=f,
+                   max_iter=10, e_rel=1e-9, callback=tb)
+        runs[name] = (A, S, len(tb.trace))
+    np.testing.assert_array_equal(runs["user"][0], runs["library"][0])
+    np.testing.assert_array_equal(runs["user"][1], runs["library"][1])
+    assert runs["user"][2] == runs["library"][2]
+    # the callable is handed T[j] S[j] (algorithms.py:108, :125): the fixed step times a power of 1/2
+    assert seen[0] == pytest.approx(fixed[0], rel=1e-6)
+    assert all(abs(np.log2(fixed[0] / s) - round(np.log2(fixed[0] / s))) < 1e-4 for s in seen), seen[:8]
+    # both blocks with user callables, one of them a soft threshold, against the oracle
+    seen_S = []
+
+    def my_soft(X, step):
+        seen_S.append(float(step))
+        return np.sign(X) * np.maximum(np.abs(X) - 0.01 * step, 0)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, prox_A=my_plus, prox_S=my_soft, step=pm.nmf.constant_step(*fixed), accelerated=accel, backtracking=True, f=f,
+               max_iter=10, e_rel=1e-9)
+    Ao, So = A0.copy(), S0.copy()
+    orc.pgm_nmf(Y, Ao, So, prox_A=("plus",), prox_S=("soft", 0.01, "relative"), step=lambda a, s, it, g: fixed, accelerated=accel,
+                backtracking=True, max_iter=10, e_rel=1e-9)
+    assert_factors_close(A, Ao, np.float32, "user prox + backtracking A")
+    assert_factors_close(S, So, np.float32, "user prox + backtracking S")
+    assert min(seen + seen_S) < 0.6 * min(fixed), "a 4 x too long step must have been halved on one of the blocks"
+    # a user `step` AND a user prox with the line search
+    A, S = A0.copy(), S0.copy()
+    pm.pgm([A, S], partial(pm.nmf.grad_likelihood, Y=Y), lambda *X, it=None: fixed, prox=[my_plus, pm.operators.prox_plus], accelerated=accel,
+           backtracking=True, f=f, e_rel=1e-9, max_iter=10)
+    np.testing.assert_array_equal(A, runs["library"][0])
+    np.testing.assert_array_equal(S, runs["library"][1])
