@@ -369,12 +369,20 @@ struct PgmArgs {
                              // contribute exact zeros to the partial sums (their entries already hold zeros) and one ticket
                              // each -- 512 atomics on one address are 5 us of a small problem's 13 us update
     double e_rel[2];
+    // [r4] the NEXT iteration's step rule starts here: every row of the point the next gradient is evaluated at passes through
+    // this kernel's registers, so workgroup b leaves the partial Gram matrix of ITS 32 rows -- k_gram_partial's own share and
+    // summation order at 4096 rows (bit-identical partials), another grouping of the same sum otherwise -- in gramPart[j][b];
+    // the slots of workgroups that do not exist (nbx < 128) are zeroed by the ones that do.  Only where one batch of rows per
+    // workgroup covers the factor (rows <= 4096 in both blocks) and K <= 64; nullptr: off (k_gram_partial runs as before).
+    float* gramPart;         // [2][128][KP*KP]
+    int KP;
 };
 __device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt = false);
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
     __shared__ int s_last;
+    __shared__ float gtile[NC <= 2 ? 32 : 1][NC <= 2 ? 32 * NC + 1 : 1];   // the workgroup's 32 rows of the next evaluation point
     const int j = blockIdx.y;
     // (the halt flag and the step size travel together: one round trip to memory instead of two)
     const int halted = __builtin_nontemporal_load(&a.status->halt);
@@ -418,6 +426,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
                 a.G[j][e] = g[c];
                 float xnext = v[c];          // the point the next gradient is evaluated at
                 if (a.accelerated) { xnext = v[c] + a.omega_next * (v[c] - xo[c]); Xe[e] = xnext; }
+                if constexpr (NC <= 2) { if (a.gramPart != nullptr) gtile[threadIdx.x >> 5][l32 + 32 * c] = xnext; }
                 xmax = fmaxf(xmax, fabsf(xnext));
                 const float d = v[c] - xo[c];
                 d2 += d * d;
@@ -426,6 +435,24 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
         }
     ROW_LOOP_END
     if (mode == 1) return;
+    if constexpr (NC <= 2) {
+        if (a.gramPart != nullptr) {         // (uniform) partial Gram matrix of this workgroup's rows 32 b .. 32 b + 31
+            const int KP = a.KP, nb = gridDim.x;
+            const int64_t row0 = (int64_t)blockIdx.x * (EW_THREADS / 32);
+            const int nrow = rows - row0 < EW_THREADS / 32 ? (int)(rows - row0) : EW_THREADS / 32;
+            __syncthreads();
+            float* out = a.gramPart + ((int64_t)j * 128 + blockIdx.x) * KP * KP;
+            for (int e = threadIdx.x; e < KP * KP; e += EW_THREADS) {
+                const int gi = e / KP, gj = e - gi * KP;
+                float acc = 0.f;
+                if (gi < K && gj < K)
+                    for (int rr = 0; rr < nrow; ++rr) acc += gtile[rr][gi] * gtile[rr][gj];     // k_gram_partial's order: rows ascending
+                out[e] = acc;
+                for (int b = blockIdx.x + nb; b < 128; b += nb) out[(int64_t)(b - blockIdx.x) * KP * KP + e] = 0.f;
+            }
+            __syncthreads();
+        }
+    }
     if (a.absmax_out != nullptr) {
         const double m = wave_max((double)xmax);
         if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;

@@ -103,6 +103,10 @@ struct pmx_ctx {
     // row-sharded adaprox: the last kernels enqueued were an iteration tail (k_ada_finish left the factor maxima in
     // `absmax`); every entry point that can change the factors otherwise clears it
     bool absmax_by_finish = false;
+    // pgm: the partial Gram matrices in gramPart were left by the last k_pgm_update for the point the next iteration evaluates
+    // (PgmArgs::gramPart): the step rule skips k_gram_partial.  Cleared wherever the factors can change behind the solver's back.
+    bool gram_by_update = false;
+    bool gram_in_update = true;            // PMX_GRAM_IN_UPDATE=0 (read at context creation): off
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
     int64_t rowsPad[2] = {0, 0};
@@ -312,6 +316,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         if (e != hipSuccess) { delete c; FAIL(PMX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
+    if (const char* e = getenv("PMX_GRAM_IN_UPDATE")) c->gram_in_update = atoi(e) != 0;
     if (const char* e = getenv("PMX_INJECT_K1_FAULT")) c->hook_inject_k1 = atoi(e);
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     c->use_small = grad_small_applies(M, N, K);
@@ -650,7 +655,7 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
 }
 
 extern "C" int pmx_upload(pmx_ctx* c, int buf, const float* host, int64_t count) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     float** slot; int64_t n;
@@ -675,7 +680,7 @@ extern "C" int pmx_download(pmx_ctx* c, int buf, float* host, int64_t count) {
 }
 
 extern "C" int pmx_buffer_ptr(pmx_ctx* c, int buf, void** dptr, int64_t* count) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     if (!c || !dptr) FAIL(PMX_E_INVALID, "NULL argument");
     float** slot; int64_t n;
     int rc = buf_lookup(c, buf, &slot, &n, true);
@@ -807,6 +812,7 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
     c->hstatus->halt = 0;
     c->hstatus->reason = 0;
     c->absmax_by_finish = false;
+    c->gram_by_update = false;
     *again = 1;
     return PMX_OK;
 }
@@ -965,7 +971,7 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
 }
 
 // Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
-static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale) {
+static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale, bool have_partials = false) {
     if (eig_small_applies(c)) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig_small forms G itself)
         const EigArgs e = small_eig_args(c, A, St, wantStepA, wantStepS, scale);
         HIP_CHECK(launch_eig(e, c->stream));
@@ -979,7 +985,7 @@ static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantS
     g.status = c->dstatus;
     g.want[0] = wantStepS;   // factor 0 (A)  -> step of block 1 (S)
     g.want[1] = wantStepA;   // factor 1 (St) -> step of block 0 (A)
-    launch_gram(g, c->KP, c->stream);
+    if (!have_partials) launch_gram(g, c->KP, c->stream);     // (have_partials: k_pgm_update left them, PgmArgs::gramPart)
     GramReduceArgs r{};
     r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
     r.want[0] = g.want[0]; r.want[1] = g.want[1];
@@ -1296,7 +1302,7 @@ extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
 }
 
 extern "C" int pmx_prox_apply(pmx_ctx* c, int buf, const pmx_proxseq* prox, const float* step_k) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     if (!c || !prox || !step_k) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     int rc = check_prox(*prox, "prox_apply", true);
@@ -1336,7 +1342,7 @@ extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const p
 // PGM / FISTA                                             (proxmin/algorithms.py:12-144)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -1442,7 +1448,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         if (rc != PMX_OK) return rc;
     } else {
         if (!p.use_fixed_steps && !p.bb_type) {
-            rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);   // algorithms.py:106
+            rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale, c->gram_by_update);   // algorithms.py:106
             if (rc != PMX_OK) return rc;
         }
         rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
@@ -1493,8 +1499,14 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     // the fp16 K1's operand maxima for the next iteration come from this kernel (every workgroup writes its partial: full grid only)
     u.absmax_out = (c->f16_scales && u.nbx == EW_BLOCKS) ? c->absmax : nullptr;
     u.e_rel[0] = p.e_rel[0]; u.e_rel[1] = p.e_rel[1];
+    // the next iteration's partial Gram matrices from this launch (PgmArgs::gramPart): the Lipschitz rule on factors of <= 4096
+    // rows each, K <= 64 (cfg2); PMX_GRAM_IN_UPDATE=0 keeps k_gram_partial (A/B)
+    const bool gram_here = !p.use_fixed_steps && !p.bb_type && !c->use_small && c->K <= 64 && c->rows[0] <= 4096 && c->rows[1] <= 4096 && c->gram_in_update;
+    u.gramPart = gram_here ? c->gramPart : nullptr;
+    u.KP = c->KP;
     launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
     HIP_CHECK(hipGetLastError());
+    c->gram_by_update = gram_here;
     c->absmax_by_finish = u.absmax_out != nullptr;
     c->it += 1;
     return PMX_OK;
@@ -1633,7 +1645,7 @@ static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
 }
 
 extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) c->absmax_by_finish = false;      // (gram_by_update survives: nothing but this solver's own update kernel has touched the factors since)
     int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
@@ -1704,7 +1716,7 @@ extern "C" int pmx_pgm_step_arrays(pmx_ctx* c, int mask) {
 }
 
 extern "C" int pmx_pgm_bt_split(pmx_ctx* c, int phase, int* need, double eff_steps[2], pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!need || !eff_steps) FAIL(PMX_E_INVALID, "NULL argument");
@@ -1727,7 +1739,7 @@ extern "C" int pmx_pgm_bt_split(pmx_ctx* c, int phase, int* need, double eff_ste
 }
 
 extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
@@ -1832,7 +1844,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
 // adaprox                                                 (proxmin/algorithms.py:248-423)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int warm_moments) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -2053,7 +2065,7 @@ static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev, bool 
 }
 
 extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double b1_prev, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
@@ -2147,7 +2159,7 @@ extern "C" int pmx_adaprox_set_alpha(pmx_ctx* c, const float* alpha) {
 }
 
 extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, double b1_prev, const int* host_tau, double* maxpsi, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
@@ -2203,7 +2215,7 @@ extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, do
 // block-SDMM                                              (proxmin/algorithms.py:653-850)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -2289,7 +2301,7 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
 //   phase 2  the constraint updates with the user members' results taken from PMX_BUF_TG0 + .. (if any), the Boyd test of
 //            the block; last_block: end-of-iteration bookkeeping (iteration counter, stop when every block has converged)
 extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigned host_g, int last_block, double step_f_host, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
@@ -2368,7 +2380,7 @@ extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigne
 }
 
 extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
@@ -2651,7 +2663,7 @@ static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
 }
 
 extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_PGM) FAIL(PMX_E_STATE, "pmx_pgm_begin has not been called");
@@ -2730,7 +2742,7 @@ static int bsdmm_enqueue_decide(pmx_ctx* c, int j, const float* comm_scalars, in
 }
 
 extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
-    if (c) c->absmax_by_finish = false;
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
     int rc = require_ready(c);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
