@@ -44,7 +44,10 @@ __global__ __launch_bounds__(GRAM_THREADS) void k_gram_partial(GramArgs a) {
     for (int i = 0; i < TS; ++i)
 #pragma unroll
         for (int jx = 0; jx < TS; ++jx) acc[i][jx] = 0.f;
-    const int64_t per = (rows + GRAM_BLOCKS - 1) / GRAM_BLOCKS;
+    // shares of at least 32 rows: the grouping k_pgm_update leaves when IT produces the partials (PgmArgs::gramPart: workgroup b
+    // holds rows 32 b .. 32 b + 31), so that the step rule is the same number bit for bit whichever kernel summed the rows
+    int64_t per = (rows + GRAM_BLOCKS - 1) / GRAM_BLOCKS;
+    if (per < 32) per = 32;
     const int64_t r0 = (int64_t)blockIdx.x * per;
     const int64_t r1 = r0 + per < rows ? r0 + per : rows;
     for (int64_t rb = r0; rb < r1; rb += GRAM_CHUNK) {
