@@ -54,7 +54,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     fake = int(os.environ.get("PMX_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
     eff_world = fake if fake > 1 else world
     # S-split whenever it applies: adaprox with a projection-type prox_S (cfg4), N divisible by the rank count
-    s_split = backend == "adaprox" and not unity and eff_world > 1 and N % eff_world == 0 and os.environ.get("PMX_S_SPLIT", "1") != "0"
+    s_split = ((backend == "adaprox" and not unity) or backend == "pgm") and eff_world > 1 and N % eff_world == 0 and os.environ.get("PMX_S_SPLIT", "1") != "0"
     eng = ShardEngine(dev, eff_world, 0 if fake > 1 else rank, M * fake if fake > 1 else M, backend, s_split=s_split)
     pA = ops.device_proxseq(ops.prox_plus, 0)
     pS = ops.device_proxseq(partial(ops.prox_unity_plus, axis=0) if unity else ops.prox_plus, 1)
@@ -74,6 +74,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         run = lambda n: drv.run(n, b1)
     elif backend == "pgm":
         dev.pgm_begin([pA, pS], accelerated=False, e_rel=(1e-12, 1e-12))
+        eng.bind_eval_buffer()
         loop = ShardedLoop(eng, None, deferred_test=True, dist_module=coll)
         run = loop.run
     else:

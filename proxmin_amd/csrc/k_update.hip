@@ -2205,6 +2205,7 @@ struct PackSplitArgs {
     int world;
     int64_t sncol, chunk;
     int zero_gram;           // write zeros into every chunk's (unused) Gram section: the first pack into a buffer only
+    const double* gramA;     // [r4] pgm: the local A^T A (KP*KP doubles) into every chunk's Gram section, every iteration; nullptr: adaprox
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a) {
@@ -2257,7 +2258,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_shard_pack_split(PackSplitArgs a
     fold_partials_many<4>(four, sums);
     for (int q = 0; q < a.world; ++q) {
         float* ex = a.comm + q * a.chunk + ex0;
-        if (a.zero_gram)
+        if (a.gramA != nullptr)
+            for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = (float)a.gramA[e];
+        else if (a.zero_gram)
             for (int e = t; e < a.KP * a.KP; e += EW_THREADS) ex[e] = 0.f;
         if (t < 32) ex[a.KP * a.KP + 2 * MAXK + t] = t < 4 ? (float)sums[t] : 0.f;
     }

@@ -1028,7 +1028,7 @@ static int enqueue_eig_only(pmx_ctx* c, bool wantA_factor, bool wantS_factor, do
 }
 static int shard_gram_in(pmx_ctx* c) {
     GramInArgs g{};
-    g.comm_gram = c->comm + c->N * c->K;
+    g.comm_gram = c->ssplit ? c->comm_out + c->sncol * c->K : c->comm + c->N * c->K;     // (S-split: this rank's reduced chunk)
     g.G = c->gramG;
     g.n = c->KP * c->KP;
     g.status = c->dstatus;
@@ -2532,8 +2532,9 @@ extern "C" int pmx_set_comm_out(pmx_ctx* c, float* dptr, int64_t count) {
     c->comm_out = dptr;
     return PMX_OK;
 }
-static int shard_pack_split(pmx_ctx* c, int fold_grad) {
+static int shard_pack_split(pmx_ctx* c, int fold_grad, bool with_gram = false) {
     PackSplitArgs p{};
+    p.gramA = with_gram ? c->gramG : nullptr;       // factor 0 = A (pgm: reduced with gS, read back by shard_gram_in)
     p.slabS = slab_ref(c, 1);
     p.comm = c->comm;
     p.N = c->N;
@@ -2558,12 +2559,13 @@ static int shard_post_split(pmx_ctx* c, int have_prev) {
     q.rows_global[0] = c->M_global;
     q.rows_global[1] = c->N;
     q.K = (int)c->K;
-    q.use_fixed = c->ada.use_fixed_steps;
+    const bool ada = c->algo == ALG_ADAPROX;
+    q.use_fixed = ada ? c->ada.use_fixed_steps : 2;              // pgm: no adaprox step sizes to derive (2: leave DevStatus::alpha alone)
     q.fixed[0] = (float)c->ada.fixed_alpha[0];
     q.fixed[1] = (float)c->ada.fixed_alpha[1];
-    q.e_rel[0] = c->ada.e_rel[0];
-    q.e_rel[1] = c->ada.e_rel[1];
-    q.check_convergence = c->ada.check_convergence;
+    q.e_rel[0] = ada ? c->ada.e_rel[0] : c->pgm.e_rel[0];
+    q.e_rel[1] = ada ? c->ada.e_rel[1] : c->pgm.e_rel[1];
+    q.check_convergence = ada ? c->ada.check_convergence : 1;
     q.have_prev = have_prev;
     launch_shard_post_split(q, c->stream);
     HIP_CHECK(hipGetLastError());
@@ -2637,15 +2639,15 @@ extern "C" int pmx_adaprox_phase(pmx_ctx* c, int phase, int it, double b1_it, do
 static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
     const pmx_pgm_params& p = c->pgm;
     PgmArgs u{};
-    for (int j = 0; j < 2; ++j) {
-        u.X[j] = c->X[j];
-        u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
-        u.G[j] = c->G[j];
+    for (int j = 0; j < 2; ++j) {            // S-split: block 1 is this rank's sncol columns of S (rows of S^T) only
+        u.X[j] = s_view(c, j, c->X[j]);
+        u.Xe[j] = s_view(c, j, p.accelerated ? c->Xe[j] : c->X[j]);
+        u.G[j] = s_view(c, j, c->G[j]);
         u.slab[j] = slab_ref(c, j);
-        u.rows[j] = c->rows[j];
+        u.rows[j] = upd_rows(c, j);
         u.prox[j] = to_dev(p.prox[j]);
     }
-    if (gS_from_comm) { u.slab[1].base = c->comm; u.slab[1].n = 1; }
+    if (gS_from_comm) { u.slab[1].base = c->ssplit ? c->comm_out : c->comm; u.slab[1].n = 1; }
     u.K = (int)c->K;
     u.status = c->dstatus;
     u.partials = c->partials;
@@ -2670,6 +2672,7 @@ extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
     if (!c->comm) FAIL(PMX_E_STATE, "pmx_set_comm_buffer has not been called");
     const pmx_pgm_params& p = c->pgm;
     if (p.bb_type || p.backtracking) FAIL(PMX_E_UNSUPPORTED, "row-sharded pgm supports the Lipschitz rule or fixed steps only");
+    if (c->ssplit && !c->comm_out) FAIL(PMX_E_STATE, "pmx_set_comm_out has not been called");
     const float* A = p.accelerated ? c->Xe[0] : c->X[0];
     const float* St = p.accelerated ? c->Xe[1] : c->X[1];
     switch (phase) {
@@ -2683,11 +2686,11 @@ extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
             rc = enqueue_grad(c, A, St, 1, 1);
             if (rc == PMX_OK) rc = phase_mark(c, 1);
             if (rc != PMX_OK) return rc;
-            rc = shard_pack(c, 1, !p.use_fixed_steps, 0);
+            rc = c->ssplit ? shard_pack_split(c, 1, !p.use_fixed_steps) : shard_pack(c, 1, !p.use_fixed_steps, 0);
             return rc == PMX_OK ? phase_mark(c, 2) : rc;
         case 1:
             rc = phase_mark(c, 3);
-            if (rc == PMX_OK) rc = shard_post(c, it > 0);
+            if (rc == PMX_OK) rc = c->ssplit ? shard_post_split(c, it > 0) : shard_post(c, it > 0);
             if (rc != PMX_OK) return rc;
             if (p.use_fixed_steps) rc = set_fixed_steps(c, p.fixed_steps);
             else {
@@ -2699,8 +2702,8 @@ extern "C" int pmx_pgm_phase(pmx_ctx* c, int phase, int it) {
             c->it += 1;
             rc = pgm_enqueue_update(c, true, 0);
             return rc == PMX_OK ? phase_mark(c, 5) : rc;
-        case 2: return shard_pack(c, 0, false, 0);
-        case 3: return shard_post(c, 1);
+        case 2: return c->ssplit ? shard_pack_split(c, 0, false) : shard_pack(c, 0, false, 0);
+        case 3: return c->ssplit ? shard_post_split(c, 1) : shard_post(c, 1);
         default: FAIL(PMX_E_INVALID, "bad phase %d", phase);
     }
 }

@@ -313,16 +313,22 @@ class ShardedLoop:
         self.stopped = False
 
     def _allreduce(self):
-        self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
+        if getattr(self.eng, "s_split", False):     # S-split: reduce-scatter here, the all-gather follows the update
+            reduce_scatter_sum(self.dist, self.eng.comm_out, self.eng.comm, self.group)
+        else:
+            self.dist.all_reduce(self.eng.comm, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def run(self, n_iter):
         target = self.it + int(n_iter)
+        split = getattr(self.eng, "s_split", False)
         while self.it < target and not self.stopped:
             hi = min(target, self.it + self.chunk)
             for it in range(self.it, hi):
                 self.eng.phase(0, it)
                 self._allreduce()
                 self.eng.phase(1, it)
+                if split:                            # every rank's columns of the next evaluation point
+                    all_gather_chunks(self.dist, self.eng.st_full, self.group)
             halted, reason, it_done, _ = self.eng.chain_status()
             self.it = it_done
             if halted and reason == HALT_CONVERGED:
@@ -335,6 +341,8 @@ class ShardedLoop:
             self.eng.phase(3, self.it)
             halted, reason, _, _ = self.eng.chain_status()
             self.stopped = bool(halted and reason == HALT_CONVERGED)
+        if split and getattr(self.eng, "st_iterate", None) is not None and n_iter > 0:
+            all_gather_chunks(self.dist, self.eng.st_iterate, self.group)      # FISTA: the iterate S itself, once per run
         return self.it
 
 
@@ -349,7 +357,7 @@ class ShardEngine:
         _lib.check(lib.pmx_set_world(dev.h, rank, world, int(M_global)))
         self.s_split = bool(s_split)
         if self.s_split:
-            assert algorithm == "adaprox", "S-split is implemented for the adaprox back-end"
+            assert algorithm in ("adaprox", "pgm"), "S-split is implemented for the adaprox and pgm back-ends"
             _lib.check(lib.pmx_set_s_split(dev.h, 1))
             cnt, chunk = C.c_int64(), C.c_int64()
             offs = (C.c_int64 * 4)()
@@ -362,13 +370,8 @@ class ShardEngine:
             self.comm_out = torch.zeros(chunk.value, dtype=torch.float32, device=device)
             _lib.check(lib.pmx_set_comm_buffer(dev.h, C.c_void_p(self.comm.data_ptr()), cnt.value))
             _lib.check(lib.pmx_set_comm_out(dev.h, C.c_void_p(self.comm_out.data_ptr()), chunk.value))
-            ptr, n = C.c_void_p(), C.c_int64()
-            _lib.check(lib.pmx_buffer_ptr(dev.h, _lib.BUF_ST, C.byref(ptr), C.byref(n)))
-            self.st_full = _device_tensor(ptr.value, n.value, dev.device)      # S^T (N x K) as the library holds it
-            # the all-gather must land in the library's own buffer: a tensor that COPIED it would leave K1 reading stale columns
-            if self.st_full.data_ptr() != ptr.value or self.st_full.numel() != n.value:
-                raise _lib.PmxError("S-split: torch did not alias the library's S^T buffer (%#x, %d floats) but made a copy"
-                                    % (ptr.value, n.value))
+            self.st_full = self._alias(_lib.BUF_ST)      # S^T (N x K) as the library holds it: the all-gather buffer
+            self.st_iterate = None                       # pgm / FISTA: see bind_eval_buffer()
             return
         cnt = C.c_int64()
         offs = (C.c_int64 * 3)()
@@ -377,6 +380,26 @@ class ShardEngine:
         assert (cnt.value, offs[0], offs[1], offs[2]) == (self.layout.count, self.layout.gram, self.layout.colsum, self.layout.scalars)
         self.comm = torch.zeros(cnt.value, dtype=torch.float32, device=torch.device("cuda", dev.device))
         _lib.check(lib.pmx_set_comm_buffer(dev.h, C.c_void_p(self.comm.data_ptr()), cnt.value))
+
+    def _alias(self, buf):
+        """zero-copy torch view of one of the library's N x K buffers (the all-gather writes into the library's own memory)"""
+        ptr, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.dev.lib.pmx_buffer_ptr(self.dev.h, buf, C.byref(ptr), C.byref(n)))
+        t = _device_tensor(ptr.value, n.value, self.dev.device)
+        # a tensor that COPIED the buffer would leave K1 reading stale columns
+        if t.data_ptr() != ptr.value or t.numel() != n.value:
+            raise _lib.PmxError("S-split: torch did not alias the library's buffer %d (%#x, %d floats) but made a copy" % (buf, ptr.value, n.value))
+        return t
+
+    def bind_eval_buffer(self):
+        """pgm, S-split, AFTER pgm_begin: what the ranks gather every iteration is the point the next gradient is evaluated at --
+        the extrapolated iterate under FISTA (PMX_BUF_EVAL_ST), S itself otherwise; under FISTA the iterate S proper is gathered
+        once, when a run ends (st_iterate)."""
+        if not self.s_split or self.algorithm != "pgm":
+            return
+        ev = self._alias(_lib.BUF_EVAL_ST)
+        if ev.data_ptr() != self.st_full.data_ptr():
+            self.st_iterate, self.st_full = self.st_full, ev
 
     def phase(self, phase, it, b1_it=0.0, b1_prev=0.0, nsub=0):
         lib, h = self.dev.lib, self.dev.h
@@ -472,9 +495,12 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
 
 
 def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, accelerated=False, step_scale=1.0,
-                    fixed_steps=None, e_rel=1e-3, max_iter=1000, group=None, device=None, comm=None):
+                    fixed_steps=None, e_rel=1e-3, max_iter=1000, group=None, device=None, comm=None, s_split="auto"):
     """Row-sharded `nmf(Y, A, S, algorithm=pgm, ...)` for one rank (Lipschitz steps x step_scale, or fixed steps).
-    Returns (converged, iterations)."""
+    [r4] s_split ("auto": whenever N divides by the rank count): the S update sharded too -- reduce-scatter of gS (with A's
+    partial Gram matrix and the stopping sums riding in every chunk), each rank updates its N / world columns (and, under
+    FISTA, extrapolates them), all-gather of the next evaluation point; any device prox_S (pgm applies it once, row by row of
+    S^T).  Returns (converged, iterations)."""
     import torch
     import torch.distributed as dist
     from . import operators
@@ -490,8 +516,12 @@ def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, acc
                                                stream=tstream.cuda_stream) as dev:
         dev.set_Y(Y_local)
         dev.set_factors(A_local, S)
-        eng = ShardEngine(dev, world, rank, M_global, "pgm")
+        can_split = world > 1 and S.shape[1] % world == 0
+        if s_split is True and not can_split:
+            raise NotImplementedError("S-split needs N divisible by the number of ranks")
+        eng = ShardEngine(dev, world, rank, M_global, "pgm", s_split=bool(s_split) and can_split)
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=step_scale, fixed_steps=fixed_steps, e_rel=e)
+        eng.bind_eval_buffer()
         loop = ShardedLoop(eng, group, deferred_test=True, dist_module=_collectives(comm, dev, rank, world, group))
         its = loop.run(max_iter)
         dA, dS = dev.get_factors()

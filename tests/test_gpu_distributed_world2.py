@@ -22,6 +22,10 @@ CASES = {
     "adaprox_k64_split": dict(M=1024, N=1280, K=64, unity=False, its=6, s_split=True),
     "adaprox_k128_split": dict(M=512, N=640, K=128, unity=False, its=5, modes=("f32", "f16x2"), s_split=True),
     "pgm": dict(M=520, N=700, K=12, its=7),
+    # [r4] S-split for pgm / FISTA: A's partial Gram matrix rides in the reduce-scatter's chunks, the ranks gather the next
+    # evaluation point (the extrapolated iterate under FISTA) and, once, the iterate itself
+    "pgm_split": dict(M=520, N=700, K=12, its=7, s_split=True),
+    "fista_split": dict(M=1024, N=1280, K=64, its=7, s_split=True, accelerated=True),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
     # (PMX_INJECT_K1_FAULT): it falls back to slabs, rank 0 is stopped at the same iteration through the collective halt
@@ -70,8 +74,9 @@ def _worker(rank, world, port, name, mode, out_dir):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
             conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme="amsgrad",
                                                 check_convergence=False, e_rel=1e-3, max_iter=c["its"], s_split=c.get("s_split", False))
-        elif name == "pgm":
-            conv, n = pdist.nmf_pgm_sharded(Y[r0:r1], A_l, S, M, e_rel=1e-9, max_iter=c["its"])
+        elif name in ("pgm", "pgm_split", "fista_split"):
+            conv, n = pdist.nmf_pgm_sharded(Y[r0:r1], A_l, S, M, e_rel=1e-9, max_iter=c["its"], s_split=c.get("s_split", False),
+                                            accelerated=c.get("accelerated", False), step_scale=0.5 if c.get("accelerated") else 1.0)
         else:
             pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
             conv, n = pdist.nmf_bsdmm_sharded(Y[r0:r1], A_l, S, M, proxs_g=pgl, e_rel=1e-9, max_iter=c["its"])
@@ -102,8 +107,9 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
             pm.nmf.nmf(Y, A1, S1, algorithm=pm.adaprox, scheme="amsgrad", prox_S=pS, max_iter=c["its"], e_rel=1e-3,
                        check_convergence=False, callback=tb)
-        elif name == "pgm":
-            pm.nmf.nmf(Y, A1, S1, max_iter=c["its"], e_rel=1e-9, callback=tb)
+        elif name in ("pgm", "pgm_split", "fista_split"):
+            kwp = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if c.get("accelerated") else {}
+            pm.nmf.nmf(Y, A1, S1, max_iter=c["its"], e_rel=1e-9, callback=tb, **kwp)
         else:
             pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
             pm.nmf.nmf(Y, A1, S1, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=c["its"], e_rel=1e-9, callback=tb)
@@ -145,8 +151,9 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     if name.startswith("adaprox"):
         orc.adaprox_nmf(Y64, Ao, So, ("plus",), ("unity_plus", 0) if c.get("unity") else ("plus",), scheme="amsgrad",
                         max_iter=c["its"], e_rel=1e-3, check_convergence=False)
-    elif name == "pgm":
-        orc.pgm_nmf(Y64, Ao, So, max_iter=c["its"], e_rel=1e-9)
+    elif name in ("pgm", "pgm_split", "fista_split"):
+        okw = dict(accelerated=True, step=lambda a, s_, it, g: tuple(0.5 * x for x in orc.lipschitz_steps(a, s_))) if c.get("accelerated") else {}
+        orc.pgm_nmf(Y64, Ao, So, max_iter=c["its"], e_rel=1e-9, **okw)
     else:
         orc.bsdmm_nmf(Y64, Ao, So, proxs_g=[[("plus",), ("soft", 0.01, "relative")]] * 2, max_iter=c["its"], e_rel=1e-9)
     smooth = not name.startswith("adaprox")      # amsgrad's eps clamp: a fraction, as everywhere else (test_gpu_parity_strict.py)
