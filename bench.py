@@ -293,7 +293,7 @@ def other_configs(Y3, local):
             dev.set_factors(A0, S0)
             run = begin_solver(dev, backend, unity)
             run(warm)
-            dev.set_timing(True, every=2)
+            dev.set_timing(True, every=4)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             r = run(steps)
