@@ -461,6 +461,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
             double mm = scratch[0];
             for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
             a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
+            for (int b = blockIdx.x + gridDim.x; b < EW_BLOCKS; b += gridDim.x) a.absmax_out[j * EW_BLOCKS + b] = 0.f;   // (a grid of nbx < 256)
         }
         __syncthreads();
     }

@@ -26,6 +26,7 @@
 #include "k_grad.hip"
 #include "k_grad_bf16.hip"
 #include "k_grad_k128.hip"
+#include "k_grad_f16_k32.hip"
 #include "k_grad_f32pc.hip"
 #include "k_update.hip"
 #include "k_gram.hip"
@@ -93,6 +94,7 @@ struct pmx_ctx {
     bool use_bf16 = false;                 // split-bf16 kernel (mode BF16X3 / F16X2 and K <= 64), else exact fp32 MFMA
     bool use_f16 = false;                  // mode F16X2 at a shape the two-term fp16 kernel takes
     bool k128 = false;                     // mode F16X2, K = 128 at a shape k_grad_f16_k128 takes
+    bool k32f16 = false;                   // mode F16X2, K = 32, M % 128 = 0, N % 256 = 0: k_grad_f16_k32 (no weights)
     bool f32pc = false;                    // exact-fp32 arithmetic at a shape the producer / consumer kernel k_grad_f32_pc takes
     bool f16_fell_back = false;            // use_f16, but the last launch ran the split-bf16 kernel (Y / W not fetchable in 8-byte pairs)
     bool f16_scales = false;               // use_f16 || k128: the K1 kernel needs the factor maxima (absmax) and max|Y|
@@ -325,9 +327,11 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
     c->k128 = mode == PMX_MODE_F16X2 && !c->use_small && grad_k128_applies(M, N, K);
     if (c->k128) c->plan = grad_plan_k128(M, N);
-    c->f32pc = !c->use_small && !c->use_bf16 && !c->k128 && grad_f32pc_applies(M, N, K);
+    c->k32f16 = mode == PMX_MODE_F16X2 && !c->use_small && grad_f16_k32_applies(M, N, K);
+    if (c->k32f16) { c->plan = grad_plan_f16_k32(M, N); c->use_bf16 = false; c->use_f16 = false; }
+    c->f32pc = !c->use_small && !c->use_bf16 && !c->k128 && !c->k32f16 && grad_f32pc_applies(M, N, K);
     if (c->f32pc) c->plan = grad_plan_f32pc(M, N, K);
-    c->f16_scales = c->use_f16 || c->k128;
+    c->f16_scales = c->use_f16 || c->k128 || c->k32f16;
     c->nSlabA = c->plan.nSlabA;
     c->nSlabS = c->plan.nSlabS;
     const bool v7_shape = c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);     // k_grad_bf16_v7 / k_grad_f16_v8: the chained frame
@@ -502,7 +506,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->f64 ? 7 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64 ? 7 : c->k32f16 ? 8 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -589,6 +593,7 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    if (c->k32f16) FAIL(PMX_E_UNSUPPORTED, "k_grad_f16_k32 takes no weights; create the context with PMX_MODE_F32");
     if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
         FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64 with M %% 128 = 0, N %% 256 = 0 or K = 128 with M %% 128 = 0, N %% 128 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
@@ -894,6 +899,27 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         }
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
+        c->nloss = c->plan.gridX * c->plan.gridY;
+    } else if (c->k32f16) {
+        AbsmaxArgs am{};
+        am.X[0] = A; am.X[1] = St;
+        am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+        am.out = c->absmax;
+        am.status = c->dstatus;
+        if (!absmax_fresh) launch_absmax(am, c->stream);
+        GradV4Args g{};
+        g.Y = c->Y; g.ldY = c->ldY;
+        g.A = A; g.St = St;
+        g.slabA = c->slab[0]; g.slabS = c->slab[1];
+        g.lossPart = c->lossPart;
+        g.status = c->dstatus;
+        g.M = (int)c->M; g.N = (int)c->N;
+        g.RP = c->plan.RP;
+        g.doA = doA; g.doS = doS;
+        g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
+        g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = 1.f;
+        if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
+        HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
     } else if (c->use_bf16) {
         PresplitArgs ps{};
@@ -1497,7 +1523,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         u.ticket_last = c->ticketLaunches - 1u;
     }
     // the fp16 K1's operand maxima for the next iteration come from this kernel (every workgroup writes its partial: full grid only)
-    u.absmax_out = (c->f16_scales && u.nbx == EW_BLOCKS) ? c->absmax : nullptr;
+    u.absmax_out = c->f16_scales ? c->absmax : nullptr;       // ([r4] any grid: the workgroups that exist zero the slots of those that do not)
     u.e_rel[0] = p.e_rel[0]; u.e_rel[1] = p.e_rel[1];
     // the next iteration's partial Gram matrices from this launch (PgmArgs::gramPart): the Lipschitz rule on factors of <= 4096
     // rows each, K <= 64 (cfg2); PMX_GRAM_IN_UPDATE=0 keeps k_gram_partial (A/B)

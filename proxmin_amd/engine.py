@@ -80,7 +80,7 @@ class DeviceNMF:
         # K outside {64, 128} run the generic split-bf16 kernels or the exact-fp32 one, 1.5-3 x slower per pass
         if mode not in ("f32", "f64"):
             k = self.k1_info()["kernel"]
-            fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small")}[mode]
+            fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small")}[mode]
             generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
             if k not in fast or generic_bf16 or (mode == "f16x2" and k == "k_grad_bf16"):
                 _notice((mode, k, self.K, self.M % 128 == 0, self.N % 256 == 0),
@@ -210,7 +210,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
         return d

@@ -25,6 +25,7 @@ LIMITS = {
     "15k_grad_f16_k128ILb0ELb1E": 12,     # 10  chained gA (the previous sum arrives in two halves of 32 registers); every spill store
                                           #     sits in the prologue, every reload behind the loops (checked in the ISA: none inside)
     "15k_grad_f16_k128ILb1ELb1E": 16,     # 12  weighted, chained
+    "14k_grad_f16_k32": 4,                # 0   [r4] two-term fp16 K1 at K = 32 (cfg2 in mode f16x2)
     "13k_grad_f32_pc": 4,                 # 0   exact-fp32 K1 with producer / consumer wavefronts (eight instances: 2 in the
                                           #     weighted, chained K = 64 one, 0 in the others)
     "10k_ada_tailILi2E": 0,               # 0   fused adaprox tail (K <= 64)

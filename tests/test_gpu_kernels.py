@@ -513,6 +513,42 @@ def test_k128_two_term_fp16_kernel(eng, orc, M, N):
                 assert dev.k1_info()["kernel"] == "k_grad_f32"
 
 
+@pytest.mark.parametrize("M,N", [(128, 256), (1024, 768), (4096, 4096), (5120, 1024), (384, 16384), (8320, 512)])
+def test_k32_two_term_fp16_kernel(eng, orc, M, N):
+    """[r4] K = 32 in mode f16x2 (k_grad_f16_k32: BASELINE cfg2's shape): one region, many regions, short last row regions,
+    more workgroups than CUs; gradients and loss against the fp64 oracle at the tolerance of every fp32-class K1, bitwise
+    repeatable, operands of very different magnitudes (the power-of-two scales).  Neighbouring shapes keep the split-bf16
+    kernels; a weighted context says it has no kernel for that (the host wrapper reopens in fp32)."""
+    Y, A, S = orc.synthetic_problem(M, N, 32, np.float32, seed=M + N)
+    with eng.DeviceNMF(M, N, 32, mode="f16x2") as dev:
+        info = dev.k1_info()
+        assert info["kernel"] == "k_grad_f16_k32" and info["col_regions"] == N // 256 and info["slabs_S"] == info["row_regions"], info
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+        gA2, gS2 = dev.grad()
+        A2, S2 = (A * 1e-3).astype(np.float32), (S * 40.0).astype(np.float32)
+        dev.set_factors(A2, S2)
+        hA, hS = dev.grad()
+        if M == 128:
+            with pytest.raises(NotImplementedError):
+                dev.set_W(np.ones((M, N), np.float32))
+    assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)
+    x64 = [x.astype(np.float64) for x in (A, S, Y)]
+    rA, rS = orc.residual_gradients(*x64)
+    np.testing.assert_allclose(gA, rA, rtol=2e-5, atol=2e-5 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(*x64), rel=2e-5)
+    qA, qS = orc.residual_gradients(A2.astype(np.float64), S2.astype(np.float64), x64[2])
+    np.testing.assert_allclose(hA, qA, rtol=2e-5, atol=2e-5 * np.abs(qA).max())
+    np.testing.assert_allclose(hS, qS, rtol=2e-5, atol=2e-5 * np.abs(qS).max())
+    if M == 128:
+        for Mr, Nr, Kr in ((128, 128, 32), (136, 256, 32), (128, 256, 24)):
+            with eng.DeviceNMF(Mr, Nr, Kr, mode="f16x2") as dev:
+                assert dev.k1_info()["kernel"] in ("k_grad_bf16", "k_grad_small")
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 def test_full_size_gradient_against_subsampled_oracle(eng, mode):
     """BASELINE's headline shape (16384 x 16384, K = 64): the gradients of 256 random rows of A and 256 random columns of

@@ -167,10 +167,12 @@ def test_k128_kernel_thirty_iterations_against_exact_fp32(eng, backend):
     assert rel < 5e-6, rel
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16x2"])
 @pytest.mark.parametrize("fista", [False, True])
-def test_cfg2_end_to_end_at_full_size(eng, orc, fista):
+def test_cfg2_end_to_end_at_full_size(eng, orc, fista, mode):
     """BASELINE cfg2 (4096 x 4096, K = 32, prox_plus, fp32): PGM and damped FISTA (step = 0.5 step_pgm),
-    10 iterations through nmf() against the fp64 oracle: EVERY entry within rtol 1e-4."""
+    10 iterations through nmf() against the fp64 oracle: EVERY entry within rtol 1e-4 -- in the exact-fp32 mode BASELINE quotes
+    the configuration in and [r4] in the two-term fp16 mode (k_grad_f16_k32)."""
     import torch
     import bench
     import proxmin_amd as pm
@@ -178,16 +180,21 @@ def test_cfg2_end_to_end_at_full_size(eng, orc, fista):
     Yd, A0, S0 = bench.make_problem_device(M, N, K, False, 1234, torch.device("cuda", 0))
     Y = Yd.cpu().numpy()
     del Yd
-    pm.set_default_mode("f32")
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+        assert dev.k1_info()["kernel"] == ("k_grad_f32_pc" if mode == "f32" else "k_grad_f16_k32")
+    pm.set_default_mode(mode)
     A, S = A0.copy(), S0.copy()
     kw = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if fista else {}
-    pm.nmf.nmf(Y, A, S, max_iter=10, e_rel=1e-12, **kw)
+    try:
+        pm.nmf.nmf(Y, A, S, max_iter=10, e_rel=1e-12, **kw)
+    finally:
+        pm.set_default_mode("f32")
     A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
     step = (lambda A_, S_, it, grads: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_))) if fista else None
     orc.pgm_nmf(Y.astype(np.float64), A64, S64, max_iter=10, e_rel=1e-12, accelerated=fista, step=step)
     fA, wA = frac_within(A, A64)
     fS, wS = frac_within(S, S64)
-    REPORT["cfg2 full %s, 10 its vs fp64 oracle (f32 mode)" % ("fista/2" if fista else "pgm")] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
+    REPORT["cfg2 full %s, 10 its vs fp64 oracle (%s mode)" % ("fista/2" if fista else "pgm", mode)] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
     assert fA == 1.0 and fS == 1.0, (fA, fS, wA, wS)
 
 
