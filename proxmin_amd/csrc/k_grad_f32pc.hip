@@ -19,7 +19,7 @@
 // CHAIN: gA summed in place along chains of workgroups on one XCD, exactly as in k_grad_f16_v8<.., CHAIN> (same region map,
 // rotation of the panels, arrival words with the writer's XCC_ID, fault -> the host falls back to slabs): the 64 gA slabs
 // of cfg3 (268 MB written here, read back by the update kernel) become 2.
-// Outputs as every K1: one gA slab per column region (per chain with CHAIN), S_SPLIT gSt slabs per row region (the consumers split the block's 128
+// Outputs as every K1: one gA slab per column region (per chain with CHAIN), one gSt slab per row region ([r4]: the consumers split the block's 128
 // rows: halves at K = 64 -- two k tiles x two halves --, quarters at K = 32), a loss partial per workgroup.
 // ------------------------------------------------------------------------------------------------
 template <int K> struct F32pcCfg {
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
     if (T <= 0) {                            // region outside the matrix: its gSt slab parts and loss partial are zero
         if (!producer && a.doS) {
             const int part = KT == 2 ? (j >> 1) : j, kt = KT == 2 ? (j & 1) : 0;
-            float* dst = a.slabS + (int64_t)(rowRegion * S_SPLIT + part) * N * K;
-            for (int c = 0; c < NCB; ++c)
+            float* dst = a.slabS + (int64_t)rowRegion * N * K;      // (one slab per row region: the parts are merged in LDS, below)
+            for (int c = part * (NCB / S_SPLIT); c < (part + 1) * (NCB / S_SPLIT); ++c)
                 for (int i = 0; i < 16; ++i) {
                     const int gn = col0 + c * 32 + tile_row(i, lane);
                     if (gn < N) dst[(int64_t)gn * K + kt * 32 + l31] = 0.f;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
         slot(T, p0, p1, yO, wO, no{}, yes{});
         slot(T + 1, p1, p0, yE, wE, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt parts)
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -354,13 +355,35 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
             }
         }
         if constexpr (CHAIN) link.publish();
-        if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * S_SPLIT + part) * N * K;
+        // [r4] ONE gSt slab per row region: the S_SPLIT row parts of a tile (held by S_SPLIT different waves) are summed here, through
+        // the launch's own LDS (every image is dead by now: 128 KB of partial tiles fit), in the fixed order part 0, 1, ..: round 3
+        // wrote S_SPLIT slabs per row region and left the sum to the update kernel -- 64 slabs = 32 MB to fold at cfg2
+        {
+            // tile (part, kt, c) of this wave -> fsm[((kt * S_SPLIT + part) * NCB + c) * 1024 + i * 64 + lane]
+            float* park = fsm + ((kt * S_SPLIT + part) * NCB) * 1024 + lane;
+            if (a.doS) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                const int bcol = col0 + c * 32;
+                for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dst[(int64_t)(bcol + tile_row(i, lane)) * K + kt * 32 + l31] = accS[c][i];
+                    for (int i = 0; i < 16; ++i) park[c * 1024 + i * 64] = accS[c][i];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            if (a.doS) {
+                constexpr int CB = NCB / S_SPLIT;    // blocks this wave finishes: part * CB .. (for its k tile)
+                float* dst = a.slabS + (int64_t)rowRegion * N * K;
+#pragma unroll
+                for (int cc = 0; cc < CB; ++cc) {
+                    const int c = part * CB + cc;
+                    const int bcol = col0 + c * 32;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int q = 0; q < S_SPLIT; ++q) v += fsm[((kt * S_SPLIT + q) * NCB + c) * 1024 + i * 64 + lane];
+                        dst[(int64_t)(bcol + tile_row(i, lane)) * K + kt * 32 + l31] = v;
+                    }
+                }
             }
         }
     }
@@ -398,8 +421,9 @@ GradPlan grad_plan_f32pc(int64_t M, int64_t N, int64_t K) {
     p.RP = (int)((panels + wantX - 1) / wantX);
     p.gridX = (int)((panels + p.RP - 1) / p.RP);
     p.nSlabA = p.gridY;
-    p.nSlabS = p.gridX * (K == 64 ? 2 : 4);
+    p.nSlabS = p.gridX;                                  // ([r4] the row parts are merged inside the launch)
     p.ldsBytes = sizeof(float) * (K == 64 ? F32pcCfg<64>::LDS_FLOATS : F32pcCfg<32>::LDS_FLOATS);
+    if (p.ldsBytes < (size_t)4 * 8 * 1024 * sizeof(float)) p.ldsBytes = (size_t)4 * 8 * 1024 * sizeof(float);   // the gSt merge parks 4 x 8 tiles (K = 32: more than its images)
     p.variant = -2;
     return p;
 }
