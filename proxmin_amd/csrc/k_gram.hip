@@ -92,28 +92,44 @@ struct GramReduceArgs {
     int KP;
     const DevStatus* status;
     int want[2];
+    // [r4] pgm: the stopping test of the iteration whose update kernel ran just before (algorithms.py:130-135) rides in THIS launch
+    // as one more workgroup -- it used to be the last-arriving workgroup of k_pgm_update, ~2.5 us behind everybody else; here it runs
+    // beside the fold, and k_eig / K1 behind this launch see its verdict (halt) before they touch anything.  nullptr: no test here.
+    double* dec_partials;
+    DevStatus* dec_status;
+    double dec_e_rel[2];
 };
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt);
+// Entry e of factor f: FOUR threads fold 32 partials each (two batches of 16 loads in flight: the partials come from other
+// XCDs, a load-add-load-add loop pays one memory round trip per term), then the four sums are added in a fixed order.
+// (Round 3: one thread per entry, eight batches: 5.2 us at K = 32; now two round trips.)
 __global__ __launch_bounds__(256) void k_gram_reduce(GramReduceArgs a) {
     if (chain_halted(a.status)) return;
+    const int n = a.KP * a.KP;
+    if ((int)blockIdx.x == (n * 4 + 255) / 256) {          // the extra workgroup: the stopping test (block y == 0 only)
+        if (blockIdx.y == 0 && a.dec_partials != nullptr) pgm_decide_body(a.dec_status, a.dec_partials, a.dec_e_rel, 1, false);
+        return;
+    }
     const int f = blockIdx.y;
     if (!a.want[f]) return;
-    const int n = a.KP * a.KP;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + e;
-    // fixed summation order, but 16 loads are issued before the first add (the partials come from other XCDs: a
-    // load-add-load-add loop pays one memory round trip per term)
+    const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 2, q = t & 3;
+    static_assert(GRAM_BLOCKS == 128, "four threads x 32 partials");
     double s = 0.0;
-    static_assert(GRAM_BLOCKS % 16 == 0, "");
-    for (int b0 = 0; b0 < GRAM_BLOCKS; b0 += 16) {
-        float v[16];
+    if (e < n) {
+        const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + (int64_t)(q * 32) * n + e;
+        for (int b0 = 0; b0 < 32; b0 += 16) {
+            float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i) * n];
+            for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i) * n];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += (double)v[i];
+            for (int i = 0; i < 16; ++i) s += (double)v[i];
+        }
     }
-    a.G[(int64_t)f * n + e] = s;
+    const int base = threadIdx.x & 60;       // (a quad never straddles a wave; every lane takes part in the shuffles)
+    const double s0 = __shfl(s, base), s1 = __shfl(s, base + 1), s2 = __shfl(s, base + 2), s3 = __shfl(s, base + 3);
+    if (e < n && q == 0) a.G[(int64_t)f * n + e] = ((s0 + s1) + s2) + s3;
 }
+
 
 struct EigArgs {
     const double* G;       // [2][KP*KP]  (factor f)
@@ -630,7 +646,7 @@ void launch_gram(const GramArgs& a, int KP, hipStream_t s) {
     else hipLaunchKernelGGL(k_gram_partial<128>, grid, dim3(GRAM_THREADS), 0, s, a);
 }
 void launch_gram_reduce(const GramReduceArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((a.KP * a.KP + 255) / 256, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((a.KP * a.KP * 4 + 255) / 256 + 1, 2), dim3(256), 0, s, a);
 }
 hipError_t launch_eig(const EigArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * a.KP * (a.KP + 1);

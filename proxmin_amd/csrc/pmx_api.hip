@@ -109,6 +109,8 @@ struct pmx_ctx {
     // (PgmArgs::gramPart): the step rule skips k_gram_partial.  Cleared wherever the factors can change behind the solver's back.
     bool gram_by_update = false;
     bool gram_in_update = true;            // PMX_GRAM_IN_UPDATE=0 (read at context creation): off
+    bool decide_pending = false;           // pgm: the stopping test of the last enqueued iteration has not been enqueued yet (it rides in the
+                                           // next k_gram_reduce launch, or pgm_flush_decide() launches it at the end of a chunk)
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
     __bf16* Bt[2] = {nullptr, nullptr};    // presplit terms, transposed  [2][KP][rowsPad]
     int64_t rowsPad[2] = {0, 0};
@@ -997,7 +999,7 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
 }
 
 // Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
-static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale, bool have_partials = false) {
+static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale, bool have_partials = false, bool with_decide = false) {
     if (eig_small_applies(c)) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig_small forms G itself)
         const EigArgs e = small_eig_args(c, A, St, wantStepA, wantStepS, scale);
         HIP_CHECK(launch_eig(e, c->stream));
@@ -1015,6 +1017,10 @@ static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantS
     GramReduceArgs r{};
     r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
     r.want[0] = g.want[0]; r.want[1] = g.want[1];
+    if (with_decide) {                       // pgm: the previous iteration's stopping test as one more workgroup of this launch
+        r.dec_partials = c->partials; r.dec_status = c->dstatus;
+        r.dec_e_rel[0] = c->pgm.e_rel[0]; r.dec_e_rel[1] = c->pgm.e_rel[1];
+    }
     launch_gram_reduce(r, c->stream);
     EigArgs e{};
     e.G = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
@@ -1404,6 +1410,7 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     c->pgm = *p;
     c->algo = ALG_PGM;
     c->it = 0;
+    c->decide_pending = false;
     c->nest_t = 1.0;
     c->omega_cur = 0.f;
     rc = reset_status(c);
@@ -1474,8 +1481,9 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         if (rc != PMX_OK) return rc;
     } else {
         if (!p.use_fixed_steps && !p.bb_type) {
-            rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale, c->gram_by_update);   // algorithms.py:106
+            rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale, c->gram_by_update, c->decide_pending);   // algorithms.py:106
             if (rc != PMX_OK) return rc;
+            c->decide_pending = false;
         }
         rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
         if (rc != PMX_OK) return rc;
@@ -1515,12 +1523,17 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         HIP_CHECK(hipMemsetAsync(c->tickets, 0, sizeof(unsigned), c->stream));
         c->ticketLaunches = 0;
     }
-    u.tickets = c->tickets;
+    // [r4] where the next launch on the stream is the step rule's k_gram_reduce, the stopping test rides in IT (beside the fold)
+    // instead of in this kernel's last-arriving workgroup (behind everybody else): pgm_flush_decide() covers the last iteration of a chunk
+    const bool defer_decide = !p.use_fixed_steps && !p.bb_type && !eig_small_applies(c);     // (small factors: k_eig_small, no k_gram_reduce launch)
+    u.tickets = defer_decide ? nullptr : c->tickets;
     {
         const int64_t rmax = c->rows[0] > c->rows[1] ? c->rows[0] : c->rows[1];
         u.nbx = rmax <= (int64_t)EW_BLOCKS * (EW_THREADS / 32) ? (int)((rmax + EW_THREADS / 32 - 1) / (EW_THREADS / 32)) : EW_BLOCKS;
-        c->ticketLaunches += 2u * (unsigned)u.nbx;       // tickets drawn so far
-        u.ticket_last = c->ticketLaunches - 1u;
+        if (!defer_decide) {
+            c->ticketLaunches += 2u * (unsigned)u.nbx;   // tickets drawn so far
+            u.ticket_last = c->ticketLaunches - 1u;
+        }
     }
     // the fp16 K1's operand maxima for the next iteration come from this kernel (every workgroup writes its partial: full grid only)
     u.absmax_out = c->f16_scales ? c->absmax : nullptr;       // ([r4] any grid: the workgroups that exist zero the slots of those that do not)
@@ -1533,6 +1546,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
     launch_pgm_update(u, c->stream);                                      // algorithms.py:107-108
     HIP_CHECK(hipGetLastError());
     c->gram_by_update = gram_here;
+    c->decide_pending = defer_decide;
     c->absmax_by_finish = u.absmax_out != nullptr;
     c->it += 1;
     return PMX_OK;
@@ -1670,6 +1684,18 @@ static int set_fixed_steps(pmx_ctx* c, const double s[2]) {
     return PMX_OK;
 }
 
+static int pgm_flush_decide(pmx_ctx* c) {
+    if (!c->decide_pending) return PMX_OK;
+    DecideArgs d{};
+    d.status = c->dstatus; d.partials = c->partials;
+    d.e_rel[0] = c->pgm.e_rel[0]; d.e_rel[1] = c->pgm.e_rel[1];
+    d.check = 1;
+    launch_pgm_decide(d, c->stream);
+    HIP_CHECK(hipGetLastError());
+    c->decide_pending = false;
+    return PMX_OK;
+}
+
 extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c) c->absmax_by_finish = false;      // (gram_by_update survives: nothing but this solver's own update kernel has touched the factors since)
     int rc = require_ready(c, true);
@@ -1701,6 +1727,8 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
             rc = c->pgm.backtracking ? pgm_bt_iteration(c) : pgm_enqueue_iteration(c);
             if (rc != PMX_OK) return rc;
         }
+        rc = pgm_flush_decide(c);
+        if (rc != PMX_OK) return rc;
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
         int again = 0;
