@@ -84,6 +84,7 @@ _SIGNATURES = {
     "pmx_get_phase_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pmx_time_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmx_k1_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pmx_k1_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "pmx_grad": (C.c_int, [C.c_void_p]),
     "pmx_loglike": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "pmx_step_pgm": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -342,6 +342,24 @@ struct GradPlan {
     int variant;   // split-bf16 kernels only: which K1 implementation whole-block shapes take (PMX_K1_VARIANT, tuning A/B)
 };
 
+// Row regions of a grid whose workgroups sit one (or `slots` / 256) per CU: `panels` row panels, gridY column regions.  A region of RP
+// panels costs RP panel-times and the grid runs in ceil(gridX gridY / slots) rounds, so take the gridX with the smallest
+// rounds x RP -- the fewest row regions among equals (= gSt slabs).  (Rounds 1-3 took ceil(slots / gridY) row regions: exact for
+// the aligned bench shapes, but e.g. 125 panels x 63 column regions became 5 x 63 = 315 workgroups, a second round for 59 of them.)
+static void plan_row_regions(int64_t panels, int gridY, int slots, int* RP, int* gridX) {
+    int64_t best = 1, bestCost = -1;
+    const int64_t hi = panels < 4096 ? panels : 4096;
+    for (int64_t x = 1; x <= hi; ++x) {
+        const int64_t rp = (panels + x - 1) / x;
+        const int64_t gx = (panels + rp - 1) / rp;              // the regions that many panels per region really make
+        const int64_t rounds = (gx * gridY + slots - 1) / slots;
+        const int64_t cost = rounds * rp;
+        if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = x; }
+    }
+    *RP = (int)((panels + best - 1) / best);
+    *gridX = (int)((panels + *RP - 1) / *RP);
+}
+
 GradPlan grad_plan_f32(int64_t M, int64_t N, int64_t K) {
     GradPlan p{};
     p.KP = K <= 32 ? 32 : (K <= 64 ? 64 : 128);

@@ -2067,11 +2067,7 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     // one resident workgroup per CU for the 8-wave variants: a single round of 256 measured 1-12 % faster than two of
     // 512 (fewer prologues / accumulator flushes, half the gSt slabs); PMX_K1_WGS overrides (tuning)
     const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : (p.variant >= 4 && K == 64 ? 256 : 512);
-    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
-    if (wantX < 1) wantX = 1;
-    if (wantX > panels) wantX = panels;
-    p.RP = (int)((panels + wantX - 1) / wantX);
-    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    plan_row_regions(panels, p.gridY, wantWG, &p.RP, &p.gridX);
     p.nSlabA = p.gridY * splitA;
     p.nSlabS = p.gridX * splitS;
     p.ldsBytes = 2 * ((size_t)3 * BG_BN * (p.KP + 8) + (size_t)2 * p.KP * (BG_BN + 8) + (size_t)2 * p.KP * (BG_BM + 8)) +

@@ -397,11 +397,7 @@ GradPlan grad_plan_f16_k32(int64_t M, int64_t N) {
     const int64_t panels = M / V5_BM;
     p.gridY = (int)(N / (V5_NB * V5_BN));
     const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : 256;   // one resident workgroup per CU
-    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
-    if (wantX < 1) wantX = 1;
-    if (wantX > panels) wantX = panels;
-    p.RP = (int)((panels + wantX - 1) / wantX);
-    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    plan_row_regions(panels, p.gridY, wantWG, &p.RP, &p.gridX);
     p.nSlabA = p.gridY;
     p.nSlabS = p.gridX;
     p.ldsBytes = V8_LDS_BYTES;

@@ -415,11 +415,7 @@ GradPlan grad_plan_f32pc(int64_t M, int64_t N, int64_t K) {
     const int64_t panels = M / 128;
     p.gridY = (int)(N / 256);
     const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : 256;   // one resident workgroup per CU
-    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
-    if (wantX < 1) wantX = 1;
-    if (wantX > panels) wantX = panels;
-    p.RP = (int)((panels + wantX - 1) / wantX);
-    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    plan_row_regions(panels, p.gridY, wantWG, &p.RP, &p.gridX);
     p.nSlabA = p.gridY;
     p.nSlabS = p.gridX;                                  // ([r4] the row parts are merged inside the launch)
     p.ldsBytes = sizeof(float) * (K == 64 ? F32pcCfg<64>::LDS_FLOATS : F32pcCfg<32>::LDS_FLOATS);

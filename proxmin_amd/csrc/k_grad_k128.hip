@@ -604,11 +604,7 @@ GradPlan grad_plan_k128(int64_t M, int64_t N) {
     const int64_t panels = M / V5_BM;
     p.gridY = (int)(N / (W8_NCB * V5_BN));
     const int wantWG = getenv("PMX_K1_WGS") ? atoi(getenv("PMX_K1_WGS")) : 256;   // one resident workgroup per CU
-    int64_t wantX = (wantWG + p.gridY - 1) / p.gridY;
-    if (wantX < 1) wantX = 1;
-    if (wantX > panels) wantX = panels;
-    p.RP = (int)((panels + wantX - 1) / wantX);
-    p.gridX = (int)((panels + p.RP - 1) / p.RP);
+    plan_row_regions(panels, p.gridY, wantWG, &p.RP, &p.gridX);
     p.nSlabA = p.gridY;
     p.nSlabS = p.gridX;
     p.ldsBytes = W8_LDS_BYTES;

@@ -226,8 +226,9 @@ __device__ __forceinline__ void prox_row(float (&v)[NC], const bool (&ok)[NC], c
 #define ROW_LOOP_END }
 
 struct SlabRef {
-    const float* base;   // [n][rows][K]
+    const float* base;   // [n][stride]: slab i's row r at base + i * stride + r * K
     int n;
+    int64_t stride;      // floats between slabs: rows x K of K1's FRAME (the factor's rows, or more: zero-padded frame of a ragged shape)
 };
 
 template <int NC>
@@ -237,7 +238,7 @@ __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], 
     // batches of 4 were 5 of the 8 us of its moment phase)
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
-    const int64_t stride = rows * K;
+    const int64_t stride = s.stride;
     const float* p = s.base + r * K + l32;
     int i = 0;
     constexpr int UB = NC == 1 ? 16 : (NC == 2 ? 8 : 4);

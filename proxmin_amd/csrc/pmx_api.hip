@@ -61,6 +61,12 @@ struct pmx_ctx {
     float* Yown = nullptr;
     int64_t ldY = 0;
     bool haveY = false;
+    // K1's FRAME (choose_frame): M x N, or -- a ragged shape whose K has a producer / consumer kernel -- M and N rounded up to that
+    // kernel's tile.  Y (and W) then live in a zero-padded copy of the frame's size, the factor arrays K1 reads and the gradient
+    // slabs it writes have the frame's rows (the extra ones zero / never read); everything else works on the M and N real rows.
+    int64_t Mk = 0, Nk = 0;
+    int64_t rowsK[2] = {0, 0};
+    bool framed = false;
 
     float* X[2] = {nullptr, nullptr};      // A, St
     float* G[2] = {nullptr, nullptr};
@@ -294,6 +300,48 @@ extern "C" int pmx_device_count(void) {
     return n;
 }
 
+// The producer / consumer K1s take M % 128 = 0 and N % 256 = 0 (128 at K = 128) only; the guarded kernels that take anything are
+// 1.5-3 x slower.  A ragged problem with one of those K therefore runs on a zero-padded frame when that costs at most a quarter
+// more entries: zero rows of A / St give zero rows of P, the padding of Y (and W) is zero, so R and both gradients are zero there
+// and the loss is unchanged -- the arithmetic on the real entries is the aligned problem's.  PMX_FRAME=0 switches it off (A/B, tests).
+static void choose_frame(int mode, int64_t M, int64_t N, int64_t K, int64_t* Mk, int64_t* Nk) {
+    *Mk = M; *Nk = N;
+    if (getenv("PMX_FRAME") && atoi(getenv("PMX_FRAME")) == 0) return;
+    if (mode == PMX_MODE_F64 || grad_small_applies(M, N, K)) return;
+    int64_t an = 256;
+    if (K == 128) { if (mode != PMX_MODE_F16X2) return; an = 128; }          // k_grad_f16_k128
+    else if (K == 32) { if (mode == PMX_MODE_BF16X3) return; }               // k_grad_f16_k32 / k_grad_f32_pc<32>
+    else if (K != 64) return;                                                // k_grad_f16_v8 / k_grad_bf16_v7 / k_grad_f32_pc<64>
+    const int64_t m = (M + 127) / 128 * 128, n = (N + an - 1) / an * an;
+    if ((m == M && n == N) || (double)m * (double)n > 1.25 * (double)M * (double)N) return;
+    *Mk = m; *Nk = n;
+}
+
+// which K1 runs on the frame Mk x Nk, its grid, and whether gA is summed along chains there
+static void select_k1(pmx_ctx* c, int64_t Mk, int64_t Nk, int ncu) {
+    const int64_t M = c->M, N = c->N, K = c->K;
+    const int mode = c->mode;
+    c->use_small = grad_small_applies(M, N, K);
+    c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
+    c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(Mk, Nk, K) : grad_plan_f32(Mk, Nk, K));
+    c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, Mk, Nk, K);   // same shapes as v7
+    c->k128 = mode == PMX_MODE_F16X2 && !c->use_small && grad_k128_applies(Mk, Nk, K);
+    if (c->k128) c->plan = grad_plan_k128(Mk, Nk);
+    c->k32f16 = mode == PMX_MODE_F16X2 && !c->use_small && grad_f16_k32_applies(Mk, Nk, K);
+    if (c->k32f16) { c->plan = grad_plan_f16_k32(Mk, Nk); c->use_bf16 = false; c->use_f16 = false; }
+    c->f32pc = !c->use_small && !c->use_bf16 && !c->k128 && !c->k32f16 && grad_f32pc_applies(Mk, Nk, K);
+    if (c->f32pc) c->plan = grad_plan_f32pc(Mk, Nk, K);
+    c->f16_scales = c->use_f16 || c->k128 || c->k32f16;
+    c->nSlabA = c->plan.nSlabA;
+    c->nSlabS = c->plan.nSlabS;
+    c->chainL = 0;
+    const bool v7_shape = c->use_bf16 && grad_bf16_takes_weights(c->plan, Mk, Nk, K);     // k_grad_bf16_v7 / k_grad_f16_v8: the chained frame
+    if (v7_shape || c->f32pc || c->k128) {
+        c->chainL = grad_chain_length(c->plan, Mk, ncu, (c->use_f16 || c->k128) ? 16 : 32);
+        if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
+    }
+}
+
 extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, int64_t K, int mode, void* stream) {
     if (!out) FAIL(PMX_E_INVALID, "out is NULL");
     if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -323,26 +371,30 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (const char* e = getenv("PMX_GRAM_IN_UPDATE")) c->gram_in_update = atoi(e) != 0;
     if (const char* e = getenv("PMX_INJECT_K1_FAULT")) c->hook_inject_k1 = atoi(e);
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
-    c->use_small = grad_small_applies(M, N, K);
-    c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
-    c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(M, N, K) : grad_plan_f32(M, N, K));
-    c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);   // same shapes as v7
-    c->k128 = mode == PMX_MODE_F16X2 && !c->use_small && grad_k128_applies(M, N, K);
-    if (c->k128) c->plan = grad_plan_k128(M, N);
-    c->k32f16 = mode == PMX_MODE_F16X2 && !c->use_small && grad_f16_k32_applies(M, N, K);
-    if (c->k32f16) { c->plan = grad_plan_f16_k32(M, N); c->use_bf16 = false; c->use_f16 = false; }
-    c->f32pc = !c->use_small && !c->use_bf16 && !c->k128 && !c->k32f16 && grad_f32pc_applies(M, N, K);
-    if (c->f32pc) c->plan = grad_plan_f32pc(M, N, K);
-    c->f16_scales = c->use_f16 || c->k128 || c->k32f16;
-    c->nSlabA = c->plan.nSlabA;
-    c->nSlabS = c->plan.nSlabS;
-    const bool v7_shape = c->use_bf16 && grad_bf16_takes_weights(c->plan, M, N, K);     // k_grad_bf16_v7 / k_grad_f16_v8: the chained frame
-    if (v7_shape || c->f32pc || c->k128) {
-        int ncu = 0;
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
-        c->chainL = grad_chain_length(c->plan, M, ncu, (c->use_f16 || c->k128) ? 16 : 32);
-        if (c->chainL > 0) c->nSlabA = c->plan.gridY / c->chainL;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
+    choose_frame(mode, M, N, K, &c->Mk, &c->Nk);
+    c->framed = c->Mk != M || c->Nk != N;
+    select_k1(c, c->Mk, c->Nk, ncu);
+    if (c->framed && c->chainL == 0 && (c->use_bf16 || c->f32pc || c->k128)) {
+        // a frame the chained accumulation of gA does not take (e.g. 125 panels x 63 column regions): a few more panels / column
+        // regions often make one that it does (128 x 64) -- worth up to 6 % more entries (the chain is ~10 % of an iteration: one
+        // gA slab per 16 column regions instead of one each, for K1 to write and the update kernel to fold)
+        const int64_t an = K == 128 ? 128 : 256, m0 = c->Mk, n0 = c->Nk;
+        int64_t bm = 0, bn = 0;
+        for (int i = 0; i <= 8; ++i)
+            for (int j = 0; j <= 8; ++j) {
+                const int64_t m = m0 + 128 * i, n = n0 + an * j;
+                if ((double)m * (double)n > 1.06 * (double)m0 * (double)n0 || (double)m * (double)n > 1.25 * (double)M * (double)N) continue;
+                if (bm && m * n >= bm * bn) continue;
+                select_k1(c, m, n, ncu);
+                if (c->chainL > 0) { bm = m; bn = n; }
+            }
+        if (bm) { c->Mk = bm; c->Nk = bn; }
+        select_k1(c, c->Mk, c->Nk, ncu);
     }
+    c->rowsK[0] = c->Mk; c->rowsK[1] = c->Nk;
+    const int64_t Mk = c->Mk, Nk = c->Nk;
     if (mode == PMX_MODE_F64) {              // fp64 context: its own arrays and kernels (k_small_f64.hip), nothing of the fp32 state
         c->f64 = true;
         c->use_small = true;
@@ -375,20 +427,20 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     int rc = PMX_OK;
     if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
     if (c->f16_scales) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
-    for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)M * K, false);
+    for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)Mk * K, c->framed);   // (framed: the rows behind M stay zero)
     if (c->use_bf16) {
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
-            c->rowsPad[j] = (c->rows[j] + 127) / 128 * 128;
+            c->rowsPad[j] = (c->rowsK[j] + 127) / 128 * 128;
             rc = dallocT(c, &c->Bp[j], (size_t)3 * c->rowsPad[j] * c->KP, false);
             if (rc == PMX_OK) rc = dallocT(c, &c->Bt[j], (size_t)2 * c->KP * c->rowsPad[j], false);
         }
     }
     for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
-        rc = dallocT(c, &c->X[j], (size_t)c->rows[j] * K);
+        rc = dallocT(c, &c->X[j], (size_t)c->rowsK[j] * K);
         if (rc == PMX_OK) rc = dallocT(c, &c->G[j], (size_t)c->rows[j] * K);
     }
-    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * M * K, false);
-    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * N * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * Mk * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * Nk * K, false);
     if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)2 * c->plan.gridX * c->plan.gridY);
     if (rc == PMX_OK) rc = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
     if (rc == PMX_OK) rc = dallocT(c, &c->colpart, (size_t)2 * EW_BLOCKS * MAXK);
@@ -519,6 +571,13 @@ extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     return PMX_OK;
 }
 
+extern "C" int pmx_k1_frame(pmx_ctx* c, int64_t frame[2]) {
+    if (!c || !frame) FAIL(PMX_E_INVALID, "NULL argument");
+    frame[0] = c->f64 ? c->M : c->Mk;
+    frame[1] = c->f64 ? c->N : c->Nk;
+    return PMX_OK;
+}
+
 extern "C" int pmx_ctx_sync(pmx_ctx* c) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -540,17 +599,27 @@ static int measure_ymax(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// the context's own copy of an M x N array (Y, W) in K1's frame: Mk x Nk, zero outside M x N (the buffer is zeroed when it is created
+// and nothing ever writes there)
+static int own_frame_copy(pmx_ctx* c, float** own, const float* src, int64_t ld, hipMemcpyKind kind) {
+    if (!*own) {
+        int rc = dallocT(c, own, (size_t)c->Mk * c->Nk, c->framed);
+        if (rc != PMX_OK) return rc;
+    }
+    HIP_CHECK(hipMemcpy2DAsync(*own, c->Nk * sizeof(float), src, ld * sizeof(float), c->N * sizeof(float), c->M, kind, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PMX_OK;
+}
+
 extern "C" int pmx_set_Y_host(pmx_ctx* c, const float* Y, int64_t ld) {
     if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
     if (c->f64) FAIL(PMX_E_UNSUPPORTED, "an fp64 context takes Y through pmx_set_Y_host_f64");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
-    int rc = dallocT(c, &c->Yown, (size_t)c->M * c->N, false);
+    int rc = own_frame_copy(c, &c->Yown, Y, ld, hipMemcpyHostToDevice);
     if (rc != PMX_OK) return rc;
-    HIP_CHECK(hipMemcpy2DAsync(c->Yown, c->N * sizeof(float), Y, ld * sizeof(float), c->N * sizeof(float), c->M, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
     c->Y = c->Yown;
-    c->ldY = c->N;
+    c->ldY = c->Nk;
     c->haveY = true;
     return measure_ymax(c);
 }
@@ -560,12 +629,11 @@ extern "C" int pmx_set_Y_device(pmx_ctx* c, const float* dY, int64_t ld, int cop
     if (c->f64) FAIL(PMX_E_UNSUPPORTED, "an fp64 context takes Y through pmx_set_Y_host_f64");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
-    if (copy) {
-        int rc = dallocT(c, &c->Yown, (size_t)c->M * c->N, false);
+    if (copy || c->framed) {                 // (a framed context always works on its own zero-padded copy: pmx.h)
+        int rc = own_frame_copy(c, &c->Yown, dY, ld, hipMemcpyDeviceToDevice);
         if (rc != PMX_OK) return rc;
-        HIP_CHECK(hipMemcpy2DAsync(c->Yown, c->N * sizeof(float), dY, ld * sizeof(float), c->N * sizeof(float), c->M, hipMemcpyDeviceToDevice, c->stream));
         c->Y = c->Yown;
-        c->ldY = c->N;
+        c->ldY = c->Nk;
     } else {
         c->Y = dY;
         c->ldY = ld;
@@ -596,20 +664,15 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     if (c->k32f16) FAIL(PMX_E_UNSUPPORTED, "k_grad_f16_k32 takes no weights; create the context with PMX_MODE_F32");
-    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->M, c->N, c->K))
+    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->Mk, c->Nk, c->K))
         FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64 with M %% 128 = 0, N %% 256 = 0 or K = 128 with M %% 128 = 0, N %% 128 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     HIP_CHECK(hipSetDevice(c->device));
-    if (from_host || copy) {
-        if (!c->Wown) {
-            int rc = dallocT(c, &c->Wown, (size_t)c->M * c->N, false);
-            if (rc != PMX_OK) return rc;
-        }
-        HIP_CHECK(hipMemcpy2DAsync(c->Wown, c->N * sizeof(float), W, ld * sizeof(float), c->N * sizeof(float), c->M,
-                                   from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (from_host || copy || c->framed) {
+        int rc = own_frame_copy(c, &c->Wown, W, ld, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+        if (rc != PMX_OK) return rc;
         c->W = c->Wown;
-        c->ldW = c->N;
+        c->ldW = c->Nk;
     } else {
         c->W = W;
         c->ldW = ld;
@@ -654,7 +717,7 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
     *count = c->rows[j] * c->K;
     if (!*p) {
         if (!create) FAIL(PMX_E_STATE, "buffer %d has not been created yet", buf);
-        int rc = dallocT(c, p, (size_t)*count);
+        int rc = dallocT(c, p, (size_t)c->rowsK[j] * c->K);     // (K1 may read it: the frame's rows, zero behind the real ones)
         if (rc != PMX_OK) return rc;
     }
     *slot = p;
@@ -780,7 +843,7 @@ static int chain_disable(pmx_ctx* c) {
     c->chainL = 0;
     c->nSlabA = c->plan.nSlabA;
     float* big = nullptr;
-    int rc = dallocT(c, &big, (size_t)c->nSlabA * c->M * c->K, false);
+    int rc = dallocT(c, &big, (size_t)c->nSlabA * c->Mk * c->K, false);
     if (rc != PMX_OK) return rc;
     c->slab[0] = big;
     return PMX_OK;
@@ -832,7 +895,7 @@ static GradArgs small_grad_args(pmx_ctx* c, const float* A, const float* St, int
     g.slabA = c->slab[0]; g.slabS = c->slab[1];
     g.lossPart = c->lossPart;
     g.status = c->dstatus;
-    g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
+    g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)c->K;
     g.RP = c->plan.RP;
     g.doA = doA; g.doS = doS;
     return g;
@@ -876,7 +939,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         am.status = c->dstatus;
         if (!absmax_fresh) launch_absmax(am, c->stream);
         SplitAArgs sp{};
-        sp.X = A; sp.count = c->M * c->K; sp.absmax = c->absmax; sp.H = c->A16[0]; sp.L = c->A16[1]; sp.status = c->dstatus;
+        sp.X = A; sp.count = c->M * c->K; /* (a frame's extra rows stay zero) */ sp.absmax = c->absmax; sp.H = c->A16[0]; sp.L = c->A16[1]; sp.status = c->dstatus;
         launch_split_a_f16(sp, c->stream);
         GradK128Args g{};
         g.Y = c->Y; g.ldY = c->ldY;
@@ -884,7 +947,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.slabA = c->slab[0]; g.slabS = c->slab[1];
         g.lossPart = c->lossPart;
         g.status = c->dstatus;
-        g.M = (int)c->M; g.N = (int)c->N;
+        g.M = (int)c->Mk; g.N = (int)c->Nk;
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
@@ -915,7 +978,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.slabA = c->slab[0]; g.slabS = c->slab[1];
         g.lossPart = c->lossPart;
         g.status = c->dstatus;
-        g.M = (int)c->M; g.N = (int)c->N;
+        g.M = (int)c->Mk; g.N = (int)c->Nk;
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
@@ -926,10 +989,10 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     } else if (c->use_bf16) {
         PresplitArgs ps{};
         ps.X[0] = A; ps.X[1] = St;
-        for (int j = 0; j < 2; ++j) { ps.Xp[j] = c->Bp[j]; ps.Xt[j] = c->Bt[j]; ps.rows[j] = c->rows[j]; ps.rowsPad[j] = c->rowsPad[j]; }
+        for (int j = 0; j < 2; ++j) { ps.Xp[j] = c->Bp[j]; ps.Xt[j] = c->Bt[j]; ps.rows[j] = c->rowsK[j]; ps.rowsPad[j] = c->rowsPad[j]; }
         ps.K = (int)c->K; ps.KP = c->KP;
         ps.status = c->dstatus;
-        if (!grad_bf16_reads_fp32(c->plan, c->M, c->N, c->K)) launch_presplit(ps, c->stream);
+        if (!grad_bf16_reads_fp32(c->plan, c->Mk, c->Nk, c->K)) launch_presplit(ps, c->stream);
         GradBfArgs g{};
         g.Y = c->Y; g.ldY = c->ldY;
         g.Ap = c->Bp[0]; g.At = c->Bt[0]; g.Sp = c->Bp[1]; g.Stt = c->Bt[1];
@@ -937,7 +1000,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.slabA = c->slab[0]; g.slabS = c->slab[1];
         g.lossPart = c->lossPart;
         g.status = c->dstatus;
-        g.M = (int)c->M; g.N = (int)c->N; g.K = (int)c->K;
+        g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)c->K;
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         g.prof = c->k1prof;
@@ -988,6 +1051,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
 
 static SlabRef slab_ref(pmx_ctx* c, int j) {
     SlabRef s;
+    s.stride = c->rowsK[j] * c->K;
     if (c->host_grad) {      // the caller's gradient: ONE "slab", the G buffer itself (the update kernels fold it onto itself)
         s.base = c->G[j];
         s.n = 1;
@@ -1427,12 +1491,12 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     if (p->backtracking)
         for (int j = 0; j < 2; ++j)
             if (p->host_prox[j]) {               // [r4] every trial of that block takes a host round trip (pmx_pgm_bt_split)
-                rc = dallocT(c, &c->btBuf[j], (size_t)c->rows[j] * c->K, false);
+                rc = dallocT(c, &c->btBuf[j], (size_t)c->rowsK[j] * c->K, c->framed);
                 if (rc != PMX_OK) return rc;
             }
     for (int j = 0; j < 2; ++j)
         if (p->host_prox[j]) {
-            rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
+            rc = dallocT(c, &c->Xp[j], (size_t)c->rowsK[j] * c->K, c->framed);
             if (rc != PMX_OK) return rc;
         }
     c->btT[0] = c->btT[1] = 1.0;
@@ -1442,14 +1506,14 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     }
     if (p->backtracking)
         for (int j = 0; j < 2; ++j) {
-            rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false);
-            if (rc == PMX_OK) rc = dallocT(c, &c->Xe[j], (size_t)c->rows[j] * c->K, false);
+            rc = dallocT(c, &c->Xp[j], (size_t)c->rowsK[j] * c->K, c->framed);
+            if (rc == PMX_OK) rc = dallocT(c, &c->Xe[j], (size_t)c->rowsK[j] * c->K, c->framed);
             if (rc != PMX_OK) return rc;
             HIP_CHECK(hipMemcpyAsync(c->Xe[j], c->X[j], c->rows[j] * c->K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         }
     if (p->accelerated) {
         for (int j = 0; j < 2; ++j) {
-            rc = dallocT(c, &c->Xe[j], (size_t)c->rows[j] * c->K, false);
+            rc = dallocT(c, &c->Xe[j], (size_t)c->rowsK[j] * c->K, c->framed);
             if (rc != PMX_OK) return rc;
             // omega = 0 on the first read (utils.py:201-203): the first extrapolated point is X itself
             HIP_CHECK(hipMemcpyAsync(c->Xe[j], c->X[j], c->rows[j] * c->K * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

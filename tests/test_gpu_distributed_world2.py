@@ -27,6 +27,10 @@ CASES = {
     "pgm_split": dict(M=520, N=700, K=12, its=7, s_split=True),
     "fista_split": dict(M=1024, N=1280, K=64, its=7, s_split=True, accelerated=True),
     "bsdmm": dict(M=480, N=640, K=10, its=6),
+    # [r4] ragged shards: 1000 rows per rank x 1500 columns run the tuned kernels on a zero-padded 1024 x 1536 frame (pmx_k1_frame);
+    # the pack / post kernels and the collectives see the real N
+    "adaprox_ragged": dict(M=2000, N=1500, K=64, unity=False, its=6, scheme="adam"),    # (adam: no eps clamp, every entry is held to the bound)
+    "pgm_ragged_split": dict(M=2000, N=1500, K=64, its=6, s_split=True),
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
     # (PMX_INJECT_K1_FAULT): it falls back to slabs, rank 0 is stopped at the same iteration through the collective halt
     # flag, both go on from there.  (Two processes on one GPU can also fault for real -- not co-resident -- same path.)
@@ -72,9 +76,9 @@ def _worker(rank, world, port, name, mode, out_dir):
         ops = pm.operators
         if name.startswith("adaprox"):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
-            conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme="amsgrad",
+            conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme=c.get("scheme", "amsgrad"),
                                                 check_convergence=False, e_rel=1e-3, max_iter=c["its"], s_split=c.get("s_split", False))
-        elif name in ("pgm", "pgm_split", "fista_split"):
+        elif name.startswith(("pgm", "fista")):
             conv, n = pdist.nmf_pgm_sharded(Y[r0:r1], A_l, S, M, e_rel=1e-9, max_iter=c["its"], s_split=c.get("s_split", False),
                                             accelerated=c.get("accelerated", False), step_scale=0.5 if c.get("accelerated") else 1.0)
         else:
@@ -105,9 +109,9 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
         tb = pm.utils.Traceback()
         if name.startswith("adaprox"):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
-            pm.nmf.nmf(Y, A1, S1, algorithm=pm.adaprox, scheme="amsgrad", prox_S=pS, max_iter=c["its"], e_rel=1e-3,
+            pm.nmf.nmf(Y, A1, S1, algorithm=pm.adaprox, scheme=c.get("scheme", "amsgrad"), prox_S=pS, max_iter=c["its"], e_rel=1e-3,
                        check_convergence=False, callback=tb)
-        elif name in ("pgm", "pgm_split", "fista_split"):
+        elif name.startswith(("pgm", "fista")):
             kwp = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if c.get("accelerated") else {}
             pm.nmf.nmf(Y, A1, S1, max_iter=c["its"], e_rel=1e-9, callback=tb, **kwp)
         else:
@@ -151,14 +155,14 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     # ---- every rank against the ORACLE (fp64, whole problem, identical fp32 inputs) --------------------------------------
     Ao, So, Y64 = A0.astype(np.float64), S0.astype(np.float64), Y.astype(np.float64)
     if name.startswith("adaprox"):
-        orc.adaprox_nmf(Y64, Ao, So, ("plus",), ("unity_plus", 0) if c.get("unity") else ("plus",), scheme="amsgrad",
+        orc.adaprox_nmf(Y64, Ao, So, ("plus",), ("unity_plus", 0) if c.get("unity") else ("plus",), scheme=c.get("scheme", "amsgrad"),
                         max_iter=c["its"], e_rel=1e-3, check_convergence=False)
-    elif name in ("pgm", "pgm_split", "fista_split"):
+    elif name.startswith(("pgm", "fista")):
         okw = dict(accelerated=True, step=lambda a, s_, it, g: tuple(0.5 * x for x in orc.lipschitz_steps(a, s_))) if c.get("accelerated") else {}
         orc.pgm_nmf(Y64, Ao, So, max_iter=c["its"], e_rel=1e-9, **okw)
     else:
         orc.bsdmm_nmf(Y64, Ao, So, proxs_g=[[("plus",), ("soft", 0.01, "relative")]] * 2, max_iter=c["its"], e_rel=1e-9)
-    smooth = not name.startswith("adaprox")      # amsgrad's eps clamp: a fraction, as everywhere else (test_gpu_parity_strict.py)
+    smooth = not name.startswith("adaprox") or c.get("scheme") == "adam"      # amsgrad's eps clamp: a fraction, as everywhere else (test_gpu_parity_strict.py)
     for r in range(2):
         z = np.load(tmp_path / ("rank%d.npz" % r))
         for got, want, what in ((z["A"], Ao[int(z["r0"]):int(z["r1"])], "A rows of rank %d" % r), (z["S"], So, "S on rank %d" % r)):
