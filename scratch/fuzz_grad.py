@@ -10,9 +10,11 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for case in range(n_cases):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 8)
     if kind == 4:      # K = 128 whole blocks (k_grad_f16_k128 in mode f16x2)
         M, N, K = 128 * int(rng.integers(1, 40)), 128 * int(rng.integers(1, 24)), 128
+    elif kind >= 6:    # [r4] ragged shapes with a tuned K: the zero-padded frame (pmx_k1_frame)
+        M, N, K = int(rng.integers(300, 7000)), int(rng.integers(300, 7000)), int(rng.choice([32, 64, 128]))
     elif kind == 5:    # small problems (k_grad_small<8|16>)
         M, N, K = int(rng.integers(1, 1500)), int(rng.integers(1, 700)), int(rng.integers(1, 17))
     elif kind == 0:      # anything
