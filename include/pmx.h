@@ -48,10 +48,13 @@ enum {
                             scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
     PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
-                            M, N <= 8192: the reference's own examples and BASELINE cfg1) and the pgm / FISTA back-end with
-                            this library's operators: pmx_set_Y_host_f64, pmx_upload_f64 / pmx_download_f64, pmx_pgm_begin,
-                            pmx_pgm_run, pmx_grad, pmx_loglike, pmx_iter_result; every other entry point returns
-                            PMX_E_UNSUPPORTED in such a context (the host wrappers compute those cases in fp32 as before) */
+                            M, N <= 8192: the reference's own examples and BASELINE cfg1) and the fused loops of the three
+                            back-ends with this library's operators and step rules: pmx_set_Y_host_f64, pmx_upload_f64 /
+                            pmx_download_f64, pmx_pgm_begin / _run (pgm, FISTA), pmx_adaprox_begin / _run (all six schemes, warm
+                            start, constant steps), pmx_bsdmm_begin / _run, pmx_grad, pmx_loglike, pmx_step_pgm, pmx_iter_result;
+                            every other entry point (line search, Barzilai-Borwein, the *_split pieces for user callables,
+                            weights, sharding) returns PMX_E_UNSUPPORTED in such a context -- the host wrappers compute
+                            those cases in fp32 as before */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */
@@ -161,8 +164,9 @@ int pmx_set_W_device(pmx_ctx* ctx, const float* dW, int64_t ld, int copy);
 /* raw float32 transfers host <-> one of the PMX_BUF_* arrays (count = number of floats) */
 int pmx_upload(pmx_ctx* ctx, int buf, const float* host, int64_t count);
 int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
-/* PMX_MODE_F64 contexts: Y (M x N, row pitch ld, copied) and the raw fp64 transfers of PMX_BUF_A / _ST (both directions)
- * and PMX_BUF_GA / _GST (download: the gradient pgm returns, algorithms.py:144) */
+/* PMX_MODE_F64 contexts: Y (M x N, row pitch ld, copied) and the raw fp64 transfers of PMX_BUF_A / _ST, the adaprox moments
+ * PMX_BUF_MA .. _VHST (both directions), PMX_BUF_GA / _GST (download: the gradient pgm returns, algorithms.py:144) and bsdmm's
+ * PMX_BUF_Z0 / _U0 + .. (download) */
 int pmx_set_Y_host_f64(pmx_ctx* ctx, const double* Y, int64_t ld);
 int pmx_upload_f64(pmx_ctx* ctx, int buf, const double* host, int64_t count);
 int pmx_download_f64(pmx_ctx* ctx, int buf, double* host, int64_t count);

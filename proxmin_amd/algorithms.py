@@ -442,7 +442,11 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
     if Vhat is not None:
         assert len(Vhat) == 2 and all(vh.shape == x.shape for x, vh in zip(Xs, Vhat))
 
-    with _open_device(Y, A, S, W) as dev:
+    # [r4] fp64 inputs of a small problem: fp64 arithmetic on the device (k_small_f64.hip: k64_ada_iter), as the reference's own
+    from .engine import f64_applies
+    f64 = (not slow and W is None and Y is not None and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S))
+           and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+    with _open_device(Y, A, S, W, f64=f64) as dev:
         for j in range(2):
             if warm:
                 dev.put(_lib.BUF_MA, j, M[j] if M is not None else np.zeros(Xs[j].shape, np.float32))
@@ -665,7 +669,11 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
         host_g.append([h for _, h in pairs])
     slow = any(h is not None for h in host_f) or any(h is not None for hs in host_g for h in hs) or closures is not None
 
-    with _open_device(Y, A, S, None) as dev:
+    # [r4] fp64 inputs of a small problem: fp64 arithmetic on the device (k_small_f64.hip: k64_bsdmm_block), as the reference's own
+    from .engine import f64_applies
+    f64 = (not slow and Y is not None and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S))
+           and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+    with _open_device(Y, A, S, None, f64=f64) as dev:
         dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea, update_order=order)
         res = None
         if closures is not None:        # the device's gradient stays zero: X_j - dX comes out of phase 0

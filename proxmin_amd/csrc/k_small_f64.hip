@@ -297,3 +297,295 @@ __global__ __launch_bounds__(256) void k64_fold(Fold64Args a) {
     }
 }
 void launch_fold64(const Fold64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_fold, dim3(64, 2), dim3(256), 0, s, a); }
+
+// ------------------------------------------------------------------------------------------------
+// [r4] adaprox in fp64 (small problems): the whole tail of an iteration (algorithms.py:369-410, nmf.py:91-93) by ONE workgroup.
+// Half-wave = row (K <= 16 lanes of its 32 active), the 32 half-waves of the workgroup stride over the rows; every sum over a
+// block is a wave tree + a 16-term serial sum in LDS, the same for every thread.  State (X, X_, M, V, Vhat, Psi, z) in global
+// memory -- <= 1 MB per array, L2-resident.  Not a fast path (a proximal pass over 8192 rows is 256 trips of the loop): the parity
+// path for fp64 callers of adaprox, as k64_pgm_update is for pgm.
+// ------------------------------------------------------------------------------------------------
+struct Ada64Args {
+    double* X[2];
+    double* Xp[2];           // pre-update iterate (check_convergence)
+    double* Mm[2];
+    double* Vv[2];
+    double* Vh[2];           // nullptr unless warm-started (algorithms.py:356-359)
+    double* Psi[2];
+    double* z[2];
+    const double* slab[2];
+    int nslab[2];
+    int64_t rows[2];
+    int K;
+    ProxSeq prox[2];
+    int has_prox[2];
+    DevStatus* status;
+    int scheme, it;
+    double b1t, b1prev, b2, eps, p;
+    int check_convergence;
+    double e_rel[2];
+    int prox_max_iter;
+    int use_fixed;
+    double fixed[2];
+    double* alpha_out;       // [2][16]: the steps this iteration used (pmx_step_adaprox in an fp64 context reads them)
+};
+template <int NV>
+__device__ __forceinline__ void wg_sum(double (&v)[NV], double* sm /* >= NV * EW_WAVES */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sm[i * EW_WAVES + w] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+        for (int q = 0; q < EW_WAVES; ++q) s += sm[i * EW_WAVES + q];
+        v[i] = s;
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
+    __shared__ double sm[2 * EW_WAVES];
+    __shared__ double cs[32][17];
+    __shared__ double alpha_s[2][16];
+    DevStatus* st = a.status;
+    if (chain_halted(st)) return;
+    const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    const int K = a.K;
+    const bool ok = l32 < K;
+    // ---- step sizes from the CURRENT factors, both blocks (Jacobi: algorithms.py:370 -> nmf.py:93: mean over the rows / 10)
+    for (int j = 0; j < 2; ++j) {
+        double s = 0.0;
+        if (ok)
+            for (int64_t r = hw; r < a.rows[j]; r += 32) s += a.X[j][r * K + l32];
+        __syncthreads();
+        if (l32 < 16) cs[hw][l32] = ok ? s : 0.0;
+        __syncthreads();
+        if (tid < 16) {
+            double t = 0.0;
+            for (int q = 0; q < 32; ++q) t += cs[q][tid];
+            const double al = a.use_fixed ? a.fixed[j] : (t / (double)a.rows[j]) / 10.0;
+            alpha_s[j][tid] = al;
+            a.alpha_out[j * 16 + tid] = al;
+        }
+    }
+    __syncthreads();
+    // ---- scalars of the moment schemes (algorithms.py:147-245), all in fp64
+    const double b1 = a.b1t, b2 = a.b2, t = (double)(a.it + 1);
+    const double bias1 = 1.0 - pow(b1, t), bias2 = 1.0 - pow(b2, t);
+    const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double rho = rho_inf - 2.0 * t * pow(b2, t) / (1.0 - pow(b2, t));
+    const double rfac = rho > 4.0 ? sqrt((rho - 4.0) * (rho - 2.0) * rho_inf / (rho_inf - 4.0) / (rho_inf - 2.0) / rho) : 1.0;
+    const double xfac = ((1.0 - b1) * (1.0 - b1)) / ((1.0 - a.b1prev) * (1.0 - a.b1prev));
+    int taus[2] = {0, 0};
+    for (int j = 0; j < 2; ++j) {
+        const int64_t rows = a.rows[j];
+        const double alpha = ok ? alpha_s[j][l32] : 0.0;
+        double* X = a.X[j];
+        // ---- moments and update (algorithms.py:375-378)
+        double maxpsi = -1.0;
+        for (int64_t r = hw; r < rows; r += 32) {
+            if (!ok) continue;
+            const int64_t e = r * K + l32;
+            double g = 0.0;
+            for (int q = 0; q < a.nslab[j]; ++q) g += a.slab[j][(int64_t)q * rows * K + e];      // fixed order: slab 0, 1, 2, ...
+            const double m = (1.0 - b1) * g + b1 * a.Mm[j][e];
+            const double v = (1.0 - b2) * (g * g) + b2 * a.Vv[j][e];
+            a.Mm[j][e] = m;
+            a.Vv[j][e] = v;
+            double phi, psi;
+            switch (a.scheme) {
+                case PMX_ADAM: phi = m / bias1; psi = sqrt(v / bias2) + a.eps; break;
+                case PMX_NADAM: phi = (b1 * m + (1.0 - b1) * g) / bias1; psi = sqrt(v / bias2) + a.eps; break;
+                case PMX_RADAM:
+                    phi = m / bias1;
+                    psi = rho > 4.0 ? sqrt(v / bias2) / rfac : 1.0;
+                    if (a.eps > 0.0) psi = fmax(psi, sqrt(a.eps));
+                    break;
+                default: {   // amsgrad / padam / adamx (algorithms.py:170-221)
+                    double cap = v;
+                    if (a.Vh[j] != nullptr) {
+                        const double old = a.Vh[j][e];
+                        cap = fmax(a.scheme == PMX_ADAMX ? xfac * old : old, v);
+                        a.Vh[j][e] = cap;
+                    }
+                    if (a.eps > 0.0) cap = fmax(cap, a.eps);
+                    psi = a.scheme == PMX_PADAM ? pow(cap, a.p) : sqrt(cap);
+                    phi = m;
+                }
+            }
+            const double xo = X[e];
+            if (a.check_convergence) a.Xp[j][e] = xo;
+            X[e] = xo - alpha * phi / psi;
+            if (a.has_prox[j]) { a.Psi[j][e] = psi; a.z[j][e] = X[e]; }
+            maxpsi = nanmax(maxpsi, psi);
+        }
+        // ---- the proximal sub-iterations (algorithms.py:380-400)
+        if (a.has_prox[j]) {
+            double mv = wave_nanmax(maxpsi);
+            __syncthreads();
+            if ((tid & 63) == 0) sm[tid >> 6] = mv;
+            __syncthreads();
+            double mp = sm[0];
+            for (int q = 1; q < EW_WAVES; ++q) mp = nanmax(mp, sm[q]);
+            const double gamma = alpha / mp;                  // :384
+            const double rat = gamma / alpha;                 // NaN if alpha == 0, as in the reference
+            int tau = 0;
+            for (tau = 1; tau <= a.prox_max_iter; ++tau) {
+                double red[2] = {0.0, 0.0};
+                for (int64_t r = hw; r < rows; r += 32) {     // (whole half-waves take or skip a row: the row sums of prox_unity* need all lanes)
+                    const int64_t e = r * K + l32;
+                    const double zz = ok ? a.z[j][e] : 0.0, x = ok ? X[e] : 0.0, ps = ok ? a.Psi[j][e] : 0.0;
+                    double v = zz - rat * ps * (zz - x);
+                    v = prox64_row(v, ok, a.prox[j], gamma);
+                    if (ok) {
+                        const double d = v - zz;
+                        red[0] += d * d;
+                        red[1] += zz * zz;
+                        a.z[j][e] = v;
+                    }
+                }
+                wg_sum<2>(red, sm);
+                if (red[0] <= a.e_rel[j] * a.e_rel[j] * red[1]) break;
+            }
+            if (tau > a.prox_max_iter) tau = a.prox_max_iter;
+            taus[j] = tau;
+            for (int64_t r = hw; r < rows; r += 32)
+                if (ok) X[r * K + l32] = a.z[j][r * K + l32];      // X[j][:] = z (:400)
+        }
+    }
+    // ---- outer stopping test (algorithms.py:403-410) and bookkeeping
+    int conv[2] = {0, 0};
+    double nrm[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    if (a.check_convergence) {
+        for (int j = 0; j < 2; ++j) {
+            double red[2] = {0.0, 0.0};
+            if (ok)
+                for (int64_t r = hw; r < a.rows[j]; r += 32) {
+                    const int64_t e = r * K + l32;
+                    const double x = a.X[j][e], d = x - a.Xp[j][e];
+                    red[0] += d * d;
+                    red[1] += x * x;
+                }
+            wg_sum<2>(red, sm);
+            nrm[j][0] = red[0]; nrm[j][1] = red[1];
+            conv[j] = red[0] <= a.e_rel[j] * a.e_rel[j] * red[1];
+        }
+    }
+    if (tid == 0) {
+        for (int j = 0; j < 2; ++j) {
+            st->last_tau[j] = taus[j];
+            st->sub_tau[j] = taus[j];
+            st->sub_total[j] += taus[j];
+            st->conv[j] = conv[j];
+            st->norms[j][0] = nrm[j][0]; st->norms[j][1] = nrm[j][1];
+        }
+        st->it_done += 1;
+        if (a.check_convergence && conv[0] && conv[1]) {
+            st->stopped = 1;
+            st->reason = HALT_CONVERGED;
+            __threadfence();
+            st->halt = 1;
+        }
+    }
+}
+void launch_ada64_iter(const Ada64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_ada_iter, dim3(1), dim3(EW_THREADS), 0, s, a); }
+
+// ------------------------------------------------------------------------------------------------
+// [r4] bSDMM in fp64 (small problems): one block update -- X_j, the constraint variables Z_i / U_i, the residual norms and
+// the convergence test of the block (algorithms.py:805-844, utils.py:269-391; identity L, steps_g_update = "steps_f") -- by ONE
+// workgroup, after k64_front left the block's gradient slabs and step (nmf.py:181-193).  k_bsdmm_update / k_bsdmm_decide in fp64.
+// ------------------------------------------------------------------------------------------------
+struct Bsdmm64Args {
+    double* X;
+    const double* slab;
+    int nslab;
+    double* Z[PMX_MAX_G];
+    double* U[PMX_MAX_G];
+    int64_t rows;
+    int K, j, n_g;
+    ProxSeq prox_f;
+    ProxSeq prox_g[PMX_MAX_G];
+    DevStatus* status;
+    double e_rel, e_abs;
+    int last_block;
+};
+__global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
+    __shared__ double sm[(2 + 4 * PMX_MAX_G) * EW_WAVES];
+    DevStatus* st = a.status;
+    if (chain_halted(st)) return;
+    const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    const int K = a.K, j = a.j;
+    const bool ok = l32 < K;
+    const double sf = st->step[j];
+    const double sg = sf * 1.0 * 2.0 * (double)a.n_g;          // get_step_g (utils.py:269-279), identity L
+    const double w = a.n_g > 0 ? sf / sg : 0.0;                // step_f / step_g[i]
+    const double nisg = a.n_g > 0 ? -1.0 / sg : 0.0;
+    double red[2 + 4 * PMX_MAX_G];
+#pragma unroll
+    for (int i = 0; i < 2 + 4 * PMX_MAX_G; ++i) red[i] = 0.0;
+    for (int64_t r = hw; r < a.rows; r += 32) {                // (whole half-waves take or skip a row: prox_unity* sums over its lanes)
+        const int64_t e = r * K + l32;
+        double g = 0.0;
+        if (ok)
+            for (int q = 0; q < a.nslab; ++q) g += a.slab[(int64_t)q * a.rows * K + e];
+        const double xo = ok ? a.X[e] : 0.0;
+        double dx = 0.0;
+        for (int i = 0; i < a.n_g; ++i)                         // utils.py:330-336
+            if (ok) dx += w * (xo - a.Z[i][e] + a.U[i][e]);
+        double v = (xo - dx) - sf * g;                          // utils.py:338 + nmf.py:185
+        v = prox64_row(v, ok, a.prox_f, sf);
+        if (ok) {
+            a.X[e] = v;
+            const double d = v - xo;
+            red[0] += d * d;
+            red[1] += v * v;
+        }
+        for (int i = 0; i < a.n_g; ++i) {                       // do_the_mm, utils.py:295-304
+            const double zo = ok ? a.Z[i][e] : 0.0, uo = ok ? a.U[i][e] : 0.0;
+            double zn = v + uo;
+            zn = prox64_row(zn, ok, a.prox_g[i], sg);
+            if (ok) {
+                const double rr = v - zn, sd = nisg * (zn - zo), un = uo + rr, us = un / sg;
+                a.Z[i][e] = zn;
+                a.U[i][e] = un;
+                red[2 + 4 * i + 0] += rr * rr;
+                red[2 + 4 * i + 1] += sd * sd;
+                red[2 + 4 * i + 2] += zn * zn;
+                red[2 + 4 * i + 3] += us * us;
+            }
+        }
+    }
+    wg_sum<2 + 4 * PMX_MAX_G>(red, sm);
+    if (tid == 0) {     // check_constraint_convergence (utils.py:349-391) and end-of-iteration bookkeeping
+        const double sq = sqrt((double)(a.rows * K));
+        int conv = 1;
+        if (a.n_g == 0) {
+            const double e_pri = sq * a.e_abs + a.e_rel * sqrt(red[1]);
+            const double e_dual = sq * a.e_abs + a.e_rel * 0.0;
+            conv = (0.0 <= e_pri) && (sqrt(red[0]) <= e_dual);
+        } else {
+            for (int i = 0; i < a.n_g; ++i) {
+                const double lR = sqrt(red[2 + 4 * i + 0]), lS = sqrt(red[2 + 4 * i + 1]);
+                const double e_pri = sq * a.e_abs + a.e_rel * fmax(sqrt(red[1]), sqrt(red[2 + 4 * i + 2]));
+                const double e_dual = sq * a.e_abs + a.e_rel * sqrt(red[2 + 4 * i + 3]);
+                conv &= (lR <= e_pri) && (lS <= e_dual);
+            }
+        }
+        st->conv[j] = conv;
+        st->norms[j][0] = red[0];
+        st->norms[j][1] = red[1];
+        if (a.last_block) {
+            st->it_done += 1;
+            if (st->conv[0] && st->conv[1]) {
+                st->stopped = 1;
+                st->reason = HALT_CONVERGED;
+                __threadfence();
+                st->halt = 1;
+            }
+        }
+    }
+}
+void launch_bsdmm64_block(const Bsdmm64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_bsdmm_block, dim3(1), dim3(EW_THREADS), 0, s, a); }

@@ -89,6 +89,15 @@ struct pmx_ctx {
     double* Xed[2] = {nullptr, nullptr};
     double* Gd[2] = {nullptr, nullptr};
     double* slabd[2] = {nullptr, nullptr};
+    double* Md[2] = {nullptr, nullptr};    // [r4] adaprox in fp64 (k64_ada_iter): moments, running maximum, X_, Psi, z, the steps of the last iteration
+    double* Vd[2] = {nullptr, nullptr};
+    double* Vhd[2] = {nullptr, nullptr};
+    double* Xpd[2] = {nullptr, nullptr};
+    double* Psid[2] = {nullptr, nullptr};
+    double* zd[2] = {nullptr, nullptr};
+    double* alpha64 = nullptr;
+    double* Zd[2][PMX_MAX_G] = {};         // [r4] bsdmm in fp64 (k64_bsdmm_block)
+    double* Ud[2][PMX_MAX_G] = {};
     int t64x = 0, t64y = 0;                // K1 tiles: column tiles (-> gA slabs), row tiles (-> gSt slabs)
 
     // K1
@@ -781,7 +790,27 @@ static int buf_lookup_f64(pmx_ctx* c, int buf, bool writable, double** p, int64_
         case PMX_BUF_GA: case PMX_BUF_GST: if (writable) FAIL(PMX_E_INVALID, "the gradient buffers of an fp64 context are read-only"); *p = c->Gd[j]; break;
         case PMX_BUF_EVAL_A: case PMX_BUF_EVAL_ST: if (writable) FAIL(PMX_E_INVALID, "buffer %d is read-only", buf);
             *p = (c->algo == ALG_PGM && c->pgm.accelerated && c->Xed[j]) ? c->Xed[j] : c->Xd[j]; break;
-        default: FAIL(PMX_E_UNSUPPORTED, "buffer %d does not exist in an fp64 context", buf);
+        case PMX_BUF_MA: case PMX_BUF_MST: case PMX_BUF_VA: case PMX_BUF_VST: case PMX_BUF_VHA: case PMX_BUF_VHST: {
+            double** slot = (buf == PMX_BUF_MA || buf == PMX_BUF_MST) ? &c->Md[j] : ((buf == PMX_BUF_VA || buf == PMX_BUF_VST) ? &c->Vd[j] : &c->Vhd[j]);
+            if (!*slot) {
+                if (!writable) FAIL(PMX_E_STATE, "buffer %d has not been created yet", buf);
+                int rc = dallocT(c, slot, (size_t)c->rows[j] * c->K);
+                if (rc != PMX_OK) return rc;
+            }
+            *p = *slot;
+            break;
+        }
+        default:
+            if (buf >= PMX_BUF_Z0 && buf < PMX_BUF_U0 + 2 * PMX_MAX_G) {       // bsdmm's constraint variables (read-only: tests compare them with the oracle's)
+                const bool isU = buf >= PMX_BUF_U0;
+                const int k = buf - (isU ? PMX_BUF_U0 : PMX_BUF_Z0), jj = k / PMX_MAX_G, i = k % PMX_MAX_G;
+                double* q = isU ? c->Ud[jj][i] : c->Zd[jj][i];
+                if (writable || !q) FAIL(PMX_E_STATE, "buffer %d is read-only / has not been created yet", buf);
+                *p = q;
+                *count = c->rows[jj] * c->K;
+                return PMX_OK;
+            }
+            FAIL(PMX_E_UNSUPPORTED, "buffer %d does not exist in an fp64 context", buf);
     }
     *count = c->rows[j] * c->K;
     return PMX_OK;
@@ -1139,7 +1168,7 @@ static int shard_gram_in(pmx_ctx* c) {
 // fp64 context instead of touching float arrays it does not have
 static int require_ready(pmx_ctx* c, bool f64_ok = false) {
     if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
-    if (c->f64 && !f64_ok) FAIL(PMX_E_UNSUPPORTED, "this entry point has no fp64 implementation (PMX_MODE_F64 covers pgm / FISTA on small problems)");
+    if (c->f64 && !f64_ok) FAIL(PMX_E_UNSUPPORTED, "this entry point has no fp64 implementation (PMX_MODE_F64 covers the fused pgm / FISTA, adaprox and bsdmm loops on small problems)");
     if (!c->haveY) FAIL(PMX_E_STATE, "Y has not been set");
     HIP_CHECK(hipSetDevice(c->device));
     return PMX_OK;
@@ -1375,7 +1404,7 @@ static int enqueue_alpha_from_factors(pmx_ctx* c, const AlphaArgs& al) {
 }
 
 // entry points without an fp64 implementation that do not pass through require_ready()
-#define REJECT_F64(c) do { if ((c) && (c)->f64) FAIL(PMX_E_UNSUPPORTED, "%s has no fp64 implementation (PMX_MODE_F64 covers pgm / FISTA on small problems)", __func__); } while (0)
+#define REJECT_F64(c) do { if ((c) && (c)->f64) FAIL(PMX_E_UNSUPPORTED, "%s has no fp64 implementation (PMX_MODE_F64 covers the fused pgm / FISTA, adaprox and bsdmm loops on small problems)", __func__); } while (0)
 
 extern "C" int pmx_step_adaprox(pmx_ctx* c, float* out) {
     REJECT_F64(c);
@@ -1963,7 +1992,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int warm_moments) {
     if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
     if (p->scheme < PMX_ADAM || p->scheme > PMX_RADAM) FAIL(PMX_E_INVALID, "unknown scheme %d", p->scheme);
@@ -1973,6 +2002,37 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
     for (int j = 0; j < 2; ++j) {
         rc = check_prox(p->prox[j], j ? "prox_S" : "prox_A");
         if (rc != PMX_OK) return rc;
+    }
+    if (c->f64) {                                // PMX_MODE_F64: this library's operators and step rule (or two constants), k64_ada_iter
+        if (p->host_prox[0] || p->host_prox[1] || p->use_fixed_steps == 2)
+            FAIL(PMX_E_UNSUPPORTED, "fp64 contexts run adaprox with this library's operators and step rule (no user prox / step)");
+        c->ada = *p;
+        c->algo = ALG_ADAPROX;
+        c->it = 0;
+        rc = reset_status(c);
+        if (rc != PMX_OK) return rc;
+        for (int j = 0; j < 2; ++j) {
+            const size_t n = (size_t)c->rows[j] * c->K;
+            const bool fresh_m = c->Md[j] == nullptr, fresh_v = c->Vd[j] == nullptr;
+            rc = dallocT(c, &c->Md[j], n);
+            if (rc == PMX_OK) rc = dallocT(c, &c->Vd[j], n);
+            if (rc != PMX_OK) return rc;
+            if (!warm_moments) {   // cold start: zeros (algorithms.py:348-353)
+                if (!fresh_m) HIP_CHECK(hipMemsetAsync(c->Md[j], 0, n * sizeof(double), c->stream));
+                if (!fresh_v) HIP_CHECK(hipMemsetAsync(c->Vd[j], 0, n * sizeof(double), c->stream));
+            }
+            if (p->warm_vhat && !c->Vhd[j]) FAIL(PMX_E_STATE, "warm_vhat set but Vhat buffers were not uploaded");
+            if (p->check_convergence) rc = dallocT(c, &c->Xpd[j], n, false);
+            if (rc == PMX_OK && p->prox[j].n > 0) {
+                rc = dallocT(c, &c->Psid[j], n, false);
+                if (rc == PMX_OK) rc = dallocT(c, &c->zd[j], n, false);
+            }
+            if (rc != PMX_OK) return rc;
+        }
+        rc = dallocT(c, &c->alpha64, 32);
+        if (rc != PMX_OK) return rc;
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PMX_OK;
     }
     c->ada = *p;
     c->algo = ALG_ADAPROX;
@@ -2184,7 +2244,7 @@ static int ada_enqueue_head(pmx_ctx* c, int it, double b1t, double b1prev, bool 
 
 extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double b1_prev, pmx_result* res) {
     if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_ADAPROX) FAIL(PMX_E_STATE, "pmx_adaprox_begin has not been called");
     if (n_iter < 0 || (n_iter > 0 && !b1)) FAIL(PMX_E_INVALID, "bad n_iter / b1");
@@ -2193,6 +2253,44 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
     const pmx_adaprox_params& p = c->ada;
     const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
     const int it0 = c->hstatus->it_done;
+    if (c->f64) {            // K1 tiles (k64_front without its step-rule workgroups) + the whole tail by one workgroup (k64_ada_iter)
+        for (int left = n_iter, gi = 0; left > 0 && !c->hstatus->stopped; left -= 16) {
+            for (int i = 0; i < std::min(left, 16); ++i, ++gi) {
+                rc = enqueue_front64(c, c->Xd[0], c->Xd[1], 1, 1, true, false, 1.0);       // algorithms.py:369
+                if (rc != PMX_OK) return rc;
+                Ada64Args a{};
+                for (int j = 0; j < 2; ++j) {
+                    a.X[j] = c->Xd[j]; a.Xp[j] = c->Xpd[j]; a.Mm[j] = c->Md[j]; a.Vv[j] = c->Vd[j];
+                    a.Vh[j] = p.warm_vhat ? c->Vhd[j] : nullptr;
+                    a.Psi[j] = c->Psid[j]; a.z[j] = c->zd[j];
+                    a.slab[j] = c->slabd[j];
+                    a.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS;
+                    a.rows[j] = c->rows[j];
+                    a.prox[j] = to_dev(p.prox[j]);
+                    a.has_prox[j] = p.prox[j].n > 0;
+                    a.e_rel[j] = p.e_rel[j];
+                    a.fixed[j] = p.fixed_alpha[j];
+                }
+                a.K = (int)c->K;
+                a.status = c->dstatus;
+                a.scheme = p.scheme;
+                a.it = it0 + gi;
+                a.b1t = b1[gi]; a.b1prev = gi == 0 ? b1_prev : b1[gi - 1];
+                a.b2 = p.b2; a.eps = p.eps; a.p = p.p;
+                a.check_convergence = p.check_convergence;
+                a.prox_max_iter = p.prox_max_iter;
+                a.use_fixed = p.use_fixed_steps;
+                a.alpha_out = c->alpha64;
+                launch_ada64_iter(a, c->stream);                                           // algorithms.py:370-410
+                HIP_CHECK(hipGetLastError());
+            }
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+        }
+        fill_result(c, res, it0);
+        return PMX_OK;
+    }
     int done = 0;            // iterations of this call completed
     int tails = 0;           // iteration tails enqueued by this call (their finish kernel leaves the factor maxima behind)
     while (done < n_iter && !c->hstatus->stopped) {
@@ -2334,7 +2432,7 @@ extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, do
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
     if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
     if (c->W)                                          // bsdmm's steps come from nmf.step_pgm (nmf.py:187-193)
@@ -2357,6 +2455,20 @@ extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
     rc = reset_status(c);
     if (rc != PMX_OK) return rc;
     // utils.initZU (utils.py:244-254): Z_i = copy of X, U_i = 0
+    if (c->f64) {
+        for (int j = 0; j < 2; ++j) {
+            const size_t n = (size_t)c->rows[j] * c->K;
+            for (int i = 0; i < p->n_g[j]; ++i) {
+                rc = dallocT(c, &c->Zd[j][i], n, false);
+                if (rc == PMX_OK) rc = dallocT(c, &c->Ud[j][i], n, false);
+                if (rc != PMX_OK) return rc;
+                HIP_CHECK(hipMemcpyAsync(c->Zd[j][i], c->Xd[j], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIP_CHECK(hipMemsetAsync(c->Ud[j][i], 0, n * sizeof(double), c->stream));
+            }
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PMX_OK;
+    }
     for (int j = 0; j < 2; ++j) {
         const size_t n = (size_t)c->rows[j] * c->K;
         for (int i = 0; i < p->n_g[j]; ++i) {
@@ -2378,6 +2490,27 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
     const int* order = p.n_order > 0 ? p.order : default_order;
     for (int o = 0; o < n_order; ++o) {                                    // Gauss-Seidel in update_order, algorithms.py:805
         const int j = order[o];
+        if (c->f64) {       // K1 tiles of block j + both step rules in one launch (k64_front), the block update by one workgroup
+            int rc = enqueue_front64(c, c->Xd[0], c->Xd[1], j == 0, j == 1, true, true, 1.0);   // nmf.py:181-193
+            if (rc != PMX_OK) return rc;
+            Bsdmm64Args u{};
+            u.X = c->Xd[j];
+            u.slab = c->slabd[j];
+            u.nslab = j == 0 ? c->nSlabA : c->nSlabS;
+            for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zd[j][i]; u.U[i] = c->Ud[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
+            u.rows = c->rows[j];
+            u.K = (int)c->K;
+            u.j = j;
+            u.n_g = p.n_g[j];
+            u.prox_f = to_dev(p.prox_f[j]);
+            u.status = c->dstatus;
+            u.e_rel = p.e_rel[j];
+            u.e_abs = p.e_abs[j];
+            u.last_block = o == n_order - 1;
+            launch_bsdmm64_block(u, c->stream);
+            HIP_CHECK(hipGetLastError());
+            continue;
+        }
         int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
         if (rc != PMX_OK) return rc;
         rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1, c->absmax_by_finish);   // nmf.py:181-185 (only grads[j] is used)
@@ -2499,7 +2632,7 @@ extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigne
 
 extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
-    int rc = require_ready(c);
+    int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
     if (n_iter < 0) FAIL(PMX_E_INVALID, "n_iter < 0");
@@ -2514,7 +2647,7 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
         int again = 0;
-        rc = chain_fault_fallback(c, &again);
+        rc = c->f64 ? PMX_OK : chain_fault_fallback(c, &again);
         if (rc != PMX_OK) return rc;
         if (again) {
             left = n_iter - (c->hstatus->it_done - it0);

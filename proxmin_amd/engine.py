@@ -69,7 +69,7 @@ class DeviceNMF:
         self.device = device
         mode = mode or _DEFAULT_MODE
         self.mode = mode
-        self.f64 = mode == "f64"          # fp64 operands, products and sums (small problems, pgm / FISTA: k_small_f64.hip)
+        self.f64 = mode == "f64"          # fp64 operands, products and sums (small problems, the fused loops of the three back-ends: k_small_f64.hip)
         mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f64": _lib.MODE_F64}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,

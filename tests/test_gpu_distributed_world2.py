@@ -46,7 +46,14 @@ def _free_port():
     return port
 
 
+JOIN_S = int(os.environ.get("PMX_W2_TIMEOUT", "300"))      # seconds a rank may take before the test gives up on it
+
+
 def _worker(rank, world, port, name, mode, out_dir):
+    # a rank that is still running shortly before the parent gives up writes where every thread stands (read back by the test)
+    import faulthandler
+    _fh = open(os.path.join(out_dir, "stuck_rank%d.txt" % rank), "w")
+    faulthandler.dump_traceback_later(max(JOIN_S - 15, 5), file=_fh, exit=False)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     # two processes share the GPU here: the fused adaprox tail (the product configuration's) needs all of it to itself, so
@@ -119,18 +126,35 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
             pm.nmf.nmf(Y, A1, S1, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=c["its"], e_rel=1e-9, callback=tb)
     finally:
         pm.set_default_mode("f32")
-    port = _free_port()
+    import time
+    import warnings
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, mode, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    alive = [p for p in procs if p.is_alive()]
-    for p in alive:                      # never leave a rank behind: it would keep the GPU (and pytest) busy
-        p.terminate()
-        p.join(10)
-    assert not alive, "rank process(es) did not finish within 300 s"
+    for attempt in range(2):
+        # Two processes on ONE GPU with gloo is a test-only arrangement, and once in several hundred executions (round 4: 1 of
+        # ~500) a pair of ranks did not come back within the patience below.  A TIMEOUT (never a wrong result or a failed
+        # rank) is retried once, with where the ranks stood written into the test's warnings.
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, name, mode, str(tmp_path))) for r in range(2)]
+        for p in procs:
+            p.start()
+        deadline = time.time() + JOIN_S
+        for p in procs:
+            p.join(max(deadline - time.time(), 1))
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:                      # never leave a rank behind: it would keep the GPU (and pytest) busy
+            p.terminate()
+            p.join(10)
+        if not alive:
+            break
+        stuck = ""
+        for r in range(2):
+            f = tmp_path / ("stuck_rank%d.txt" % r)
+            if f.exists():
+                stuck += "\n--- rank %d ---\n%s" % (r, f.read_text()[-3000:])
+        msg = "rank process(es) did not finish within %d s (attempt %d)%s" % (JOIN_S, attempt + 1, stuck)
+        if attempt == 1:
+            raise AssertionError(msg)
+        warnings.warn(msg)
     for p in procs:
         assert p.exitcode == 0, "rank process failed (exit code %r)" % p.exitcode
     S_ranks = []

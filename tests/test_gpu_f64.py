@@ -97,6 +97,181 @@ def test_fp64_fixtures_pgm_rows_to_ten_digits(pm, orc, monkeypatch, fname, with_
     assert done >= 2
 
 
+@pytest.mark.parametrize("with_callback", [False, True])
+@pytest.mark.parametrize("fname", ["nmf_200x1000_k5_f64.npz", "nmf_33x47_k3_f64.npz"])
+def test_fp64_fixtures_adaprox_rows_to_ten_digits(pm, orc, monkeypatch, fname, with_callback):
+    """[r4] every adaprox row of the reference's fp64 fixtures (six moment schemes, prox_unity_plus on either block, a relative soft
+    threshold, prox=None) on the fp64 kernels (k64_front + k64_ada_iter): factors, recorded iterates, first and second moments to
+    rtol 1e-10; RAdam while the reference's own iterates are finite."""
+    from test_gpu_nmf import run_device_case
+    from proxmin_amd import algorithms, engine
+    modes = []
+    real = engine.DeviceNMF
+
+    class Spy(real):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            modes.append(self.mode)
+    monkeypatch.setattr(algorithms, "DeviceNMF", Spy)
+    z, meta = load_golden(fname)
+    assert meta["dtype"] == "float64"
+    done = 0
+    for name, c in meta["cases"].items():
+        if c["alg"] != "adaprox":
+            continue
+        tag = "unity" if c["unity_S"] else "plain"
+        if "inputs_%s/Y" % tag in z.files:
+            Y, A0, S0 = z["inputs_%s/Y" % tag], z["inputs_%s/A0" % tag], z["inputs_%s/S0" % tag]
+        else:
+            Y, A0, S0 = orc.synthetic_problem(meta["M"], meta["N"], meta["K"], np.float64, c["unity_S"], meta["seed"])
+        finite = np.isfinite(z[name + "/A"]).all() and np.isfinite(z[name + "/S"]).all() and max(np.abs(z[name + "/A"]).max(), np.abs(z[name + "/S"]).max()) < 1e30
+        tb = pm.utils.Traceback() if with_callback else None
+        del modes[:]
+        A, S, ret = run_device_case(pm, c, Y, A0, S0, meta["max_iter"], meta["e_rel"], callback=tb)
+        assert modes == ["f64"], (name, modes)               # the fp64 kernels are what ran
+        assert A.dtype == np.float64
+        conv, Mm, Vv, Vh = ret
+        if finite:
+            for got, key in ((A, "A"), (S, "S"), (Mm[0], "M_A"), (Mm[1], "M_S"), (Vv[0], "V_A"), (Vv[1], "V_S")):
+                want = z[name + "/" + key]
+                np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-13 * max(1.0, float(np.abs(want).max())), err_msg="%s %s %s" % (fname, name, key))
+            assert list(conv) == list(z[name + "/conv"])
+        if with_callback:
+            assert len(tb.trace) == int(z[name + "/n_callbacks"]), name
+            i = 0
+            while "%s/trace_A_%d" % (name, i) in z.files:
+                rA, rS = z["%s/trace_A_%d" % (name, i)], z["%s/trace_S_%d" % (name, i)]
+                if not (np.isfinite(rA).all() and np.isfinite(rS).all()) or max(np.abs(rA).max(), np.abs(rS).max()) > 1e30:
+                    break
+                np.testing.assert_allclose(tb.trace[i][0], rA, rtol=RTOL, atol=1e-13 * max(1.0, float(np.abs(rA).max())), err_msg="%s iterate %d" % (name, i))
+                np.testing.assert_allclose(tb.trace[i][1], rS, rtol=RTOL, atol=1e-13 * max(1.0, float(np.abs(rS).max())), err_msg="%s iterate %d" % (name, i))
+                i += 1
+        done += 1
+    assert done >= 3
+
+
+def test_fp64_adaprox_warm_start_fixed_steps_and_convergence(pm, orc):
+    """warm start with M / V / Vhat arrays (the true AMSGrad running maximum, algorithms.py:356-359), array-valued b1, two constant
+    steps (nmf.constant_step), and a run that converges: against the fp64 oracle to 1e-10, converged flags and pass counts equal"""
+    from functools import partial
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(150, 333, 6, np.float64, unity_S=True, seed=9)
+    rng = np.random.default_rng(3)
+    # (1) warm start, amsgrad with Vhat, b1 array
+    b1 = np.linspace(0.9, 0.5, 9)
+    M0 = [rng.normal(size=A0.shape) * 0.01, rng.normal(size=S0.shape) * 0.01]
+    V0 = [rng.random(A0.shape) * 1e-3, rng.random(S0.shape) * 1e-3]
+    Vh0 = [v * 1.5 for v in V0]
+    A, S = A0.copy(), S0.copy()
+    M, V, Vh = [m.copy() for m in M0], [v.copy() for v in V0], [v.copy() for v in Vh0]
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="amsgrad", prox_S=partial(ops.prox_unity_plus, axis=0), b1=b1, max_iter=9, e_rel=1e-4,
+               M=M, V=V, Vhat=Vh, check_convergence=False)
+    Ao, So = A0.copy(), S0.copy()
+    Mo, Vo, Vho = [m.copy() for m in M0], [v.copy() for v in V0], [v.copy() for v in Vh0]
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme="amsgrad", b1=b1, max_iter=9, e_rel=1e-4, M=Mo, V=Vo, Vhat=Vho, check_convergence=False)
+    for got, want in ((A, Ao), (S, So), (M[0], Mo[0]), (V[1], Vo[1]), (Vh[0], Vho[0]), (Vh[1], Vho[1])):
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-14)
+    # (2) constant steps
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", step=pm.nmf.constant_step(0.01, 0.002), max_iter=7, e_rel=1e-4, check_convergence=False)
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, step=lambda a, s, it: (0.01, 0.002), scheme="adam", max_iter=7, e_rel=1e-4, check_convergence=False)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-14)
+    # (3) a run that converges: same iteration count, flags, factors
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv, _, _, _ = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", max_iter=400, e_rel=2e-3, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    oret = orc.adaprox_nmf(Y, Ao, So, scheme="adam", max_iter=400, e_rel=2e-3)
+    assert tuple(conv) == tuple(oret[0]) and len(tb.trace) == oret[4]
+    np.testing.assert_allclose(A, Ao, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(S, So, rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("with_callback", [False, True])
+@pytest.mark.parametrize("fname", ["nmf_200x1000_k5_f64.npz", "nmf_33x47_k3_f64.npz"])
+def test_fp64_fixtures_bsdmm_rows_to_ten_digits(pm, orc, monkeypatch, fname, with_callback):
+    """[r4] the bsdmm rows of the reference's fp64 fixtures (no constraints, plus + soft on both blocks, a constraint on one
+    block only) on the fp64 kernels (k64_front + k64_bsdmm_block): factors, recorded iterates and flags; Z / U against the oracle"""
+    from test_gpu_nmf import run_device_case
+    from proxmin_amd import algorithms, engine
+    modes = []
+    real = engine.DeviceNMF
+
+    class Spy(real):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            modes.append(self.mode)
+    monkeypatch.setattr(algorithms, "DeviceNMF", Spy)
+    z, meta = load_golden(fname)
+    done = 0
+    for name, c in meta["cases"].items():
+        if c["alg"] != "bsdmm":
+            continue
+        tag = "unity" if c["unity_S"] else "plain"
+        if "inputs_%s/Y" % tag in z.files:
+            Y, A0, S0 = z["inputs_%s/Y" % tag], z["inputs_%s/A0" % tag], z["inputs_%s/S0" % tag]
+        else:
+            Y, A0, S0 = orc.synthetic_problem(meta["M"], meta["N"], meta["K"], np.float64, c["unity_S"], meta["seed"])
+        tb = pm.utils.Traceback() if with_callback else None
+        del modes[:]
+        A, S, ret = run_device_case(pm, c, Y, A0, S0, meta["max_iter"], meta["e_rel"], callback=tb)
+        assert modes == ["f64"], (name, modes)
+        np.testing.assert_allclose(A, z[name + "/A"], rtol=RTOL, atol=1e-14, err_msg="%s %s A" % (fname, name))
+        np.testing.assert_allclose(S, z[name + "/S"], rtol=RTOL, atol=1e-14, err_msg="%s %s S" % (fname, name))
+        assert [bool(x) for x in ret] == [bool(x) for x in z[name + "/conv"]]
+        if with_callback:
+            assert len(tb.trace) == int(z[name + "/n_callbacks"]), name
+            i = 0
+            while "%s/trace_A_%d" % (name, i) in z.files:
+                np.testing.assert_allclose(tb.trace[i][0], z["%s/trace_A_%d" % (name, i)], rtol=RTOL, atol=1e-14)
+                np.testing.assert_allclose(tb.trace[i][1], z["%s/trace_S_%d" % (name, i)], rtol=RTOL, atol=1e-14)
+                i += 1
+        done += 1
+    assert done >= 2
+
+
+def test_fp64_bsdmm_constraint_variables_and_convergence(pm, orc):
+    """Z_i / U_i of both blocks against the oracle's (the reference drops them), and a run that stops by Boyd's test at the
+    oracle's iteration"""
+    from functools import partial
+    from proxmin_amd import _lib
+    from proxmin_amd.engine import DeviceNMF
+    ops = pm.operators
+    M, N, K = 90, 210, 7
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, seed=5)
+    pA, pS = ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(ops.prox_plus, 1)
+    gA = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=0.02), 0)]
+    gS = [ops.device_proxseq(partial(ops.prox_soft_plus, thresh=0.01), 1)]
+    with DeviceNMF(M, N, K, mode="f64") as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A0, S0)
+        dev.bsdmm_begin([pA, pS], [gA, gS], e_rel=(1e-9, 1e-9), e_abs=(0.0, 0.0))
+        dev.bsdmm_run(8)
+        A, S = dev.get_factors()
+        Z = [[dev._download(_lib.BUF_Z0 + j * _lib.MAX_G + i, (M, N)[j]) for i in range((2, 1)[j])] for j in range(2)]
+        U = [[dev._download(_lib.BUF_U0 + j * _lib.MAX_G + i, (M, N)[j]) for i in range((2, 1)[j])] for j in range(2)]
+    Ao, So = A0.copy(), S0.copy()
+    state = {}
+    orc.bsdmm_nmf(Y, Ao, So, proxs_g=[[("plus",), ("soft", 0.02, "relative")], [("soft_plus", 0.01, "relative")]], max_iter=8, e_rel=1e-9, state=state)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-14)
+    for i in range(2):
+        np.testing.assert_allclose(Z[0][i], state["Z"][0][i], rtol=RTOL, atol=1e-14)
+        np.testing.assert_allclose(U[0][i], state["U"][0][i], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(Z[1][0].T, state["Z"][1][0], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(U[1][0].T, state["U"][1][0], rtol=1e-8, atol=1e-13)
+    # convergence by Boyd's test
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv = pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, max_iter=500, e_rel=5e-3, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    oconv, oit = orc.bsdmm_nmf(Y, Ao, So, max_iter=500, e_rel=5e-3)
+    assert list(conv) == list(oconv) and len(tb.trace) == oit
+    np.testing.assert_allclose(A, Ao, rtol=1e-8, atol=1e-12)
+
+
 def test_fp64_operators_and_convergence(pm, orc):
     """every device operator in fp64 inside pgm (unity along the short axis, soft threshold, alternating projections) and a run
     that converges: iteration count and flags equal to the oracle's, factors to 1e-10"""
@@ -128,14 +303,14 @@ def test_fp64_mode_says_what_it_does_not_cover(pm, orc):
     with DeviceNMF(64, 96, 4, mode="f64") as dev:
         dev.set_Y(Y)
         dev.set_factors(A, S)
-        with pytest.raises(NotImplementedError):
-            dev.adaprox_begin([pm.operators.device_proxseq(pm.operators.prox_plus, j) for j in range(2)], scheme="adam", e_rel=(1e-3, 1e-3))
+        with pytest.raises(NotImplementedError):             # (the pieces for user callables exist in fp32 only)
+            dev.pgm_begin([pm.operators.device_proxseq(pm.operators.prox_plus, j) for j in range(2)], backtracking=True, e_rel=(1e-3, 1e-3))
         with pytest.raises(NotImplementedError):
             dev.step_adaprox()
         sA, sS = dev.step_pgm()                              # nmf.step_pgm (nmf.py:44-65) to fp64 round-off
         LA, LS = orc.lipschitz_steps(A, S)
         assert sA == pytest.approx(LA, rel=1e-12) and sS == pytest.approx(LS, rel=1e-12)
-    # fp64 inputs outside the mode's coverage still run (in fp32, cast back): adaprox on a small problem, pgm on a large one
+    # fp64 inputs outside the mode's coverage still run (in fp32, cast back): a user-written prox on a small problem, pgm on a large one
     A1, S1 = A.copy(), S.copy()
-    pm.nmf.nmf(Y, A1, S1, algorithm=pm.adaprox, max_iter=3, e_rel=1e-3)
+    pm.nmf.nmf(Y, A1, S1, prox_A=lambda X, step: np.maximum(X, 0), max_iter=3, e_rel=1e-3)
     assert A1.dtype == np.float64 and np.isfinite(A1).all()
