@@ -183,14 +183,18 @@ hipError_t launch_front64(const Grad64Args& ga, const EigArgs& ea, const double*
 
 // every operator of proxmin.operators on ONE fp64 value per lane (K <= 16: a row lives in lanes 0 .. K-1 of its 32)
 // -- prox_one (k_update.hip) restated for double, same expressions in the same order (operators.py:20-160)
-__device__ __forceinline__ double row_sum32_d(double v) {
-    v += swz16_d(v);
-    v += __shfl_xor(v, 8);
+// sum over the G lanes that share a row (G = 32: a half-wave; 16 / 8: [r4] the single-workgroup adaprox / bsdmm kernels pack 2 / 4 rows
+// into a half-wave when K <= 16 / 8).  Lanes >= K hold zeros, so the 32-lane butterfly and the shorter ones give the same bits.
+template <int G>
+__device__ __forceinline__ double row_sum_d(double v) {
+    if (G > 16) v += swz16_d(v);
+    if (G > 8) v += __shfl_xor(v, 8);
     v += __shfl_xor(v, 4);
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_XOR1>(v);
     return v;
 }
+template <int G = 32>
 __device__ __forceinline__ double prox64_one(double v, bool ok, const pmx_prox& p, double sk) {
     switch (p.op) {
         case PMX_PROX_ID: return v;
@@ -199,7 +203,7 @@ __device__ __forceinline__ double prox64_one(double v, bool ok, const pmx_prox& 
         case PMX_PROX_UNITY:
         case PMX_PROX_UNITY_PLUS: {
             if (p.op == PMX_PROX_UNITY_PLUS) v = v < 0.0 ? 0.0 : v;
-            const double s = row_sum32_d(ok ? v : 0.0);
+            const double s = row_sum_d<G>(ok ? v : 0.0);
             return v / s;                                   // (no zero guard, like the reference)
         }
         default: {
@@ -225,9 +229,10 @@ __device__ __forceinline__ double prox64_one(double v, bool ok, const pmx_prox& 
         }
     }
 }
+template <int G = 32>
 __device__ __forceinline__ double prox64_row(double v, bool ok, const ProxSeq& ps, double sk) {
     for (int r = 0; r < ps.repeat; ++r)
-        for (int q = 0; q < ps.n; ++q) v = prox64_one(v, ok, ps.seq[q], sk);
+        for (int q = 0; q < ps.n; ++q) v = prox64_one<G>(v, ok, ps.seq[q], sk);
     return v;
 }
 
@@ -346,27 +351,31 @@ __device__ __forceinline__ void wg_sum(double (&v)[NV], double* sm /* >= NV * EW
         v[i] = s;
     }
 }
+// G lanes per row (8 / 16 / 32 for K <= 8 / 16 / ..): 1024 / G rows per trip of the loops
+template <int G>
 __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
+    constexpr int NG = EW_THREADS / G;       // row groups of the workgroup
     __shared__ double sm[2 * EW_WAVES];
-    __shared__ double cs[32][17];
+    __shared__ double cs[NG][17];
     __shared__ double alpha_s[2][16];
     DevStatus* st = a.status;
     if (chain_halted(st)) return;
-    const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    const int tid = threadIdx.x, l32 = tid % G, hw = tid / G;
     const int K = a.K;
     const bool ok = l32 < K;
     // ---- step sizes from the CURRENT factors, both blocks (Jacobi: algorithms.py:370 -> nmf.py:93: mean over the rows / 10)
     for (int j = 0; j < 2; ++j) {
         double s = 0.0;
         if (ok)
-            for (int64_t r = hw; r < a.rows[j]; r += 32) s += a.X[j][r * K + l32];
+            for (int64_t r = hw; r < a.rows[j]; r += NG) s += a.X[j][r * K + l32];
         __syncthreads();
-        if (l32 < 16) cs[hw][l32] = ok ? s : 0.0;
+        if (ok) cs[hw][l32] = s;
         __syncthreads();
         if (tid < 16) {
             double t = 0.0;
-            for (int q = 0; q < 32; ++q) t += cs[q][tid];
-            const double al = a.use_fixed ? a.fixed[j] : (t / (double)a.rows[j]) / 10.0;
+            if (tid < K)
+                for (int q = 0; q < NG; ++q) t += cs[q][tid];
+            const double al = tid >= K ? 0.0 : (a.use_fixed ? a.fixed[j] : (t / (double)a.rows[j]) / 10.0);
             alpha_s[j][tid] = al;
             a.alpha_out[j * 16 + tid] = al;
         }
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
         double* X = a.X[j];
         // ---- moments and update (algorithms.py:375-378)
         double maxpsi = -1.0;
-        for (int64_t r = hw; r < rows; r += 32) {
+        for (int64_t r = hw; r < rows; r += NG) {
             if (!ok) continue;
             const int64_t e = r * K + l32;
             double g = 0.0;
@@ -435,11 +444,11 @@ __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
             int tau = 0;
             for (tau = 1; tau <= a.prox_max_iter; ++tau) {
                 double red[2] = {0.0, 0.0};
-                for (int64_t r = hw; r < rows; r += 32) {     // (whole half-waves take or skip a row: the row sums of prox_unity* need all lanes)
+                for (int64_t r = hw; r < rows; r += NG) {     // (whole half-waves take or skip a row: the row sums of prox_unity* need all lanes)
                     const int64_t e = r * K + l32;
                     const double zz = ok ? a.z[j][e] : 0.0, x = ok ? X[e] : 0.0, ps = ok ? a.Psi[j][e] : 0.0;
                     double v = zz - rat * ps * (zz - x);
-                    v = prox64_row(v, ok, a.prox[j], gamma);
+                    v = prox64_row<G>(v, ok, a.prox[j], gamma);
                     if (ok) {
                         const double d = v - zz;
                         red[0] += d * d;
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
             }
             if (tau > a.prox_max_iter) tau = a.prox_max_iter;
             taus[j] = tau;
-            for (int64_t r = hw; r < rows; r += 32)
+            for (int64_t r = hw; r < rows; r += NG)
                 if (ok) X[r * K + l32] = a.z[j][r * K + l32];      // X[j][:] = z (:400)
         }
     }
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
         for (int j = 0; j < 2; ++j) {
             double red[2] = {0.0, 0.0};
             if (ok)
-                for (int64_t r = hw; r < a.rows[j]; r += 32) {
+                for (int64_t r = hw; r < a.rows[j]; r += NG) {
                     const int64_t e = r * K + l32;
                     const double x = a.X[j][e], d = x - a.Xp[j][e];
                     red[0] += d * d;
@@ -491,7 +500,10 @@ __global__ __launch_bounds__(EW_THREADS) void k64_ada_iter(Ada64Args a) {
         }
     }
 }
-void launch_ada64_iter(const Ada64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_ada_iter, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_ada64_iter(const Ada64Args& a, hipStream_t s) {
+    if (a.K <= 8) hipLaunchKernelGGL(k64_ada_iter<8>, dim3(1), dim3(EW_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k64_ada_iter<16>, dim3(1), dim3(EW_THREADS), 0, s, a);
+}
 
 // ------------------------------------------------------------------------------------------------
 // [r4] bSDMM in fp64 (small problems): one block update -- X_j, the constraint variables Z_i / U_i, the residual norms and
@@ -512,11 +524,13 @@ struct Bsdmm64Args {
     double e_rel, e_abs;
     int last_block;
 };
+template <int G>
 __global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
+    constexpr int NG = EW_THREADS / G;
     __shared__ double sm[(2 + 4 * PMX_MAX_G) * EW_WAVES];
     DevStatus* st = a.status;
     if (chain_halted(st)) return;
-    const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+    const int tid = threadIdx.x, l32 = tid % G, hw = tid / G;
     const int K = a.K, j = a.j;
     const bool ok = l32 < K;
     const double sf = st->step[j];
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
     double red[2 + 4 * PMX_MAX_G];
 #pragma unroll
     for (int i = 0; i < 2 + 4 * PMX_MAX_G; ++i) red[i] = 0.0;
-    for (int64_t r = hw; r < a.rows; r += 32) {                // (whole half-waves take or skip a row: prox_unity* sums over its lanes)
+    for (int64_t r = hw; r < a.rows; r += NG) {                // (whole half-waves take or skip a row: prox_unity* sums over its lanes)
         const int64_t e = r * K + l32;
         double g = 0.0;
         if (ok)
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
         for (int i = 0; i < a.n_g; ++i)                         // utils.py:330-336
             if (ok) dx += w * (xo - a.Z[i][e] + a.U[i][e]);
         double v = (xo - dx) - sf * g;                          // utils.py:338 + nmf.py:185
-        v = prox64_row(v, ok, a.prox_f, sf);
+        v = prox64_row<G>(v, ok, a.prox_f, sf);
         if (ok) {
             a.X[e] = v;
             const double d = v - xo;
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
         for (int i = 0; i < a.n_g; ++i) {                       // do_the_mm, utils.py:295-304
             const double zo = ok ? a.Z[i][e] : 0.0, uo = ok ? a.U[i][e] : 0.0;
             double zn = v + uo;
-            zn = prox64_row(zn, ok, a.prox_g[i], sg);
+            zn = prox64_row<G>(zn, ok, a.prox_g[i], sg);
             if (ok) {
                 const double rr = v - zn, sd = nisg * (zn - zo), un = uo + rr, us = un / sg;
                 a.Z[i][e] = zn;
@@ -588,4 +602,7 @@ __global__ __launch_bounds__(EW_THREADS) void k64_bsdmm_block(Bsdmm64Args a) {
         }
     }
 }
-void launch_bsdmm64_block(const Bsdmm64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_bsdmm_block, dim3(1), dim3(EW_THREADS), 0, s, a); }
+void launch_bsdmm64_block(const Bsdmm64Args& a, hipStream_t s) {
+    if (a.K <= 8) hipLaunchKernelGGL(k64_bsdmm_block<8>, dim3(1), dim3(EW_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k64_bsdmm_block<16>, dim3(1), dim3(EW_THREADS), 0, s, a);
+}
