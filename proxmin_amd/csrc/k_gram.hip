@@ -12,7 +12,7 @@
 // No host round trip: the step sizes land in DevStatus::step and are read by the update kernels.
 #include "pmx_common.h"
 
-constexpr int GRAM_BLOCKS = 128;
+// GRAM_BLOCKS, gram_per, gram_nparts: pmx_common.h (the update kernels that leave partial Gram matrices behind use them too)
 constexpr int GRAM_THREADS = 256;
 // rows staged per LDS tile: all of a tile's requests go out before the first is used (a dependent round trip to memory
 // is ~1.3 us; with 32-row tiles a 128-row share took four of them and the kernel 18 us at 16384 x 64, now 7)
@@ -44,11 +44,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void k_gram_partial(GramArgs a) {
     for (int i = 0; i < TS; ++i)
 #pragma unroll
         for (int jx = 0; jx < TS; ++jx) acc[i][jx] = 0.f;
-    // shares of at least 32 rows: the grouping k_pgm_update leaves when IT produces the partials (PgmArgs::gramPart: workgroup b
-    // holds rows 32 b .. 32 b + 31), so that the step rule is the same number bit for bit whichever kernel summed the rows
-    int64_t per = (rows + GRAM_BLOCKS - 1) / GRAM_BLOCKS;
-    if (per < 32) per = 32;
+    const int64_t per = gram_per(rows);
     const int64_t r0 = (int64_t)blockIdx.x * per;
+    if (r0 >= rows) return;                     // (the fold reads gram_nparts(rows) slots)
     const int64_t r1 = r0 + per < rows ? r0 + per : rows;
     for (int64_t rb = r0; rb < r1; rb += GRAM_CHUNK) {
         float ld[NLD];
@@ -92,42 +90,53 @@ struct GramReduceArgs {
     int KP;
     const DevStatus* status;
     int want[2];
+    int nparts[2];         // valid partial slots of factor f (gram_nparts(rows))
     // [r4] pgm: the stopping test of the iteration whose update kernel ran just before (algorithms.py:130-135) rides in THIS launch
     // as one more workgroup -- it used to be the last-arriving workgroup of k_pgm_update, ~2.5 us behind everybody else; here it runs
     // beside the fold, and k_eig / K1 behind this launch see its verdict (halt) before they touch anything.  nullptr: no test here.
     double* dec_partials;
     DevStatus* dec_status;
     double dec_e_rel[2];
+    // bsdmm: the Boyd test of the block whose update kernel ran just before (utils.py:349-391), likewise (dec_bsdmm.status != nullptr)
+    BsdmmDecideArgs dec_bsdmm;
 };
 __device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt);
-// Entry e of factor f: FOUR threads fold 32 partials each (two batches of 16 loads in flight: the partials come from other
-// XCDs, a load-add-load-add loop pays one memory round trip per term), then the four sums are added in a fixed order.
+// Entry e of factor f: EIGHT threads fold up to 32 partials each (two batches of 16 loads in flight: the partials come from other
+// XCDs, a load-add-load-add loop pays one memory round trip per term), then the eight sums are added in a fixed order.
 // (Round 3: one thread per entry, eight batches: 5.2 us at K = 32; now two round trips.)
 __global__ __launch_bounds__(256) void k_gram_reduce(GramReduceArgs a) {
     if (chain_halted(a.status)) return;
     const int n = a.KP * a.KP;
-    if ((int)blockIdx.x == (n * 4 + 255) / 256) {          // the extra workgroup: the stopping test (block y == 0 only)
+    if ((int)blockIdx.x == (n * 8 + 255) / 256) {          // the extra workgroup: the stopping test (block y == 0 only)
         if (blockIdx.y == 0 && a.dec_partials != nullptr) pgm_decide_body(a.dec_status, a.dec_partials, a.dec_e_rel, 1, false);
+        if (blockIdx.y == 0 && a.dec_bsdmm.status != nullptr) {
+            __shared__ double dscratch[EW_WAVES];
+            bsdmm_decide_body(a.dec_bsdmm, dscratch);
+        }
         return;
     }
     const int f = blockIdx.y;
     if (!a.want[f]) return;
-    const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 2, q = t & 3;
-    static_assert(GRAM_BLOCKS == 128, "four threads x 32 partials");
+    const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 3, q = t & 7;
+    static_assert(GRAM_BLOCKS == 256, "eight threads x 32 partials");
+    const int np = a.nparts[f];
     double s = 0.0;
     if (e < n) {
         const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + (int64_t)(q * 32) * n + e;
-        for (int b0 = 0; b0 < 32; b0 += 16) {
+        const int mine = np - q * 32 < 32 ? np - q * 32 : 32;          // partials of this thread (<= 0: none)
+        for (int b0 = 0; b0 < mine; b0 += 16) {
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i) * n];
+            for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i < mine ? b0 + i : mine - 1) * n];   // (unconditional loads: all 16 in flight)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += (double)v[i];
+            for (int i = 0; i < 16; ++i) s += b0 + i < mine ? (double)v[i] : 0.0;
         }
     }
-    const int base = threadIdx.x & 60;       // (a quad never straddles a wave; every lane takes part in the shuffles)
-    const double s0 = __shfl(s, base), s1 = __shfl(s, base + 1), s2 = __shfl(s, base + 2), s3 = __shfl(s, base + 3);
-    if (e < n && q == 0) a.G[(int64_t)f * n + e] = ((s0 + s1) + s2) + s3;
+    const int base = threadIdx.x & 56;       // (an octet never straddles a wave; every lane takes part in the shuffles)
+    double tot = __shfl(s, base);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) tot += __shfl(s, base + i);
+    if (e < n && q == 0) a.G[(int64_t)f * n + e] = tot;
 }
 
 
@@ -646,7 +655,7 @@ void launch_gram(const GramArgs& a, int KP, hipStream_t s) {
     else hipLaunchKernelGGL(k_gram_partial<128>, grid, dim3(GRAM_THREADS), 0, s, a);
 }
 void launch_gram_reduce(const GramReduceArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((a.KP * a.KP * 4 + 255) / 256 + 1, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((a.KP * a.KP * 8 + 255) / 256 + 1, 2), dim3(256), 0, s, a);
 }
 hipError_t launch_eig(const EigArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * a.KP * (a.KP + 1);

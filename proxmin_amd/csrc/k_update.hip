@@ -372,10 +372,10 @@ struct PgmArgs {
     double e_rel[2];
     // [r4] the NEXT iteration's step rule starts here: every row of the point the next gradient is evaluated at passes through
     // this kernel's registers, so workgroup b leaves the partial Gram matrix of ITS 32 rows -- k_gram_partial's own share and
-    // summation order at 4096 rows (bit-identical partials), another grouping of the same sum otherwise -- in gramPart[j][b];
-    // the slots of workgroups that do not exist (nbx < 128) are zeroed by the ones that do.  Only where one batch of rows per
-    // workgroup covers the factor (rows <= 4096 in both blocks) and K <= 64; nullptr: off (k_gram_partial runs as before).
-    float* gramPart;         // [2][128][KP*KP]
+    // summation order (gram_per: bit-identical partials) -- in gramPart[j][b]; k_gram_reduce folds the gram_nparts(rows) slots
+    // that exist.  Only where one batch of rows per workgroup covers the factor (rows <= 4096 in both blocks) and K <= 64;
+    // nullptr: off (k_gram_partial runs as before).
+    float* gramPart;         // [2][GRAM_BLOCKS][KP*KP]
     int KP;
 };
 __device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt = false);
@@ -438,18 +438,17 @@ __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     if (mode == 1) return;
     if constexpr (NC <= 2) {
         if (a.gramPart != nullptr) {         // (uniform) partial Gram matrix of this workgroup's rows 32 b .. 32 b + 31
-            const int KP = a.KP, nb = gridDim.x;
+            const int KP = a.KP;
             const int64_t row0 = (int64_t)blockIdx.x * (EW_THREADS / 32);
             const int nrow = rows - row0 < EW_THREADS / 32 ? (int)(rows - row0) : EW_THREADS / 32;
             __syncthreads();
-            float* out = a.gramPart + ((int64_t)j * 128 + blockIdx.x) * KP * KP;
+            float* out = a.gramPart + ((int64_t)j * GRAM_BLOCKS + blockIdx.x) * KP * KP;
             for (int e = threadIdx.x; e < KP * KP; e += EW_THREADS) {
                 const int gi = e / KP, gj = e - gi * KP;
                 float acc = 0.f;
                 if (gi < K && gj < K)
                     for (int rr = 0; rr < nrow; ++rr) acc += gtile[rr][gi] * gtile[rr][gj];     // k_gram_partial's order: rows ascending
-                out[e] = acc;
-                for (int b = blockIdx.x + nb; b < 128; b += nb) out[(int64_t)(b - blockIdx.x) * KP * KP + e] = 0.f;
+                out[e] = acc;          // (the fold reads gram_nparts(rows) = this grid's workgroups-with-rows slots)
             }
             __syncthreads();
         }
@@ -1838,10 +1837,14 @@ struct BsdmmArgs {
     unsigned host_g;     // bit i: proxs_g[j][i] is a user callable
     float* Tf;
     float* T[PMX_MAX_G];
+    float* gramPart;     // [r4] [2][GRAM_BLOCKS][KP*KP] or nullptr: leave the partial Gram matrices of the new X_j here (stage 0, K <= 64,
+    int KP;              //      gram_per(rows) <= BSDMM_GRAM_ROWS)
 };
+constexpr int BSDMM_GRAM_ROWS = 64;      // rows of X_j a workgroup keeps in LDS for its partial Gram matrix (factors of <= 16384 rows)
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     __shared__ double scratch[EW_WAVES * (2 + 4 * PMX_MAX_G)];
+    __shared__ __attribute__((aligned(16))) float gtile[NC <= 2 ? BSDMM_GRAM_ROWS : 1][NC <= 2 ? 32 * NC + 4 : 4];   // the workgroup's rows of the new X_j (gramPart)
     if (chain_halted(a.status)) return;
     const int j = a.j;
     const int K = a.K;
@@ -1856,7 +1859,16 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     float r2[PMX_MAX_G], s2[PMX_MAX_G], z2[PMX_MAX_G], u2[PMX_MAX_G];
 #pragma unroll
     for (int i = 0; i < PMX_MAX_G; ++i) r2[i] = s2[i] = z2[i] = u2[i] = 0.f;
-    ROW_LOOP_BEGIN(a.rows)
+    // [r4] workgroup b holds the CONTIGUOUS rows per * b .. per * b + per - 1 (gram_per: k_gram_partial's shares), half-wave h of
+    // it the rows h, h + 32, ..: the rows of the new X_j pass through this kernel anyway, so it leaves their partial Gram matrix
+    // for the step rule of the OTHER block behind (gramPart; k_gram_partial's own summation order: bit-identical partials)
+    const int l32 = threadIdx.x & 31;
+    const int64_t per = gram_per(a.rows), row0 = (int64_t)blockIdx.x * per;
+    const bool gram_out = NC <= 2 && a.gramPart != nullptr;
+    for (int bi = 0; bi < (int)(per / 32); ++bi) {
+        const int lrow = (threadIdx.x >> 5) + 32 * bi;
+        const int64_t r = row0 + lrow;
+        if (r >= a.rows) break;
         bool ok[NC];
         float g[NC], xo[NC], v[NC], sk[NC];
 #pragma unroll
@@ -1892,6 +1904,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
                     d2 += d * d;
                     x2 += v[c] * v[c];
                     xmax = fmaxf(xmax, fabsf(v[c]));
+                    if constexpr (NC <= 2) { if (gram_out) gtile[lrow][l32 + 32 * c] = v[c]; }
                 }
             if (a.stage == 2 && a.host_g != 0u) {               // arguments of the user-defined members of proxs_g
                 for (int i = 0; i < a.n_g; ++i)
@@ -1934,8 +1947,47 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
                     u2[i] += us * us;
                 }
         }
-    ROW_LOOP_END
+    }
     if (a.stage == 1) return;
+    if constexpr (NC <= 2) {
+        if (gram_out) {                      // (uniform) partial Gram matrix of this workgroup's rows
+            const int KP = a.KP;
+            const int nrow = a.rows - row0 < per ? (int)(a.rows - row0 > 0 ? a.rows - row0 : 0) : (int)per;
+            __syncthreads();
+            float* out = a.gramPart + ((int64_t)j * GRAM_BLOCKS + blockIdx.x) * KP * KP;
+            // 4 x 4 entries per thread, two 16-byte LDS reads per row and 16 products (one entry per thread read 2 words per product:
+            // LDS-bound, slower than the k_gram_partial launch it replaces); every entry sums its rows in ascending order
+            const int tpr = KP / 4;                              // threads per tile row
+            if (nrow > 0 && (int)threadIdx.x < tpr * tpr) {
+                const int ti = threadIdx.x / tpr, tj = threadIdx.x - ti * tpr;
+                float acc[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) acc[i][jx] = 0.f;
+                for (int rr = 0; rr < nrow; ++rr) {
+                    const float4 av = *reinterpret_cast<const float4*>(&gtile[rr][4 * ti]);
+                    const float4 bv = *reinterpret_cast<const float4*>(&gtile[rr][4 * tj]);
+                    const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) acc[i][jx] += a4[i] * b4[jx];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gi = 4 * ti + i;
+                    float4 o;
+                    o.x = (gi < K && 4 * tj + 0 < K) ? acc[i][0] : 0.f;
+                    o.y = (gi < K && 4 * tj + 1 < K) ? acc[i][1] : 0.f;
+                    o.z = (gi < K && 4 * tj + 2 < K) ? acc[i][2] : 0.f;
+                    o.w = (gi < K && 4 * tj + 3 < K) ? acc[i][3] : 0.f;
+                    *reinterpret_cast<float4*>(&out[(int64_t)gi * KP + 4 * tj]) = o;
+                }
+            }
+            __syncthreads();
+        }
+    }
     double red[2 + 4 * PMX_MAX_G];
     red[0] = d2;
     red[1] = x2;
@@ -1982,9 +2034,8 @@ struct BsdmmDecideArgs {
     int last_block;      // 1 for the second block: closes the iteration (algorithms.py:841-844)
     const float* comm_scalars;   // row-sharded block A: all-reduced sums [d2, x2, q0..] instead of the local partials
 };
-__global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) {
-    __shared__ double scratch[EW_WAVES];
-    if (chain_halted(a.status)) return;
+// (body: also the extra workgroup of k_gram_reduce, 256 threads -- fold_partials is per wave, any workgroup size)
+__device__ __forceinline__ void bsdmm_decide_body(const BsdmmDecideArgs& a, double* scratch) {
     const int j = a.j;
     double d2, x2, q[4 * PMX_MAX_G];
     if (a.comm_scalars != nullptr) {
@@ -2026,6 +2077,11 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) 
             }
         }
     }
+}
+__global__ __launch_bounds__(EW_THREADS) void k_bsdmm_decide(BsdmmDecideArgs a) {
+    __shared__ double scratch[EW_WAVES];
+    if (chain_halted(a.status)) return;
+    bsdmm_decide_body(a, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -123,6 +123,9 @@ struct pmx_ctx {
     // pgm: the partial Gram matrices in gramPart were left by the last k_pgm_update for the point the next iteration evaluates
     // (PgmArgs::gramPart): the step rule skips k_gram_partial.  Cleared wherever the factors can change behind the solver's back.
     bool gram_by_update = false;
+    bool bsd_decide_pending = false;       // bsdmm: the Boyd test of the block updated last has not been enqueued yet (it rides in the next k_gram_reduce launch)
+    BsdmmDecideArgs bsd_decide{};
+    bool gram_fresh[2] = {false, false};   // bsdmm: gramPart[f] holds the partial Gram matrices of the CURRENT factor f (left by k_bsdmm_update)
     bool gram_in_update = true;            // PMX_GRAM_IN_UPDATE=0 (read at context creation): off
     bool decide_pending = false;           // pgm: the stopping test of the last enqueued iteration has not been enqueued yet (it rides in the
                                            // next k_gram_reduce launch, or pgm_flush_decide() launches it at the end of a chunk)
@@ -1092,8 +1095,17 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
 }
 
 // Gram matrices + largest eigenvalues -> DevStatus::step.  wantA: step of block 0 (needs factor 1 = St)
+static int bsdmm_flush_decide(pmx_ctx* c) {
+    if (!c->bsd_decide_pending) return PMX_OK;
+    launch_bsdmm_decide(c->bsd_decide, c->stream);
+    HIP_CHECK(hipGetLastError());
+    c->bsd_decide_pending = false;
+    return PMX_OK;
+}
 static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantStepA, bool wantStepS, double scale, bool have_partials = false, bool with_decide = false) {
-    if (eig_small_applies(c)) {       // small factors: Gram + reduce + lmax in ONE launch (k_eig_small forms G itself)
+    if (eig_small_applies(c)) {
+        int frc = bsdmm_flush_decide(c);
+        if (frc != PMX_OK) return frc;       // small factors: Gram + reduce + lmax in ONE launch (k_eig_small forms G itself)
         const EigArgs e = small_eig_args(c, A, St, wantStepA, wantStepS, scale);
         HIP_CHECK(launch_eig(e, c->stream));
         return PMX_OK;
@@ -1110,9 +1122,14 @@ static int enqueue_steps(pmx_ctx* c, const float* A, const float* St, bool wantS
     GramReduceArgs r{};
     r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
     r.want[0] = g.want[0]; r.want[1] = g.want[1];
+    r.nparts[0] = gram_nparts(c->M); r.nparts[1] = gram_nparts(c->N);
     if (with_decide) {                       // pgm: the previous iteration's stopping test as one more workgroup of this launch
         r.dec_partials = c->partials; r.dec_status = c->dstatus;
         r.dec_e_rel[0] = c->pgm.e_rel[0]; r.dec_e_rel[1] = c->pgm.e_rel[1];
+    }
+    if (c->bsd_decide_pending) {             // bsdmm: the Boyd test of the block updated just before, likewise
+        r.dec_bsdmm = c->bsd_decide;
+        c->bsd_decide_pending = false;
     }
     launch_gram_reduce(r, c->stream);
     EigArgs e{};
@@ -1137,6 +1154,7 @@ static int enqueue_gram_only(pmx_ctx* c, const float* A, const float* St, bool w
     GramReduceArgs r{};
     r.part = c->gramPart; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
     r.want[0] = g.want[0]; r.want[1] = g.want[1];
+    r.nparts[0] = gram_nparts(c->M); r.nparts[1] = gram_nparts(c->N);
     launch_gram_reduce(r, c->stream);
     HIP_CHECK(hipGetLastError());
     return PMX_OK;
@@ -2511,11 +2529,18 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
             HIP_CHECK(hipGetLastError());
             continue;
         }
-        int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0);   // nmf.py:187-193
+        // (the step of block j comes from the OTHER factor's Gram matrix; its partials are there if that factor's update left them)
+        int rc = enqueue_steps(c, c->X[0], c->X[1], j == 0, j == 1, 1.0, c->gram_fresh[1 - j]);   // nmf.py:187-193
         if (rc != PMX_OK) return rc;
         rc = enqueue_grad(c, c->X[0], c->X[1], j == 0, j == 1, c->absmax_by_finish);   // nmf.py:181-185 (only grads[j] is used)
         if (rc != PMX_OK) return rc;
         BsdmmArgs u{};
+        // [r4] the partial Gram matrices of the new X_j from this launch (BsdmmArgs::gramPart): K <= 64, factors of <= 16384 rows
+        // (cfg5); PMX_GRAM_IN_UPDATE=0 keeps k_gram_partial (A/B)
+        const bool gram_here = c->gram_in_update && !eig_small_applies(c) && c->K <= 64 && gram_per(c->rows[j]) <= BSDMM_GRAM_ROWS;
+        u.gramPart = gram_here ? c->gramPart : nullptr;
+        u.KP = c->KP;
+        c->gram_fresh[j] = gram_here;
         u.X = c->X[j];
         u.slab = slab_ref(c, j);
         for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
@@ -2539,7 +2564,10 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
         d.e_rel = p.e_rel[j];
         d.e_abs = p.e_abs[j];
         d.last_block = o == n_order - 1;
-        launch_bsdmm_decide(d, c->stream);
+        // [r4] the test rides in the next step rule's k_gram_reduce launch (one launch less per block); pmx_bsdmm_run flushes the
+        // last one of a chunk before it reads the status
+        c->bsd_decide = d;
+        c->bsd_decide_pending = true;
         HIP_CHECK(hipGetLastError());
     }
     return PMX_OK;
@@ -2637,6 +2665,8 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c->algo != ALG_BSDMM) FAIL(PMX_E_STATE, "pmx_bsdmm_begin has not been called");
     if (n_iter < 0) FAIL(PMX_E_INVALID, "n_iter < 0");
     const int it0 = c->hstatus->it_done;
+    c->gram_fresh[0] = c->gram_fresh[1] = false;     // (the caller may have touched the factors since the last call)
+    c->bsd_decide_pending = false;
     int left = n_iter;
     while (left > 0 && !c->hstatus->stopped) {
         const int chunk = std::min(left, 16);
@@ -2644,6 +2674,8 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
             rc = bsdmm_enqueue_iteration(c);
             if (rc != PMX_OK) return rc;
         }
+        rc = bsdmm_flush_decide(c);
+        if (rc != PMX_OK) return rc;
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
         int again = 0;
@@ -2651,6 +2683,7 @@ extern "C" int pmx_bsdmm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
         if (rc != PMX_OK) return rc;
         if (again) {
             left = n_iter - (c->hstatus->it_done - it0);
+            c->gram_fresh[0] = c->gram_fresh[1] = false;
             continue;
         }
         left -= chunk;

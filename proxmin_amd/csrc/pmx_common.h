@@ -17,6 +17,13 @@ constexpr int WAVE = 64;
 constexpr int EW_BLOCKS = 256;   // one per CU, 16 wavefronts each: factor-sized kernels are latency-bound
 constexpr int EW_THREADS = 1024;
 constexpr int EW_WAVES = EW_THREADS / 64;
+constexpr int GRAM_BLOCKS = 256;          // [r4] 256 (was 128): one share per workgroup of the update kernels (EW_BLOCKS), see gram_per
+// Rows of a factor per partial Gram matrix: contiguous shares of a multiple of 32 rows, the same for k_gram_partial and for the
+// update kernels that leave the partials of their own rows behind (k_pgm_update, k_bsdmm_update: workgroup b holds rows
+// per * b .. per * b + per - 1) -- so the step rule is the same number bit for bit whichever kernel summed the rows.
+__host__ __device__ inline int64_t gram_per(int64_t rows) { return 32 * ((rows + (int64_t)GRAM_BLOCKS * 32 - 1) / ((int64_t)GRAM_BLOCKS * 32)); }
+__host__ __device__ inline int gram_nparts(int64_t rows) { const int64_t per = gram_per(rows); return (int)((rows + per - 1) / per); }
+
 constexpr int LPR = 32;          // lanes per row (half a wavefront): K <= 128 -> <= 4 values per lane
 constexpr int MAXC = 4;          // ceil(128 / LPR)
 constexpr int MAXK = 128;

@@ -12,6 +12,7 @@ grep -E "passed|failed" $O/pytest_gpu.txt | tail -2
 ./scratch/measure_traffic.sh cfg3 f32 >> $O/traffic.log 2>&1
 ./scratch/measure_traffic.sh cfg5 f16x2 >> $O/traffic.log 2>&1
 ./scratch/measure_traffic.sh cfg2 f32 >> $O/traffic.log 2>&1
+./scratch/measure_traffic.sh cfg2 f16x2 >> $O/traffic.log 2>&1
 ./scratch/measure_traffic.sh cfg4 f16x2 8192 >> $O/traffic.log 2>&1
 cp gpurun_out/k1_traffic.json profiles/k1_traffic.json
 cp gpurun_out/k1_traffic.json $O/k1_traffic.json

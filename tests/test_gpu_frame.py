@@ -179,8 +179,11 @@ def test_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
 def test_framed_line_search(pm, orc, accel):
     """algorithms.py:110-127 on a framed problem: the trial points (Xe / X_ buffers) are K1 inputs as well.  A 1.5 x too long
     fixed step forces halvings; against the fp64 oracle and against the same run on the guarded kernels (PMX_FRAME=0)."""
-    M, N, K = 1000, 1500, 64
+    M, N, K = 600, 700, 64                                    # frame 640 x 768 (17 % more entries); small enough for the host oracle
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, seed=17)
+    from proxmin_amd.engine import DeviceNMF
+    with DeviceNMF(M, N, K, mode="f32") as dev:
+        assert dev.k1_info()["frame"] == (640, 768)
     sA, sS = orc.lipschitz_steps(A0.astype(np.float64), S0.astype(np.float64))
     fixed = (1.5 * sA, 1.5 * sS)
 
