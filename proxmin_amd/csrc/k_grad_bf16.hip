@@ -1641,9 +1641,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
     };
 
     if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
-        if (!producer) {
-            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+        if (!producer && (j >> 1) == 0) {      // (one gSt slab per row region)
+            const int kk = (j & 1) * 32 + l31;
+            float* dst = a.slabS + (int64_t)rowRegion * N * K;
             for (int c = 0; c < NCB; ++c)
                 for (int i = 0; i < 16; ++i) {
                     const int gn = col0 + c * V5_BN + tile_row(i, lane);
@@ -1833,6 +1833,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
         slot(T, p0, p1, yO, wO, no{}, yes{});
         slot(T + 1, p1, p0, yE, wE, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt row halves)
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1980,18 +1981,38 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v7(GradV4Args a) {
             }
         }
         if constexpr (CHAIN) link.publish();
-        if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            const int kk = kt * 32 + l31;
+        // [r4] ONE gSt slab per row region: the two row halves of a tile are summed through LDS (k_grad_f16_v8.hip has the comment)
+        {
+            constexpr int CB = NCB / 2;
+            float* fsm = reinterpret_cast<float*>(smem);
+            auto halves = [&](auto MH) {
+                constexpr int m = decltype(MH)::value;
+                float* park = fsm + ((kt * 2 + m) * CB) * 1024 + lane;
+                if (a.doS) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                const int bcol = col0 + c * V5_BN;
+                    for (int cc = 0; cc < CB; ++cc)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = bcol + tile_row(i, lane);
-                    dst[(int64_t)gn * K + kk] = accS[c][i];
+                        for (int i = 0; i < 16; ++i) park[cc * 1024 + i * 64] = accS[(1 - m) * CB + cc][i];
                 }
-            }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                if (a.doS) {
+                    const float* oth = fsm + ((kt * 2 + (1 - m)) * CB) * 1024 + lane;
+                    float* dst = a.slabS + (int64_t)rowRegion * N * K;
+                    const int kk = kt * 32 + l31;
+#pragma unroll
+                    for (int cc = 0; cc < CB; ++cc) {
+                        const int bcol = col0 + (m * CB + cc) * V5_BN;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float o = oth[cc * 1024 + i * 64], own = accS[m * CB + cc][i];
+                            dst[(int64_t)(bcol + tile_row(i, lane)) * K + kk] = m == 0 ? own + o : o + own;      // rows 0-63 + rows 64-127
+                        }
+                    }
+                }
+            };
+            if (mh == 0) halves(std::integral_constant<int, 0>{});
+            else halves(std::integral_constant<int, 1>{});
         }
     }
     {
@@ -2070,6 +2091,8 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     plan_row_regions(panels, p.gridY, wantWG, &p.RP, &p.gridX);
     p.nSlabA = p.gridY * splitA;
     p.nSlabS = p.gridX * splitS;
+    // [r4] k_grad_bf16_v7 / k_grad_f16_v8 (what grad_launch_bf16 runs at these shapes) merge the two row halves of gSt inside the launch
+    if (p.variant >= 7 && p.KP == 64 && K == 64 && (M % V4_BM) == 0 && (N % V4_BN) == 0 && (N % (V5_NB * V5_BN)) == 0) p.nSlabS = p.gridX;
     p.ldsBytes = 2 * ((size_t)3 * BG_BN * (p.KP + 8) + (size_t)2 * p.KP * (BG_BN + 8) + (size_t)2 * p.KP * (BG_BM + 8)) +
                  sizeof(float) * ((size_t)BG_BM * (BG_BN + 4) + (size_t)(BG_THREADS / 64) * 1024);
     return p;

@@ -156,9 +156,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     };
 
     if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
-        if (!producer) {
-            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
+        if (!producer && (j >> 1) == 0) {      // (one gSt slab per row region)
+            const int kk = (j & 1) * 32 + l31;
+            float* dst = a.slabS + (int64_t)rowRegion * N * K;
             for (int c = 0; c < NCB; ++c)
                 for (int i = 0; i < 16; ++i) {
                     const int gn = block_col(c, tile_row(i, lane));
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         slot(nrp, c0{}, p0, p1, no{}, yes{});
         slot(nrp, c1{}, p1, p0, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt row halves)
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -577,17 +578,41 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             }
         }
         if constexpr (CHAIN) link.publish();
-        if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            const int kk = kt * 32 + l31;
+        // [r4] ONE gSt slab per row region: the two row halves of a tile (waves mh = 0 / 1 of a k tile) are summed here through the
+        // launch's own LDS (every image is dead behind the loop's last barrier): each wave parks the four blocks the OTHER half
+        // finishes and adds the other's to its own four -- half the stores of rounds 1-3 (which wrote two slabs per row region and
+        // left the sum to the update kernel: 8 slabs = 32 MB to fold at cfg3, a third of the adaprox tail's traffic)
+        {
+            constexpr int CB = NCB / 2;
+            float* fsm = reinterpret_cast<float*>(smem);
+            auto halves = [&](auto MH) {
+                constexpr int m = decltype(MH)::value;
+                float* park = fsm + ((kt * 2 + m) * CB) * 1024 + lane;               // [kt][writer][block][i][lane]
+                if (a.doS) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) {
+                    for (int cc = 0; cc < CB; ++cc)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = block_col(c, tile_row(i, lane));
-                    dst[(int64_t)gn * K + kk] = accS[c][i] * unS;
+                        for (int i = 0; i < 16; ++i) park[cc * 1024 + i * 64] = accS[(1 - m) * CB + cc][i];
                 }
-            }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                if (a.doS) {
+                    const float* oth = fsm + ((kt * 2 + (1 - m)) * CB) * 1024 + lane;
+                    float* dst = a.slabS + (int64_t)rowRegion * N * K;
+                    const int kk = kt * 32 + l31;
+#pragma unroll
+                    for (int cc = 0; cc < CB; ++cc) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int gn = block_col(m * CB + cc, tile_row(i, lane));
+                            const float o = oth[cc * 1024 + i * 64], own = accS[m * CB + cc][i];
+                            dst[(int64_t)gn * K + kk] = (m == 0 ? own + o : o + own) * unS;        // rows 0-63 + rows 64-127
+                        }
+                    }
+                }
+            };
+            if (mh == 0) halves(std::integral_constant<int, 0>{});
+            else halves(std::integral_constant<int, 1>{});
         }
     }
     {
