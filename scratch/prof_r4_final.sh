@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-4 final measurement batch (tag r04_i): full GPU test suite, traffic (PMC) for this build in every config the bench quotes,
+# round-4 final measurement batch (tag r04_j): full GPU test suite, traffic (PMC) for this build in every config the bench quotes,
 # kernel stats + timeline + SQ counters of the default bench, bench lines of the other configs / modes, power trace
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04_i
+O=$R/gpurun_out/r04_j
 mkdir -p $O
 cd $R
 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
@@ -16,7 +16,7 @@ grep -E "passed|failed" $O/pytest_gpu.txt | tail -2
 ./scratch/measure_traffic.sh cfg4 f16x2 8192 >> $O/traffic.log 2>&1
 cp gpurun_out/k1_traffic.json profiles/k1_traffic.json
 cp gpurun_out/k1_traffic.json $O/k1_traffic.json
-PMC=1 ./scratch/prof_r2.sh r04_i > $O/prof.log 2>&1
+PMC=1 ./scratch/prof_r2.sh r04_j > $O/prof.log 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_20_5.json 2>/dev/null
 python bench.py --mode f32 --no-cpu > $O/bench_f32.json 2>/dev/null
