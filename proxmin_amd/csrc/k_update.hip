@@ -74,6 +74,44 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+template <int PAT>
+__device__ __forceinline__ double swz_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, PAT);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), PAT);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// [r4] SIXTEEN wave sums at the price of about three: instead of 16 butterflies over all 64 lanes (16 x 6 adds, 16 x 8 DPP moves,
+// 16 x 4 LDS-crossbar moves per lane -- 5 us for the 16 waves of a workgroup, measured in k_ada_tail), every exchange step HALVES
+// the values a lane carries: with its partner at distance 1, 2, 4, 8 a lane keeps the values whose index bit equals its own lane bit
+// and hands over the others (8 + 4 + 2 + 1 adds), then lane l holds the sum of value l & 15 over its 16 lanes and two butterfly
+// steps finish it.  Every add has the same two operands as the butterfly's (x + y and y + x are the same bits): the result is
+// wave_sum()'s, bit for bit.  Returns the total of value (lane & 15).
+__device__ __forceinline__ double wave_sum16(const double (&v)[16]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    double w[8], x[4], y[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_d<DPP_XOR1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b1 ? w[2 * i + 1] : w[2 * i], send = b1 ? w[2 * i] : w[2 * i + 1];
+        x[i] = keep + dpp_d<DPP_XOR2>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b2 ? x[2 * i + 1] : x[2 * i], send = b2 ? x[2 * i] : x[2 * i + 1];
+        y[i] = keep + swz_d<SWZ_XOR4>(send);
+    }
+    double z = (b3 ? y[1] : y[0]) + swz_d<SWZ_XOR8>(b3 ? y[0] : y[1]);
+    z += swz16_d(z);
+    z += __shfl_xor(z, 32);
+    return z;
+}
+
 // block-wide sum of NV doubles; thread 0 writes dst[i * stride]
 template <int NV>
 __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* dst, int64_t stride, double* scratch /* >= NV*EW_WAVES */) {
@@ -1451,10 +1489,11 @@ struct TailArgs {
     GridBar* bar;
     int slots[2];                // LDS row slots per thread of block j: ceil(rows[j] / 8192)
     long long* prof;             // tuning (PMX_TAIL_PROF=1): 100 MHz time stamps of workgroup 0 at the phase boundaries, else nullptr
+    int prof_fine;               // PMX_TAIL_PROF=2: three more stamps inside the proximal passes' phase (passes A | sums A | passes S | sums S)
 };
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
-    __shared__ double scratch[2 * TAIL_NT * EW_WAVES];
+    __shared__ double scratch[4 * TAIL_NT * EW_WAVES];
     __shared__ double dbuf[EW_BLOCKS + 8];
     __shared__ unsigned s_word;
     extern __shared__ float lds[];           // [3 arrays: X, z, Psi][slots[0] + slots[1]][NC][EW_THREADS]
@@ -1491,6 +1530,16 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) x_pre[c] = ok[c] ? a.m.X[0][hw * K + l32 + 32 * c] : 0.f;
     }
+    // what the previous launch (or the host) left in the control block, requested before the census wait as well: this iteration's
+    // step sizes (nmf.py:93) and the pass counts of the last iteration ([r4] they used to be loaded where they are first needed --
+    // a round trip to memory in front of the moment phase and another in front of the proximal passes)
+    float alpha0[NC], alpha1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        alpha0[c] = ok[c] ? st->alpha[0][l32 + 32 * c] : 0.f;
+        alpha1[c] = ok[c] ? st->alpha[1][l32 + 32 * c] : 0.f;
+    }
+    const int last_tau0 = st->last_tau[0], last_tau1 = st->last_tau[1];
     {   // census B0: every workgroup must be resident before the first store of the launch
         if (tid == 0) s_word = gb_wait(bar, ep + 1, 200000);
         __syncthreads();
@@ -1506,12 +1555,6 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
         ep += 1;
     }
     stamp();
-    float alpha0[NC], alpha1[NC];            // this iteration's step sizes (nmf.py:93), both blocks
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        alpha0[c] = ok[c] ? st->alpha[0][l32 + 32 * c] : 0.f;
-        alpha1[c] = ok[c] ? st->alpha[1][l32 + 32 * c] : 0.f;
-    }
     for (int j = 0; j < 2; ++j) {
         const int64_t rows = a.m.rows[j];
         float alpha[NC];
@@ -1628,10 +1671,16 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
         for (int round = 0; !(done0 && done1); ++round) {
             int nt_0 = TAIL_NT, nt_1 = TAIL_NT;
             if (round == 0) {
-                const int l0 = st->last_tau[0], l1 = st->last_tau[1];
+                const int l0 = last_tau0, l1 = last_tau1;
                 nt_0 = l0 >= 1 && l0 <= TAIL_NT ? l0 : TAIL_NT;
                 nt_1 = l1 >= 1 && l1 <= TAIL_NT ? l1 : TAIL_NT;
             }
+            // [r4] ONE workgroup-wide reduction for the sums of BOTH blocks (the passes of A, then of S, then 16 values through the
+            // same tree each -- wave sum, 16-term serial fold: bit-identical partials): two reductions cost two barrier pairs and
+            // twice the wait for the slowest wave, 2.2 us each in the phase stamps
+            double red[2][2 * TAIL_NT];
+#pragma unroll
+            for (int q = 0; q < 2 * TAIL_NT; ++q) { red[0][q] = 0.0; red[1][q] = 0.0; }
             for (int j = 0; j < 2; ++j) {
                 if (j ? done1 : done0) continue;
                 const int nt = j ? nt_1 : nt_0;
@@ -1649,10 +1698,31 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
                         for (int c = 0; c < NC; ++c) Lz[slot(j, i, c)] = z[c];
                     }
                 }
-                double red[2 * TAIL_NT];
 #pragma unroll
-                for (int q = 0; q < TAIL_NT; ++q) { red[2 * q] = (double)d2[q]; red[2 * q + 1] = (double)n2[q]; }
-                block_sum_store_wt<2 * TAIL_NT>(red, part_ptr(a.m.partials, SL_SUBR0 + 2 * TAIL_NT * (round & 3), j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+                for (int q = 0; q < TAIL_NT; ++q) {
+                    if (j) { red[1][2 * q] = (double)d2[q]; red[1][2 * q + 1] = (double)n2[q]; }
+                    else { red[0][2 * q] = (double)d2[q]; red[0][2 * q + 1] = (double)n2[q]; }
+                }
+                if (round == 0 && a.prof_fine) stamp();
+            }
+            {
+                static_assert(4 * TAIL_NT == 16, "wave_sum16");
+                const int lane = tid & 63, w = tid >> 6;
+                double all[16];
+#pragma unroll
+                for (int q = 0; q < 2 * TAIL_NT; ++q) { all[q] = red[0][q]; all[2 * TAIL_NT + q] = red[1][q]; }
+                const double tot = wave_sum16(all);          // value (lane & 15), wave_sum()'s bits
+                __syncthreads();
+                if (lane < 16) scratch[lane * EW_WAVES + w] = tot;
+                __syncthreads();
+                if (tid < 4 * TAIL_NT) {
+                    const int jj = tid / (2 * TAIL_NT), q = tid - jj * 2 * TAIL_NT;
+                    if (!(jj ? done1 : done0)) {
+                        double sum = 0.0;
+                        for (int u = 0; u < EW_WAVES; ++u) sum += scratch[tid * EW_WAVES + u];
+                        sc1_store(part_ptr(a.m.partials, SL_SUBR0 + 2 * TAIL_NT * (round & 3), jj) + blockIdx.x + (int64_t)q * 2 * EW_BLOCKS, sum);
+                    }
+                }
             }
             if (round == 0) stamp();
             gb_sync(bar, ++ep, st);          // B2: the round's sums
@@ -2000,6 +2070,26 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
     }
     // slots: SL_DIFF2, SL_NORM2, then SL_G0.. ; consecutive slots are 2*EW_BLOCKS doubles apart, but
     // SL_G0 is not adjacent to SL_NORM2, so store in two groups
+    if (do_x && do_g && a.n_g <= 3) {
+        // [r4] the fused path with up to three constraints (2 + 4 n_g <= 14 sums): ONE transposed reduction of 16 values (wave_sum16)
+        // instead of 34 butterflies -- the same sums bit for bit, a third of the instructions
+        double all[16];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) all[i] = red[i];
+        all[14] = 0.0; all[15] = 0.0;
+        const double tot = wave_sum16(all);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane < 16) scratch[lane * EW_WAVES + w] = tot;
+        __syncthreads();
+        if ((int)threadIdx.x < 2 + 4 * a.n_g) {
+            double sum = 0.0;
+            for (int q = 0; q < EW_WAVES; ++q) sum += scratch[threadIdx.x * EW_WAVES + q];
+            double* dst = threadIdx.x < 2 ? part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x + (int64_t)threadIdx.x * 2 * EW_BLOCKS
+                                          : part_ptr(a.partials, SL_G0, j) + blockIdx.x + (int64_t)(threadIdx.x - 2) * 2 * EW_BLOCKS;
+            *dst = sum;
+        }
+    } else {
     if (do_x) {
         double head[2] = {red[0], red[1]};
         block_sum_store<2>(head, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
@@ -2009,6 +2099,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bsdmm_update(BsdmmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4 * PMX_MAX_G; ++i) tail[i] = red[2 + i];
         block_sum_store<4 * PMX_MAX_G>(tail, part_ptr(a.partials, SL_G0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    }
     }
     if (a.absmax_out != nullptr && do_x) {
         const double m = wave_max((double)xmax);

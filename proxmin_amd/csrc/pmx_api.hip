@@ -2231,6 +2231,7 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
     t.decide_check = c->comm ? 0 : 1;     // row-sharded: the outer test is made after the next all-reduce (k_shard_post)
     t.bar = c->gridbar;
     t.prof = c->tailprof;
+    t.prof_fine = getenv("PMX_TAIL_PROF") && atoi(getenv("PMX_TAIL_PROF")) == 2;
     // PMX_TAIL_LOCKFILE (tests only): several processes share ONE GPU -- their persistent tails (one workgroup per CU each,
     // a census barrier at the top) cannot be resident together, so each is run to completion under an inter-process lock.
     // The product configuration is one process per GPU and never sets it.
@@ -2373,9 +2374,12 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
         long long h[16];
         HIP_CHECK(hipMemcpy(h, c->tailprof, sizeof(h), hipMemcpyDeviceToHost));
         static const char* nm[] = {"census", "moment", "B1", "maxpsi", "sub", "B2", "judge+replay", "finish", "B3", "decide"};
+        static const char* nf[] = {"census", "moment", "B1", "maxpsi", "passesA", "sumsA", "passesS", "sumsS", "(end)", "B2", "judge+replay", "finish", "B3", "decide"};
+        const bool fine = getenv("PMX_TAIL_PROF") && atoi(getenv("PMX_TAIL_PROF")) == 2;
+        const int np = fine ? 14 : 10;
         fprintf(stderr, "[tailprof] us:");
-        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.2f", nm[i], (double)(h[i + 1] - h[i]) / 100.0);
-        fprintf(stderr, " total=%.2f\n", (double)(h[10] - h[0]) / 100.0);
+        for (int i = 0; i < np; ++i) fprintf(stderr, " %s=%.2f", fine ? nf[i] : nm[i], (double)(h[i + 1] - h[i]) / 100.0);
+        fprintf(stderr, " total=%.2f\n", (double)(h[np] - h[0]) / 100.0);
     }
     fill_result(c, res, it0);
     return PMX_OK;
