@@ -1555,6 +1555,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
         ep += 1;
     }
     stamp();
+    float mpsi0 = -1.f, mpsi1 = -1.f;
     for (int j = 0; j < 2; ++j) {
         const int64_t rows = a.m.rows[j];
         float alpha[NC];
@@ -1585,14 +1586,18 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
                 maxpsi = nanmaxf(maxpsi, psi);
             }
         }
-        double mv = wave_nanmax((double)maxpsi);
+        if (j) mpsi1 = maxpsi; else mpsi0 = maxpsi;
+    }
+    {   // [r4] both blocks' maxima of Psi in one staged reduction (one barrier pair behind BOTH row loops, none between them)
+        const double mv0 = wave_nanmax((double)mpsi0), mv1 = wave_nanmax((double)mpsi1);
         __syncthreads();
-        if ((tid & 63) == 0) scratch[tid >> 6] = mv;
+        if ((tid & 63) == 0) { scratch[tid >> 6] = mv0; scratch[EW_WAVES + (tid >> 6)] = mv1; }
         __syncthreads();
-        if (tid == 0) {
-            double m = scratch[0];
-            for (int q = 1; q < EW_WAVES; ++q) m = nanmax(m, scratch[q]);
-            sc1_store(part_ptr(a.m.partials, SL_MAXPSI, j) + blockIdx.x, m);
+        if (tid == 0 || tid == 64) {
+            const int jj = tid >> 6;
+            double m = scratch[jj * EW_WAVES];
+            for (int q = 1; q < EW_WAVES; ++q) m = nanmax(m, scratch[jj * EW_WAVES + q]);
+            sc1_store(part_ptr(a.m.partials, SL_MAXPSI, jj) + blockIdx.x, m);
         }
     }
 
@@ -1764,6 +1769,13 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
     // ---------------- phase F: X <- z, outer norms, column sums (k_ada_finish) --------------------------------------
     stamp();
     float* sm = Lp;                      // colsum_store's scratch (Psi is no longer needed)
+    // [r4] both blocks' rows first, then ONE staged reduction for everything this phase sums (outer norms, maxima, column sums): four
+    // workgroup barriers instead of fourteen (each block used to run its own three reductions); every sum through its own tree as
+    // before (wave tree + 16-term fold; column sums: 32 half-waves in order): bit-identical to k_ada_finish
+    float f_d2[2] = {0.f, 0.f}, f_n2[2] = {0.f, 0.f}, f_xmax[2] = {0.f, 0.f};
+    float cs0[NC], cs1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { cs0[c] = 0.f; cs1[c] = 0.f; }
     for (int j = 0; j < 2; ++j) {
         const int64_t rows = a.m.rows[j];
         const float* src = a.m.has_prox[j] ? Lz : Lx;
@@ -1789,31 +1801,49 @@ __global__ __launch_bounds__(EW_THREADS) void k_ada_tail(TailArgs a) {
                 cs[c] += x;
             }
         }
-        double red[2] = {(double)d2, (double)n2};
-        block_sum_store_wt<2>(red, part_ptr(a.m.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
-        {   // colsum_store, write-through
-            const int hwi = tid >> 5;
-            __syncthreads();
+        f_d2[j] = d2; f_n2[j] = n2; f_xmax[j] = xmax;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) sm[hwi * MAXK + l32 + 32 * c] = cs[c];
-            __syncthreads();
-            if (tid < 32 * NC) {
-                double s = 0.0;
-                for (int h = 0; h < EW_THREADS / 32; ++h) s += (double)sm[h * MAXK + tid];
-                sc1_store(a.colpart + ((int64_t)j * EW_BLOCKS + blockIdx.x) * MAXK + tid, s);
-            }
-            __syncthreads();
+        for (int c = 0; c < NC; ++c) { if (j) cs1[c] = cs[c]; else cs0[c] = cs[c]; }
+    }
+    {
+        const int lane = tid & 63, w = tid >> 6, hwi = tid >> 5;
+        double r4[4] = {wave_sum((double)f_d2[0]), wave_sum((double)f_n2[0]), wave_sum((double)f_d2[1]), wave_sum((double)f_n2[1])};
+        const double m0 = wave_max((double)f_xmax[0]), m1 = wave_max((double)f_xmax[1]);
+        __syncthreads();                                     // (the rows' reads of Lp's neighbours are done: sm may be overwritten)
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) scratch[q * EW_WAVES + w] = r4[q];
+            scratch[4 * EW_WAVES + w] = m0;
+            scratch[5 * EW_WAVES + w] = m1;
         }
-        if (a.absmax_out != nullptr) {
-            const double m = wave_max((double)xmax);
-            __syncthreads();
-            if ((tid & 63) == 0) scratch[tid >> 6] = m;
-            __syncthreads();
-            if (tid == 0) {
-                double mm = scratch[0];
-                for (int q = 1; q < EW_WAVES; ++q) mm = fmax(mm, scratch[q]);
-                a.absmax_out[j * EW_BLOCKS + blockIdx.x] = (float)mm;
-            }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sm[hwi * MAXK + l32 + 32 * c] = cs0[c];
+        __syncthreads();
+        if (tid < 32 * NC) {                                  // column sums of block 0 (colsum_store's order)
+            double t = 0.0;
+            for (int h = 0; h < EW_THREADS / 32; ++h) t += (double)sm[h * MAXK + tid];
+            sc1_store(a.colpart + ((int64_t)0 * EW_BLOCKS + blockIdx.x) * MAXK + tid, t);
+        }
+        if (tid >= 64 * 8 && tid < 64 * 8 + 4) {              // (another wave: the four outer sums; block_sum_store's order)
+            const int q = tid - 64 * 8;
+            double t = 0.0;
+            for (int u = 0; u < EW_WAVES; ++u) t += scratch[q * EW_WAVES + u];
+            sc1_store(part_ptr(a.m.partials, SL_DIFF2, q >> 1) + blockIdx.x + (int64_t)(q & 1) * 2 * EW_BLOCKS, t);
+        }
+        if (a.absmax_out != nullptr && tid >= 64 * 9 && tid < 64 * 9 + 2) {
+            const int q = tid - 64 * 9;
+            double mm = scratch[(4 + q) * EW_WAVES];
+            for (int u = 1; u < EW_WAVES; ++u) mm = fmax(mm, scratch[(4 + q) * EW_WAVES + u]);
+            a.absmax_out[q * EW_BLOCKS + blockIdx.x] = (float)mm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sm[hwi * MAXK + l32 + 32 * c] = cs1[c];
+        __syncthreads();
+        if (tid < 32 * NC) {                                  // column sums of block 1
+            double t = 0.0;
+            for (int h = 0; h < EW_THREADS / 32; ++h) t += (double)sm[h * MAXK + tid];
+            sc1_store(a.colpart + ((int64_t)1 * EW_BLOCKS + blockIdx.x) * MAXK + tid, t);
         }
     }
     stamp();
