@@ -7,11 +7,13 @@ import bench
 from proxmin_amd.engine import DeviceNMF
 which = sys.argv[1]
 total = int(sys.argv[2])
-cfg = {"cfg2": (4096, 4096, 32, "pgm", "f32", False), "cfg3": (16384, 16384, 64, "adaprox", "f16x2", True)}[which]
+cfg = {"cfg2": (4096, 4096, 32, "pgm", "f32", False), "cfg3": (16384, 16384, 64, "adaprox", "f16x2", True),
+       "cfg5": (16384, 16384, 64, "bsdmm", "f16x2", False), "cfg2h": (4096, 4096, 32, "pgm", "f16x2", False),      # [r4]
+       "ragged": (16000, 16000, 64, "adaprox", "f16x2", True)}[which]
 M, N, K, backend, mode, unity = cfg
 Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
 finals = []
-for rep in range(1):
+for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     dev = DeviceNMF(M, N, K, mode=mode)
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
