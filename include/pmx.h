@@ -144,13 +144,17 @@ int pmx_ctx_sync(pmx_ctx* ctx);
  * alive).  Y is read-only for the solvers (nmf.py:116). */
 int pmx_set_Y_host(pmx_ctx* ctx, const float* Y, int64_t ld);
 int pmx_set_Y_device(pmx_ctx* ctx, const float* dY, int64_t ld, int copy);
-/* K1's frame.  The producer / consumer kernels take M % 128 == 0 and N % 256 == 0 (N % 128 at K = 128) only.  A context with a ragged
- * shape and K = 32 / 64 (128 in PMX_MODE_F16X2) works on a ZERO-PADDED frame instead of dropping to the guarded kernels, when rounding
- * M and N up costs at most 25 % more entries: frame[0] x frame[1] (= M x N when the context is not framed).  Results are those of
- * the M x N problem (zero rows / columns contribute nothing to the residual, the gradients or the loss).  A framed context keeps
- * its OWN padded copy of Y and W: pmx_set_Y_device / pmx_set_W_device with copy = 0 copy anyway (the caller's buffer is not
- * referenced after the call; call again after changing it).  PMX_FRAME=0 in the environment switches framing off. */
-int pmx_k1_frame(pmx_ctx* ctx, int64_t frame[2]);
+/* K1's frame.  The producer / consumer kernels take M % 128 == 0, N % 256 == 0 (N % 128 at K = 128) and K = 32 / 64 (128 in
+ * PMX_MODE_F16X2) only.  A context with another shape works on a ZERO-PADDED frame instead of dropping to the guarded kernels:
+ *   rows / columns  M and N rounded up, when that costs at most 25 % more entries: the context keeps its OWN padded copy of Y and W
+ *                   (pmx_set_Y_device / pmx_set_W_device with copy = 0 copy anyway: the caller's buffer is not referenced after the
+ *                   call; call again after changing it), factor arrays and gradient slabs have the frame's rows;
+ *   components      a K between the tuned ones runs the next one's kernel on copies of the factors with that many floats per row
+ *                   (made in front of every gradient pass), zero behind column K.
+ * frame[0] x frame[1] x frame[2] (= M x N x K when the context is not framed).  Results are those of the M x N x K problem: zero rows /
+ * columns / components contribute nothing to the residual, the gradients or the loss; everything outside K1 (update kernels, step
+ * rules, collectives) works on the real shape.  PMX_FRAME=0 in the environment switches framing off. */
+int pmx_k1_frame(pmx_ctx* ctx, int64_t frame[3]);
 /* Weighted likelihood: W is the M x N weight array of nmf.log_likelihood / grad_likelihood (proxmin/nmf.py:13-41),
  * loss = 1/2 sum W (Y - A S)^2, D = W (A S - Y).  Row-major float32, leading dimension ld >= N.  Without a call
  * W == 1 (the reference's default).  A PMX_MODE_F32 context takes weights at any shape; a split-bf16 context where its

@@ -267,6 +267,7 @@ struct SlabRef {
     const float* base;   // [n][stride]: slab i's row r at base + i * stride + r * K
     int n;
     int64_t stride;      // floats between slabs: rows x K of K1's FRAME (the factor's rows, or more: zero-padded frame of a ragged shape)
+    int ld;              // floats between rows of a slab: K, or K1's padded K (pmx_k1_frame: a K without a tuned kernel runs the next one's)
 };
 
 template <int NC>
@@ -277,7 +278,7 @@ __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], 
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
     const int64_t stride = s.stride;
-    const float* p = s.base + r * K + l32;
+    const float* p = s.base + r * s.ld + l32;
     int i = 0;
     constexpr int UB = NC == 1 ? 16 : (NC == 2 ? 8 : 4);
     for (; i + UB <= s.n; i += UB) {
@@ -322,6 +323,27 @@ struct FoldArgs {
     int K;
     const DevStatus* status;
 };
+// [r4] K1's operands when the context's K has no tuned kernel: the factors copied into arrays with the next tuned K as row pitch
+// (columns K .. Kk - 1 and the frame's extra rows were zeroed when the arrays were created and are never written)
+struct PadArgs {
+    const float* src[2];
+    float* dst[2];
+    int64_t rows[2];
+    int K, Kk;
+    const DevStatus* status;
+};
+__global__ __launch_bounds__(256) void k_pad_factors(PadArgs a) {
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t n = a.rows[j] * a.K;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / a.K;
+        const int k = (int)(e - r * a.K);
+        a.dst[j][r * a.Kk + k] = a.src[j][e];
+    }
+}
+void launch_pad_factors(const PadArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pad_factors, dim3(512, 2), dim3(256), 0, s, a); }
+
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_fold(FoldArgs a) {
     if (a.status != nullptr && chain_halted(a.status)) return;

@@ -67,6 +67,11 @@ struct pmx_ctx {
     int64_t Mk = 0, Nk = 0;
     int64_t rowsK[2] = {0, 0};
     bool framed = false;
+    // ... and K: a K that has no tuned K1 (anything but 32 / 64 / 128) runs the next one's (Kk) on COPIES of the factors with Kk
+    // floats per row, zero behind column K (k_pad_factors in front of every K1 launch); the gradient slabs have Kk floats per row
+    // (SlabRef::ld), the folds read the first K of them.  Everything outside K1 keeps the real K and its own arrays.
+    int64_t Kk = 0;
+    float* Xk[2] = {nullptr, nullptr};
 
     float* X[2] = {nullptr, nullptr};      // A, St
     float* G[2] = {nullptr, nullptr};
@@ -331,9 +336,9 @@ static void choose_frame(int mode, int64_t M, int64_t N, int64_t K, int64_t* Mk,
 
 // which K1 runs on the frame Mk x Nk, its grid, and whether gA is summed along chains there
 static void select_k1(pmx_ctx* c, int64_t Mk, int64_t Nk, int ncu) {
-    const int64_t M = c->M, N = c->N, K = c->K;
+    const int64_t M = c->M, N = c->N, K = c->Kk;
     const int mode = c->mode;
-    c->use_small = grad_small_applies(M, N, K);
+    c->use_small = grad_small_applies(M, N, c->K);
     c->use_bf16 = (mode == PMX_MODE_BF16X3 || mode == PMX_MODE_F16X2) && K <= 64 && !c->use_small;
     c->plan = c->use_small ? grad_plan_small(M, N, K) : (c->use_bf16 ? grad_plan_bf16(Mk, Nk, K) : grad_plan_f32(Mk, Nk, K));
     c->use_f16 = mode == PMX_MODE_F16X2 && c->use_bf16 && grad_bf16_takes_weights(c->plan, Mk, Nk, K);   // same shapes as v7
@@ -385,14 +390,25 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
-    choose_frame(mode, M, N, K, &c->Mk, &c->Nk);
-    c->framed = c->Mk != M || c->Nk != N;
-    select_k1(c, c->Mk, c->Nk, ncu);
+    c->Kk = K;
+    if (!(getenv("PMX_FRAME") && atoi(getenv("PMX_FRAME")) == 0) && mode != PMX_MODE_F64 && !grad_small_applies(M, N, K)) {
+        if (K < 32 && mode != PMX_MODE_BF16X3) c->Kk = 32;           // k_grad_f16_k32 / k_grad_f32_pc<32>
+        else if (K > 32 && K < 64) c->Kk = 64;                       // k_grad_f16_v8 / k_grad_bf16_v7 / k_grad_f32_pc<64>
+        else if (K > 64 && K < 128 && mode == PMX_MODE_F16X2) c->Kk = 128;   // k_grad_f16_k128
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        choose_frame(mode, M, N, c->Kk, &c->Mk, &c->Nk);
+        c->framed = c->Mk != M || c->Nk != N;
+        select_k1(c, c->Mk, c->Nk, ncu);
+        const bool tuned = c->k128 || c->k32f16 || c->f32pc || (c->use_bf16 && grad_bf16_takes_weights(c->plan, c->Mk, c->Nk, c->Kk));
+        if (c->Kk == K || tuned) break;
+        c->Kk = K;                                                   // (padding K buys nothing where the shape keeps the guarded kernels)
+    }
     if (c->framed && c->chainL == 0 && (c->use_bf16 || c->f32pc || c->k128)) {
         // a frame the chained accumulation of gA does not take (e.g. 125 panels x 63 column regions): a few more panels / column
         // regions often make one that it does (128 x 64) -- worth up to 6 % more entries (the chain is ~10 % of an iteration: one
         // gA slab per 16 column regions instead of one each, for K1 to write and the update kernel to fold)
-        const int64_t an = K == 128 ? 128 : 256, m0 = c->Mk, n0 = c->Nk;
+        const int64_t an = c->Kk == 128 ? 128 : 256, m0 = c->Mk, n0 = c->Nk;
         int64_t bm = 0, bn = 0;
         for (int i = 0; i <= 8; ++i)
             for (int j = 0; j <= 8; ++j) {
@@ -439,7 +455,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     int rc = PMX_OK;
     if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
     if (c->f16_scales) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
-    for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)Mk * K, c->framed);   // (framed: the rows behind M stay zero)
+    for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)Mk * c->Kk, c->framed || c->Kk != K);   // (framed: the rows behind M / the columns behind K stay zero)
+    for (int j = 0; j < 2 && rc == PMX_OK && c->Kk != K; ++j) rc = dallocT(c, &c->Xk[j], (size_t)c->rowsK[j] * c->Kk);          // K1's zero-padded operands
     if (c->use_bf16) {
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) {
             c->rowsPad[j] = (c->rowsK[j] + 127) / 128 * 128;
@@ -451,8 +468,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         rc = dallocT(c, &c->X[j], (size_t)c->rowsK[j] * K);
         if (rc == PMX_OK) rc = dallocT(c, &c->G[j], (size_t)c->rows[j] * K);
     }
-    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * Mk * K, false);
-    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * Nk * K, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * Mk * c->Kk, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * Nk * c->Kk, false);
     if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)2 * c->plan.gridX * c->plan.gridY);
     if (rc == PMX_OK) rc = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
     if (rc == PMX_OK) rc = dallocT(c, &c->colpart, (size_t)2 * EW_BLOCKS * MAXK);
@@ -583,10 +600,11 @@ extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     return PMX_OK;
 }
 
-extern "C" int pmx_k1_frame(pmx_ctx* c, int64_t frame[2]) {
+extern "C" int pmx_k1_frame(pmx_ctx* c, int64_t frame[3]) {
     if (!c || !frame) FAIL(PMX_E_INVALID, "NULL argument");
     frame[0] = c->f64 ? c->M : c->Mk;
     frame[1] = c->f64 ? c->N : c->Nk;
+    frame[2] = c->f64 ? c->K : c->Kk;
     return PMX_OK;
 }
 
@@ -676,7 +694,7 @@ static int set_W_common(pmx_ctx* c, const float* W, int64_t ld, int from_host, i
     if (!W) { c->W = nullptr; c->ldW = 0; c->wmax = 1.f; return PMX_OK; }
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     if (c->k32f16) FAIL(PMX_E_UNSUPPORTED, "k_grad_f16_k32 takes no weights; create the context with PMX_MODE_F32");
-    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->Mk, c->Nk, c->K))
+    if (c->use_bf16 && !grad_bf16_takes_weights(c->plan, c->Mk, c->Nk, c->Kk))
         FAIL(PMX_E_UNSUPPORTED, "a weighted likelihood in a split-precision mode needs K = 64 with M %% 128 = 0, N %% 256 = 0 or K = 128 with M %% 128 = 0, N %% 128 = 0; create the context with PMX_MODE_F32");
     if (c->comm) FAIL(PMX_E_UNSUPPORTED, "weights are not supported in row-sharded runs");
     HIP_CHECK(hipSetDevice(c->device));
@@ -875,7 +893,7 @@ static int chain_disable(pmx_ctx* c) {
     c->chainL = 0;
     c->nSlabA = c->plan.nSlabA;
     float* big = nullptr;
-    int rc = dallocT(c, &big, (size_t)c->nSlabA * c->Mk * c->K, false);
+    int rc = dallocT(c, &big, (size_t)c->nSlabA * c->Mk * c->Kk, false);
     if (rc != PMX_OK) return rc;
     c->slab[0] = big;
     return PMX_OK;
@@ -927,7 +945,7 @@ static GradArgs small_grad_args(pmx_ctx* c, const float* A, const float* St, int
     g.slabA = c->slab[0]; g.slabS = c->slab[1];
     g.lossPart = c->lossPart;
     g.status = c->dstatus;
-    g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)c->K;
+    g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)c->Kk;
     g.RP = c->plan.RP;
     g.doA = doA; g.doS = doS;
     return g;
@@ -962,16 +980,27 @@ static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, doub
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
     if (c->host_grad) return PMX_OK;       // a user `grad` callable: its result is already in G (see slab_ref)
+    if (c->Kk != c->K) {                   // K1 runs the next tuned K: its operands are zero-padded copies of the factors
+        PadArgs pa{};
+        pa.src[0] = A; pa.src[1] = St;
+        pa.dst[0] = c->Xk[0]; pa.dst[1] = c->Xk[1];
+        pa.rows[0] = c->M; pa.rows[1] = c->N;
+        pa.K = (int)c->K; pa.Kk = (int)c->Kk;
+        pa.status = c->dstatus;
+        launch_pad_factors(pa, c->stream);
+        A = c->Xk[0]; St = c->Xk[1];
+    }
+    const int64_t Kq = c->Kk;              // K as K1 sees it (rows of A / St are Kq floats apart)
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
     if (c->k128) {
         AbsmaxArgs am{};
         am.X[0] = A; am.X[1] = St;
-        am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+        am.count[0] = c->M * Kq; am.count[1] = c->N * Kq;
         am.out = c->absmax;
         am.status = c->dstatus;
         if (!absmax_fresh) launch_absmax(am, c->stream);
         SplitAArgs sp{};
-        sp.X = A; sp.count = c->M * c->K; /* (a frame's extra rows stay zero) */ sp.absmax = c->absmax; sp.H = c->A16[0]; sp.L = c->A16[1]; sp.status = c->dstatus;
+        sp.X = A; sp.count = c->M * Kq; /* (a frame's extra rows stay zero) */ sp.absmax = c->absmax; sp.H = c->A16[0]; sp.L = c->A16[1]; sp.status = c->dstatus;
         launch_split_a_f16(sp, c->stream);
         GradK128Args g{};
         g.Y = c->Y; g.ldY = c->ldY;
@@ -1000,7 +1029,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
     } else if (c->k32f16) {
         AbsmaxArgs am{};
         am.X[0] = A; am.X[1] = St;
-        am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+        am.count[0] = c->M * Kq; am.count[1] = c->N * Kq;
         am.out = c->absmax;
         am.status = c->dstatus;
         if (!absmax_fresh) launch_absmax(am, c->stream);
@@ -1022,9 +1051,9 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         PresplitArgs ps{};
         ps.X[0] = A; ps.X[1] = St;
         for (int j = 0; j < 2; ++j) { ps.Xp[j] = c->Bp[j]; ps.Xt[j] = c->Bt[j]; ps.rows[j] = c->rowsK[j]; ps.rowsPad[j] = c->rowsPad[j]; }
-        ps.K = (int)c->K; ps.KP = c->KP;
+        ps.K = (int)Kq; ps.KP = c->KP;
         ps.status = c->dstatus;
-        if (!grad_bf16_reads_fp32(c->plan, c->Mk, c->Nk, c->K)) launch_presplit(ps, c->stream);
+        if (!grad_bf16_reads_fp32(c->plan, c->Mk, c->Nk, Kq)) launch_presplit(ps, c->stream);
         GradBfArgs g{};
         g.Y = c->Y; g.ldY = c->ldY;
         g.Ap = c->Bp[0]; g.At = c->Bt[0]; g.Sp = c->Bp[1]; g.Stt = c->Bt[1];
@@ -1032,7 +1061,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.slabA = c->slab[0]; g.slabS = c->slab[1];
         g.lossPart = c->lossPart;
         g.status = c->dstatus;
-        g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)c->K;
+        g.M = (int)c->Mk; g.N = (int)c->Nk; g.K = (int)Kq;
         g.RP = c->plan.RP;
         g.doA = doA; g.doS = doS;
         g.prof = c->k1prof;
@@ -1040,7 +1069,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         if (c->use_f16) {   // operand scales of the two-term fp16 kernel: maxima of THESE factor arrays
             AbsmaxArgs am{};
             am.X[0] = A; am.X[1] = St;
-            am.count[0] = c->M * c->K; am.count[1] = c->N * c->K;
+            am.count[0] = c->M * Kq; am.count[1] = c->N * Kq;
             am.out = c->absmax;
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
@@ -1083,10 +1112,12 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
 
 static SlabRef slab_ref(pmx_ctx* c, int j) {
     SlabRef s;
-    s.stride = c->rowsK[j] * c->K;
+    s.stride = c->rowsK[j] * c->Kk;
+    s.ld = (int)c->Kk;
     if (c->host_grad) {      // the caller's gradient: ONE "slab", the G buffer itself (the update kernels fold it onto itself)
         s.base = c->G[j];
         s.n = 1;
+        s.ld = (int)c->K;
         return s;
     }
     s.base = c->slab[j];
@@ -1620,7 +1651,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
         u.G[j] = c->G[j];
         u.slab[j] = slab_ref(c, j);
-        if (p.bb_type) { u.slab[j].base = c->G[j]; u.slab[j].n = 1; }    // already folded by k_bb_reduce
+        if (p.bb_type) { u.slab[j].base = c->G[j]; u.slab[j].n = 1; u.slab[j].ld = (int)c->K; }    // already folded by k_bb_reduce
         u.rows[j] = c->rows[j];
         u.prox[j] = to_dev(p.prox[j]);
     }
@@ -1922,7 +1953,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
             u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
             u.G[j] = c->G[j];
             u.slab[j].base = c->G[j];    // folded by phase 0
-            u.slab[j].n = 1;
+            u.slab[j].n = 1; u.slab[j].ld = (int)c->K;
             u.rows[j] = c->rows[j];
             u.prox[j] = to_dev(p.prox[j]);
             u.T[j] = c->Xp[j];
@@ -2182,7 +2213,7 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     }
     if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer (S-split: this rank's chunk of it)
         m.slab[1].base = c->ssplit ? c->comm_out : c->comm;
-        m.slab[1].n = 1;
+        m.slab[1].n = 1; m.slab[1].ld = (int)c->K;
     }
     m.K = (int)c->K;
     m.status = c->dstatus;
@@ -2213,7 +2244,7 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
         t.e_rel[j] = p.e_rel[j];
         t.slots[j] = (int)((upd_rows(c, j) + 8191) / 8192);
     }
-    if (c->shard_grad_from_comm) { m.slab[1].base = c->ssplit ? c->comm_out : c->comm; m.slab[1].n = 1; }
+    if (c->shard_grad_from_comm) { m.slab[1].base = c->ssplit ? c->comm_out : c->comm; m.slab[1].n = 1; m.slab[1].ld = (int)c->K; }
     m.K = (int)c->K;
     m.status = c->dstatus;
     m.partials = c->partials;
@@ -2935,7 +2966,7 @@ static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
         u.rows[j] = upd_rows(c, j);
         u.prox[j] = to_dev(p.prox[j]);
     }
-    if (gS_from_comm) { u.slab[1].base = c->ssplit ? c->comm_out : c->comm; u.slab[1].n = 1; }
+    if (gS_from_comm) { u.slab[1].base = c->ssplit ? c->comm_out : c->comm; u.slab[1].n = 1; u.slab[1].ld = (int)c->K; }
     u.K = (int)c->K;
     u.status = c->dstatus;
     u.partials = c->partials;
@@ -3001,7 +3032,7 @@ static int bsdmm_enqueue_block(pmx_ctx* c, int j, bool gS_from_comm, const float
     BsdmmArgs u{};
     u.X = c->X[j];
     u.slab = slab_ref(c, j);
-    if (gS_from_comm) { u.slab.base = c->comm; u.slab.n = 1; }
+    if (gS_from_comm) { u.slab.base = c->comm; u.slab.n = 1; u.slab.ld = (int)c->K; }
     for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
     u.rows = c->rows[j];
     u.K = (int)c->K;

@@ -213,9 +213,10 @@ class DeviceNMF:
         d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
-        fr = (C.c_int64 * 2)()
+        fr = (C.c_int64 * 3)()
         _lib.check(self.lib.pmx_k1_frame(self.h, fr))
         d["frame"] = (fr[0], fr[1])          # != (M, N): a ragged shape on a zero-padded frame (include/pmx.h: pmx_k1_frame)
+        d["frame_K"] = fr[2]                 # != K: K1 runs the next tuned K on zero-padded copies of the factors
         return d
 
     # -- single operations --------------------------------------------------------------------

@@ -25,11 +25,16 @@ def run(M, N, K, mode, algo, unity):
         it = (time.perf_counter() - t0) / 50 * 1e3
     return info, k1, it
 
-for M, N, K, mode, algo, unity in ((16000, 16000, 64, "f16x2", "adaprox", True), (16000, 16000, 64, "f32", "adaprox", True), (5000, 7000, 64, "f16x2", "adaprox", True),
-                                   (5000, 7000, 64, "f32", "pgm", False), (10000, 12000, 128, "f16x2", "adaprox", True), (4000, 4000, 32, "f16x2", "pgm", False),
-                                   (4000, 4000, 32, "f32", "pgm", False), (16000, 16000, 64, "f16x2", "bsdmm", False)):
+CASES = ((16000, 16000, 64, "f16x2", "adaprox", True), (16000, 16000, 64, "f32", "adaprox", True), (5000, 7000, 64, "f16x2", "adaprox", True),
+         (5000, 7000, 64, "f32", "pgm", False), (10000, 12000, 128, "f16x2", "adaprox", True), (4000, 4000, 32, "f16x2", "pgm", False),
+         (4000, 4000, 32, "f32", "pgm", False), (16000, 16000, 64, "f16x2", "bsdmm", False))
+if len(sys.argv) > 1 and sys.argv[1] == "K":        # K between the tuned ones (the frame pads the components as well)
+    CASES = ((16384, 16384, 50, "f16x2", "adaprox", True), (16384, 16384, 50, "f32", "adaprox", True), (16384, 16384, 100, "f16x2", "adaprox", True),
+             (16000, 16000, 40, "f16x2", "adaprox", True), (4096, 4096, 20, "f16x2", "pgm", False), (4096, 4096, 20, "f32", "pgm", False),
+             (16384, 16384, 50, "f16x2", "bsdmm", False), (8192, 8192, 10, "f16x2", "pgm", False))
+for M, N, K, mode, algo, unity in CASES:
     for fr in ("1", "0"):
         os.environ["PMX_FRAME"] = fr
         info, k1, it = run(M, N, K, mode, algo, unity)
-        print("%6d x %6d x %3d %-6s %-7s frame=%s %-16s %-14s chain %2d slabs %3d/%d grid %dx%d  K1 %.4f ms  iteration %.4f ms" % (
-            M, N, K, mode, algo, fr, info["kernel"], info["frame"], info["chain"], info["slabs_A"], info["slabs_S"], info["row_regions"], info["col_regions"], k1, it), flush=True)
+        print("%6d x %6d x %3d %-6s %-7s frame=%s %-16s %-14s K %3d chain %2d slabs %3d/%d grid %dx%d  K1 %.4f ms  iteration %.4f ms" % (
+            M, N, K, mode, algo, fr, info["kernel"], info["frame"], info["frame_K"], info["chain"], info["slabs_A"], info["slabs_S"], info["row_regions"], info["col_regions"], k1, it), flush=True)

@@ -1,4 +1,4 @@
-"""GPU: ragged shapes on K1's zero-padded FRAME (include/pmx.h: pmx_k1_frame; pmx_api.hip: choose_frame).
+"""GPU: ragged shapes and in-between K on K1's zero-padded FRAME (include/pmx.h: pmx_k1_frame; pmx_api.hip: choose_frame).
 
 The producer / consumer K1s take M % 128 = 0 and N % 256 = 0 (N % 128 at K = 128).  A ragged M x N problem whose K has such a kernel
 runs it on M and N rounded up, with Y (and W) in a zero-padded copy, factor arrays whose extra rows are zero and gradient slabs whose
@@ -26,8 +26,8 @@ FRAMED = [
     (16383, 4097, 64, "f16x2", (16384, 4352), "k_grad_f16_v8"),
 ]
 # shapes that must NOT be framed: padding too expensive, no tuned kernel for that K / mode, already aligned, small problem
-UNFRAMED = [(300, 260, 64, "f16x2"), (1000, 1500, 48, "f16x2"), (1100, 2000, 128, "bf16x3"), (1000, 1400, 32, "bf16x3"),
-            (1024, 1536, 64, "f16x2"), (200, 1000, 5, "f32"), (1100, 2000, 128, "f32")]
+UNFRAMED = [(300, 260, 64, "f16x2"), (1100, 2000, 128, "bf16x3"), (1000, 1400, 32, "bf16x3"), (1000, 1400, 20, "bf16x3"),
+            (1024, 1536, 64, "f16x2"), (200, 1000, 5, "f32"), (1100, 2000, 128, "f32"), (1100, 2000, 100, "f32"), (300, 260, 50, "f16x2")]
 
 
 @pytest.fixture(scope="module")
@@ -101,7 +101,7 @@ def test_framed_gradient_matches_oracle(eng, orc, M, N, K, mode, frame, kernel):
 @pytest.mark.parametrize("M,N,K,mode", UNFRAMED)
 def test_shapes_that_keep_their_own_frame(eng, M, N, K, mode):
     with eng.DeviceNMF(M, N, K, mode=mode) as dev:
-        assert dev.k1_info()["frame"] == (M, N), dev.k1_info()
+        assert dev.k1_info()["frame"] == (M, N) and dev.k1_info()["frame_K"] == K, dev.k1_info()
 
 
 def test_frame_switch_and_device_y(eng, orc):
@@ -161,6 +161,83 @@ def test_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
     from proxmin_amd.engine import DeviceNMF
     with DeviceNMF(M, N, K, mode=mode) as dev:
         assert dev.k1_info()["frame"] != (M, N)
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=21)
+    pm.set_default_mode(mode)
+    try:
+        A, S, Ao, So = _solve_pair(pm, orc, name, kw, Y, A0, S0, unity, np.float64)
+    finally:
+        pm.set_default_mode("f32")
+    fA, wA = frac_within(A, Ao)
+    fS, wS = frac_within(S, So)
+    if name.startswith(SMOOTH):
+        assert fA == 1.0 and fS == 1.0, "%s %s: %.6f / %.6f within rtol 1e-4 (worst %.1f x)" % (mode, name, fA, fS, max(wA, wS))
+    else:
+        assert fA >= 0.9995 and fS >= 0.998, (fA, fS, wA, wS)
+
+
+# ---- K between the tuned ones: K1 runs the next tuned K on zero-padded copies of the factors --------------------------------------
+KFRAMED = [
+    # (M, N, K, mode) -> K1's K, kernel
+    (1024, 1536, 50, "f16x2", 64, "k_grad_f16_v8"),
+    (1024, 1536, 50, "bf16x3", 64, "k_grad_bf16"),
+    (1024, 1536, 50, "f32", 64, "k_grad_f32_pc"),
+    (1000, 1500, 40, "f16x2", 64, "k_grad_f16_v8"),        # ragged rows / columns AND components
+    (2048, 1024, 20, "f16x2", 32, "k_grad_f16_k32"),
+    (2048, 1024, 20, "f32", 32, "k_grad_f32_pc"),
+    (1100, 2000, 100, "f16x2", 128, "k_grad_f16_k128"),
+    (2048, 2048, 9, "f16x2", 32, "k_grad_f16_k32"),         # (more than 2^20 entries: not the small-problem path)
+]
+
+
+@pytest.mark.parametrize("M,N,K,mode,Kk,kernel", KFRAMED)
+def test_k_framed_gradient_matches_oracle(eng, orc, M, N, K, mode, Kk, kernel):
+    """nmf.grad_likelihood / log_likelihood with a K that has no tuned kernel, through the next tuned K's kernel: the oracle on the
+    real K; weights; repeated launches bit-identical; PMX_FRAME=0 (the guarded kernels) agrees within the K1 tolerance"""
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=M + N + K)
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+        info = dev.k1_info()
+        assert info["frame_K"] == Kk and info["kernel"] == kernel, info
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = _check_grad(orc, dev, A, S, Y)
+        gA2, gS2 = dev.grad()
+        assert np.array_equal(gA, gA2) and np.array_equal(gS, gS2)
+        if kernel != "k_grad_f16_k32":
+            rng = np.random.default_rng(8)
+            W = (0.1 + 2.0 * rng.random((M, N))).astype(np.float32)
+            W[rng.random((M, N)) < 0.15] = 0
+            dev.set_W(W)
+            _check_grad(orc, dev, A, S, Y, W)
+            dev.set_W(None)
+        A2 = (A * 3.0 + 0.25).astype(np.float32)
+        S2 = (S * 0.5 + 0.125).astype(np.float32)
+        dev.set_factors(A2, S2)
+        _check_grad(orc, dev, A2, S2, Y)
+    os.environ["PMX_FRAME"] = "0"
+    try:
+        with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+            assert dev.k1_info()["frame_K"] == K
+            dev.set_Y(Y)
+            dev.set_factors(A, S)
+            hA, hS = _check_grad(orc, dev, A, S, Y)
+    finally:
+        del os.environ["PMX_FRAME"]
+    np.testing.assert_allclose(gA, hA, rtol=4e-5, atol=4e-5 * np.abs(hA).max())
+    np.testing.assert_allclose(gS, hS, rtol=4e-5, atol=4e-5 * np.abs(hS).max())
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(1024, 1536, 50, "f16x2"), (1000, 1500, 40, "f32"), (1100, 2000, 100, "f16x2"), (2048, 1024, 20, "f16x2")])
+@pytest.mark.parametrize("name,kw", CASES)
+def test_k_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
+    """six iterations of every back-end with an in-between K against the fp64 oracle: smooth back-ends every entry within the north
+    star's bound, amsgrad + prox_unity_plus the floor of the aligned shapes"""
+    from test_gpu_parity_strict import SMOOTH, _solve_pair, frac_within
+    unity = name.endswith("unity")
+    if unity and K == 20:
+        pytest.skip("covered at K = 50 / 100")
+    from proxmin_amd.engine import DeviceNMF
+    with DeviceNMF(M, N, K, mode=mode) as dev:
+        assert dev.k1_info()["frame_K"] != K
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=21)
     pm.set_default_mode(mode)
     try:

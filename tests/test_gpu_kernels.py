@@ -467,9 +467,11 @@ def test_exact_fp32_producer_consumer_kernel(eng, orc, M, N, K, weighted):
     np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
     assert loss == pytest.approx(orc.half_sq_residual(*x64), rel=2e-5)
     if M == 128 and not weighted:
-        for Mr, Nr, Kr in ((128, 128, K), (136, 256, K), (128, 256, 48)):
+        for Mr, Nr, Kr in ((128, 128, K), (136, 256, K)):
             with eng.DeviceNMF(Mr, Nr, Kr, mode="f32") as dev:
                 assert dev.k1_info()["kernel"] in ("k_grad_f32", "k_grad_small")
+        with eng.DeviceNMF(128, 256, 48, mode="f32") as dev:       # an in-between K runs the next tuned one (tests/test_gpu_frame.py)
+            assert dev.k1_info()["kernel"] == "k_grad_f32_pc" and dev.k1_info()["frame_K"] == 64
 
 
 @pytest.mark.parametrize("M,N", [(128, 128), (2048, 1024), (1024, 4096), (3200, 2176), (8192, 384), (8320, 16384)])
@@ -545,9 +547,11 @@ def test_k32_two_term_fp16_kernel(eng, orc, M, N):
     np.testing.assert_allclose(hA, qA, rtol=2e-5, atol=2e-5 * np.abs(qA).max())
     np.testing.assert_allclose(hS, qS, rtol=2e-5, atol=2e-5 * np.abs(qS).max())
     if M == 128:
-        for Mr, Nr, Kr in ((128, 128, 32), (136, 256, 32), (128, 256, 24)):
+        for Mr, Nr, Kr in ((128, 128, 32), (136, 256, 32)):
             with eng.DeviceNMF(Mr, Nr, Kr, mode="f16x2") as dev:
                 assert dev.k1_info()["kernel"] in ("k_grad_bf16", "k_grad_small")
+        with eng.DeviceNMF(128, 256, 24, mode="f16x2") as dev:     # an in-between K runs the next tuned one (tests/test_gpu_frame.py)
+            assert dev.k1_info()["kernel"] == "k_grad_f16_k32" and dev.k1_info()["frame_K"] == 32
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
