@@ -11,9 +11,11 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 bad = 0
 for case in range(n_cases):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 7)
     if kind == 0:
         M, N, K = int(rng.integers(2, 900)), int(rng.integers(2, 900)), int(rng.integers(1, 65))
+    elif kind >= 5:    # [r4] any K on a shape large enough for the matrix-core kernels: the frame pads the components too
+        M, N, K = int(rng.integers(500, 2500)), int(rng.integers(500, 2500)), int(rng.integers(17, 129))
     elif kind >= 3:    # [r4] ragged shapes with a tuned K: the zero-padded frame
         M, N, K = int(rng.integers(500, 2500)), int(rng.integers(500, 2500)), int(rng.choice([32, 64, 128]))
     elif kind == 1:
