@@ -115,6 +115,7 @@ struct GradBfArgs {
     unsigned chainBase;
     DevStatus* wstatus;
     int chainInject;
+    float rangeRatio;    // (see GradV4Args)
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -864,6 +865,7 @@ struct GradV4Args {
     unsigned chainBase;  // launch sequence number * 64
     DevStatus* wstatus;  // writable view of `status` (fault report)
     int chainInject;     // tests: report a fault from this launch (exercises the host's fall-back)
+    float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 3 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
 };
 
 template <bool PROF>
@@ -2153,7 +2155,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
         const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
-        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject;
+        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio;
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
         const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)

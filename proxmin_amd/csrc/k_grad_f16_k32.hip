@@ -79,6 +79,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         float mA = red[0], mS = red[8];
         for (int i = 1; i < 8; ++i) { mA = fmaxf(mA, red[i]); mS = fmaxf(mS, red[8 + i]); }
         __syncthreads();                     // red aliases Sl
+        if (f16_range_fault((float)K * mA * mS, a.ymax, a.rangeRatio, a.doA, a.doS, a.wstatus, tid)) return;
         int qA = 0, qS = 0, qR = 0;
         (void)frexpf(mA, &qA);
         (void)frexpf(mS, &qS);

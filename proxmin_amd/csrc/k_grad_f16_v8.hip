@@ -35,6 +35,27 @@ __device__ __forceinline__ f16x8 v8_tr_pair(const unsigned char* base, int off0,
     return __builtin_bit_cast(f16x8, v3_tr_pair(base, off0, off1));   // the transposing read moves 16-bit payloads
 }
 
+// [r4] The residual R = P - Y is scaled for fp16 by a BOUND, max|Y| + K max|A| max|S|: one power of two for the whole launch.  An
+// entry of R keeps both of its fp16 terms down to 2^-28 of that bound and is flushed to zero below 2^-38 of it.  Where the model
+// term is far above the data -- factors that ran away (RAdam's unrectified first steps with nmf.step_adaprox reach 1e6 within two
+// iterations of a unit-scale problem: bound / max|Y| ~ 2^40), components scaled apart by many orders of magnitude -- the entries
+// with P = 0 (rows of A / columns of S the prox has set to zero: R = -Y there, and the whole gradient of such a row comes from
+// them) fall below that.  fp32 carries an exponent per entry and does not care.  The kernels therefore refuse to run when
+// K max|A| max|S| > ratio * max|Y| (ratio 2^16: R = -Y entries down to 2^-8 max|Y| keep both terms): every workgroup returns
+// before anything is written, workgroup 0 reports DevStatus::k1_fault = 3 and halts the chain of kernels; the host continues
+// the SAME iteration with the exact-fp32 kernel of the frame for the rest of the context's life (pmx_api.hip: k1_leave_f16).
+// Gradient passes only: the loss-only instance sums fp32 residuals before the split.  Uniform over the grid (same inputs).
+__device__ __forceinline__ bool f16_range_fault(float boundP, float ymax, float ratio, int doA, int doS, DevStatus* wst, int tid) {
+    if (!(ratio > 0.f) || wst == nullptr || !(doA | doS) || !(ymax > 0.f) || !(boundP > ratio * ymax)) return false;
+    if (blockIdx.x == 0 && tid == 0) {
+        wst->k1_fault = 3;
+        wst->reason = HALT_ERROR;
+        __threadfence();
+        wst->halt = 1;
+    }
+    return true;
+}
+
 // absmax[f * V8_NPART + b] = max |X_f| over workgroup b's share (f = 0: A, M x 64; f = 1: St, N x 64)
 struct AbsmaxArgs {
     const float* X[2];
@@ -182,6 +203,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         float mA = red[0], mS = red[8];
         for (int i = 1; i < 8; ++i) { mA = fmaxf(mA, red[i]); mS = fmaxf(mS, red[8 + i]); }
         __syncthreads();                     // red aliases Sl
+        if (f16_range_fault((float)K * mA * mS, a.ymax, a.rangeRatio, a.doA, a.doS, a.wstatus, tid)) return;
         int qA = 0, qS = 0, qR = 0;
         (void)frexpf(mA, &qA);               // m = f 2^q, f in [0.5, 1)  ->  m 2^(14-q) < 2^14
         (void)frexpf(mS, &qS);

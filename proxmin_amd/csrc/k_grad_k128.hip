@@ -64,6 +64,7 @@ struct GradK128Args {
     unsigned chainBase;      // launch sequence number * 64
     DevStatus* wstatus;      // writable view of `status` (fault report)
     int chainInject;         // tests: report a fault from this launch
+    float rangeRatio;        // [r4] f16_range_fault (k_grad_f16_v8.hip); 0: no check
 };
 
 struct SplitAArgs {
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         float mA = red[0], mS = red[8];
         for (int i = 1; i < 8; ++i) { mA = fmaxf(mA, red[i]); mS = fmaxf(mS, red[8 + i]); }
         __syncthreads();                     // red aliases the S images
+        if (f16_range_fault((float)K * mA * mS, a.ymax, a.rangeRatio, a.doA, a.doS, a.wstatus, tid)) return;
         int qA = 0, qS = 0, qR = 0;
         (void)frexpf(mA, &qA);
         (void)frexpf(mS, &qS);

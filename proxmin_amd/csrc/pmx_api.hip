@@ -118,6 +118,11 @@ struct pmx_ctx {
     bool f32pc = false;                    // exact-fp32 arithmetic at a shape the producer / consumer kernel k_grad_f32_pc takes
     bool f16_fell_back = false;            // use_f16, but the last launch ran the split-bf16 kernel (Y / W not fetchable in 8-byte pairs)
     bool f16_scales = false;               // use_f16 || k128: the K1 kernel needs the factor maxima (absmax) and max|Y|
+    // [r4] the two-term fp16 kernels refuse a launch whose residual bound K max|A| max|S| exceeds rangeRatio max|Y| (f16_range_fault,
+    // k_grad_f16_v8.hip): the context then continues in exact fp32 on the same frame (k1_leave_f16).  PMX_F16_RANGE=n: ratio 2^n, 0: no check
+    float rangeRatio = 65536.f;
+    int rangeFaults = 0;
+    int ncu = 0;
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
     float ymax = 0.f;                      // max |Y|
@@ -390,6 +395,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
+    c->ncu = ncu;
+    if (const char* e = getenv("PMX_F16_RANGE")) c->rangeRatio = atoi(e) > 0 ? ldexpf(1.f, atoi(e)) : 0.f;
     c->Kk = K;
     if (!(getenv("PMX_FRAME") && atoi(getenv("PMX_FRAME")) == 0) && mode != PMX_MODE_F64 && !grad_small_applies(M, N, K)) {
         if (K < 32 && mode != PMX_MODE_BF16X3) c->Kk = 32;           // k_grad_f16_k32 / k_grad_f32_pc<32>
@@ -596,7 +603,7 @@ extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     info[4] = c->plan.gridX;
     info[5] = c->plan.gridY;
     info[6] = c->plan.RP;
-    info[7] = c->chainFaults + 1000 * c->tailFaults + (c->tail_fused ? 1000000 : 0);
+    info[7] = c->chainFaults + 1000 * c->tailFaults + (c->tail_fused ? 1000000 : 0) + 10000000 * std::min(c->rangeFaults, 9);
     return PMX_OK;
 }
 
@@ -879,6 +886,12 @@ static int reset_status(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// what to tell the caller when a chain stopped with HALT_ERROR on a path that cannot repeat the iteration (one iteration per call)
+static const char* chain_error_text(pmx_ctx* c) {
+    if (c->hstatus && c->hstatus->k1_fault == 3)
+        return "mode f16x2: K max|A| max|S| is more than 2^16 max|Y| -- one fp16 scale cannot carry this residual (f16_range_fault); create the context with PMX_MODE_F32";
+    return "device chain reported an error";
+}
 // clear `halt` (and adaprox's need_sub flags) before resuming a chain
 static int clear_halt(pmx_ctx* c) {
     static const int zeros[2] = {0, 0};
@@ -898,6 +911,25 @@ static int chain_disable(pmx_ctx* c) {
     c->slab[0] = big;
     return PMX_OK;
 }
+// DevStatus::k1_fault == 3 (f16_range_fault, k_grad_f16_v8.hip): the two-term fp16 K1 refused a launch because one power-of-two
+// scale cannot carry this residual.  Leave the fp16 kernels for good: the exact-fp32 K1 of the SAME frame (k_grad_f32_pc at
+// K1's K = 32 / 64, k_grad_f32<128> else; zero-padded Y / factor copies stay as they are), with its own grid, slabs, loss
+// partials and chain words.  The buffers of the fp16 plan stay allocated until the context is destroyed.
+static int k1_leave_f16(pmx_ctx* c) {
+    c->mode = PMX_MODE_F32;
+    select_k1(c, c->Mk, c->Nk, c->ncu);
+    c->chainFlags = nullptr;
+    c->chainSeq = 0;
+    c->slab[0] = c->slab[1] = nullptr;
+    c->lossPart = nullptr;
+    int rc = PMX_OK;
+    if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[0], (size_t)c->nSlabA * c->Mk * c->Kk, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->slab[1], (size_t)c->plan.nSlabS * c->Nk * c->Kk, false);
+    if (rc == PMX_OK) rc = dallocT(c, &c->lossPart, (size_t)2 * c->plan.gridX * c->plan.gridY);
+    c->rangeFaults += 1;
+    return rc;
+}
 // After read_status: a chained K1 launch found that its hand-off does not hold here (a predecessor on another XCD, or
 // workgroups that are not co-resident: DevStatus::k1_fault) and stopped the chain of kernels before anything was updated.
 // Fall back to slabs and clear the halt; the caller re-enqueues from DevStatus::it_done.  *again = 1 if that happened.
@@ -908,7 +940,10 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
     if (c->hstatus->tail_fault == 2)         // a barrier inside the fused tail never completed: the iteration is half applied
         FAIL(PMX_E_HIP, "k_ada_tail: a grid barrier timed out after the census had passed (a workgroup was lost); the factors are not usable");
     int rc = PMX_OK;
-    if (c->hstatus->k1_fault) {
+    if (c->hstatus->k1_fault == 3) {
+        rc = k1_leave_f16(c);
+        if (rc != PMX_OK) return rc;
+    } else if (c->hstatus->k1_fault) {
         rc = chain_disable(c);
         if (rc != PMX_OK) return rc;
         c->chainFaults += 1;
@@ -1014,6 +1049,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
         g.absmax = c->absmax; g.ymax = c->ymax;
         g.W = c->W; g.ldW = c->ldW; g.wmax = c->wmax;
+        g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         if (c->chainL > 0 && (doA & 1)) {    // k_grad_f16_k128<.., CHAIN>
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
                 HIP_CHECK(hipMemsetAsync(c->chainFlags, 0, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4 * sizeof(unsigned), c->stream));
@@ -1044,6 +1080,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         g.doA = doA; g.doS = doS;
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
         g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = 1.f;
+        g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -1074,6 +1111,7 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
+            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         }
         if (c->chainL > 0) {                 // k_grad_f16_v8<.., CHAIN> / k_grad_bf16_v7<.., CHAIN>
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
@@ -1331,7 +1369,7 @@ extern "C" int pmx_grad(pmx_ctx* c) {
         f.status = c->dstatus;
         launch_fold(f, 2, c->stream);
         HIP_CHECK(hipGetLastError());
-        if (c->chainL == 0) { HIP_CHECK(hipStreamSynchronize(c->stream)); break; }
+        if (c->chainL == 0 && !c->f16_scales) { HIP_CHECK(hipStreamSynchronize(c->stream)); break; }
         rc = read_status(c);
         if (rc != PMX_OK) return rc;
         int again = 0;
@@ -1857,7 +1895,7 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
             }
             rc = read_status(c);
             if (rc != PMX_OK) return rc;
-            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
         }
         fill_result(c, res, it0);
         return PMX_OK;
@@ -2336,7 +2374,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             }
             rc = read_status(c);
             if (rc != PMX_OK) return rc;
-            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
         }
         fill_result(c, res, it0);
         return PMX_OK;
@@ -2399,7 +2437,7 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
             if (again) { tails = 0; continue; }
         }
         if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
-        if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+        if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
     }
     if (c->tailprof && c->tail_fused) {
         long long h[16];
@@ -2475,7 +2513,7 @@ extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, do
     }
     if (any_prox) c->nsub_guess = std::max(2, std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]));
     c->host_tau[0] = c->host_tau[1] = 0;
-    if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "device chain reported an error");
+    if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
     fill_result(c, res, it0);
     return PMX_OK;
 }

@@ -90,6 +90,13 @@ class DeviceNMF:
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "h", None):
+            try:
+                if self.mode == "f16x2" and self.k1_info()["range_faults"]:
+                    _notice(("range", self.M, self.N, self.K),
+                            "proxmin_amd: mode f16x2 at %d x %d x %d: the factors ran away from the data (K max|A| max|S| > 2^16 max|Y|: one fp16 "
+                            "scale cannot carry that residual); the run went on with the exact-fp32 kernel" % (self.M, self.N, self.K))
+            except Exception:
+                pass
             self.lib.pmx_ctx_destroy(self.h)
             self.h = None
 
@@ -212,7 +219,8 @@ class DeviceNMF:
         d = dict(zip(keys, list(v)))
         d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32")[d["kernel"]]
         v7 = d.pop("chain_faults")
-        d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool(v7 // 1000000)
+        d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool((v7 // 1000000) % 10)
+        d["range_faults"] = v7 // 10000000   # 1: a two-term fp16 K1 refused the residual's range, the context went on in exact fp32 (f16_range_fault)
         fr = (C.c_int64 * 3)()
         _lib.check(self.lib.pmx_k1_frame(self.h, fr))
         d["frame"] = (fr[0], fr[1])          # != (M, N): a ragged shape on a zero-padded frame (include/pmx.h: pmx_k1_frame)

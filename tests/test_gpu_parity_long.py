@@ -75,7 +75,7 @@ def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, 
     M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
     Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 4321, torch.device("cuda", 0))
     dev_out = {}
-    for mode in ("f32", "f16x2"):
+    for mode in ("f32", "f16x2", "bf16x3"):     # (bf16x3: recorded beside the other two -- three bf16 terms in A S, two in the gradient products)
         dev_out[mode] = _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, 3)
     Y32 = Yd.cpu().numpy()
     del Yd
