@@ -90,8 +90,7 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
     # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
     fast = "k_grad_f16_v8" if mode == "f16x2" else "k_grad_bf16_v7"
-    bf16_kernel = ((fast if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and M % 128 == 0 and N % 64 == 0)
-                   else "k_grad_bf16<%d>" % kp)
+    bf16_kernel = fast if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp
     if kernel == "k_grad_f16_k32":           # K = 32 in mode f16x2: 6K/4 = 48 flop/B, the single pass over Y is the roof
         bf16_kernel = kernel
     passes = MFMA_PASSES["f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3"]

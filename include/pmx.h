@@ -45,7 +45,12 @@ enum {
     PMX_MODE_BF16X3 = 2, /* Y fp32 in HBM, operands split into bf16 terms (3 for A@S, 2 for the gradients), fp32 accumulate */
     PMX_MODE_F16X2 = 3,  /* as BF16X3, but K = 64 / M % 128 = 0 / N % 256 = 0 shapes and K = 128 / M % 128 = 0 / N % 128 = 0
                             shapes (the latter without weights) run the two-term fp16 kernels (power-of-two operand
-                            scales from the factor maxima; 9 instead of 12 MFMA products per MAC) */
+                            scales from the factor maxima; 9 instead of 12 MFMA products per MAC).  The residual is scaled
+                            by ONE power of two from the bound max|Y| + K max|A| max|S|: a gradient launch that finds
+                            K max|A| max|S| > 2^16 max|Y| (factors that ran away from the data: entries with A S = 0 would
+                            fall out of fp16's range) is refused before anything is written, and the context repeats the
+                            iteration with the exact-f32 kernel of its frame and keeps it (pmx_k1_info reports both);
+                            entry points that run one iteration per call return PMX_E_HIP with that explanation. */
     PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
                             M, N <= 8192: the reference's own examples and BASELINE cfg1) and the fused loops of the three
@@ -208,7 +213,8 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
  * k_grad_f16_k128, 6 exact fp32 with producer / consumer wavefronts k_grad_f32_pc), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
- * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now. */
+ * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now + 10000000 if a two-term fp16 kernel
+ * refused the residual's range and the context went on in exact fp32 (PMX_MODE_F16X2 above; info[0] then names the fp32 kernel). */
 int pmx_k1_info(pmx_ctx* ctx, int info[8]);
 
 /* ---- single operations (unit parity tests, and what the reference exposes as functions) --- */

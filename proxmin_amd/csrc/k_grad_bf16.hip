@@ -865,307 +865,12 @@ struct GradV4Args {
     unsigned chainBase;  // launch sequence number * 64
     DevStatus* wstatus;  // writable view of `status` (fault report)
     int chainInject;     // tests: report a fault from this launch (exercises the host's fall-back)
-    float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 3 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
+    float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 4 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
 };
 
-template <bool PROF>
-__global__ __launch_bounds__(V4_THREADS, 2) void k_grad_bf16_v4(GradV4Args a) {
-    constexpr int K = 64, KS = 4, ROWB = 144, S_TERM = 64 * ROWB, A_TERM = 128 * ROWB;
-    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    unsigned char* Aimg = smem + V4_OFF_A;
-    unsigned char* Rb = smem + V4_OFF_R;
-
-    if (chain_halted(a.status)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int M = a.M, N = a.N;
-    int rowRegion, colRegion;
-    {
-        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
-            const int xcd = lin & 7, idx = lin >> 3;
-            rowRegion = idx % gx;
-            colRegion = xcd * (gy >> 3) + idx / gx;
-        } else {
-            rowRegion = lin % gx;
-            colRegion = lin / gx;
-        }
-    }
-    const int row0 = rowRegion * a.RP * V4_BM;
-    const int col0 = colRegion * BG_CB * V4_BN;
-    const int mt = w >> 1, nt = w & 1;                       // GEMM1 tile; GEMM2 tile (mt, kt = nt)
-    const int kt3 = (w >> 1) & 1, part = w >> 2;             // GEMM3 tile (nt, kt3), row half `part`
-
-    f32x16 accS[BG_CB];
-#pragma unroll
-    for (int cb = 0; cb < BG_CB; ++cb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accS[cb][i] = 0.f;
-    f32x16 accA;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accA[i] = 0.f;
-    f32x16 p;
-    float lossAcc = 0.f;
-
-    int nrp = (M - row0 + V4_BM - 1) / V4_BM;
-    if (nrp > a.RP) nrp = a.RP;
-    if (nrp < 0) nrp = 0;
-    int ncb = (N - col0 + V4_BN - 1) / V4_BN;
-    if (ncb > BG_CB) ncb = BG_CB;
-    if (ncb < 0) ncb = 0;
-    const int nsteps = nrp * ncb;
-    const bool noY = (a.doA & 2) != 0;
-
-    // ---- prefetch registers and their loaders -----------------------------------------------------------
-    float4 sreg[2], areg[4];
-    float yreg[16];
-    auto load_S = [&](int bcol0) {
-        const float4* src = reinterpret_cast<const float4*>(a.St + (int64_t)bcol0 * K);
-        sreg[0] = src[tid];
-        sreg[1] = src[tid + V4_THREADS];
-    };
-    auto load_A = [&](int prow0) {
-        const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)prow0 * K);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) areg[i] = src[tid + i * V4_THREADS];
-    };
-    // Y is requested a full step ahead, in the accumulator layout (lane = column, 16 rows)
-    auto load_Y = [&](int prow0, int bcol0) {
-        const float* src = a.Y + (int64_t)(prow0 + mt * 32 + 4 * hi) * a.ldY + bcol0 + nt * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) yreg[i] = src[(int64_t)((i & 3) + 8 * (i >> 2)) * a.ldY];
-    };
-    // element (row = f >> 4, k = (f & 15) * 4) of a [rows][64] fp32 block lands at row * 144 + k * 2 of each term image
-    const int st_off = (tid >> 4) * ROWB + (tid & 15) * 8;
-    auto store_S = [&](int buf) {
-        unsigned char* dst = smem + buf * V4_SL_BYTES + st_off;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x4 t0, t1, t2;
-            v4_split3(sreg[i], t0, t1, t2);
-            unsigned char* d = dst + i * 32 * ROWB;
-            *reinterpret_cast<bf16x4*>(d) = t0;
-            *reinterpret_cast<bf16x4*>(d + S_TERM) = t1;
-            *reinterpret_cast<bf16x4*>(d + 2 * S_TERM) = t2;
-        }
-    };
-    auto store_A = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 t0, t1, t2;
-            v4_split3(areg[i], t0, t1, t2);
-            unsigned char* d = Aimg + st_off + i * 32 * ROWB;
-            *reinterpret_cast<bf16x4*>(d) = t0;
-            *reinterpret_cast<bf16x4*>(d + A_TERM) = t1;
-            *reinterpret_cast<bf16x4*>(d + 2 * A_TERM) = t2;
-        }
-    };
-    auto flush_gA = [&](int prow0) {
-        float* dst = a.slabA + (int64_t)colRegion * M * K;
-        const int kk = nt * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int gr = prow0 + mt * 32 + tile_row(i, lane);
-            dst[(int64_t)gr * K + kk] = accA[i];
-        }
-    };
-
-    // ---- step-invariant LDS addresses ---------------------------------------------------------------------
-    const int li = lane & 15, lq = lane >> 4;
-    const int a_g1 = (mt * 32 + l31) * ROWB + hi * 16;                        // GEMM1 A operand (b128), + ks*32 + t*A_TERM
-    const int s_g1 = (nt * 32 + l31) * ROWB + hi * 16;                        // GEMM1 B operand (b128), + ks*32 + t*S_TERM
-    const int n_w = nt * 32 + l31;
-    const int r_w = n_w * 256 + (((4 * mt) ^ v4_swz(n_w)) << 4) + 8 * hi;    // R producer, ^ (g << 4)
-    int r_t0, r_t1;                                                           // GEMM2 A operand (R, transposing read)
-    {
-        const int m = mt * 32 + 16 * (lq & 1) + 4 * (li & 3);
-        const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
-        r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
-        r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
-    }
-    const int s_t = (8 * hi + (li >> 2)) * ROWB + (nt * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM2 B operand (tr)
-    const int r_g3 = n_w * 256 + (((8 * part + hi) ^ v4_swz(n_w)) << 4);      // GEMM3 A operand (b128), ^ (ks << 5)
-    const int a_t = (64 * part + 8 * hi + (li >> 2)) * ROWB + (kt3 * 32 + 16 * (lq & 1) + 4 * (li & 3)) * 2;   // GEMM3 B operand (tr)
-
-    if (nsteps > 0) {   // prologue: first panel, first S block, first Y tile
-        load_A(row0);
-        load_S(col0);
-        if (!noY) load_Y(row0, col0);
-        store_A();
-        store_S(0);
-    }
-    unsigned long long ph[PROF ? 10 : 1] = {};
-    const bool prof = PROF && a.prof != nullptr && w == 0;
-#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
-    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
-    int rp = 0, cb = 0;
-#pragma nounroll
-    for (int step = 0; step < nsteps; ++step) {
-        const int prow0 = row0 + rp * V4_BM;
-        int nrp_ = rp, ncb_ = cb + 1;
-        if (ncb_ == ncb) { ncb_ = 0; nrp_ = rp + 1; }
-        const bool more = step + 1 < nsteps;
-        const int nprow0 = row0 + nrp_ * V4_BM, nbcol0 = col0 + ncb_ * V4_BN;
-        const unsigned char* Slb = smem + (step & 1) * V4_SL_BYTES;
-        // ---- TOP: Sl(step) published, everyone done with step - 1 ------------------------------------------
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own LDS writes retired before the barrier
-        __builtin_amdgcn_s_barrier();
-        PH(0)
-        if (cb == 0 && step > 0) {            // new row panel: Aimg may be overwritten only now
-            store_A();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_s_barrier();
-        }
-        PH(1)
-        if (noY) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) p[i] = 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) p[i] = -yreg[i];
-        }
-        // keep the new loads BELOW the uses of the old ones: hoisted above, the compiler's wait for Y would have to
-        // cover them too (vmcnt(0)) and the S/A latency would be exposed on every step
-        asm volatile("" : "+v"(p));
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {                           // next step's Y tile and S block (stored into the other Sl buffer at the end of this step)
-            if (!noY) load_Y(nprow0, nbcol0);
-            load_S(nbcol0);
-        }
-        PH(2)
-        // ---- GEMM1: P = A S - Y ---------------------------------------------------------------------------------
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32 + A_TERM);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(Aimg + a_g1 + ks * 32 + 2 * A_TERM);
-            const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32);
-            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32 + S_TERM);
-            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + s_g1 + ks * 32 + 2 * S_TERM);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, s0, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, s1, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s2, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, s0, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s1, p, 0, 0, 0);
-            p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, s0, p, 0, 0, 0);
-        }
-        PH(3)
-        // ---- R: loss, split into two bf16 terms, park as [n][m] images -------------------------------------------
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float r = p[4 * g + j];
-                lossAcc += r * r;
-                const __bf16 hh = (__bf16)r;
-                h[j] = hh;
-                l[j] = (__bf16)(r - (float)hh);
-            }
-            const int o = r_w ^ (g << 4);
-            *reinterpret_cast<bf16x4*>(Rb + o) = h;
-            *reinterpret_cast<bf16x4*>(Rb + V4_R_TERM + o) = l;
-        }
-        PH(4)
-        // ---- B_R: R visible ----------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
-        PH(5)
-        // ---- GEMM2: gA += R S^T (both operands through the transposing read) --------------------------------------
-        if (a.doA & 1) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                const bf16x8 r1 = v3_tr_pair(Rb + V4_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                const bf16x8 s0 = v3_tr_pair(Slb, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
-                const bf16x8 s1 = v3_tr_pair(Slb + S_TERM, s_t + ks * 16 * ROWB, s_t + ks * 16 * ROWB + 4 * ROWB);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s0, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s1, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s0, accA, 0, 0, 0);
-            }
-            if (cb + 1 == ncb) {
-                flush_gA(prow0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) accA[i] = 0.f;
-            }
-        }
-        PH(6)
-        // ---- GEMM3: gSt += R^T A ----------------------------------------------------------------------------------
-        if (a.doS) {
-#define V4_GEMM3_INTO(ACC)                                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                 \
-        const int ro = r_g3 ^ (ks << 5);                                                                \
-        const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);                                    \
-        const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V4_R_TERM + ro);                        \
-        const bf16x8 a0 = v3_tr_pair(Aimg, a_t + ks * 16 * ROWB, a_t + ks * 16 * ROWB + 4 * ROWB);      \
-        const bf16x8 a1 = v3_tr_pair(Aimg + A_TERM, a_t + ks * 16 * ROWB, a_t + ks * 16 * ROWB + 4 * ROWB); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, ACC, 0, 0, 0);                            \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, ACC, 0, 0, 0);                            \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, ACC, 0, 0, 0);                            \
-    }
-            switch (cb) {
-                case 0: V4_GEMM3_INTO(accS[0]) break;
-                case 1: V4_GEMM3_INTO(accS[1]) break;
-                case 2: V4_GEMM3_INTO(accS[2]) break;
-                default: V4_GEMM3_INTO(accS[3]) break;
-            }
-#undef V4_GEMM3_INTO
-        }
-        PH(7)
-        // ---- next S block into the other Sl buffer (its last readers finished before this step's TOP) -------------
-        if (more) store_S((step + 1) & 1);
-        // next panel's A rows: requested here, where nothing but the accumulators is live (held any longer, the
-        // register allocator splits the tuples and waits on them mid-step), split and stored after the next TOP
-        if (more && ncb_ == 0) load_A(nprow0);
-        PH(8)
-        cb = ncb_;
-        rp = nrp_;
-    }
-    if (a.doS) {
-        float* dst = a.slabS + (int64_t)(rowRegion * 2 + part) * N * K;
-        const int kk = kt3 * 32 + l31;
-#pragma unroll
-        for (int cbi = 0; cbi < BG_CB; ++cbi) {
-            const int bcol0 = col0 + cbi * V4_BN;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gn = bcol0 + nt * 32 + tile_row(i, lane);
-                if (gn < N) dst[(int64_t)gn * K + kk] = accS[cbi][i];
-            }
-        }
-    }
-    {
-        float v = lossAcc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        if (lane == 0) red[w] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < V4_NW; ++i) s += (double)red[i];
-            a.lossPart[blockIdx.x] = s;
-        }
-    }
-    PH(9)
-    if constexpr (PROF) {
-        if (prof && lane == 0)
-            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
-    }
-#undef PH
-}
-
-template <bool PROF>
-static hipError_t grad_launch_bf16_v4_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v4<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_bf16_v4<PROF>, dim3(a.gridX * a.gridY), dim3(V4_THREADS), V4_LDS_BYTES, stream, a);
-    return hipGetLastError();
-}
-static hipError_t grad_launch_bf16_v4(const GradV4Args& a, hipStream_t stream) {
-    return a.prof ? grad_launch_bf16_v4_t<true>(a, stream) : grad_launch_bf16_v4_t<false>(a, stream);
-}
+// (k_grad_bf16_v4's kernel was removed in round 4 together with k_grad_bf16_v5's: with K1's zero-padded frame -- pmx_k1_frame -- the
+// shapes they served, M % 128 = 0 with N % 64 = 0 but not N % 256 = 0, run k_grad_bf16_v7 / k_grad_f16_v8 on columns rounded up, or
+// the guarded kernel where that would cost more than a quarter more entries; the constants and helpers above are v7's as well)
 
 
 // ------------------------------------------------------------------------------------------------
@@ -1195,378 +900,8 @@ static_assert(V5_OFF_R % 256 == 0, "R images must start on a bank row");
 static_assert(V5_LDS_BYTES <= 160 * 1024, "");
 static_assert(V5_NB * V5_BN == BG_CB * BG_BN, "same region width as the other variants (shared plan)");
 
-template <bool PROF>
-__global__ __launch_bounds__(V5_THREADS, 2) void k_grad_bf16_v5(GradV4Args a) {
-    // Sl and Aimg: [row][64 bf16] images with 128-byte rows whose 16-byte chunks are XOR-swizzled by the row
-    // (v3_swz), which makes the b128 reads (lane = row), the transposing reads (4 rows x 64 bytes per 32 lanes) and
-    // the staging writes all bank-conflict-free (a padded 144-byte row left the transposing reads 2-way conflicted:
-    // SQ_LDS_BANK_CONFLICT was 84 % of SQ_ACTIVE_INST_LDS)
-    constexpr int K = 64, ROWB = 128;
-    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-
-    if (chain_halted(a.status)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int li = lane & 15, lq = lane >> 4;
-    const int M = a.M, N = a.N;
-    int rowRegion, colRegion;
-    {
-        const int lin = blockIdx.x, gx = a.gridX, gy = a.gridY;
-        if (gy % 8 == 0) {
-            const int xcd = lin & 7, idx = lin >> 3;
-            rowRegion = idx % gx;
-            colRegion = xcd * (gy >> 3) + idx / gx;
-        } else {
-            rowRegion = lin % gx;
-            colRegion = lin / gx;
-        }
-    }
-    const int row0 = rowRegion * a.RP * V5_BM;
-    const int col0 = colRegion * V5_NB * V5_BN;
-    int nrp = (M - row0 + V5_BM - 1) / V5_BM;
-    if (nrp > a.RP) nrp = a.RP;
-    if (nrp < 0) nrp = 0;
-    int ncb = (N - col0 + V5_BN - 1) / V5_BN;
-    if (ncb > V5_NB) ncb = V5_NB;
-    if (ncb < 0) ncb = 0;
-    const int T = nrp * ncb;                 // blocks of this region; slots = T + 1
-    const bool noY = (a.doA & 2) != 0;
-    const bool producer = w < 4;
-    const int j = w & 3;                     // index within the role
-    float lossAcc = 0.f;
-    // phase profiler: wave 0 (producer) fills slots 0-5, wave 4 (consumer) slots 6-9
-    unsigned long long ph[PROF ? 10 : 1] = {};
-    const bool prof = PROF && a.prof != nullptr && (w == 0 || w == 4);
-#define PH(i) if constexpr (PROF) { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } }
-    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
-
-    // ---- S staging (all 512 threads): one float4 of the 32 x 64 fp32 block per thread ------------------------
-    // Loads are issued on EVERY slot (block index clamped at the end of the region), all of them right after the
-    // slot's uses of the previous ones: whatever the compiler's wait for an old load also covers was requested a
-    // whole slot ago.  (Hand-counted waits on inline-asm loads were tried and dropped: the register allocator
-    // copies in-flight destination registers around the asm statements.)
-    float4 sreg;
-    const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
-    int s_cb = 0;                            // column block of the next S request (wraps at ncb; no integer division in the loop)
-    auto load_S = [&]() {
-        sreg = reinterpret_cast<const float4*>(a.St + (int64_t)(col0 + s_cb * V5_BN) * K)[tid];
-        if (++s_cb == ncb) s_cb = 0;
-    };
-    auto store_S = [&](int t) {
-        bf16x4 t0, t1, t2;
-        v4_split3(sreg, t0, t1, t2);
-        unsigned char* d = smem + (t % 3) * V5_SL_BYTES + st_off;
-        *reinterpret_cast<bf16x4*>(d) = t0;
-        *reinterpret_cast<bf16x4*>(d + V5_S_TERM) = t1;
-        *reinterpret_cast<bf16x4*>(d + 2 * V5_S_TERM) = t2;
-    };
-    if (T <= 0) {                              // region outside the matrix: its gSt slab part and loss partial are zero
-        if (!producer) {
-            const int mh = j >> 1, kk = (j & 1) * 32 + l31;
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            for (int c = 0; c < V5_NB; ++c)
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = col0 + c * V5_BN + tile_row(i, lane);
-                    if (gn < N && a.doS) dst[(int64_t)gn * K + kk] = 0.f;
-                }
-        }
-        if (tid == 0) a.lossPart[blockIdx.x] = 0.0;
-        return;
-    }
-    load_S();
-    store_S(0);
-    load_S();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();              // Sl(0) published
-
-    if (producer) {
-        // ================================ producers: GEMM1 and R =================================================
-        f32x16 p;
-        float4 areg[4][2];
-        bf16x8 afr[4][3];
-        // Y tile of the next block: LDS-DMA into a private 32 x 32 landing tile, requested one slot ahead (4 requests
-        // of 1 KiB per wave instead of 16 dword loads: the request count, not the bytes, is what the CU's address unit charges)
-        float* Ytile = reinterpret_cast<float*>(smem + V5_OFF_Y) + j * 1024;
-        const unsigned ytile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Ytile;
-        int y_rp = 0, y_cb = 0;              // block of the next Y request
-        auto dma_Y = [&]() {
-            const float* src = a.Y + (int64_t)(row0 + y_rp * V5_BM + j * 32 + (lane >> 3)) * a.ldY + col0 + y_cb * V5_BN + (lane & 7) * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                lds_dma16(src + (int64_t)q * 8 * a.ldY, __builtin_amdgcn_readfirstlane(ytile_lds + q * 1024));
-            if (++y_cb == ncb) { y_cb = 0; if (y_rp + 1 < nrp) ++y_rp; }
-        };
-        auto load_A = [&](int prow) {
-            const float4* src = reinterpret_cast<const float4*>(a.A + (int64_t)(prow + j * 32 + l31) * K + hi * 8);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                areg[ks][0] = src[ks * 4];
-                areg[ks][1] = src[ks * 4 + 1];
-            }
-        };
-        auto make_afr = [&]() {              // split the panel rows into bf16 terms (register fragments of GEMM1's A operand)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
-                                    areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const __bf16 t0 = (__bf16)x[q];
-                    const float e1 = x[q] - (float)t0;
-                    const __bf16 t1 = (__bf16)e1;
-                    afr[ks][0][q] = t0;
-                    afr[ks][1][q] = t1;
-                    afr[ks][2][q] = (__bf16)(e1 - (float)t1);
-                }
-            }
-        };
-        auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
-            const int pa = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<bf16x8*>(smem + V5_OFF_A + (pa ^ (ks << 5))) = afr[ks][0];
-                *reinterpret_cast<bf16x8*>(smem + V5_OFF_A + V5_A_TERM + (pa ^ (ks << 5))) = afr[ks][1];
-            }
-        };
-        const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
-        const int r_w = l31 * 256 + (((4 * j) ^ v4_swz(l31)) << 4) + 8 * hi;      // R producer, ^ (g << 4)
-        load_A(row0);
-        dma_Y();
-        int rp = 0, cb = 0;
-        bool new_panel = false;              // the previous block opened a row panel: its A terms go to Aimg now
-        // One slot: stage S(t+1), then block t: P = A S - Y, R -> R[t & 1].
-        auto slot = [&](int t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last slot's requests (Y tile by DMA, S, A) have landed
-            store_S(t + 1);                  // Sl[(t+1) % 3]: its last readers (consumers, block t-2) finished in slot t-1
-            if (new_panel) {                 // consumers are past the old panel (block t-2); they read the new one from this slot on
-                publish_A();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_s_barrier();
-            }
-            PH(5)
-            if (t < T) {
-                new_panel = cb == 0;
-                if (cb == 0) make_afr();
-                PH(1)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) p[i] = -Ytile[tile_row(i, lane) * 32 + l31];
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p));
-                __builtin_amdgcn_sched_barrier(0);
-                // next slot's requests: S block, next panel's rows (on the panel's last block), Y tile
-                load_S();
-                if (cb + 1 == ncb && rp + 1 < nrp) load_A(row0 + (rp + 1) * V5_BM);
-                dma_Y();
-                PH(2)
-                const unsigned char* Slb = smem + (t % 3) * V5_SL_BYTES;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int so = s_g1 ^ (ks << 5);
-                    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(Slb + so);
-                    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(Slb + so + V5_S_TERM);
-                    const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(Slb + so + 2 * V5_S_TERM);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][2], s0, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s1, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s2, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][1], s0, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s1, p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][0], s0, p, 0, 0, 0);
-                }
-                PH(3)
-                unsigned char* Rb = smem + V5_OFF_R + (t & 1) * V5_R_BYTES;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 h, l;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float r = p[4 * g + q];
-                        lossAcc += r * r;
-                        const __bf16 hh = (__bf16)r;
-                        h[q] = hh;
-                        l[q] = (__bf16)(r - (float)hh);
-                    }
-                    const int o = r_w ^ (g << 4);
-                    *reinterpret_cast<bf16x4*>(Rb + o) = h;
-                    *reinterpret_cast<bf16x4*>(Rb + V5_R_TERM + o) = l;
-                }
-                if (++cb == ncb) { cb = 0; ++rp; }
-                PH(4)
-            } else {
-                new_panel = false;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes retired before the barrier
-            __builtin_amdgcn_s_barrier();
-            PH(0)
-        };
-#pragma nounroll
-        for (int t = 0; t <= T; ++t) slot(t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        // ================================ consumers: GEMM2 and GEMM3 of the previous block ======================
-        f32x16 accS[V5_NB];
-#pragma unroll
-        for (int c = 0; c < V5_NB; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
-        f32x16 accA0, accA1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-        const int kt = j & 1, mh = j >> 1;   // GEMM3 tile; GEMM2: rows 32j.., both k tiles
-        int r_t0, r_t1;                      // GEMM2 A operand (R, transposing read)
-        {
-            const int m = j * 32 + 16 * (lq & 1) + 4 * (li & 3);
-            const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
-            r_t0 = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
-            r_t1 = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
-        }
-        // transposing reads of a swizzled [row][k] image: source lane (li, lq) supplies row r0 + 4 u + (li >> 2), 4 k's from
-        // k0 + 16 (lq & 1) + 4 (li & 3); + 16 rows per ks leaves the swizzle unchanged
-        auto tr_src = [&](int row, int k0) {
-            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
-            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
-        };
-        const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // GEMM2 B operand; k tile 1: ^ 64
-        const int r_g3 = l31 * 256 + (((8 * mh + hi) ^ v4_swz(l31)) << 4);                     // GEMM3 A operand, ^ (ks << 5)
-        const int a_t0 = tr_src(64 * mh + 8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(64 * mh + 8 * hi + 4 + (li >> 2), kt * 32);   // GEMM3 B operand
-        // two base pointers per lane and compile-time row offsets (immediates): sixteen separate 64-bit addresses kept
-        // live across the slot loop cost the consumers 32 VGPRs they need for operand prefetch
-        auto flush_gA = [&](int prow) {
-            float* p0 = a.slabA + (int64_t)colRegion * M * K + (int64_t)(prow + j * 32 + 4 * hi) * K + l31;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float* ph_ = p0 + half * 16 * K;
-                asm volatile("" : "+v"(ph_));          // keep it ONE pointer: the offsets below fold into the store's immediate
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
-                    const int ro = ((q & 3) + 8 * (q >> 2)) * K;
-                    ph_[ro] = accA0[i];
-                    ph_[ro + 32] = accA1[i];
-                }
-            }
-        };
-        // slot t works on block t - 1; the column-block loop is unrolled so that each gSt accumulator is a fixed
-        // register tuple (a switch over 8 accumulators makes the compiler shuffle them through scratch)
-        auto stage = [&](int t) {            // top of slot t (see the producers)
-            store_S(t + 1);
-            load_S();
-            PH(8)
-        };
-        auto sync = [&]() {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_s_barrier();
-            PH(9)
-        };
-        auto consume = [&](int t, int rp, int cb, f32x16& accSc) {
-            const int prow = row0 + rp * V5_BM;
-            const unsigned char* Rb = smem + V5_OFF_R + ((t - 1) & 1) * V5_R_BYTES;
-            const unsigned char* Slb = smem + ((t - 1) % 3) * V5_SL_BYTES;
-            const unsigned char* Ab = smem + V5_OFF_A;
-            if (a.doA & 1) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 r0 = v3_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                    const bf16x8 r1 = v3_tr_pair(Rb + V5_R_TERM, r_t0 + ks * 4096, r_t1 + ks * 4096);
-                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
-                    const bf16x8 s00 = v3_tr_pair(Slb, so0, so1);
-                    const bf16x8 s01 = v3_tr_pair(Slb + V5_S_TERM, so0, so1);
-                    const bf16x8 s10 = v3_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
-                    const bf16x8 s11 = v3_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s00, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, s10, accA1, 0, 0, 0);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s01, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s11, accA1, 0, 0, 0);
-                    accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s00, accA0, 0, 0, 0);
-                    accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, s10, accA1, 0, 0, 0);
-                }
-            }
-            PH(6)
-            if (a.doS) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int ro = r_g3 ^ (ks << 5);
-                    const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(Rb + ro);
-                    const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(Rb + V5_R_TERM + ro);
-                    const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
-                    const bf16x8 a0 = v3_tr_pair(Ab, ao0, ao1);
-                    const bf16x8 a1 = v3_tr_pair(Ab + V5_A_TERM, ao0, ao1);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, a0, accSc, 0, 0, 0);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a1, accSc, 0, 0, 0);
-                    accSc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r0, a0, accSc, 0, 0, 0);
-                }
-            }
-            // the panel's gA goes out AFTER the gSt contraction: a branch between the two contractions would keep the
-            // scheduler from starting the second one's LDS reads under the first one's MFMAs
-            if ((a.doA & 1) && cb + 1 == ncb) {
-                flush_gA(prow);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
-            }
-        };
-        stage(0);
-        sync();
-        int t = 1;
-#pragma nounroll
-        for (int rp = 0; rp < nrp; ++rp) {
-#pragma unroll
-            for (int cb = 0; cb < V5_NB; ++cb) {
-                if (cb < ncb) {
-                    stage(t);
-                    if (cb == 0) {           // this block opens a row panel: the producers publish its A terms now
-                        __builtin_amdgcn_s_waitcnt(0xc07f);
-                        __builtin_amdgcn_s_barrier();
-                    }
-                    consume(t, rp, cb, accS[cb]);
-                    PH(7)
-                    sync();
-                    ++t;
-                }
-            }
-        }
-        if (a.doS) {
-            float* dst = a.slabS + (int64_t)(rowRegion * 2 + mh) * N * K;
-            const int kk = kt * 32 + l31;
-#pragma unroll
-            for (int c = 0; c < V5_NB; ++c) {
-                const int bcol = col0 + c * V5_BN;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int gn = bcol + tile_row(i, lane);
-                    if (gn < N) dst[(int64_t)gn * K + kk] = accS[c][i];
-                }
-            }
-        }
-    }
-    {
-        float v = lossAcc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        if (lane == 0) red[w] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < 4; ++i) s += (double)red[i];
-            a.lossPart[blockIdx.x] = s;
-        }
-    }
-    if constexpr (PROF) {
-        if (prof && lane == 0)
-            for (int i = 0; i < 10; ++i) atomicAdd(&a.prof[i], ph[i]);
-    }
-#undef PH
-}
-
-template <bool PROF>
-static hipError_t grad_launch_bf16_v5_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_bf16_v5<PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_bf16_v5<PROF>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V5_LDS_BYTES, stream, a);
-    return hipGetLastError();
-}
-static hipError_t grad_launch_bf16_v5(const GradV4Args& a, hipStream_t stream) {
-    return a.prof ? grad_launch_bf16_v5_t<true>(a, stream) : grad_launch_bf16_v5_t<false>(a, stream);
-}
+// (kernel removed in round 4, see above: what is left of v5 is its frame -- the constants, roles and image layouts k_grad_bf16_v7,
+// k_grad_f16_v8, k_grad_f16_k32 and k_grad_f16_k128 are built on)
 
 // ------------------------------------------------------------------------------------------------
 // k_grad_bf16_v7 (K = 64, M % 128 == 0, N % 256 == 0): v5's producer / consumer split, deeper pipeline, fewer joules.
@@ -2081,8 +1416,9 @@ GradPlan grad_plan_bf16(int64_t M, int64_t N, int64_t K) {
     p.KP = K <= 32 ? 32 : 64;
     p.BN = BG_BN;
     // PMX_K1_VARIANT (read per context; tuning A/B and the variant tests): 0 guarded kernel only, 1 LDS-DMA pipeline
-    // 128 x 64 / 8 waves, 4 fp32 operands split in-kernel, 5 the same with producer / consumer wavefronts, 7 (default)
-    // those with the deeper pipeline, resident S terms and Y loaded straight into registers (N % 256 == 0, else 5)
+    // 128 x 64 / 8 waves, 7 (default) fp32 operands split in-kernel by producer / consumer wavefronts with resident S terms
+    // and Y loaded straight into registers (K = 64, M % 128 == 0, N % 256 == 0; other shapes as 1).  (4 and 5, the
+    // intermediate variants of rounds 1-2, were removed in round 4: values in between select like 1.)
     p.variant = getenv("PMX_K1_VARIANT") ? atoi(getenv("PMX_K1_VARIANT")) : 7;
     const int splitA = p.KP == 64 ? 1 : 2, splitS = p.KP == 64 ? 2 : 4;
     const int64_t panels = (M + BG_BM - 1) / BG_BM;
@@ -2131,10 +1467,10 @@ static hipError_t grad_launch_bf16_t(const GradPlan& p, const GradBfArgs& a, hip
 bool grad_bf16_takes_weights(const GradPlan& p, int64_t M, int64_t N, int64_t K);
 // true when the launch below will take the variant that reads A and St as fp32 (no presplit pass needed)
 bool grad_bf16_reads_fp32(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
-    return p.variant >= 4 && p.KP == 64 && K == 64 && (M % V4_BM) == 0 && (N % V4_BN) == 0;
+    return p.variant >= 7 && p.KP == 64 && K == 64 && (M % V4_BM) == 0 && (N % (V5_NB * V5_BN)) == 0;
 }
 bool grad_bf16_takes_weights(const GradPlan& p, int64_t M, int64_t N, int64_t K) {
-    return grad_bf16_reads_fp32(p, M, N, K) && p.variant >= 7 && (N % (V5_NB * V5_BN)) == 0;
+    return grad_bf16_reads_fp32(p, M, N, K);
 }
 // took_f16 (optional): whether the two-term fp16 kernel is what runs -- a context in mode f16x2 drops to the split-bf16 kernel of
 // the same frame at launch time when Y (or W) cannot be fetched eight bytes at a time (odd pitch, misaligned base, ldW != ldY)
@@ -2151,19 +1487,15 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.M = a.M; g.N = a.N; g.RP = a.RP; g.doA = a.doA; g.doS = a.doS;
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
         g.W = a.W; g.ldW = a.ldW;
-        if (a.W != nullptr && !(variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0)) return hipErrorInvalidValue;   // see grad_bf16_takes_weights
-        // v5 streams Y by LDS-DMA (16-byte pieces: needs aligned rows); v4 takes any row pitch
-        const bool dma_ok = (a.ldY % 4) == 0 && (((uintptr_t)a.Y) & 15) == 0;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
         g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio;
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
         const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)
-        const bool f16 = a.absmax != nullptr && (a.N % (V5_NB * V5_BN)) == 0 && pairs_ok;
+        const bool f16 = a.absmax != nullptr && pairs_ok;
         if (took_f16) *took_f16 = f16;
         if (f16) return grad_launch_f16_v8(g, stream);
-        if (variant >= 7 && (a.N % (V5_NB * V5_BN)) == 0) return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
-        return variant >= 5 && dma_ok ? grad_launch_bf16_v5(g, stream) : grad_launch_bf16_v4(g, stream);
+        return grad_launch_bf16_v7(g, stream);   // plain loads: any row pitch
     }
     if (a.W != nullptr) return hipErrorInvalidValue;
     // Whole blocks with 16-byte-aligned rows take an LDS-DMA variant; anything else the guarded kernel.

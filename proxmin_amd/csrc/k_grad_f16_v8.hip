@@ -42,13 +42,13 @@ __device__ __forceinline__ f16x8 v8_tr_pair(const unsigned char* base, int off0,
 // with P = 0 (rows of A / columns of S the prox has set to zero: R = -Y there, and the whole gradient of such a row comes from
 // them) fall below that.  fp32 carries an exponent per entry and does not care.  The kernels therefore refuse to run when
 // K max|A| max|S| > ratio * max|Y| (ratio 2^16: R = -Y entries down to 2^-8 max|Y| keep both terms): every workgroup returns
-// before anything is written, workgroup 0 reports DevStatus::k1_fault = 3 and halts the chain of kernels; the host continues
+// before anything is written, workgroup 0 reports DevStatus::k1_fault = 4 and halts the chain of kernels; the host continues
 // the SAME iteration with the exact-fp32 kernel of the frame for the rest of the context's life (pmx_api.hip: k1_leave_f16).
 // Gradient passes only: the loss-only instance sums fp32 residuals before the split.  Uniform over the grid (same inputs).
 __device__ __forceinline__ bool f16_range_fault(float boundP, float ymax, float ratio, int doA, int doS, DevStatus* wst, int tid) {
     if (!(ratio > 0.f) || wst == nullptr || !(doA | doS) || !(ymax > 0.f) || !(boundP > ratio * ymax)) return false;
     if (blockIdx.x == 0 && tid == 0) {
-        wst->k1_fault = 3;
+        wst->k1_fault = 4;
         wst->reason = HALT_ERROR;
         __threadfence();
         wst->halt = 1;

@@ -888,7 +888,7 @@ static int reset_status(pmx_ctx* c) {
 
 // what to tell the caller when a chain stopped with HALT_ERROR on a path that cannot repeat the iteration (one iteration per call)
 static const char* chain_error_text(pmx_ctx* c) {
-    if (c->hstatus && c->hstatus->k1_fault == 3)
+    if (c->hstatus && c->hstatus->k1_fault == 4)
         return "mode f16x2: K max|A| max|S| is more than 2^16 max|Y| -- one fp16 scale cannot carry this residual (f16_range_fault); create the context with PMX_MODE_F32";
     return "device chain reported an error";
 }
@@ -911,7 +911,7 @@ static int chain_disable(pmx_ctx* c) {
     c->slab[0] = big;
     return PMX_OK;
 }
-// DevStatus::k1_fault == 3 (f16_range_fault, k_grad_f16_v8.hip): the two-term fp16 K1 refused a launch because one power-of-two
+// DevStatus::k1_fault == 4 (f16_range_fault, k_grad_f16_v8.hip): the two-term fp16 K1 refused a launch because one power-of-two
 // scale cannot carry this residual.  Leave the fp16 kernels for good: the exact-fp32 K1 of the SAME frame (k_grad_f32_pc at
 // K1's K = 32 / 64, k_grad_f32<128> else; zero-padded Y / factor copies stay as they are), with its own grid, slabs, loss
 // partials and chain words.  The buffers of the fp16 plan stay allocated until the context is destroyed.
@@ -940,7 +940,7 @@ static int chain_fault_fallback(pmx_ctx* c, int* again) {
     if (c->hstatus->tail_fault == 2)         // a barrier inside the fused tail never completed: the iteration is half applied
         FAIL(PMX_E_HIP, "k_ada_tail: a grid barrier timed out after the census had passed (a workgroup was lost); the factors are not usable");
     int rc = PMX_OK;
-    if (c->hstatus->k1_fault == 3) {
+    if (c->hstatus->k1_fault == 4) {
         rc = k1_leave_f16(c);
         if (rc != PMX_OK) return rc;
     } else if (c->hstatus->k1_fault) {

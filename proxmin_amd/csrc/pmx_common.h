@@ -72,7 +72,7 @@ struct DevStatus {
     int tail_fault;      // k_ada_tail: its census barrier found the workgroups not co-resident; nothing was written (host falls back to the separate kernels)
     int pad2;
     int k1_fault;        // k_grad_f16_v8<CHAIN>: 1 a chain predecessor never arrived, 2 it runs on another XCD (host falls back to slabs);
-                         // [r4] 3: a two-term fp16 K1 found the residual's bound too far above max|Y| for ONE fp16 scale (host falls back to exact fp32)
+                         // (3: injected by the tests) [r4] 4: a two-term fp16 K1 found the residual's bound too far above max|Y| for ONE fp16 scale (host falls back to exact fp32)
 };
 enum { HALT_NONE = 0, HALT_CONVERGED = 1, HALT_NEED_SUB = 2, HALT_ERROR = 3,
        HALT_RETRY = 4,   // (host view) a kernel reported a recoverable fault before anything was updated: re-enqueue from it_done

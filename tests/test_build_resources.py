@@ -32,7 +32,6 @@ LIMITS = {
     "10k_ada_tailILi4E": 0,
     "14k_grad_bf16_v7ILb0ELb0E": 4,    # 0   split-bf16 K1 at K = 64
     "14k_grad_bf16_v7ILb0ELb1E": 20,   # 6   its weighted instance (17 when chained)
-    "14k_grad_bf16_v5ILb0E": 8,
     "10k_grad_f32ILi64ELb0E": 32,      # 19  exact-fp32 K1, unweighted
     "10k_grad_f32ILi32ELb0E": 16,      # 3
     "10k_grad_f32ILi128ELb0E": 24,     # 11

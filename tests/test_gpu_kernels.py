@@ -45,11 +45,12 @@ def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     assert loss == pytest.approx(orc.half_sq_residual(A64, S64, Y64), rel=2e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 7])
 @pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1024, 640, 64), (640, 1536, 64), (2304, 832, 64), (5120, 4096, 64), (256, 320, 40), (384, 256, 32)])
 def test_split_bf16_kernel_variants_agree_with_oracle(eng, orc, monkeypatch, M, N, K, variant):
-    """Every implementation of the split-bf16 K1 (guarded, LDS-DMA pipelines, fp32-operand variant; selected per
-    context by PMX_K1_VARIANT, shapes that a variant does not take fall through to the next) gives the oracle's
+    """Every implementation of the split-bf16 K1 (guarded, LDS-DMA pipeline, the producer / consumer kernel v7; selected per
+    context by PMX_K1_VARIANT, shapes that a variant does not take fall through to the next; the intermediate variants 4
+    and 5 of rounds 1-2 were removed in round 4) gives the oracle's
     gradients and loss; asymmetric data, so a swapped tile or operand orientation cannot pass."""
     monkeypatch.setenv("PMX_K1_VARIANT", str(variant))
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, seed=11 * M + N + K)
