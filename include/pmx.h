@@ -166,7 +166,8 @@ int pmx_k1_frame(pmx_ctx* ctx, int64_t frame[3]);
  * default kernel applies (K = 64, M % 128 == 0, N % 256 == 0) and fails with PMX_E_UNSUPPORTED elsewhere (the caller then
  * creates an F32 context: proxmin_amd/engine.py:open_weighted).  pmx_set_W_host(ctx, NULL, 0) goes back to W == 1.
  * The default PGM / bSDMM step rule does not exist for an array W (nmf.step_pgm tests `W == 1` on it and raises,
- * nmf.py:63): pmx_pgm_begin without fixed or Barzilai-Borwein steps and pmx_bsdmm_begin fail with PMX_E_INVALID.   */
+ * nmf.py:63): pmx_pgm_begin without fixed or Barzilai-Borwein steps (and without pmx_pgm_params::unweighted_rule) and
+ * pmx_bsdmm_begin fail with PMX_E_INVALID.   */
 int pmx_set_W_host(pmx_ctx* ctx, const float* W, int64_t ld);
 int pmx_set_W_device(pmx_ctx* ctx, const float* dW, int64_t ld, int copy);
 
@@ -244,6 +245,9 @@ typedef struct pmx_pgm_params { /* algorithms.pgm arguments, algorithms.py:12-23
     int32_t accelerated;  /* Nesterov/FISTA extrapolation (utils.py:193-206) */
     float step_scale;     /* multiplies the Lipschitz steps of nmf.step_pgm (1 = reference default) */
     int32_t use_fixed_steps; /* 1: use fixed_steps[] instead of the Lipschitz rule (user `step`) */
+    int32_t unweighted_rule; /* (in what used to be padding) 1: the caller MEANS the unweighted Lipschitz rule although the context carries
+                                weights -- the reference's `step_pgm(*X)` called without its W argument, e.g. inside a user lambda;
+                                0: pmx_pgm_begin refuses the rule on a weighted context like `partial(step_pgm, W=W)` does (nmf.py:63,152) */
     double fixed_steps[2];
     double e_rel[2];      /* algorithms.py:66-68 */
     int32_t bb_type;      /* 0: off; 1 / 2: utils.BarzilaiBorweinStepper(type) as the step rule (utils.py:209-241) */

@@ -40,7 +40,7 @@ class ProxSeq(C.Structure):
 
 class PgmParams(C.Structure):
     _fields_ = [("prox", ProxSeq * 2), ("accelerated", C.c_int32), ("step_scale", C.c_float),
-                ("use_fixed_steps", C.c_int32), ("fixed_steps", C.c_double * 2), ("e_rel", C.c_double * 2),
+                ("use_fixed_steps", C.c_int32), ("unweighted_rule", C.c_int32), ("fixed_steps", C.c_double * 2), ("e_rel", C.c_double * 2),
                 ("bb_type", C.c_int32), ("bb_init_r", C.c_double), ("backtracking", C.c_int32), ("host_prox", C.c_int32 * 2)]
 
 

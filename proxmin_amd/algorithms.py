@@ -219,8 +219,13 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     elif isinstance(step, _nmf.constant_step):
         fixed = step.steps
     elif step is _nmf.step_pgm or (isinstance(step, partial) and step.func is _nmf.step_pgm):
-        if W is not None:            # nmf.step_pgm tests `W == 1` on the array and raises (nmf.py:63)
+        # nmf.step_pgm tests `W == 1` on ITS OWN argument (nmf.py:63): an array there raises -- which is what nmf() hands it for a
+        # weighted problem (nmf.py:152) --, the bare function (W = 1) gives the unweighted rule whatever weights the gradient carries
+        sW = step.keywords.get("W", 1) if isinstance(step, partial) else 1
+        if not np.isscalar(sW):
             raise ValueError(_nmf._AMBIGUOUS)
+        if sW != 1:
+            raise NotImplementedError("the weighted step rule of nmf.step_pgm (nmf.py:64-88) is not implemented; pass `step`")
     elif callable(step):
         user_step = step
         _warn_host_path("step (%r)" % (step,))
@@ -237,8 +242,8 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     if slow and backtracking and not (bt_user_step or bt_user_prox):
         raise NotImplementedError("a user-defined grad (or Barzilai-Borwein steps with a user prox) together with backtracking is not implemented")
 
-    if W is not None and isinstance(step, _nmf.scaled_step_pgm):
-        raise ValueError(_nmf._AMBIGUOUS)    # it calls nmf.step_pgm
+    # (scaled_step_pgm stands for `lambda *X, it=None: tuple(c * s for s in step_pgm(*X))`: step_pgm with ITS default W = 1 -- the
+    # unweighted Lipschitz rule -- also when the likelihood carries weights)
     # [r4] fp64 inputs of a small problem, everything of the iteration on the device: fp64 arithmetic (PMX_MODE_F64)
     from .engine import f64_applies
     f64 = (not slow and not backtracking and bb is None and W is None and Y is not None
@@ -246,7 +251,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     with _open_device(Y, A, S, W, f64=f64) as dev:
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
                       e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
-                      host_prox=[h is not None for h in host_prox])
+                      host_prox=[h is not None for h in host_prox], unweighted_rule=W is not None and user_step is None and fixed is None and bb is None)
         res = None
         it_done = 0
         dt = A.dtype

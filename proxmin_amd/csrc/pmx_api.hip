@@ -1581,7 +1581,7 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
         }
         return PMX_OK;
     }
-    if (c->W && !p->use_fixed_steps && !p->bb_type)   // nmf.step_pgm with an array W raises (nmf.py:63)
+    if (c->W && !p->use_fixed_steps && !p->bb_type && !p->unweighted_rule)   // nmf.step_pgm with an array W raises (nmf.py:63)
         FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
     rc = dallocT(c, &c->tickets, 4);
     if (rc != PMX_OK) return rc;

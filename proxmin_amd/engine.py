@@ -250,12 +250,13 @@ class DeviceNMF:
 
     # -- solvers ------------------------------------------------------------------------------
     def pgm_begin(self, prox, accelerated=False, step_scale=1.0, fixed_steps=None, e_rel=(1e-6, 1e-6), bb=None, backtracking=False,
-                  host_prox=(False, False)):
+                  host_prox=(False, False), unweighted_rule=False):
         p = _lib.PgmParams()
         p.prox[0], p.prox[1] = prox
         p.accelerated = int(bool(accelerated))
         p.step_scale = float(step_scale)
         p.use_fixed_steps = int(fixed_steps is not None)
+        p.unweighted_rule = int(bool(unweighted_rule))    # step_pgm(*X) without its W on a weighted problem (include/pmx.h)
         if fixed_steps is not None:
             p.fixed_steps[0], p.fixed_steps[1] = float(fixed_steps[0]), float(fixed_steps[1])
         p.e_rel[0], p.e_rel[1] = float(e_rel[0]), float(e_rel[1])

@@ -390,6 +390,39 @@ def test_weighted_likelihood_matches_reference(pm, tag):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2, algorithm=pm.bsdmm)
 
 
+@pytest.mark.parametrize("accel", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 8), (640, 1024, 64)])
+def test_weighted_pgm_with_the_unweighted_lipschitz_rule(pm, orc, M, N, K, accel):
+    """[r4, found by scratch/fuzz_nmf2.py] A weighted likelihood next to `scaled_step_pgm(c)` -- the library's name for the reference
+    idiom `lambda *X, it=None: tuple(c * s for s in step_pgm(*X))` -- or the bare `step_pgm`: step_pgm is called WITHOUT its W
+    argument there (W = 1: nmf.py:52-65), so the reference runs the unweighted Lipschitz rule on the weighted gradient.  Rounds 1-3
+    raised the ValueError of `partial(step_pgm, W=W)` (nmf.py:63,152) for these as well.  pgm / FISTA against the fp64 oracle;
+    nmf()'s own default (step=None with weights) still raises like the reference."""
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, seed=M + K)
+    rng = np.random.default_rng(2)
+    W = (0.1 + 2.0 * rng.random((M, N))).astype(np.float32)
+    W[rng.random((M, N)) < 0.2] = 0
+    c = 0.5 if accel else 1.0
+    Ao, So = A0.astype(np.float64), S0.astype(np.float64)
+    orc.pgm_nmf(Y.astype(np.float64), Ao, So, step=lambda A_, S_, it=None, grads=None: tuple(c * s for s in orc.lipschitz_steps(A_, S_)),
+                accelerated=accel, max_iter=8, e_rel=1e-12, W=W.astype(np.float64))
+    steps = [pm.nmf.scaled_step_pgm(c)] + ([pm.nmf.step_pgm] if not accel else [])
+    for step in steps:
+        A, S = A0.copy(), S0.copy()
+        grad = partial(pm.nmf.grad_likelihood, Y=Y, W=W)
+        pm.pgm([A, S], grad, step, prox=[pm.operators.prox_plus] * 2, accelerated=accel, max_iter=8, e_rel=1e-12)
+        np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(S, So, rtol=RTOL, atol=ATOL)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, W=W, step=pm.nmf.scaled_step_pgm(c), accelerated=accel, max_iter=8, e_rel=1e-12)
+    np.testing.assert_allclose(A, Ao, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=ATOL)
+    with pytest.raises(ValueError):
+        pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
+    with pytest.raises(ValueError):
+        pm.pgm([A0.copy(), S0.copy()], partial(pm.nmf.grad_likelihood, Y=Y, W=W), partial(pm.nmf.step_pgm, W=W), prox=[pm.operators.prox_plus] * 2, max_iter=2)
+
+
 @pytest.mark.parametrize("unity", [False, True])
 def test_proximal_sub_iteration_counts_match_oracle(pm, orc, unity):
     """The data-dependent inner loop (algorithms.py:383-400) must end after the same number of passes as in the
