@@ -30,7 +30,9 @@ def rd(f):
         return None
 
 
-M, N, K, backend, unity, desc = bench.CONFIGS["cfg3"]
+M, N, K, backend, unity, desc = bench.CONFIGS[os.environ.get("CFG", "cfg3")]
+if os.environ.get("ROWS"):
+    M = int(os.environ["ROWS"])          # (cfg4's 8192-row share)
 Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
 dev = DeviceNMF(M, N, K, device=0, mode="f16x2")
 dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
@@ -49,7 +51,7 @@ th = threading.Thread(target=sampler)
 th.start()
 t0, ms = time.time(), []
 while time.time() - t0 < 3.0:
-    ms.append(dev.time_grad(1, 1, 200))
+    ms.append(dev.time_grad(int(os.environ.get("DOA", "1")), int(os.environ.get("DOS", "1")), 200))
 stop[0] = True
 th.join()
 mid = samples[len(samples) // 4:]
