@@ -78,3 +78,25 @@ def test_prox_recognition():
     assert s.n == 2 and s.repeat == 3 and s.seq[0].op == _lib.PROX["plus"] and s.seq[1].op == _lib.PROX["unity"]
     with pytest.raises(NotImplementedError):
         ops.device_proxseq(lambda X, step: X, 0)
+
+
+def test_weighted_step_rule_dispatch_mirrors_step_pgms_own_argument():
+    """nmf.step_pgm tests `W == 1` on ITS OWN W (nmf.py:63): `partial(step_pgm, W=<array>)` -- what nmf() builds for a weighted
+    problem (nmf.py:152) -- raises ValueError before anything runs; the bare function and `scaled_step_pgm(c)` (= the idiom
+    `lambda *X, it=None: tuple(c * s for s in step_pgm(*X))`) carry W = 1 and must get as far as the device (no GPU here: PmxError)."""
+    from functools import partial
+    import numpy as np
+    import proxmin_amd as pm
+    from proxmin_amd import _lib
+    Y, A, S = np.ones((8, 8), np.float32), np.ones((8, 2), np.float32), np.ones((2, 8), np.float32)
+    W = np.full((8, 8), 2.0, np.float32)
+    grad = partial(pm.nmf.grad_likelihood, Y=Y, W=W)
+    with pytest.raises(ValueError):
+        pm.pgm([A.copy(), S.copy()], grad, partial(pm.nmf.step_pgm, W=W), prox=[pm.operators.prox_plus] * 2, max_iter=1)
+    with pytest.raises(ValueError):
+        pm.nmf.nmf(Y, A.copy(), S.copy(), W=W, max_iter=1)
+    for step in (pm.nmf.step_pgm, pm.nmf.scaled_step_pgm(0.5), partial(pm.nmf.step_pgm, W=1)):
+        try:
+            pm.pgm([A.copy(), S.copy()], grad, step, prox=[pm.operators.prox_plus] * 2, max_iter=1)
+        except _lib.PmxError:
+            pass                       # (no GPU in this container: the call got past the step-rule dispatch)
