@@ -122,6 +122,7 @@ struct pmx_ctx {
     // k_grad_f16_v8.hip): the context then continues in exact fp32 on the same frame (k1_leave_f16).  PMX_F16_RANGE=n: ratio 2^n, 0: no check
     float rangeRatio = 65536.f;
     int rangeFaults = 0;
+    bool k1_sync_check = false;            // one-iteration-per-call paths (nothing to repeat into): every fp16 K1 launch is awaited and, refused, repeated in fp32 on the spot (enqueue_grad)
     int ncu = 0;
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
     float* absmax = nullptr;               // [3][256] partial maxima: |A|, |St| (per K1 launch), |Y| (at set_Y)
@@ -911,6 +912,13 @@ static int chain_disable(pmx_ctx* c) {
     c->slab[0] = big;
     return PMX_OK;
 }
+// Entry points that run ONE iteration (or a piece of one) per call -- user callables, the line search, row-sharded bsdmm -- have
+// nothing to repeat an iteration into: no chained K1 there (its faults are repaired by repeating), and the fp16 kernels' range
+// guard is looked at right behind every K1 launch instead (enqueue_grad), where nothing else has been enqueued yet.
+static int one_iteration_per_call(pmx_ctx* c) {
+    c->k1_sync_check = true;
+    return chain_disable(c);
+}
 // DevStatus::k1_fault == 4 (f16_range_fault, k_grad_f16_v8.hip): the two-term fp16 K1 refused a launch because one power-of-two
 // scale cannot carry this residual.  Leave the fp16 kernels for good: the exact-fp32 K1 of the SAME frame (k_grad_f32_pc at
 // K1's K = 32 / 64, k_grad_f32<128> else; zero-padded Y / factor copies stay as they are), with its own grid, slabs, loss
@@ -1013,7 +1021,7 @@ static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, doub
 }
 
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
-static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
+static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh) {
     if (c->host_grad) return PMX_OK;       // a user `grad` callable: its result is already in G (see slab_ref)
     if (c->Kk != c->K) {                   // K1 runs the next tuned K: its operands are zero-padded copies of the factors
         PadArgs pa{};
@@ -1146,6 +1154,20 @@ static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, in
         c->ev_used += 2;
     }
     return PMX_OK;
+}
+
+static int enqueue_grad(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh = false) {
+    int rc = enqueue_grad_once(c, A, St, doA, doS, absmax_fresh);
+    if (rc != PMX_OK || !c->k1_sync_check || !c->f16_scales || c->host_grad || !(doA | doS)) return rc;
+    // a path with nothing to repeat an iteration into: the fp16 kernel's range guard (f16_range_fault) is looked at NOW, with nothing
+    // behind the launch yet -- refused: the context leaves the fp16 kernels and the same gradient pass runs in exact fp32
+    rc = read_status(c);
+    if (rc != PMX_OK) return rc;
+    if (c->hstatus->k1_fault != 4) return PMX_OK;
+    int again = 0;
+    rc = chain_fault_fallback(c, &again);
+    if (rc != PMX_OK) return rc;
+    return enqueue_grad_once(c, A, St, doA, doS, false);
 }
 
 static SlabRef slab_ref(pmx_ctx* c, int j) {
@@ -1617,7 +1639,7 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
         }
     c->btT[0] = c->btT[1] = 1.0;
     if (p->backtracking) {   // host-driven trials read device sums after every K1 pass: no room for a repeated iteration
-        rc = chain_disable(c);
+        rc = one_iteration_per_call(c);
         if (rc != PMX_OK) return rc;
     }
     if (p->backtracking)
@@ -1961,7 +1983,7 @@ extern "C" int pmx_pgm_bt_split(pmx_ctx* c, int phase, int* need, double eff_ste
         rc = set_fixed_steps(c, c->pgm.fixed_steps);
         if (rc != PMX_OK) return rc;
     }
-    if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }       // (one iteration per call: nothing to repeat into)
+    { rc = one_iteration_per_call(c); if (rc != PMX_OK) return rc; }       // (one iteration per call: nothing to repeat into)
     rc = bt_step(c, phase, need, eff_steps);
     if (rc != PMX_OK) return rc;
     if (*need == 0) {
@@ -2007,7 +2029,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
     };
     switch (phase) {
         case 0: {
-            if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }   // (one iteration per call: nothing to repeat into)
+            { rc = one_iteration_per_call(c); if (rc != PMX_OK) return rc; }   // (one iteration per call: nothing to repeat into)
             if (!p.use_fixed_steps && !p.bb_type) {
                 rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale);
                 if (rc != PMX_OK) return rc;
@@ -2474,7 +2496,7 @@ extern "C" int pmx_adaprox_split(pmx_ctx* c, int phase, int it, double b1_it, do
     if (!(b1_it >= 0 && b1_it < 1)) FAIL(PMX_E_INVALID, "b1 out of [0,1)");
     const pmx_adaprox_params& p = c->ada;
     if (phase == 0) {
-        if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+        { rc = one_iteration_per_call(c); if (rc != PMX_OK) return rc; }
         rc = ada_enqueue_head(c, it, b1_it, b1_prev, false);
         if (rc != PMX_OK) return rc;
         rc = read_status(c);
@@ -2685,7 +2707,7 @@ extern "C" int pmx_bsdmm_split(pmx_ctx* c, int j, int phase, int host_f, unsigne
     const int it0 = c->hstatus->it_done;
     switch (phase) {
         case 0: {
-            if (c->chainL > 0) { rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+            { rc = one_iteration_per_call(c); if (rc != PMX_OK) return rc; }
             if (host_f) { rc = dallocT(c, &c->Xp[j], (size_t)c->rows[j] * c->K, false); if (rc != PMX_OK) return rc; }
             for (int i = 0; i < p.n_g[j]; ++i)
                 if ((host_g >> i) & 1u) { rc = dallocT(c, &c->Tg[j][i], (size_t)c->rows[j] * c->K, false); if (rc != PMX_OK) return rc; }
@@ -2785,7 +2807,7 @@ extern "C" int pmx_set_host_grad(pmx_ctx* c, int on) {
     HIP_CHECK(hipSetDevice(c->device));
     if (on) {
         if (c->W) FAIL(PMX_E_UNSUPPORTED, "a host-side gradient and device-side weights do not go together");
-        if (c->chainL > 0) { int rc = chain_disable(c); if (rc != PMX_OK) return rc; }
+        { int rc = one_iteration_per_call(c); if (rc != PMX_OK) return rc; }
         c->haveY = true;                   // nothing M x N is needed: the fused residual kernel never runs in this context
     }
     c->host_grad = on != 0;
@@ -3110,7 +3132,9 @@ extern "C" int pmx_bsdmm_phase(pmx_ctx* c, int phase) {
     const pmx_bsdmm_params& p = c->bsd;
     const float* scal = c->comm + c->N * c->K + (int64_t)c->KP * c->KP + MAXK;
     // the A step is applied before the collective: a repeated iteration would apply it twice on the ranks that did not
-    // fault, so the chained K1 (whose faults are repaired by repeating the iteration) is not used here
+    // fault, so the chained K1 (whose faults are repaired by repeating the iteration) is not used here.  (The fp16 kernels' range
+    // guard is NOT awaited behind every launch here -- a host sync per K1 of a rank's short iteration --: a refused launch ends the
+    // run with chain_error_text's explanation.)
     rc = chain_disable(c);
     if (rc != PMX_OK) return rc;
     if (p.n_order > 0 && !(p.n_order == 2 && p.order[0] == 0 && p.order[1] == 1))

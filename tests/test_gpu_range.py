@@ -188,3 +188,45 @@ def test_ordinary_problems_never_trip_the_guard(eng, orc, monkeypatch):
         dev.set_factors(A, S)
         dev.grad()
         assert dev.k1_info()["range_faults"] == 0 and dev.k1_info()["kernel"] == "k_grad_f16_v8"
+
+
+@pytest.mark.parametrize("case", ["user_prox_pgm", "user_step_pgm", "line_search", "user_prox_adaprox", "user_prox_bsdmm"])
+def test_one_iteration_per_call_paths_switch_on_the_spot(orc, case):
+    """Paths that run one iteration (or a piece of one) per call -- user callables (algorithms.py:37-39, 73-77), the line search
+    (:110-127) -- have no iteration to repeat: there every fp16 K1 launch is awaited and, refused, repeated in exact fp32 before
+    anything else is enqueued (pmx_api.hip: enqueue_grad).  From a start that trips the guard at once, mode f16x2 gives what mode f32
+    gives, bit for bit (the callables are the library's operators written out in NumPy)."""
+    import proxmin_amd as pm
+    M, N, K = 1024, 1024, 64
+    Y, A0, S0 = _far_start(orc, M, N, K)
+
+    def my_plus(X, step):
+        return np.maximum(X, 0)
+
+    def my_step(*X, it=None):
+        return tuple(0.5 * s for s in pm.nmf.step_pgm(*X))
+
+    out = {}
+    try:
+        for mode in ("f16x2", "f32"):
+            pm.set_default_mode(mode)
+            A, S = A0.copy(), S0.copy()
+            if case == "user_prox_pgm":
+                pm.nmf.nmf(Y, A, S, prox_A=my_plus, max_iter=3, e_rel=1e-12)
+            elif case == "user_step_pgm":
+                pm.nmf.nmf(Y, A, S, step=my_step, max_iter=3, e_rel=1e-12)
+            elif case == "line_search":
+                pm.nmf.nmf(Y, A, S, backtracking=True, f=partial(pm.nmf.log_likelihood, Y=Y), max_iter=3, e_rel=1e-12)
+            elif case == "user_prox_adaprox":
+                pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="amsgrad", prox_S=my_plus, max_iter=3, e_rel=1e-3, check_convergence=False)
+            else:
+                pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, prox_A=my_plus, proxs_g=[[pm.operators.prox_plus], None], max_iter=3, e_rel=1e-12)
+            out[mode] = (A, S)
+    finally:
+        pm.set_default_mode("f32")
+    for a, b in zip(out["f16x2"], out["f32"]):
+        assert np.isfinite(a).all()
+        if case in ("user_prox_adaprox",):
+            assert np.array_equal(a, b)
+        else:      # (pgm / bsdmm: the step rule in front of the refused K1 ran twice, see above)
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * np.abs(b).max())
