@@ -50,7 +50,8 @@ enum {
                             K max|A| max|S| > 2^16 max|Y| (factors that ran away from the data: entries with A S = 0 would
                             fall out of fp16's range) is refused before anything is written, and the context repeats the
                             iteration with the exact-f32 kernel of its frame and keeps it (pmx_k1_info reports both);
-                            entry points that run one iteration per call return PMX_E_HIP with that explanation. */
+                            entry points that run one iteration per call await every such launch and switch on the spot;
+                            row-sharded bSDMM alone returns PMX_E_HIP with that explanation. */
     PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
                             M, N <= 8192: the reference's own examples and BASELINE cfg1) and the fused loops of the three
