@@ -1,0 +1,32 @@
+"""GPU: a fixed-seed slice of the randomized end-to-end sweep (tests/fuzz_nmf.py; scratch/fuzz_nmf2.py runs it at any length): nmf()
+against the fp64 oracle over random shapes (ragged, any K), back-ends, arithmetic modes, weights, FISTA, the line search and every
+operator; fp64 inputs of small problems to 1e-9.  The sweep found two defects in round 4; this keeps a slice of
+it where the driver's `pytest -m gpu` sees it."""
+import logging
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fuzz():
+    import __graft_entry__ as g
+    g.build()
+    import fuzz_nmf
+    logging.getLogger("proxmin").setLevel(logging.ERROR)
+    yield fuzz_nmf
+    logging.getLogger("proxmin").setLevel(logging.NOTSET)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_problems_against_the_fp64_oracle(fuzz, seed):
+    lines = []
+    bad = fuzz.run(seed, 40, log=lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok"))
+
+
+def test_random_small_fp64_problems_to_1e9(fuzz):
+    lines = []
+    bad = fuzz.run(5, 40, F64=True, log=lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok"))
