@@ -114,3 +114,109 @@ def run(seed, n_cases, only=None, F64=False, log=print):
     pm.set_default_mode("f32")
     return bad
 
+
+
+def run_options(seed, n_cases, only=None, log=print):
+    """Second sweep: the ARGUMENTS of the three back-ends rather than shapes and operators -- stopping tests that fire (loose e_rel,
+    bsdmm's e_abs: the iteration the run ends at must be the oracle's), adaprox's b1 as an array, b2 / eps / p, a capped proximal loop
+    (prox_max_iter 1 .. 3), warm-started moments, prox=None on a block (algorithms.py:380), bsdmm with constraints on one block only.
+    -> number of failing cases"""
+    import proxmin_amd as pm
+    from oracle import nmf_oracle as orc
+    ops = pm.operators
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(n_cases):
+        big = rng.random() < 0.4
+        if big:
+            M, N, K = int(rng.integers(300, 1800)), int(rng.integers(300, 1800)), int(rng.choice([8, 32, 50, 64, 128]))
+        else:
+            M, N, K = int(rng.integers(5, 500)), int(rng.integers(5, 500)), int(rng.integers(1, 17))
+        algo = ["pgm", "adaprox", "bsdmm"][int(rng.integers(0, 3))]
+        mode = ["f32", "f16x2"][int(rng.integers(0, 2))]
+        e_rel = float(rng.choice([1e-2, 3e-2, 1e-3]))
+        max_iter = int(rng.integers(5, 40))
+        unity = rng.random() < 0.3
+        scheme = ["adam", "amsgrad", "nadam", "padam", "adamx"][int(rng.integers(0, 5))]
+        b1_kind, b2, eps, pp = int(rng.integers(0, 3)), float(rng.choice([0.999, 0.99])), float(rng.choice([1e-8, 1e-6])), float(rng.choice([0.25, 0.125]))
+        pmi = int(rng.choice([1000, 1000, 3, 1]))
+        check = rng.random() < 0.7
+        none_blk = int(rng.integers(0, 4))           # 0 / 1: prox=None on that block (adaprox), >= 2: none
+        accel = rng.random() < 0.4
+        e_abs = float(rng.choice([0.0, 0.0, 1e-4]))
+        g_kind = int(rng.integers(0, 3))
+        sd = int(rng.integers(1 << 30))
+        if only is not None and case not in only:
+            continue
+        Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=sd)
+        pS, sS = (partial(ops.prox_unity_plus, axis=0), ("unity_plus", 0)) if unity else (ops.prox_plus, ("plus",))
+        pA, sA = ops.prox_plus, ("plus",)
+        desc = "%dx%dx%d %s %s e_rel=%g max_iter=%d unity=%d" % (M, N, K, algo, mode, e_rel, max_iter, unity)
+        counts = {"dev": 0, "orc": 0}
+
+        def counter(key):
+            def cb(*X, it=None):
+                counts[key] += 1
+            return cb
+        pm.set_default_mode(mode)
+        A, S = A0.copy(), S0.copy()
+        Ao, So = A0.astype(np.float64), S0.astype(np.float64)
+        Y64 = Y.astype(np.float64)
+        try:
+            if algo == "pgm":
+                c = 0.5 if accel else 1.0
+                desc += " accel=%d" % accel
+                pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, accelerated=accel, step=pm.nmf.scaled_step_pgm(c), max_iter=max_iter, e_rel=e_rel, callback=counter("dev"))
+                orc.pgm_nmf(Y64, Ao, So, sA, sS, step=lambda A_, S_, it=None, grads=None: tuple(c * s for s in orc.lipschitz_steps(A_, S_)),
+                            accelerated=accel, max_iter=max_iter, e_rel=e_rel, callback=counter("orc"))
+            elif algo == "adaprox":
+                b1 = [0.9, 0.8, 0.9 * 0.98 ** np.arange(max_iter)][b1_kind]
+                if none_blk == 0:
+                    pA, sA = None, None
+                elif none_blk == 1 and not unity:
+                    pS, sS = None, None
+                warm = rng.random() < 0.3
+                kw = dict(scheme=scheme, b1=b1, b2=b2, eps=eps, p=pp, prox_max_iter=pmi, check_convergence=check, max_iter=max_iter, e_rel=e_rel)
+                desc += " %s b1kind=%d b2=%g eps=%g p=%g pmi=%d check=%d none=%d warm=%d" % (scheme, b1_kind, b2, eps, pp, pmi, check, none_blk, warm)
+                kwd, kwo = {}, {}
+                if warm:
+                    m0 = [np.full(A0.shape, 0.01, np.float32), np.full(S0.shape, -0.02, np.float32)]
+                    v0 = [np.full(A0.shape, 0.5, np.float32), np.full(S0.shape, 0.25, np.float32)]
+                    kwd = dict(M=[x.copy() for x in m0], V=[x.copy() for x in v0])
+                    kwo = dict(M=[x.astype(np.float64) for x in m0], V=[x.astype(np.float64) for x in v0])
+                pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, algorithm=pm.adaprox, callback=counter("dev"), **kw, **kwd)
+                orc.adaprox_nmf(Y64, Ao, So, sA, sS, callback=counter("orc"), **kw, **kwo)
+            else:
+                soft = (partial(ops.prox_soft, thresh=1e-3), ("soft", 1e-3, "relative"))
+                gl = [[[ops.prox_plus], [soft[0], ops.prox_plus]], [None, [ops.prox_plus]], [[soft[0]], None]][g_kind]
+                go = [[[("plus",)], [soft[1], ("plus",)]], [None, [("plus",)]], [[soft[1]], None]][g_kind]
+                desc += " e_abs=%g g=%d" % (e_abs, g_kind)
+                pm.nmf.nmf(Y, A, S, prox_A=pA, prox_S=pS, algorithm=pm.bsdmm, proxs_g=gl, max_iter=max_iter, e_rel=e_rel, e_abs=e_abs, callback=counter("dev"))
+                orc.bsdmm_nmf(Y64, Ao, So, sA, sS, proxs_g=go, max_iter=max_iter, e_rel=e_rel, e_abs=e_abs, callback=counter("orc"))
+            ok = True
+            worst, fr = 0.0, 1.0
+            dn = counts["dev"] - counts["orc"]
+            if abs(dn) > 1:
+                ok = False
+            elif dn == 0:
+                for a, b in ((A, Ao), (S, So)):
+                    if not np.array_equal(np.isnan(a), np.isnan(b)):
+                        ok = False
+                    fin = np.isfinite(b) & np.isfinite(a)
+                    a, b = a[fin], b[fin]
+                    if a.size == 0:
+                        continue
+                    r = np.abs(a.astype(np.float64) - b) / (2e-5 + 2e-4 * np.abs(b))
+                    worst = max(worst, float(r.max())); fr = min(fr, float((r <= 1).mean()))
+                if fr < 0.99 or (algo != "adaprox" and worst > 50):
+                    ok = False
+        except np.linalg.LinAlgError as e:
+            log("skip case %d %s: %s" % (case, desc, e))
+            continue
+        except Exception as e:
+            ok = False; worst = fr = float("nan"); dn = 0
+            log("EXC %s %s" % (type(e).__name__, str(e)[:300]))
+        log("%s case %d %s: callbacks %d / %d frac %.5f worst %.1f" % ("ok  " if ok else "FAIL", case, desc, counts["dev"], counts["orc"], fr, worst))
+        bad += not ok
+    pm.set_default_mode("f32")
+    return bad
