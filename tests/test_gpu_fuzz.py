@@ -30,3 +30,11 @@ def test_random_small_fp64_problems_to_1e9(fuzz):
     lines = []
     bad = fuzz.run(5, 40, F64=True, log=lines.append)
     assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok"))
+
+
+def test_random_arguments_against_the_fp64_oracle(fuzz):
+    """the ARGUMENTS of the back-ends (tests/fuzz_nmf.py: run_options): stopping tests that fire -- the run must end at the oracle's
+    iteration --, b1 arrays, b2 / eps / p, capped proximal loops, warm-started moments, prox=None, bsdmm's e_abs and one-sided constraints"""
+    lines = []
+    bad = fuzz.run_options(1, 40, log=lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok"))
