@@ -34,6 +34,10 @@ CASES = {
     # 2048 rows per rank x 16384: the chained K1 (chains of 4 workgroups).  Rank 1's third chained launch reports a fault
     # (PMX_INJECT_K1_FAULT): it falls back to slabs, rank 0 is stopped at the same iteration through the collective halt
     # flag, both go on from there.  (Two processes on one GPU can also fault for real -- not co-resident -- same path.)
+    # [r4] the range guard of the two-term fp16 kernels on ONE rank: the rows of rank 1 start 1e5 x above the data, its first K1 launch is
+    # refused (K max|A_local| max|S| > 2^16 max|Y_local|), it goes on in exact fp32; rank 0 -- whose rows are ordinary -- is stopped at the
+    # same iteration through the collective halt flag, repeats it and stays on the fp16 kernel (tests/test_gpu_range.py; adam: no eps clamp)
+    "adaprox_range_fault": dict(M=2048, N=1024, K=64, unity=False, its=5, scheme="adam", modes=("f16x2",), far_rows=(1024, 2048, 1e5)),
     "adaprox_chain_fault": dict(M=4096, N=16384, K=64, unity=True, its=6, modes=("f16x2", "f32", "bf16x3"), inject={1: "3"}),   # (k_grad_f16_v8 / k_grad_f32_pc / k_grad_bf16_v7)
 }
 
@@ -78,6 +82,8 @@ def _worker(rank, world, port, name, mode, out_dir):
         c = CASES[name]
         M, N, K = c["M"], c["N"], c["K"]
         Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
+        if c.get("far_rows"):
+            A0[c["far_rows"][0]:c["far_rows"][1]] *= np.float32(c["far_rows"][2])
         r0, r1 = pdist.shard_rows(M, world)[rank]
         A_l, S = A0[r0:r1].copy(), S0.copy()
         ops = pm.operators
@@ -109,6 +115,8 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
         pytest.skip("case is specific to another arithmetic mode")
     M, N, K = c["M"], c["N"], c["K"]
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
+    if c.get("far_rows"):
+        A0[c["far_rows"][0]:c["far_rows"][1]] *= np.float32(c["far_rows"][2])
     ops = pm.operators
     pm.set_default_mode(mode)
     try:
@@ -162,7 +170,8 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
         z = np.load(tmp_path / ("rank%d.npz" % r))
         assert int(z["n"]) == len(tb.trace)
         # the all-reduce sums the ranks' gS in a different order than the single-GPU slab fold: fp32 rounding only
-        if c.get("inject"):
+        if c.get("inject") or c.get("far_rows"):
+            # (far_rows: rank 0 stays on the fp16 kernel, the single-GPU run -- whose maxima are rank 1's -- is all fp32: two arithmetics)
             # after the fall-back this rank sums gA over slabs, the single-GPU run along chains: AMSGrad's eps clamp
             # turns that rounding difference into a visible one on a few entries per ten thousand (test_gpu_nmf.py)
             for got, want in ((z["A"], A1[int(z["r0"]):int(z["r1"])]), (z["S"], S1)):
