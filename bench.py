@@ -37,12 +37,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s is what a float4 copy achieves)
 MODE_DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32-class accuracy)",
-              "f16x2": "f16x2 (two-term fp16 split MFMA, fp32 accumulate, fp32-class accuracy)"}
+              "f16x2": "f16x2 (two-term fp16 split MFMA, fp32 accumulate, fp32-class accuracy)",
+              "f16x2r": "f16x2r (fp16 split MFMA: three terms + a second accumulator in the residual, two in the gradients; fp32 accumulate)"}
 MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
              "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)",
              "f16x2": "f16x2 (operands scaled by powers of two and split into two fp16 terms: 3 MFMA passes for each of A@S and the "
-                      "two gradients; fp32 accumulate; Y fp32 in HBM)"}
-MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
+                      "two gradients; fp32 accumulate; Y fp32 in HBM)",
+             "f16x2r": "f16x2r (as f16x2, with the third fp16 terms of A and S in A@S and its small products in a second accumulator: 5 + 3 + 3 MFMA passes; the residual in exact fp32's class)"}
+MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0, "f16x2r": 11.0 / 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
 
 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "k1_traffic.json")
@@ -89,11 +91,11 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
     gbs = (M * N * 4) / t / 1e9
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
     # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
-    fast = "k_grad_f16_v8" if mode == "f16x2" else "k_grad_bf16_v7"
+    fast = "k_grad_f16_v8" if mode == "f16x2" else ("k_grad_f16_v8<R3>" if mode == "f16x2r" else "k_grad_bf16_v7")
     bf16_kernel = fast if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp
     if kernel == "k_grad_f16_k32":           # K = 32 in mode f16x2: 6K/4 = 48 flop/B, the single pass over Y is the roof
         bf16_kernel = kernel
-    passes = MFMA_PASSES["f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3"]
+    passes = MFMA_PASSES["f16x2r" if bf16_kernel == "k_grad_f16_v8<R3>" else ("f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3")]
     if kernel == "k_grad_f16_k128":
         # K = 128: 6K/4 = 192 flop/B, x 3 issued MFMA flops per algorithmic flop: the fp16 matrix pipe, not the pass over Y,
         # is the roof (192 x 3 x 8 TB/s = 4.6 PFLOP/s of issue would be needed to run at HBM speed)
@@ -332,7 +334,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
-    ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2"],
+    ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2", "f16x2r"],
                     help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (default for cfg3 / cfg5, the headline), "
                          "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in fp32)")
     args = ap.parse_args()
@@ -450,6 +452,20 @@ def main():
             out["value_f32_mode"] = {"value": 20.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 20, "warmup": 25,
                                      "note": "same workload with the library's default arithmetic (exact fp32 MFMA, %s)" % dev32.k1_info()["kernel"]}
             dev32.close()
+            # ... and in mode f16x2r: the headline's kernel with the residual in exact fp32's class (three fp16 terms of A and S and a second
+            # accumulator in A@S): the rate at which the factors meet the fp64 oracle like exact fp32 does (tests/test_gpu_parity_long.py)
+            devr = DeviceNMF(M, N, K, device=local, mode="f16x2r")
+            devr.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+            devr.set_factors(A0, S0)
+            runr = begin_solver(devr, backend, unity)
+            runr(25)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runr(40)
+            torch.cuda.synchronize()
+            out["value_f16x2r_mode"] = {"value": 40.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 40, "warmup": 25,
+                                        "note": "same workload in mode f16x2r (%s: 5 instead of 3 fp16 products in A@S, the small ones in a second accumulator; parity class of exact fp32)" % devr.k1_info()["kernel"]}
+            devr.close()
         dev.close()
         if args.config == "cfg3" and not args.rows:
             # the other BASELINE configurations, short runs in the same process (same box, same build): driver-visible

@@ -19,7 +19,7 @@ MAXK = 128
 ABI_VERSION = 3
 
 # enums (include/pmx.h)
-MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64 = 0, 2, 3, 4
+MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64, MODE_F16X2R = 0, 2, 3, 4, 5
 PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "max": 6,
         "hard": 7, "hard_plus": 8, "soft": 9, "soft_plus": 10}
 SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}

@@ -116,6 +116,7 @@ struct GradBfArgs {
     DevStatus* wstatus;
     int chainInject;
     float rangeRatio;    // (see GradV4Args)
+    int r3;
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -866,6 +867,7 @@ struct GradV4Args {
     DevStatus* wstatus;  // writable view of `status` (fault report)
     int chainInject;     // tests: report a fault from this launch (exercises the host's fall-back)
     float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 4 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
+    int r3;              // [r4] k_grad_f16_v8<.., R3>: third terms of A and S in the residual's product, two accumulators
 };
 
 // (k_grad_bf16_v4's kernel was removed in round 4 together with k_grad_bf16_v5's: with K1's zero-padded frame -- pmx_k1_frame -- the
@@ -1488,7 +1490,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
         g.W = a.W; g.ldW = a.ldW;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
-        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio;
+        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio; g.r3 = a.r3;
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
         const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)

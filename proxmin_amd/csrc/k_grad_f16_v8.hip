@@ -17,6 +17,15 @@ __device__ __forceinline__ void v8_split2(const float4& x, float sc, f16x4& h, f
         l[i] = (_Float16)(v[i] - (float)t);
     }
 }
+// three fp16 terms of x sc (R3: the residual's operands): h = fp16(v), l = fp16(v - h), m = fp16(v - h - l) -- v - h and (v - h) - l are
+// exact in fp32, so the three terms carry v to 2^-33 of its magnitude (down to fp16's subnormal floor, 2^-38 of the scaled maximum)
+__device__ __forceinline__ void v8_split3(float x, float sc, _Float16& h, _Float16& l, _Float16& m) {
+    const float v = x * sc;
+    h = (_Float16)v;
+    const float e1 = v - (float)h;
+    l = (_Float16)e1;
+    m = (_Float16)(e1 - (float)l);
+}
 // (h, l) of the pair (r0 sc, r1 sc), packed: h = fp16(x), l = fp16(x - h) with x - h formed by ONE mixed-precision fma that reads
 // its fp16 operand directly (v_fma_mix*: fp32 product r sc -- exact, sc is a power of two -- minus h, rounded once: the same
 // value as fp16(x - float(h)), whose difference is exact in fp32).  Left to itself hipcc converts h back to fp32, subtracts
@@ -122,9 +131,20 @@ static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 
 // LOSS: the sum of squares (nmf.py:13-25) is accumulated only by the instance the loss-only pass runs (doA = doS = 0:
 // pmx_loglike, the backtracking line search); gradient passes never read it and skip its 16 multiply-adds per lane and block.
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS>
+// R3 [r4]: the RESIDUAL to fp32's class.  With two terms per operand P = A S carries the operands' representation errors (2^-23 each): far
+// below P's accumulation noise entry by entry, but COHERENT -- the same dS[k][n] in every row of P -- so the gradient contractions add
+// them up over a whole column (gS picks up A^T A dS: M times, not sqrt(M) times, a single error) and they end up twice fp32's gradient
+// error.  R3 adds the THIRD terms of A and S to the residual's product -- ah s3 + a3 sh beside ah sl + al sh -- and keeps everything but
+// ah sh in a second accumulator, R = (P_hh - Y) + P_lo: what lies below half an ulp of P survives the cancellation.  Five MFMAs per k
+// step instead of three in the producers, the consumers unchanged; S's third term in LDS (160 KB in all), A's in registers.
+// scratch/r4_emulate_modes.py (NumPy, full cfg3): out-of-tolerance entries against the fp64 oracle 5.8 x / 4.2 x the fp32 oracle's with
+// two terms (any number of terms in ONE accumulator: the same), 0.9 x / 1.0 x with this.
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
+    constexpr int NT = R3 ? 3 : 2;                       // fp16 terms of A and S in the residual's product
+    constexpr int SLB = NT * V5_S_TERM, OFF_A = NCB * SLB, OFF_R = OFF_A + V5_AIMG_BYTES;
+    static_assert(OFF_R + 2 * V5_R_BYTES <= 160 * 1024 && OFF_R % 256 == 0, "");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     if (chain_halted(a.status)) return;
@@ -220,21 +240,32 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             sr[c] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(c, tid >> 4) * K)[tid & 15];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
-            f16x4 t0, t1;
-            v8_split2(sr[c], scS, t0, t1);
-            unsigned char* d = smem + c * V8_SL_BYTES + st_off;
-            *reinterpret_cast<f16x4*>(d) = t0;
-            *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+            unsigned char* d = smem + c * SLB + st_off;
+            if constexpr (R3) {
+                const float x[4] = {sr[c].x, sr[c].y, sr[c].z, sr[c].w};
+                f16x4 t0, t1, t2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { _Float16 h_, l_, m_; v8_split3(x[q], scS, h_, l_, m_); t0[q] = h_; t1[q] = l_; t2[q] = m_; }
+                *reinterpret_cast<f16x4*>(d) = t0;
+                *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+                *reinterpret_cast<f16x4*>(d + 2 * V5_S_TERM) = t2;
+            } else {
+                f16x4 t0, t1;
+                v8_split2(sr[c], scS, t0, t1);
+                *reinterpret_cast<f16x4*>(d) = t0;
+                *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+            }
         }
     }
 
     if (producer) {
         // ================================ producers: GEMM1 and R =================================================
         f32x16 p0, p1;
+        f32x16 q0, q1;                       // R3: the small products' accumulators (see the kernel's header)
         float yv[2][2][16];                  // Y in flight: [pair set][block of the pair][row i of the tile] (accumulator layout)
         float wv[2][HASW ? 16 : 1];          // weights of ONE block pair (requested a slot ahead of their first use: registers)
         float4 areg[4][2];
-        f16x8 afr[4][2];
+        f16x8 afr[4][NT];
         const int jw = __builtin_amdgcn_readfirstlane(j);
         // Y addresses: ONE wave-uniform base per request group (scalar registers: this wave's first row of the panel, the
         // block pair's first column) + sixteen per-lane byte offsets that never change (row i of the tile in the
@@ -297,19 +328,24 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
                                     areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+                if constexpr (R3) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { _Float16 h_, l_, m_; v8_split3(x[q], scA, h_, l_, m_); afr[ks][0][q] = h_; afr[ks][1][q] = l_; afr[ks][2][q] = m_; }
+                } else {
                 unsigned hh[4], ll[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v8_split_pair(x[2 * q], x[2 * q + 1], scA, hh[q], ll[q]);
                 afr[ks][0] = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
                 afr[ks][1] = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+                }
             }
         };
         const int pa0 = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
         auto publish_A = [&]() {             // terms 0,1 of the current panel -> Aimg, for the consumers' gSt contraction
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa0 ^ (ks << 5))) = afr[ks][0];
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + V5_A_TERM + (pa0 ^ (ks << 5))) = afr[ks][1];
+                *reinterpret_cast<f16x8*>(smem + OFF_A + (pa0 ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<f16x8*>(smem + OFF_A + V5_A_TERM + (pa0 ^ (ks << 5))) = afr[ks][1];
             }
         };
         const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // GEMM1 B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
@@ -318,20 +354,20 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         using no = std::integral_constant<bool, false>;
         using set0 = std::integral_constant<int, 0>;
         using set1 = std::integral_constant<int, 1>;
-        if constexpr (!HASW) load_A(row0 + panel_at(0) * V5_BM);
+        if constexpr (!HASW && !R3) load_A(row0 + panel_at(0) * V5_BM);
         load_pair(0, set0{});                // slot s (even) requests the pair of blocks s + 2, s + 3 into the set block s - 1 has just left
         // slot 0 runs the same code as every other slot (no peeled copy: the loop head then sees the same requests in flight
         // from both sides and the compiler's wait counts stay exact): its epilogue works on a zero "block -1" -- R = 0 into
         // an image nobody reads before block 1 rewrites it, nothing added to the loss -- and requests the pair of blocks 2, 3
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yv[1][1][i] = 0.f; if constexpr (HASW) { wv[0][i] = 0.f; wv[1][i] = 0.f; } }
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; q1[i] = 0.f; q0[i] = 0.f; yv[1][1][i] = 0.f; if constexpr (HASW) { wv[0][i] = 0.f; wv[1][i] = 0.f; } }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
         // One slot; cb (the block's place in its panel) is a compile-time constant: the eight slots of a panel are ONE basic
         // block, every LDS address is a register plus an immediate, and the compiler counts the loads in flight exactly.
         // GEMM: block s = (rp, cb) into pc.  EPI: block s - 1 from pp and its Y tile -> R[(s - 1) & 1].
-        auto slot = [&](int rp, auto cb_c, f32x16& pc, f32x16& pp, auto gemm_c, auto epi_c) {
+        auto slot = [&](int rp, auto cb_c, f32x16& pc, f32x16& pp, f32x16& lc, f32x16& lp, auto gemm_c, auto epi_c) {
             constexpr int cb = decltype(cb_c)::value;
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
             constexpr int pset = ((cb + 7) >> 1) & 1, ptile = (cb + 7) & 1;     // pair set and place in its pair of block s - 1 (8 blocks per panel)
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             }
             PH(5)
             if constexpr (GEMM && cb == 0) { // block s opens a row panel: its A terms (rows requested 8 slots ago), then the next panel's rows
-                if constexpr (HASW) {        // (weighted: the registers of that prefetch hold weights; the rows are fetched here, an L2 trip per panel)
+                if constexpr (HASW || R3) {  // (weighted: the registers of that prefetch hold weights -- R3: the second accumulator and the third terms --; the rows are fetched here, an L2 trip per panel)
                     load_A(row0 + panel_at(rp) * V5_BM);
                     make_afr();
                 } else {
@@ -350,14 +386,23 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                     load_A(row0 + panel_at(rp + 1 < nrp ? rp + 1 : nrp - 1) * V5_BM);
                 }
             }
-            f16x8 sv[4][2];
-            if constexpr (GEMM) {
-                const unsigned char* Slb = smem + cb * V8_SL_BYTES;
+            f16x8 sv[4][NT];
+            const unsigned char* Slb = smem + cb * SLB;
+            auto read_sv = [&](int ks) {     // R3: the fragments of k step ks, requested one k step (five MFMAs) ahead of their first reader
+                const int so = s_g1 ^ (ks << 5);
+                sv[ks][0] = *reinterpret_cast<const f16x8*>(Slb + so);
+                sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                if constexpr (R3) sv[ks][2] = *reinterpret_cast<const f16x8*>(Slb + so + 2 * V5_S_TERM);
+            };
+            if constexpr (GEMM && R3) {
+                read_sv(0);
+            } else if constexpr (GEMM) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int so = s_g1 ^ (ks << 5);
                     sv[ks][0] = *reinterpret_cast<const f16x8*>(Slb + so);
                     sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                    if constexpr (R3) sv[ks][2] = *reinterpret_cast<const f16x8*>(Slb + so + 2 * V5_S_TERM);
                 }
             }
             PH(2)
@@ -366,7 +411,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             // steps 0-7 one pair of R entries each (residual, two-term split: six vector instructions; every second step the
             // two 8-byte stores of a finished group), steps 8-11 four of the sixteen requests of the next block pair.  The
             // fences keep hipcc from regrouping it (left alone it ran the whole epilogue first and the twelve MFMAs after it).
-            unsigned char* Rb = smem + V8_OFF_R + ((cb + 1) & 1) * V5_R_BYTES;    // block s - 1 has the other parity
+            unsigned char* Rb = smem + OFF_R + ((cb + 1) & 1) * V5_R_BYTES;    // block s - 1 has the other parity
             unsigned h2[4][2], l2[4][2];
             const char* ybase_n = nullptr;
             const char* wbase_n = nullptr;
@@ -376,8 +421,28 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
-                if constexpr (GEMM) {
+            for (int t = 0; t < (R3 ? 20 : 12); ++t) {
+                if constexpr (GEMM && R3) {
+                    // per k step: al sh, ah sl, a3 sh, ah s3 into the small products' accumulator, ah sh into the other (steps 12-19 have
+                    // no epilogue piece beside them: the epilogue is eight pieces and four groups of requests as before)
+                    const int ks = t / 5, wh = t % 5;
+                    if (wh == 0 && ks < 3) read_sv(ks + 1);
+                    if (wh == 4) {
+                        f32x16 cin = pc;
+                        if (t == 4) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) cin[i] = 0.f;
+                        }
+                        pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][0], cin, 0, 0, 0);
+                    } else {
+                        f32x16 cin = lc;
+                        if (t == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) cin[i] = 0.f;
+                        }
+                        lc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][wh == 0 ? 1 : (wh == 2 ? 2 : 0)], sv[ks][wh == 1 ? 1 : (wh == 3 ? 2 : 0)], cin, 0, 0, 0);
+                    }
+                } else if constexpr (GEMM) {
                     const int ks = t / 3, wh = t % 3;        // al sh, ah sl, ah sh
                     f32x16 cin = pc;
                     if (t == 0) {
@@ -394,6 +459,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         for (int q = 0; q < 2; ++q) {
                             const int e = 4 * g + 2 * hf + q;
                             r[q] = pp[e] * unP - yv[pset][ptile][e];
+                            if constexpr (R3) r[q] = __builtin_fmaf(lp[e], unP, r[q]);     // (P_hh - Y) + P_lo
                             if constexpr (HASW) {
                                 const float ww = wv[ptile][e];
                                 if constexpr (LOSS) lossAcc += ww * (r[q] * r[q]);
@@ -409,6 +475,8 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                             *reinterpret_cast<uint2*>(Rb + V5_R_TERM + o) = make_uint2(l2[g][0], l2[g][1]);
                         }
                     } else if constexpr ((cb & 1) == 0) {
+                        if (t >= 12) {}
+                        else
                         if (t == 8) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
                         if (t == 9) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
                         if (t == 10) load_pair_rows(ybase_n, wbase_n, std::integral_constant<int, pset>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
@@ -434,17 +502,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         // even blocks: accumulator p0; odd blocks: p1
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
-            slot(rp, c0{}, p0, p1, yes{}, yes{});
-            slot(rp, c1{}, p1, p0, yes{}, yes{});
-            slot(rp, c2{}, p0, p1, yes{}, yes{});
-            slot(rp, c3{}, p1, p0, yes{}, yes{});
-            slot(rp, c4{}, p0, p1, yes{}, yes{});
-            slot(rp, c5{}, p1, p0, yes{}, yes{});
-            slot(rp, c6{}, p0, p1, yes{}, yes{});
-            slot(rp, c7{}, p1, p0, yes{}, yes{});
+            slot(rp, c0{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c1{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c2{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c3{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c4{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c5{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c6{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c7{}, p1, p0, q1, q0, yes{}, yes{});
         }
-        slot(nrp, c0{}, p0, p1, no{}, yes{});
-        slot(nrp, c1{}, p1, p0, no{}, no{});
+        slot(nrp, c0{}, p0, p1, q0, q1, no{}, yes{});
+        slot(nrp, c1{}, p1, p0, q1, q0, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt row halves)
     } else {
@@ -499,9 +567,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             PH(9)
         };
         auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
-            const unsigned char* Rb = smem + V8_OFF_R + (b & 1) * V5_R_BYTES;
-            const unsigned char* Slb = smem + cb * V8_SL_BYTES;
-            const unsigned char* Ab = smem + V8_OFF_A;
+            const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + cb * SLB;
+            const unsigned char* Ab = smem + OFF_A;
             if (a.doA & 1) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -658,14 +726,19 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS>
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
+    constexpr int lds = R3 ? V7_LDS_BYTES : V8_LDS_BYTES;        // (three S terms: the split-bf16 kernel's 160 KB)
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
+    if (a.r3 && a.W == nullptr) {    // R3: the residual to fp32's class (unweighted instances; a weighted context keeps two terms)
+        if (!(a.doA & 1) && !a.doS) return grad_launch_f16_v8_t<false, false, false, true, true>(a, stream);
+        return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, true>(a, stream);
+    }
     if (!(a.doA & 1) && !a.doS)      // the loss-only pass (no gradient is written: nothing to chain)
         return a.W != nullptr ? grad_launch_f16_v8_t<false, true, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, true>(a, stream);
     if (a.chainL > 0) return a.W != nullptr ? grad_launch_f16_v8_t<false, true, true, false>(a, stream) : grad_launch_f16_v8_t<false, false, true, false>(a, stream);

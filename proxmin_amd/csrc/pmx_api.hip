@@ -122,6 +122,7 @@ struct pmx_ctx {
     // k_grad_f16_v8.hip): the context then continues in exact fp32 on the same frame (k1_leave_f16).  PMX_F16_RANGE=n: ratio 2^n, 0: no check
     float rangeRatio = 65536.f;
     int rangeFaults = 0;
+    int f16_r3 = 0;                        // k_grad_f16_v8<.., R3>: the residual with three terms per operand and two accumulators (PMX_F16_R3=1; see the kernel)
     bool k1_sync_check = false;            // one-iteration-per-call paths (nothing to repeat into): every fp16 K1 launch is awaited and, refused, repeated in fp32 on the spot (enqueue_grad)
     int ncu = 0;
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
@@ -370,6 +371,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     if (K > MAXK) FAIL(PMX_E_UNSUPPORTED, "K=%lld > %d components is not supported", (long long)K, MAXK);
     if (M > (1ll << 30) || N > (1ll << 30)) FAIL(PMX_E_UNSUPPORTED, "dimension too large");
+    const bool want_r3 = mode == PMX_MODE_F16X2R;
+    if (want_r3) mode = PMX_MODE_F16X2;          // the same kernels, frames and fall-backs; k_grad_f16_v8 runs its <R3> instance
     if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2 && mode != PMX_MODE_F64) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
     if (mode == PMX_MODE_F64 && !(grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192))
         FAIL(PMX_E_UNSUPPORTED, "fp64 arithmetic is implemented for small problems only (K <= 16, M N <= 2^20, M, N <= 8192); %lld x %lld x %lld runs in fp32",
@@ -397,6 +400,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
     c->ncu = ncu;
+    c->f16_r3 = want_r3;
+    if (const char* e = getenv("PMX_F16_R3")) c->f16_r3 = atoi(e) != 0;        // (A/B switch: any f16x2 context)
     if (const char* e = getenv("PMX_F16_RANGE")) c->rangeRatio = atoi(e) > 0 ? ldexpf(1.f, atoi(e)) : 0.f;
     c->Kk = K;
     if (!(getenv("PMX_FRAME") && atoi(getenv("PMX_FRAME")) == 0) && mode != PMX_MODE_F64 && !grad_small_applies(M, N, K)) {
@@ -597,7 +602,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->f64 ? 7 : c->k32f16 ? 8 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? 2 : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64 ? 7 : c->k32f16 ? 8 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? 9 : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -1119,7 +1124,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
-            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
+            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio; g.r3 = c->f16_r3;
         }
         if (c->chainL > 0) {                 // k_grad_f16_v8<.., CHAIN> / k_grad_bf16_v7<.., CHAIN>
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over

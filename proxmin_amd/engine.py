@@ -34,9 +34,9 @@ _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
 def set_default_mode(mode):
-    """Select the contraction arithmetic used by nmf() and friends ("f32", "bf16x3" or "f16x2")."""
+    """Select the contraction arithmetic used by nmf() and friends ("f32", "bf16x3", "f16x2" or "f16x2r")."""
     global _DEFAULT_MODE
-    assert mode in ("f32", "bf16x3", "f16x2")
+    assert mode in ("f32", "bf16x3", "f16x2", "f16x2r")
     _DEFAULT_MODE = mode
 
 
@@ -70,7 +70,7 @@ class DeviceNMF:
         mode = mode or _DEFAULT_MODE
         self.mode = mode
         self.f64 = mode == "f64"          # fp64 operands, products and sums (small problems, the fused loops of the three back-ends: k_small_f64.hip)
-        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f64": _lib.MODE_F64}[mode]
+        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f16x2r": _lib.MODE_F16X2R, "f64": _lib.MODE_F64}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
                                            C.c_void_p(stream) if stream else None))
@@ -80,9 +80,10 @@ class DeviceNMF:
         # K outside {64, 128} run the generic split-bf16 kernels or the exact-fp32 one, 1.5-3 x slower per pass
         if mode not in ("f32", "f64"):
             k = self.k1_info()["kernel"]
-            fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small")}[mode]
+            fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small"),
+                    "f16x2r": ("k_grad_f16_v8_r3", "k_grad_small")}[mode]
             generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
-            if k not in fast or generic_bf16 or (mode == "f16x2" and k == "k_grad_bf16"):
+            if k not in fast or generic_bf16 or (mode in ("f16x2", "f16x2r") and k == "k_grad_bf16"):
                 _notice((mode, k, self.K, self.M % 128 == 0, self.N % 256 == 0),
                         "proxmin_amd: mode %s at %d x %d x %d runs %s, not the tuned kernel (those take K = 64 with M %% 128 = 0 and "
                         "N %% 256 = 0, or K = 128 with M %% 128 = 0 and N %% 128 = 0)" % (mode, self.M, self.N, self.K, k))
@@ -91,7 +92,7 @@ class DeviceNMF:
     def close(self):
         if getattr(self, "h", None):
             try:
-                if self.mode == "f16x2" and self.k1_info()["range_faults"]:
+                if self.mode in ("f16x2", "f16x2r") and self.k1_info()["range_faults"]:
                     _notice(("range", self.M, self.N, self.K),
                             "proxmin_amd: mode f16x2 at %d x %d x %d: the factors ran away from the data (K max|A| max|S| > 2^16 max|Y|: one fp16 "
                             "scale cannot carry that residual); the run went on with the exact-fp32 kernel" % (self.M, self.N, self.K))
@@ -217,7 +218,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool((v7 // 1000000) % 10)
         d["range_faults"] = v7 // 10000000   # 1: a two-term fp16 K1 refused the residual's range, the context went on in exact fp32 (f16_range_fault)

@@ -26,7 +26,7 @@ SHAPES = [(33, 47, 3), (64, 96, 8), (100, 300, 12), (513, 700, 16), (128, 128, 3
           (1024, 640, 64), (384, 1100, 100), (512, 512, 128), (4096, 4096, 32)]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2", "f16x2r"])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_fused_gradient_matches_oracle(eng, orc, M, N, K, mode):
     """K1 (nmf.grad_likelihood + log_likelihood) vs NumPy, fp32 tolerance: the contraction runs on
@@ -555,7 +555,30 @@ def test_k32_two_term_fp16_kernel(eng, orc, M, N):
             assert dev.k1_info()["kernel"] == "k_grad_f16_k32" and dev.k1_info()["frame_K"] == 32
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_third_terms_in_the_residual_remove_the_coherent_error(eng, orc):
+    """[r4] What mode f16x2r is for (k_grad_f16_v8<R3>).  With two fp16 terms per operand, P = A S carries the operands' representation
+    errors -- 2^-23 each, far below P's accumulation noise entry by entry, but the SAME dS[k][n] in every row of P: gS = A^T R picks up
+    A^T A dS, a sum that grows with M and not with sqrt(M).  On a problem with non-negative factors (every entry of A^T A positive) the
+    error of gS against fp64 is about twice exact fp32's in mode f16x2 and back at exact fp32's in mode f16x2r (NumPy emulation:
+    scratch/r4_emulate_modes.py -- 3.0e-7 / 1.5e-7 / 1.5e-7 of max|gS| at this size), gA alike through S S^T."""
+    M, N, K = 2048, 2048, 64
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float32, unity_S=True, seed=4321)
+    r64 = orc.residual_gradients(A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64))
+    err = {}
+    for mode in ("f32", "f16x2", "f16x2r"):
+        with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+            assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32_pc", "f16x2": "k_grad_f16_v8", "f16x2r": "k_grad_f16_v8_r3"}[mode]
+            dev.set_Y(Y)
+            dev.set_factors(A, S)
+            g = dev.grad()
+            g2 = dev.grad()
+            assert np.array_equal(g[0], g2[0]) and np.array_equal(g[1], g2[1])
+        err[mode] = [float(np.sqrt(((g[j] - r64[j]) ** 2).mean()) / np.abs(r64[j]).max()) for j in range(2)]
+    assert err["f16x2r"][1] <= 0.7 * err["f16x2"][1], err          # gS: the coherent part is gone ...
+    assert err["f16x2r"][1] <= 1.3 * err["f32"][1] and err["f16x2r"][0] <= 1.3 * err["f32"][0], err      # ... and both are exact fp32's class
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2", "f16x2r"])
 def test_full_size_gradient_against_subsampled_oracle(eng, mode):
     """BASELINE's headline shape (16384 x 16384, K = 64): the gradients of 256 random rows of A and 256 random columns of
     S against the fp64 oracle (which needs only those rows / columns of Y), every arithmetic mode; mode f16x2 runs the

@@ -75,7 +75,7 @@ def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, 
     M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
     Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 4321, torch.device("cuda", 0))
     dev_out = {}
-    for mode in ("f32", "f16x2", "bf16x3"):     # (bf16x3: recorded beside the other two -- three bf16 terms in A S, two in the gradient products)
+    for mode in ("f32", "f16x2", "bf16x3", "f16x2r"):     # (bf16x3: recorded beside the others -- three bf16 terms in A S, two in the gradient products)
         dev_out[mode] = _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, 3)
     Y32 = Yd.cpu().numpy()
     del Yd
@@ -97,6 +97,12 @@ def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, 
             if mode == "f32":
                 assert out_dev <= 2.0 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
                 assert got[b][1] <= 3.0 * max(yard[b][1], 1.0), (mode, b, got[b][1], yard[b][1])
+            elif mode == "f16x2r":
+                # [r4] the residual with three fp16 terms per operand and a second accumulator (k_grad_f16_v8<R3>): in exact fp32's class
+                # -- measured A 8 entries of 1 M (yardstick 1, mode f32 5), S 1.8 x the yardstick (mode f32 1.1 x, mode f16x2 4.2 x), worst
+                # entry 136 x the bound (82 x / 905 x)
+                assert out_dev <= 2.5 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
+                assert got[b][1] <= 4.0 * max(yard[b][1], 1.0), (mode, b, got[b][1], yard[b][1])
             else:
                 assert out_dev <= (2.5e-4 if b == "A" else 1e-3), (mode, b, out_dev, out_ref)
                 assert got[b][1] <= 2000.0, (mode, b, got[b][1])
