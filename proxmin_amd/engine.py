@@ -30,6 +30,9 @@ def _notice(key, msg):
 #   "f16x2"  as "bf16x3", but shapes with K = 64, M % 128 = 0, N % 256 = 0 run the two-term fp16 kernel (operands scaled
 #            by powers of two from the factor maxima: 9 instead of 12 MFMA products per multiply-add), and so do shapes
 #            with K = 128, M % 128 = 0, N % 128 = 0 (k_grad_f16_k128; no weights there)
+#   "f16x2r" "f16x2" with the RESIDUAL in exact fp32's class where k_grad_f16_v8 runs (K1's K = 64): the third fp16 terms of A and S in
+#            A@S and its small products in a second accumulator (11 instead of 9 products; include/pmx.h: PMX_MODE_F16X2R) -- the
+#            two-term product carries the operands' representation errors coherently into the gradients; other K as "f16x2"
 _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
