@@ -14,8 +14,13 @@ import __graft_entry__ as g
 
 # mangled-name fragment -> max spilled VGPRs (current values in the comments)
 LIMITS = {
-    "13k_grad_f16_v8ILb0ELb0ELb1E": 8,    # 3   two-term fp16 K1 with the chained gA accumulation (bench default)
-    "13k_grad_f16_v8ILb0ELb0ELb0E": 8,    # 0   the same with one gA slab per column region (6 in its loss-only instance)
+    "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb0E": 8,    # 3   two-term fp16 K1 with the chained gA accumulation (bench default)
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0E": 8,    # 0   the same with one gA slab per column region
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb1ELb0E": 8,    # 6   its loss-only instance
+    # [r4] <.., R3> (mode f16x2r): a second accumulator and the third terms of A and S in the producers; one scratch access in the slot loop
+    "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb1E": 12,   # 8   chained
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb1E": 12,   # 9   slabs
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb1ELb1E": 24,   # 18  loss-only
     "13k_grad_f16_v8ILb0ELb1ELb0E": 8,    # 0   weighted (5 in its loss-only instance)
     "13k_grad_f16_v8ILb0ELb1ELb1E": 8,    # 3   weighted, chained
     # two-term fp16 K1 at K = 128.  [r4] gSt re-split (one k tile per consumer wave, all 128 rows): 128 accumulator registers
