@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "adaprox_unity": dict(M=768, N=900, K=24, unity=True, its=9),
     "adaprox_k64_blocks": dict(M=1024, N=1280, K=64, unity=False, its=6),      # rows per rank 512, N % 256 = 0: the fast 16-bit-split kernels / the f32 whole-block kernel
+    "adaprox_k64_r3": dict(M=1024, N=1280, K=64, unity=True, its=6, modes=("f16x2r",)),      # [r4] k_grad_f16_v8<R3> on both ranks (mode f16x2r)
     "adaprox_k128": dict(M=512, N=640, K=128, unity=False, its=5, modes=("f32", "f16x2")),   # 256 rows per rank: k_grad_f16_k128 in mode f16x2
     # S-split: the S update sharded too (reduce-scatter -> each rank updates N / 2 columns and their moments -> all-gather);
     # the cases above keep S replicated behind an all-reduce (s_split=False), these run the other mode on the same problems
@@ -102,7 +103,7 @@ def _worker(rank, world, port, name, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2", "f16x2r"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     import torch.multiprocessing as mp
@@ -111,7 +112,7 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
     import proxmin_amd as pm
     from oracle import nmf_oracle as orc
     c = CASES[name]
-    if mode not in c.get("modes", (mode,)):
+    if mode not in c.get("modes", (mode,)) or (mode == "f16x2r" and "f16x2r" not in c.get("modes", ())):
         pytest.skip("case is specific to another arithmetic mode")
     M, N, K = c["M"], c["N"], c["K"]
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=c.get("unity", False), seed=4)
