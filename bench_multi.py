@@ -131,8 +131,8 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
                       "frac": 3.0 * ach / 2500.0, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
                       "k1_share_of_step": k1_avg_ms * nk1 * args.steps / (1e3 * dt), "k1_layout": info,
                       "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC)"} if info["kernel"] == "k_grad_f16_k128" else
-                     {"kernel": ((("k_grad_f16_v8" + ("<chain %d>" % info["chain"] if info["chain"] else "") if dev.mode == "f16x2" else "k_grad_bf16_v7") if N % 256 == 0 else "k_grad_bf16_v5") if (K == 64 and Ml % 128 == 0 and N % 64 == 0)
-                                 else "k_grad_bf16"), "bound": "hbm", "k1_layout": info,
+                     {"kernel": (info["kernel"].replace("_r3", "<R3>") + ("<chain %d>" % info["chain"] if info["chain"] else "")) if info["kernel"] != "k_grad_bf16" or not (K == 64 and Ml % 128 == 0 and N % 256 == 0)
+                      else "k_grad_bf16_v7" + ("<chain %d>" % info["chain"] if info["chain"] else ""), "bound": "hbm", "k1_layout": info,     # (pmx_k1_info names the kernel that ran)
                       "achieved": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9, "peak": 8000.0,
                       "unit": "GB/s", "frac": Ml * N * 4 / (k1_avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                       "avg_launch_ms": k1_avg_ms, "launches": k1_n, "algorithmic_tflops": ach,
