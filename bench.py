@@ -93,9 +93,9 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
     # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
     fast = "k_grad_f16_v8" if mode == "f16x2" else ("k_grad_f16_v8<R3>" if mode == "f16x2r" else "k_grad_bf16_v7")
     bf16_kernel = fast if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp
-    if kernel == "k_grad_f16_k32":           # K = 32 in mode f16x2: 6K/4 = 48 flop/B, the single pass over Y is the roof
-        bf16_kernel = kernel
-    passes = MFMA_PASSES["f16x2r" if bf16_kernel == "k_grad_f16_v8<R3>" else ("f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3")]
+    if kernel in ("k_grad_f16_k32", "k_grad_f16_k32_r3"):           # K = 32 in mode f16x2 / f16x2r: 6K/4 = 48 flop/B, the single pass over Y is the roof
+        bf16_kernel = "k_grad_f16_k32" if kernel == "k_grad_f16_k32" else "k_grad_f16_k32<R3>"
+    passes = MFMA_PASSES["f16x2r" if bf16_kernel in ("k_grad_f16_v8<R3>", "k_grad_f16_k32<R3>") else ("f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3")]
     if kernel == "k_grad_f16_k128":
         # K = 128: 6K/4 = 192 flop/B, x 3 issued MFMA flops per algorithmic flop: the fp16 matrix pipe, not the pass over Y,
         # is the roof (192 x 3 x 8 TB/s = 4.6 PFLOP/s of issue would be needed to run at HBM speed)

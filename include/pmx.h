@@ -52,12 +52,12 @@ enum {
                             iteration with the exact-f32 kernel of its frame and keeps it (pmx_k1_info reports both);
                             entry points that run one iteration per call await every such launch and switch on the spot;
                             row-sharded bSDMM alone returns PMX_E_HIP with that explanation. */
-    PMX_MODE_F16X2R = 5, /* [r4] PMX_MODE_F16X2 with the RESIDUAL to fp32's class: where k_grad_f16_v8 runs (K1's K = 64: K = 64 and 32 < K < 64
-                            shapes, unweighted) A S takes the third fp16 terms of A and S as well (ah s3 + a3 sh beside ah sl + al sh) and
+    PMX_MODE_F16X2R = 5, /* [r4] PMX_MODE_F16X2 with the RESIDUAL to fp32's class: where k_grad_f16_v8 / k_grad_f16_k32 run (K1's K = 64 or 32: every
+                            K <= 64 on the tuned frame; k_grad_f16_v8's unweighted instances) A S takes the third fp16 terms of A and S as well (ah s3 + a3 sh beside ah sl + al sh) and
                             keeps everything but ah sh in a second accumulator, R = (P_hh - Y) + P_lo -- 5 instead of 3 products in that
                             contraction, the gradient contractions unchanged.  The two-term product carries the operands' representation
                             errors COHERENTLY into the gradients (k_grad_f16_v8.hip, <R3>); this mode's factors are in exact fp32's class
-                            against the fp64 oracle at 2 x its rate.  Other K: the kernels of PMX_MODE_F16X2.  pmx_k1_info: kernel 9 */
+                            against the fp64 oracle at 2 x its rate.  K = 128: the kernel of PMX_MODE_F16X2 (its LDS is full).  pmx_k1_info: kernels 9, 10 */
     PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
                             M, N <= 8192: the reference's own examples and BASELINE cfg1) and the fused loops of the three
@@ -219,7 +219,7 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
  * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
  * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small, 5 two-term fp16 at K = 128
  * k_grad_f16_k128, 6 exact fp32 with producer / consumer wavefronts k_grad_f32_pc, 7 the fp64 small-problem kernels, 8 two-term fp16 at K = 32
- * k_grad_f16_k32, 9 k_grad_f16_v8<R3>: PMX_MODE_F16X2R), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * k_grad_f16_k32, 9 / 10 k_grad_f16_v8<R3> / k_grad_f16_k32<R3>: PMX_MODE_F16X2R), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
  * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now + 10000000 if a two-term fp16 kernel

@@ -19,9 +19,14 @@
 // No chains (16 column regions at 4096 columns: 16 gA slabs of 512 KB), no weights (a weighted context at this shape runs the
 // split-bf16 kernels or reopens in fp32: engine.open_weighted).  LDS as v8: 128 KB.
 // ------------------------------------------------------------------------------------------------
-template <bool LOSS>
+// R3 [r4]: mode f16x2r -- the third fp16 terms of A and S in the residual's product and a second accumulator, as in k_grad_f16_v8<.., R3>
+// (why: that kernel's header): 5 instead of 3 MFMAs per k step in the producers, S's third term in LDS (160 KB in all).
+template <bool LOSS, bool R3 = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
     constexpr int K = 32, ROWB = 128, NCB = V5_NB, KS = 2;
+    constexpr int NT = R3 ? 3 : 2;
+    constexpr int SLB = NT * V5_S_TERM, OFF_A = NCB * SLB, OFF_R = OFF_A + V5_AIMG_BYTES;
+    static_assert(OFF_R + 2 * V5_R_BYTES <= 160 * 1024 && OFF_R % 256 == 0, "");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     if (chain_halted(a.status)) return;
@@ -97,20 +102,31 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
             sr[c2] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(2 * c2 + (row64 >> 5), r) * K)[f4];
 #pragma unroll
         for (int c2 = 0; c2 < NCB / 2; ++c2) {
-            f16x4 t0, t1;
-            v8_split2(sr[c2], scS, t0, t1);
-            unsigned char* d = smem + (2 * c2 + (row64 >> 5)) * V8_SL_BYTES + st_off;
-            *reinterpret_cast<f16x4*>(d) = t0;
-            *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+            unsigned char* d = smem + (2 * c2 + (row64 >> 5)) * SLB + st_off;
+            if constexpr (R3) {
+                const float x[4] = {sr[c2].x, sr[c2].y, sr[c2].z, sr[c2].w};
+                f16x4 t0, t1, t2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { _Float16 h_, l_, m_; v8_split3(x[q], scS, h_, l_, m_); t0[q] = h_; t1[q] = l_; t2[q] = m_; }
+                *reinterpret_cast<f16x4*>(d) = t0;
+                *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+                *reinterpret_cast<f16x4*>(d + 2 * V5_S_TERM) = t2;
+            } else {
+                f16x4 t0, t1;
+                v8_split2(sr[c2], scS, t0, t1);
+                *reinterpret_cast<f16x4*>(d) = t0;
+                *reinterpret_cast<f16x4*>(d + V5_S_TERM) = t1;
+            }
         }
     }
 
     if (producer) {
         // ================================ producers: P = A S and R ================================================
         f32x16 p0, p1;
+        f32x16 q0, q1;                       // R3: the small products' accumulators
         float yv[2][2][16];                  // Y in flight: [pair set][block of the pair][row i of the tile] (accumulator layout)
         float4 areg[KS][2];
-        f16x8 afr[KS][2];
+        f16x8 afr[KS][NT];
         const int jw = __builtin_amdgcn_readfirstlane(j);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         unsigned yoff[16];
@@ -145,19 +161,24 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
             for (int ks = 0; ks < KS; ++ks) {
                 const float x[8] = {areg[ks][0].x, areg[ks][0].y, areg[ks][0].z, areg[ks][0].w,
                                     areg[ks][1].x, areg[ks][1].y, areg[ks][1].z, areg[ks][1].w};
+                if constexpr (R3) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { _Float16 h_, l_, m_; v8_split3(x[q], scA, h_, l_, m_); afr[ks][0][q] = h_; afr[ks][1][q] = l_; afr[ks][2][q] = m_; }
+                } else {
                 unsigned hh[4], ll[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v8_split_pair(x[2 * q], x[2 * q + 1], scA, hh[q], ll[q]);
                 afr[ks][0] = __builtin_bit_cast(f16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
                 afr[ks][1] = __builtin_bit_cast(f16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+                }
             }
         };
         const int pa0 = (j * 32 + l31) * ROWB + ((hi ^ v3_swz(j * 32 + l31)) << 4);   // chunk 2 ks + hi: ^ (ks << 5)
         auto publish_A = [&]() {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + (pa0 ^ (ks << 5))) = afr[ks][0];
-                *reinterpret_cast<f16x8*>(smem + V8_OFF_A + V5_A_TERM + (pa0 ^ (ks << 5))) = afr[ks][1];
+                *reinterpret_cast<f16x8*>(smem + OFF_A + (pa0 ^ (ks << 5))) = afr[ks][0];
+                *reinterpret_cast<f16x8*>(smem + OFF_A + V5_A_TERM + (pa0 ^ (ks << 5))) = afr[ks][1];
             }
         };
         const int s_g1 = l31 * ROWB + ((hi ^ v3_swz(l31)) << 4);                 // P's B operand: row l31, chunk 2 ks + hi: ^ (ks << 5)
@@ -168,11 +189,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         load_A(row0);
         load_pair_rows(pair_base(0), set0{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; yv[1][1][i] = 0.f; }      // the zero "block -1" of slot 0 (see k_grad_f16_v8)
+        for (int i = 0; i < 16; ++i) { p1[i] = 0.f; q0[i] = 0.f; q1[i] = 0.f; yv[1][1][i] = 0.f; }      // the zero "block -1" of slot 0 (see k_grad_f16_v8)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();        // Sl published
 
-        auto slot = [&](int rp, auto cb_c, f32x16& pc, f32x16& pp, auto gemm_c, auto epi_c) {
+        auto slot = [&](int rp, auto cb_c, f32x16& pc, f32x16& pp, f32x16& lc, f32x16& lp, auto gemm_c, auto epi_c) {
             constexpr int cb = decltype(cb_c)::value;
             constexpr bool GEMM = decltype(gemm_c)::value, EPI = decltype(epi_c)::value;
             constexpr int pset = ((cb + 7) >> 1) & 1, ptile = (cb + 7) & 1;     // pair set and place in its pair of block s - 1
@@ -185,24 +206,44 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
                 make_afr();
                 load_A(row0 + (rp + 1 < nrp ? rp + 1 : nrp - 1) * V5_BM);
             }
-            f16x8 sv[KS][2];
+            f16x8 sv[KS][NT];
             if constexpr (GEMM) {
-                const unsigned char* Slb = smem + cb * V8_SL_BYTES;
+                const unsigned char* Slb = smem + cb * SLB;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int so = s_g1 ^ (ks << 5);
                     sv[ks][0] = *reinterpret_cast<const f16x8*>(Slb + so);
                     sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                    if constexpr (R3) sv[ks][2] = *reinterpret_cast<const f16x8*>(Slb + so + 2 * V5_S_TERM);
                 }
             }
-            unsigned char* Rb = smem + V8_OFF_R + ((cb + 1) & 1) * V5_R_BYTES;    // block s - 1 has the other parity
+            unsigned char* Rb = smem + OFF_R + ((cb + 1) & 1) * V5_R_BYTES;    // block s - 1 has the other parity
             unsigned h2[4][2], l2[4][2];
             const char* ybase_n = nullptr;
             if constexpr (EPI && (cb & 1) == 0) ybase_n = pair_base(rp * 4 + (cb >> 1) + 1);      // blocks s + 2, s + 3
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 12; ++t) {
-                if constexpr (GEMM) {
+                if constexpr (GEMM && R3) {
+                    if (t < 5 * KS) {        // per k step: al sh, ah sl, a3 sh, ah s3 into the small products' accumulator, ah sh into the other
+                        const int ks = t / 5, wh = t % 5;
+                        if (wh == 4) {
+                            f32x16 cin = pc;
+                            if (t == 4) {
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) cin[i] = 0.f;
+                            }
+                            pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sv[ks][0], cin, 0, 0, 0);
+                        } else {
+                            f32x16 cin = lc;
+                            if (t == 0) {
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) cin[i] = 0.f;
+                            }
+                            lc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][wh == 0 ? 1 : (wh == 2 ? 2 : 0)], sv[ks][wh == 1 ? 1 : (wh == 3 ? 2 : 0)], cin, 0, 0, 0);
+                        }
+                    }
+                } else if constexpr (GEMM) {
                     if (t < 3 * KS) {
                         const int ks = t / 3, wh = t % 3;        // al sh, ah sl, ah sh
                         f32x16 cin = pc;
@@ -221,6 +262,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
                         for (int q = 0; q < 2; ++q) {
                             const int e = 4 * g + 2 * hf + q;
                             r[q] = pp[e] * unP - yv[pset][ptile][e];
+                            if constexpr (R3) r[q] = __builtin_fmaf(lp[e], unP, r[q]);     // (P_hh - Y) + P_lo
                             if constexpr (LOSS) lossAcc += r[q] * r[q];
                         }
                         v8_split_pair(r[0], r[1], scR, h2[g][hf], l2[g][hf]);
@@ -247,17 +289,17 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         using c6 = std::integral_constant<int, 6>; using c7 = std::integral_constant<int, 7>;
 #pragma nounroll
         for (int rp = 0; rp < nrp; ++rp) {
-            slot(rp, c0{}, p0, p1, yes{}, yes{});
-            slot(rp, c1{}, p1, p0, yes{}, yes{});
-            slot(rp, c2{}, p0, p1, yes{}, yes{});
-            slot(rp, c3{}, p1, p0, yes{}, yes{});
-            slot(rp, c4{}, p0, p1, yes{}, yes{});
-            slot(rp, c5{}, p1, p0, yes{}, yes{});
-            slot(rp, c6{}, p0, p1, yes{}, yes{});
-            slot(rp, c7{}, p1, p0, yes{}, yes{});
+            slot(rp, c0{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c1{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c2{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c3{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c4{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c5{}, p1, p0, q1, q0, yes{}, yes{});
+            slot(rp, c6{}, p0, p1, q0, q1, yes{}, yes{});
+            slot(rp, c7{}, p1, p0, q1, q0, yes{}, yes{});
         }
-        slot(nrp, c0{}, p0, p1, no{}, yes{});
-        slot(nrp, c1{}, p1, p0, no{}, no{});
+        slot(nrp, c0{}, p0, p1, q0, q1, no{}, yes{});
+        slot(nrp, c1{}, p1, p0, q1, q0, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
@@ -304,9 +346,9 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
         };
         auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
-            const unsigned char* Rb = smem + V8_OFF_R + (b & 1) * V5_R_BYTES;
-            const unsigned char* Slb = smem + cb * V8_SL_BYTES;
-            const unsigned char* Ab = smem + V8_OFF_A;
+            const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+            const unsigned char* Slb = smem + cb * SLB;
+            const unsigned char* Ab = smem + OFF_A;
             if (a.doA & 1) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {           // the block's 32 columns: two steps of 16
@@ -404,14 +446,16 @@ GradPlan grad_plan_f16_k32(int64_t M, int64_t N) {
     p.ldsBytes = V8_LDS_BYTES;
     return p;
 }
-template <bool LOSS>
+template <bool LOSS, bool R3 = false>
 static hipError_t grad_launch_f16_k32_t(const GradV4Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k32<LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS_BYTES);
+    constexpr int lds = R3 ? V7_LDS_BYTES : V8_LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k32<LOSS, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_grad_f16_k32<LOSS>, dim3(a.gridX * a.gridY), dim3(V5_THREADS), V8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_k32<LOSS, R3>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 hipError_t grad_launch_f16_k32(const GradV4Args& a, hipStream_t stream) {
+    if (a.r3) return (!(a.doA & 1) && !a.doS) ? grad_launch_f16_k32_t<true, true>(a, stream) : grad_launch_f16_k32_t<false, true>(a, stream);
     if (!(a.doA & 1) && !a.doS) return grad_launch_f16_k32_t<true>(a, stream);      // the loss-only pass (pmx_loglike, the line search)
     return grad_launch_f16_k32_t<false>(a, stream);
 }

@@ -602,7 +602,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->f64 ? 7 : c->k32f16 ? 8 : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? 9 : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64 ? 7 : c->k32f16 ? (c->f16_r3 ? 10 : 8) : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? 9 : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -1094,6 +1094,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         g.gridX = c->plan.gridX; g.gridY = c->plan.gridY;
         g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = 1.f;
         g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
+        g.r3 = c->f16_r3;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;

@@ -32,7 +32,8 @@ def _notice(key, msg):
 #            with K = 128, M % 128 = 0, N % 128 = 0 (k_grad_f16_k128; no weights there)
 #   "f16x2r" "f16x2" with the RESIDUAL in exact fp32's class where k_grad_f16_v8 runs (K1's K = 64): the third fp16 terms of A and S in
 #            A@S and its small products in a second accumulator (11 instead of 9 products; include/pmx.h: PMX_MODE_F16X2R) -- the
-#            two-term product carries the operands' representation errors coherently into the gradients; other K as "f16x2"
+#            two-term product carries the operands' representation errors coherently into the gradients; K = 32 likewise (k_grad_f16_k32),
+#            K = 128 as "f16x2"
 _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
@@ -84,7 +85,7 @@ class DeviceNMF:
         if mode not in ("f32", "f64"):
             k = self.k1_info()["kernel"]
             fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small"),
-                    "f16x2r": ("k_grad_f16_v8_r3", "k_grad_small")}[mode]
+                    "f16x2r": ("k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_small")}[mode]
             generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
             if k not in fast or generic_bf16 or (mode in ("f16x2", "f16x2r") and k == "k_grad_bf16"):
                 _notice((mode, k, self.K, self.M % 128 == 0, self.N % 256 == 0),
@@ -221,7 +222,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3", "k_grad_f16_k32_r3")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool((v7 // 1000000) % 10)
         d["range_faults"] = v7 // 10000000   # 1: a two-term fp16 K1 refused the residual's range, the context went on in exact fp32 (f16_range_fault)

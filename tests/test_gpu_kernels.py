@@ -555,19 +555,21 @@ def test_k32_two_term_fp16_kernel(eng, orc, M, N):
             assert dev.k1_info()["kernel"] == "k_grad_f16_k32" and dev.k1_info()["frame_K"] == 32
 
 
-def test_third_terms_in_the_residual_remove_the_coherent_error(eng, orc):
+@pytest.mark.parametrize("K", [64, 32])
+def test_third_terms_in_the_residual_remove_the_coherent_error(eng, orc, K):
     """[r4] What mode f16x2r is for (k_grad_f16_v8<R3>).  With two fp16 terms per operand, P = A S carries the operands' representation
     errors -- 2^-23 each, far below P's accumulation noise entry by entry, but the SAME dS[k][n] in every row of P: gS = A^T R picks up
     A^T A dS, a sum that grows with M and not with sqrt(M).  On a problem with non-negative factors (every entry of A^T A positive) the
     error of gS against fp64 is about twice exact fp32's in mode f16x2 and back at exact fp32's in mode f16x2r (NumPy emulation:
     scratch/r4_emulate_modes.py -- 3.0e-7 / 1.5e-7 / 1.5e-7 of max|gS| at this size), gA alike through S S^T."""
-    M, N, K = 2048, 2048, 64
+    M, N = 2048, 2048
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, unity_S=True, seed=4321)
     r64 = orc.residual_gradients(A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64))
     err = {}
     for mode in ("f32", "f16x2", "f16x2r"):
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
-            assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32_pc", "f16x2": "k_grad_f16_v8", "f16x2r": "k_grad_f16_v8_r3"}[mode]
+            assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32_pc", "f16x2": "k_grad_f16_v8" if K == 64 else "k_grad_f16_k32",
+                                               "f16x2r": "k_grad_f16_v8_r3" if K == 64 else "k_grad_f16_k32_r3"}[mode]
             dev.set_Y(Y)
             dev.set_factors(A, S)
             g = dev.grad()
