@@ -31,9 +31,23 @@ def scale_of(m, top=14):
     return f32(np.ldexp(1.0, int(top - q))) if m > 0 else f32(1)       # (np.float32 ** np.int64 would promote to float64)
 
 
-def make_grad(nP, drop_ll, nR, nG=2, gmax=None, balance=False, split_acc=0):
+def make_grad(nP, drop_ll, nR, nG=2, gmax=None, balance=False, split_acc=0, gram_fix=0):
     def grad(A, S, Y, W=None):
         A, S = A.astype(f32), S.astype(f32)
+        if gram_fix:
+            # the two-term gradients corrected to first order with K x K Gram matrices instead of wider products: the residual was computed
+            # from A - dA and S - dS (dA, dS: what two fp16 terms leave of the operands), so  gA += dA (S S^T),  gS += (A^T A) dS
+            # (gram_fix = 2: the cross terms A (dS S^T) and (A^T dA) S as well)
+            gA, gS = make_grad(2, True, 2)(A, S, Y)
+            sA, sS = scale_of(np.abs(A).max()), scale_of(np.abs(S).max())
+            dA = (A * sA - sum(terms16(A * sA, 2))) / sA
+            dS = (S * sS - sum(terms16(S * sS, 2))) / sS
+            gA = gA + dA @ (S @ S.T)
+            gS = gS + (A.T @ A) @ dS
+            if gram_fix >= 2:
+                gA = gA + A @ (dS @ S.T)
+                gS = gS + (A.T @ dA) @ S
+            return gA.astype(f32), gS.astype(f32)
         if split_acc:
             # TWO accumulators in A S: the high x high product in one, the small products (h l + l h [+ h 3 + 3 h: third terms of S and
             # of A, split_acc = 2] [+ l l, split_acc = 3]) in another, R = (P_hi - Y) + P_lo: what is below half an ulp of P survives
@@ -114,8 +128,13 @@ MODES = (("f32", None), ("f16x2", make_grad(2, True, 2)), ("f16r3", make_grad(3,
          ("all3", make_grad(3, True, 3, 3, 3)),
          ("2 acc: hl+lh", make_grad(2, True, 2, split_acc=1)),
          ("2 acc: +h3+3h", make_grad(2, True, 2, split_acc=2)),
-         ("2 acc: +ll", make_grad(2, True, 2, split_acc=3)))
+         ("2 acc: +ll", make_grad(2, True, 2, split_acc=3)),
+         ("f16x2 + Gram fix", make_grad(2, True, 2, gram_fix=1)),
+         ("f16x2 + Gram fix 2", make_grad(2, True, 2, gram_fix=2)))
+SEL = sys.argv[3] if len(sys.argv) > 3 else None
 for name, g in MODES:
+    if SEL and name != 'f32' and SEL not in name:
+        continue
     orc.residual_gradients = g if g is not None else real
     t0 = time.time()
     A, S = A0.copy(), S0.copy()
