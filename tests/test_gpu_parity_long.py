@@ -131,6 +131,19 @@ def test_cfg3_twenty_iterations_bench_mode_against_default_mode(eng):
     assert fA >= 0.9999 and fS >= 0.9995, (fA, fS)
     assert relA < 2e-5 and relS < 2e-4, (relA, relS)
     np.testing.assert_allclose(Sh.sum(0), 1.0, rtol=1e-5)
+    # [r4] mode f16x2r (k_grad_f16_v8<R3>) over the same 20 iterations: bit-repeatable, same pass counts, and CLOSER to exact fp32 than f16x2 is
+    Ar, Sr, subr, infor = _run_device(eng, "f16x2r", M, N, K, backend, unity, Yd, A0, S0, 20)
+    Ar2, Sr2, _, _ = _run_device(eng, "f16x2r", M, N, K, backend, unity, Yd, A0, S0, 20)
+    assert infor["kernel"] == "k_grad_f16_v8_r3" and infor["chain"] == 16 and infor["chain_faults"] == 0
+    assert np.array_equal(Ar, Ar2) and np.array_equal(Sr, Sr2), "f16x2r run is not repeatable bit for bit"
+    assert subr == subf, (subr, subf)
+    relAr = np.linalg.norm(Ar.astype(np.float64) - Af) / np.linalg.norm(Af)
+    relSr = np.linalg.norm(Sr.astype(np.float64) - Sf) / np.linalg.norm(Sf)
+    fAr, wAr = frac_within(Ar, Af)
+    fSr, wSr = frac_within(Sr, Sf)
+    REPORT["cfg3 full, 20 its: f16x2r vs f32 mode"] = {"frac_A": fAr, "frac_S": fSr, "worst_ratio": max(wAr, wSr), "rel_frobenius": [float(relAr), float(relSr)], "sub_iterations": subr}
+    assert fAr >= 0.9999 and fSr >= 0.9995 and relAr < 2e-5 and relSr < 2e-4, (fAr, fSr, relAr, relSr)
+    assert relSr <= relS and (1.0 - fSr) <= (1.0 - fS) + 1e-6, (relSr, relS, fSr, fS)
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16x2"])
