@@ -281,6 +281,7 @@ def other_configs(Y3, local):
     res = {}
     specs = [("cfg2", "f32", 4096, 4096, 32, "pgm", False, 200, 40, None),
              ("cfg2_f16x2", "f16x2", 4096, 4096, 32, "pgm", False, 200, 40, None),      # the same problem in the headline's arithmetic (k_grad_f16_k32)
+             ("cfg2_f16x2r", "f16x2r", 4096, 4096, 32, "pgm", False, 200, 40, None),    # ... and with the residual in exact fp32's class (k_grad_f16_k32<R3>)
              ("cfg5", "f16x2", 16384, 16384, 64, "bsdmm", False, 30, 10, Y3),
              ("cfg4_share8192", "f16x2", 8192, 16384, 128, "adaprox", False, 40, 20, Y3)]
     for name, mode, M, N, K, backend, unity, steps, warm, Yuse in specs:
@@ -311,7 +312,7 @@ def other_configs(Y3, local):
             k1_avg = k1_ms / max(k1_n, 1)
             info = dev.k1_info()
             roof = roofline_entry(effective_mode(dev), M, N, K, flop_launch, k1_avg, k1_n, k1_avg * nk1 * steps / (1e3 * dt), info["kernel"])
-            tr = pmc_traffic({"cfg4_share8192": "cfg4_rows8192", "cfg2_f16x2": "cfg2"}.get(name, name), effective_mode(dev))
+            tr = pmc_traffic({"cfg4_share8192": "cfg4_rows8192", "cfg2_f16x2": "cfg2", "cfg2_f16x2r": "cfg2"}.get(name, name), effective_mode(dev))
             res[name] = {"value": steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
                          "mode": mode, "backend": backend, "shape": [M, N, K], "k1_kernel": roof["kernel"] + ("<chain %d>" % info["chain"] if info["chain"] else ""),
                          "k1_ms": k1_avg, "tail_ms": 1e3 * dt / steps - nk1 * k1_avg,      # the step minus its K1 launches: update kernels, step rule, gaps
