@@ -24,6 +24,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or 0) or None
+    except Exception:
+        return None
+
+
+# the CPU leg (BLAS threads = all physical cores): asked for BEFORE NumPy loads its BLAS, which reads the
+# variable once.  A wheel whose OpenBLAS was built with a lower thread limit (NumPy's: 64) clamps it; cpu_baseline() reports
+# what the library really runs with next to what was asked.
+if _physical_cores():
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(_physical_cores()))
+
 import numpy as np  # noqa: E402
 
 CONFIGS = {
@@ -38,13 +53,16 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s is what a float4 copy achieves)
 MODE_DTYPE = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32-class accuracy)",
               "f16x2": "f16x2 (two-term fp16 split MFMA, fp32 accumulate, fp32-class accuracy)",
-              "f16x2r": "f16x2r (fp16 split MFMA: three terms + a second accumulator in the residual, two in the gradients; fp32 accumulate)"}
+              "f16x2r": "f16x2r (fp16 split MFMA, fp32 accumulate: the residual from the high x high product + an exact K x K correction, two-term gradients; exact fp32's error class)"}
 MODE_DESC = {"f32": "f32 (exact fp32 MFMA, Y fp32 in HBM)",
              "bf16x3": "bf16x3 (operands split into bf16 terms: 6 MFMA passes for A@S, 3 for each gradient; fp32 accumulate; Y fp32 in HBM)",
              "f16x2": "f16x2 (operands scaled by powers of two and split into two fp16 terms: 3 MFMA passes for each of A@S and the "
                       "two gradients; fp32 accumulate; Y fp32 in HBM)",
-             "f16x2r": "f16x2r (as f16x2, with the third fp16 terms of A and S in A@S and its small products in a second accumulator: 5 + 3 + 3 MFMA passes; the residual in exact fp32's class)"}
-MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0, "f16x2r": 11.0 / 3.0}      # issued MFMA flops per algorithmic flop (12 resp. 9 products per 3 contractions)
+             "f16x2r": "f16x2r (operands scaled by powers of two and split into fp16 terms; A@S from the HIGH terms alone -- one MFMA pass -- and what that leaves out, "
+                       "A s_r + a_r s0, restored exactly through K x K matrices (k_gfix.hip); three passes for each gradient: 1 + 3 + 3 MFMA passes per 3 contractions; "
+                       "fp32 accumulate; Y fp32 in HBM; gradients in exact fp32's error class)"}
+# issued MFMA flops per algorithmic flop (products per 3 contractions / 3): informational -- issued flops earn no roofline credit
+MFMA_PASSES = {"bf16x3": 4.0, "f16x2": 3.0, "f16x2r": 11.0 / 3.0, "f16x2g": 7.0 / 3.0}
 
 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "k1_traffic.json")
@@ -83,39 +101,36 @@ def effective_mode(dev):
 
 
 def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kernel=None):
-    """Dominant kernel = K1 (fused residual-gradient).  f32: matrix-core bound (exact-fp32 MFMA peak).
-    bf16x3: at K=64 the algorithmic intensity 6K/4 = 96 flop/B puts the kernel under the HBM roof
-    (96 x 8 TB/s = 768 TFLOP/s < bf16 MFMA peak), so the bound is the single pass over Y."""
+    """Dominant kernel = K1 (fused residual-gradient), priced on ALGORITHMIC work: 6 M N K flop and one pass over Y,
+    M N 4 bytes, per launch.  Mode f32: the exact-fp32 MFMA peak bounds it.  Split modes: the algorithmic intensity 6 K / 4 flop per
+    byte (48 / 96 / 192 at K = 32 / 64 / 128) times 8 TB/s is below the dense bf16 / fp16 MFMA peak at every K <= 128, so the pass
+    over Y is the roof: frac = (M N 4 bytes / launch time) / 8 TB/s.  Issued MFMA flops (several fp16 products per fp32-class
+    multiply-add) are reported for information only."""
     t = k1_avg_ms * 1e-3
     tflops = flop_per_launch / t / 1e12
     gbs = (M * N * 4) / t / 1e9
     kp = 32 if K <= 32 else 64 if K <= 64 else 128
-    # which split-bf16 implementation grad_launch_bf16 picks for this shape (k_grad_bf16.hip; PMX_K1_VARIANT unset)
-    fast = "k_grad_f16_v8" if mode == "f16x2" else ("k_grad_f16_v8<R3>" if mode == "f16x2r" else "k_grad_bf16_v7")
-    bf16_kernel = fast if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp
-    if kernel in ("k_grad_f16_k32", "k_grad_f16_k32_r3"):           # K = 32 in mode f16x2 / f16x2r: 6K/4 = 48 flop/B, the single pass over Y is the roof
-        bf16_kernel = "k_grad_f16_k32" if kernel == "k_grad_f16_k32" else "k_grad_f16_k32<R3>"
-    passes = MFMA_PASSES["f16x2r" if bf16_kernel in ("k_grad_f16_v8<R3>", "k_grad_f16_k32<R3>") else ("f16x2" if bf16_kernel in ("k_grad_f16_v8", "k_grad_f16_k32") else "bf16x3")]
-    if kernel == "k_grad_f16_k128":
-        # K = 128: 6K/4 = 192 flop/B, x 3 issued MFMA flops per algorithmic flop: the fp16 matrix pipe, not the pass over Y,
-        # is the roof (192 x 3 x 8 TB/s = 4.6 PFLOP/s of issue would be needed to run at HBM speed)
-        issued = MFMA_PASSES["f16x2"] * tflops
-        return {"kernel": kernel, "bound": "mfma", "achieved": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-                "algorithmic_tflops": tflops, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share,
-                "note": "achieved = issued fp16 MFMA flops (3 products per fp32-class MAC); algorithmic = achieved / 3"}
     if mode == "f32":
         return {"kernel": "k_grad_f32_pc<%d>" % K if kernel == "k_grad_f32_pc" else "k_grad_f32<%d>" % kp, "bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": k1_avg_ms,
                 "launches": k1_n, "hbm_gbs_algorithmic": gbs, "k1_share_of_step": share}
-    return {"kernel": bf16_kernel, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+    names = {"k_grad_f16_v8": ("k_grad_f16_v8", "f16x2"), "k_grad_f16_v8_r3": ("k_grad_f16_v8<R3>", "f16x2r"), "k_grad_f16_v8_hh": ("k_grad_f16_v8<HH> + k_gfix", "f16x2g"),
+             "k_grad_f16_k32": ("k_grad_f16_k32", "f16x2"), "k_grad_f16_k32_r3": ("k_grad_f16_k32<R3>", "f16x2r"),
+             "k_grad_f16_k128": ("k_grad_f16_k128", "f16x2"), "k_grad_f16_k128_hh": ("k_grad_f16_k128<HH> + k_gfix", "f16x2g")}
+    name, arith = names.get(kernel, ("k_grad_bf16_v7" if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp, "bf16x3"))
+    passes = MFMA_PASSES[arith]
+    return {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
-            "algorithmic_tflops": tflops, "mfma_issued_tflops": passes * tflops,
-            "mfma_issued_frac_of_bf16_peak": passes * tflops / PEAK_BF16_MFMA_TFLOPS, "k1_share_of_step": share}
+            "algorithmic_tflops": tflops, "algorithmic_frac_of_bf16_mfma_peak": tflops / PEAK_BF16_MFMA_TFLOPS,
+            "hbm_roof_tflops": 6.0 * K / 4.0 * PEAK_HBM_GBS / 1e3,      # what one pass over fp32 Y allows: 6K/4 flop/B x 8 TB/s
+            "mfma_issued_tflops": passes * tflops, "mfma_products_per_3_contractions": round(3 * passes), "k1_share_of_step": share}
 
 
 def make_problem_device(M, N, K, unity, seed, device):
-    """Seeded synthetic Y = A_true S_true + 0.01 noise generated on the GPU (fp32), A0/S0 on the host."""
+    """Seeded synthetic Y = A_true S_true + 0.01 noise generated ON THE GPU (fp32; torch.Generator(seed): SURVEY 8(d)'s recipe and
+    statistics, not the numbers np.random.default_rng(1234) would draw for A_true / S_true / the noise -- a 1 GiB Y drawn on the
+    host would add ~10 s and a PCIe copy to every run), A0 / S0 from np.random.default_rng(seed) on the host.  GENERATOR says so in
+    the JSON line."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -131,6 +146,10 @@ def make_problem_device(M, N, K, unity, seed, device):
     if unity:
         S0 /= S0.sum(0, keepdims=True)
     return Y, A0, S0
+
+
+GENERATOR = ("Y = A_true @ S_true + 0.01 N(0,1), A_true / S_true uniform [0,1) (S_true columns normalised where the config has prox_unity), drawn on the GPU "
+             "by torch.Generator(seed 1234); A0, S0 from np.random.default_rng(1234) on the host (SURVEY 8(d)'s recipe; the tests draw everything with NumPy)")
 
 
 def begin_solver(dev, backend, unity):
@@ -204,7 +223,7 @@ def cpu_baseline(Y, A0, S0, backend, unity, n_iter=6, transient=0):
     except Exception:
         pass
     rec = {"value": 1.0 / float(np.mean(per_t)), "unit": "it/s", "cores": cores, "kind": "port",
-           "sample": "oracle (NumPy fp32; BLAS: %s; OPENBLAS_NUM_THREADS=%s; host: %d hardware threads, %s physical cores) on the full %d x %d x %d workload "
+           "sample": "oracle (NumPy fp32; BLAS: %s; OPENBLAS_NUM_THREADS=%s asked [= physical cores; the library's own build limit clamps it: `cores` is what it runs with]; host: %d hardware threads, %s physical cores) on the full %d x %d x %d workload "
                      "(the bench's own Y and initial factors): %d untimed iterations (start-up transient), then %d timed, mean %.3f s (min %.3f, max %.3f), no scaling%s"
                      % (blas, os.environ.get("OPENBLAS_NUM_THREADS", "unset"), host_cores, phys, M, N, K, transient, len(per_t),
                         float(np.mean(per_t)), float(per_t.min()), float(per_t.max()), sub_note)}
@@ -282,8 +301,8 @@ def other_configs(Y3, local):
     specs = [("cfg2", "f32", 4096, 4096, 32, "pgm", False, 200, 40, None),
              ("cfg2_f16x2", "f16x2", 4096, 4096, 32, "pgm", False, 200, 40, None),      # the same problem in the headline's arithmetic (k_grad_f16_k32)
              ("cfg2_f16x2r", "f16x2r", 4096, 4096, 32, "pgm", False, 200, 40, None),    # ... and with the residual in exact fp32's class (k_grad_f16_k32<R3>)
-             ("cfg5", "f16x2", 16384, 16384, 64, "bsdmm", False, 30, 10, Y3),
-             ("cfg4_share8192", "f16x2", 8192, 16384, 128, "adaprox", False, 40, 20, Y3)]
+             ("cfg5", "f16x2r", 16384, 16384, 64, "bsdmm", False, 30, 10, Y3),
+             ("cfg4_share8192", "f16x2r", 8192, 16384, 128, "adaprox", False, 40, 20, Y3)]
     for name, mode, M, N, K, backend, unity, steps, warm, Yuse in specs:
         try:
             if Yuse is None:
@@ -336,11 +355,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
     ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2", "f16x2r"],
-                    help="contraction arithmetic: f16x2 = two-term fp16 split MFMA (default for cfg3 / cfg5, the headline), "
+                    help="contraction arithmetic: f16x2r = fp16 split MFMA in exact fp32's error class (default for cfg3 / cfg4 / cfg5: the headline), "
+                         "f16x2 = two-term fp16 split MFMA (faster to issue at K = 32 only; 2-4 x fp32's out-of-tolerance entries), "
                          "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in fp32)")
     args = ap.parse_args()
     if args.mode is None:
-        args.mode = "f32" if args.config == "cfg2" else "f16x2"
+        args.mode = "f32" if args.config == "cfg2" else "f16x2r"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -422,7 +442,7 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": MODE_DTYPE[effective_mode(dev)], "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": MODE_DESC[effective_mode(dev)], "parallelism": "1 GPU"},
+                   "mode": MODE_DESC[effective_mode(dev)], "parallelism": "1 GPU", "generator": GENERATOR},
         "gflops": flop_per_it * its / 1e9,
         "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
         "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
@@ -439,7 +459,7 @@ def main():
         out["roofline"]["traffic_unit"] = "HBM bytes per K1 launch, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this build (%s); null: not measured for this build; algorithmic: %d" % (
             "fetch %d + write %d, %s" % (tr["fetch_bytes"], tr["write_bytes"], tr.get("when", "")) if tr else "profiles/k1_traffic.json has no entry for source hash %s" % kernel_source_hash(), M * N * 4)
     if not args.no_cpu:
-        if args.config == "cfg3" and dev.mode != "f32":
+        if args.config == "cfg3" and dev.mode == "f16x2r":
             # the package default is the exact-fp32 MFMA mode: the same workload in that mode, short run, beside the headline
             dev32 = DeviceNMF(M, N, K, device=local, mode="f32")
             dev32.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
@@ -453,9 +473,9 @@ def main():
             out["value_f32_mode"] = {"value": 20.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 20, "warmup": 25,
                                      "note": "same workload with the library's default arithmetic (exact fp32 MFMA, %s)" % dev32.k1_info()["kernel"]}
             dev32.close()
-            # ... and in mode f16x2r: the headline's kernel with the residual in exact fp32's class (three fp16 terms of A and S and a second
-            # accumulator in A@S): the rate at which the factors meet the fp64 oracle like exact fp32 does (tests/test_gpu_parity_long.py)
-            devr = DeviceNMF(M, N, K, device=local, mode="f16x2r")
+            # ... and in mode f16x2 (two-term products everywhere: 9 MFMA products per 3 contractions, 2-4 x exact fp32's out-of-tolerance
+            # entries against the fp64 oracle -- NOT the headline's error class; tests/test_gpu_parity_long.py)
+            devr = DeviceNMF(M, N, K, device=local, mode="f16x2")
             devr.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
             devr.set_factors(A0, S0)
             runr = begin_solver(devr, backend, unity)
@@ -464,8 +484,8 @@ def main():
             t0 = time.perf_counter()
             runr(40)
             torch.cuda.synchronize()
-            out["value_f16x2r_mode"] = {"value": 40.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 40, "warmup": 25,
-                                        "note": "same workload in mode f16x2r (%s: 5 instead of 3 fp16 products in A@S, the small ones in a second accumulator; parity class of exact fp32)" % devr.k1_info()["kernel"]}
+            out["value_f16x2_mode"] = {"value": 40.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 40, "warmup": 25,
+                                       "note": "same workload in mode f16x2 (%s: two fp16 terms per operand in all three contractions; noisier than exact fp32)" % devr.k1_info()["kernel"]}
             devr.close()
         dev.close()
         if args.config == "cfg3" and not args.rows:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 3
+#define PMX_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------------------- */
 enum {
@@ -52,12 +52,18 @@ enum {
                             iteration with the exact-f32 kernel of its frame and keeps it (pmx_k1_info reports both);
                             entry points that run one iteration per call await every such launch and switch on the spot;
                             row-sharded bSDMM alone returns PMX_E_HIP with that explanation. */
-    PMX_MODE_F16X2R = 5, /* [r4] PMX_MODE_F16X2 with the RESIDUAL to fp32's class: where k_grad_f16_v8 / k_grad_f16_k32 run (K1's K = 64 or 32: every
-                            K <= 64 on the tuned frame; k_grad_f16_v8's unweighted instances) A S takes the third fp16 terms of A and S as well (ah s3 + a3 sh beside ah sl + al sh) and
-                            keeps everything but ah sh in a second accumulator, R = (P_hh - Y) + P_lo -- 5 instead of 3 products in that
-                            contraction, the gradient contractions unchanged.  The two-term product carries the operands' representation
-                            errors COHERENTLY into the gradients (k_grad_f16_v8.hip, <R3>); this mode's factors are in exact fp32's class
-                            against the fp64 oracle at 2 x its rate.  K = 128: the kernel of PMX_MODE_F16X2 (its LDS is full).  pmx_k1_info: kernels 9, 10 */
+    PMX_MODE_F16X2R = 5, /* PMX_MODE_F16X2 with the RESIDUAL in exact fp32's error class (the two-term product carries the operands' 2^-23
+                            representation errors COHERENTLY into the gradients: twice fp32's gradient error).
+                            [r5] K1's K = 64 and 128, no weights (k_grad_f16_v8<HH>, k_grad_f16_k128<HH>; pmx_k1_info kernels 11, 12): the
+                            residual comes from the HIGH x HIGH product alone, P0 = a0 s0 (one MFMA product instead of three), and what that
+                            leaves out is restored exactly through K x K matrices, A S - a0 s0 = A s_r + a_r s0 (x_r = X - x0):
+                            gA += A (s_r S^T) + a_r (s0 S^T), gS += (A^T a_r) S + (A^T a0) s_r -- three small launches beside K1
+                            (k_gfix.hip) whose result the update kernels fold like one more gradient slab.  7 instead of 9 MFMA products per
+                            MAC, no representation error left in the residual at all.
+                            [r4] K1's K = 32 (k_grad_f16_k32<R3>, kernel 10), the loss-only passes and PMX_F16_R3=1 (k_grad_f16_v8<R3>,
+                            kernel 9): A S takes the third fp16 terms of A and S (ah s3 + a3 sh beside ah sl + al sh) and keeps everything
+                            but ah sh in a second accumulator, R = (P_hh - Y) + P_lo -- 5 instead of 3 products in that contraction.
+                            Weighted contexts: the kernels of PMX_MODE_F16X2 (the missing term W o (A s_r + a_r s0) does not factor). */
     PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  SMALL problems only (K <= 16, M N <= 2^20,
                             M, N <= 8192: the reference's own examples and BASELINE cfg1) and the fused loops of the three
@@ -219,7 +225,7 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
  * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
  * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small, 5 two-term fp16 at K = 128
  * k_grad_f16_k128, 6 exact fp32 with producer / consumer wavefronts k_grad_f32_pc, 7 the fp64 small-problem kernels, 8 two-term fp16 at K = 32
- * k_grad_f16_k32, 9 / 10 k_grad_f16_v8<R3> / k_grad_f16_k32<R3>: PMX_MODE_F16X2R), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * k_grad_f16_k32, 9 / 10 k_grad_f16_v8<R3> / k_grad_f16_k32<R3>, 11 / 12 k_grad_f16_v8<HH> / k_grad_f16_k128<HH> + the correction slab of k_gfix.hip: PMX_MODE_F16X2R), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
  * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now + 10000000 if a two-term fp16 kernel
@@ -242,6 +248,11 @@ int pmx_prox_apply(pmx_ctx* ctx, int buf, const pmx_proxseq* prox, const float* 
  * place): copies to the device, runs the operator kernel, copies back.  This is what calling
  * proxmin.operators.prox_* directly on an ndarray maps to. */
 int pmx_prox_array(int device, float* X, int64_t rows, int K, const pmx_proxseq* prox, const float* step_k);
+/* [ABI v4] context-free reductions of utils.BarzilaiBorweinStepper.step called as a FUNCTION on host arrays (utils.py:216-241; inside
+ * pgm the rule runs fused, k_bb_reduce / k_bb_step): one block's X, G and the previous call's X_prev, G_prev (both NULL in the first
+ * call: s = y = 0), `count` elements of float (is_f64 = 0) or double (1).  out = { sum s^2, sum s y, sum y^2, sum G^2, max|X|, max|G| }
+ * with s = X - X_prev, y = G - G_prev formed in the arrays' type, products and sums in fp64 in a fixed order. */
+int pmx_bb_sums(int device, int is_f64, const void* X, const void* Xprev, const void* G, const void* Gprev, int64_t count, double out[6]);
 
 /* ---- solvers ------------------------------------------------------------------------------
  * Each *_run advances at most `n_iter` iterations from the current device state and returns

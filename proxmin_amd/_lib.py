@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "libpmx.so")   # PMX
 MAX_SEQ = 4
 MAX_G = 4
 MAXK = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums (include/pmx.h)
 MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64, MODE_F16X2R = 0, 2, 3, 4, 5
@@ -91,6 +91,7 @@ _SIGNATURES = {
     "pmx_step_adaprox": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pmx_prox_apply": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ProxSeq), C.c_void_p]),
     "pmx_prox_array": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(ProxSeq), C.c_void_p]),
+    "pmx_bb_sums": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
     "pmx_pgm_begin": (C.c_int, [C.c_void_p, C.POINTER(PgmParams)]),
     "pmx_pgm_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
     "pmx_pgm_split": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(Result)]),
@@ -143,17 +144,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PmxError("libpmx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). proxmin_amd has no CPU fallback." % LIB_PATH)
-    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64: if torch is imported AFTER this library (which
-    # resolves the system runtime) the process ends up with two runtimes and the second sees no device; imported first,
-    # libpmx binds to the copy already in the process.  So torch -- an OPTIONAL companion: this package itself needs only
-    # NumPy and libamdhip64; torch is used by bench.py, the tests and proxmin_amd.distributed -- is brought in first when it
-    # is installed.  PMX_TORCH_PRELOAD=0 switches that off (a torch-free deployment, or one that imports torch itself
-    # before proxmin_amd).
-    if "torch" not in sys.modules and os.environ.get("PMX_TORCH_PRELOAD", "1") != "0":
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64: a process that imports torch AFTER this library
+    # (which resolves the system runtime) ends up with two runtimes, and torch then sees no device; with torch imported FIRST
+    # libpmx binds to the copy already in the process.  This package needs NumPy and libamdhip64 only and does NOT import torch
+    # on its own account [r5: the preload used to be the default].  A process that uses both imports torch first -- or sets
+    # PMX_TORCH_PRELOAD=1 and lets this loader do it (tests/conftest.py and bench.py do; proxmin_amd.distributed, which needs
+    # torch.distributed, goes through require_torch() below and says what is wrong instead of failing inside torch).
+    if "torch" not in sys.modules and os.environ.get("PMX_TORCH_PRELOAD", "0") == "1":
+        import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
@@ -168,6 +166,16 @@ def load():
         raise PmxError("struct layouts of libpmx.so %r differ from the ctypes mirrors %r; rebuild" % (list(sizes), mine))
     _lib = lib
     return lib
+
+
+def require_torch():
+    """torch for the callers that need it (proxmin_amd.distributed, device-array helpers): imported here if the library is not
+    loaded yet, otherwise it must be in the process already (see load(): one HIP runtime per process)."""
+    if "torch" not in sys.modules and _lib is not None:
+        raise PmxError("torch must be imported BEFORE the first proxmin_amd call that loads libpmx.so (PyTorch-ROCm brings its own "
+                       "HIP runtime; loaded second it sees no device): `import torch` first, or set PMX_TORCH_PRELOAD=1")
+    import torch
+    return torch
 
 
 def check(rc):

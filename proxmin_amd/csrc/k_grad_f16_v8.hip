@@ -139,10 +139,17 @@ static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 // step instead of three in the producers, the consumers unchanged; S's third term in LDS (160 KB in all), A's in registers.
 // scratch/r4_emulate_modes.py (NumPy, full cfg3): out-of-tolerance entries against the fp64 oracle 5.8 x / 4.2 x the fp32 oracle's with
 // two terms (any number of terms in ONE accumulator: the same), 0.9 x / 1.0 x with this.
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false>
+// HH [r5]: the residual from the HIGH x HIGH product alone (four MFMAs per block instead of twelve / twenty), P0 = a0 s0 with a0 = fp16(A 2^eA),
+// s0 = fp16(S 2^eS) -- and what that leaves out restored EXACTLY, outside this kernel, through K x K matrices: A S - a0 s0 = A s_r + a_r s0
+// (x_r = X - x0: exact in fp32), so  gA += A (s_r S^T) + a_r (s0 S^T),  gS += (A^T a_r) S + (A^T a0) s_r ... (k_gfix.hip: the correction arrives as
+// one more gradient slab).  No representation error is left in P at all (mode f16x2r's third terms remove it to 2^-33), the residual's accumulation
+// noise is exact fp32's, and the producers issue a third / a fifth of the MFMAs.  The consumers (two-term R, A, S: 3 products) are unchanged.
+// scratch/r5_gradient_error_table.py: gradients 3.9e-8 / 1.5e-7 of max|g| against fp64 where NumPy fp32 has 3.6e-8 / 1.5e-7 and mode f16x2 4.0e-8 / 3.0e-7.
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
+    static_assert(!(R3 && HH) && !(HH && HASW), "HH: unweighted contexts, instead of the third terms");
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
-    constexpr int NT = R3 ? 3 : 2;                       // fp16 terms of A and S in the residual's product
+    constexpr int NT = R3 ? 3 : 2;                       // fp16 terms of A and S in the residual's product (HH: the second term serves the consumers only)
     constexpr int SLB = NT * V5_S_TERM, OFF_A = NCB * SLB, OFF_R = OFF_A + V5_AIMG_BYTES;
     static_assert(OFF_R + 2 * V5_R_BYTES <= 160 * 1024 && OFF_R % 256 == 0, "");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                 for (int ks = 0; ks < 4; ++ks) {
                     const int so = s_g1 ^ (ks << 5);
                     sv[ks][0] = *reinterpret_cast<const f16x8*>(Slb + so);
-                    sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                    if constexpr (!HH) sv[ks][1] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
                     if constexpr (R3) sv[ks][2] = *reinterpret_cast<const f16x8*>(Slb + so + 2 * V5_S_TERM);
                 }
             }
@@ -441,6 +448,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                             for (int i = 0; i < 16; ++i) cin[i] = 0.f;
                         }
                         lc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][wh == 0 ? 1 : (wh == 2 ? 2 : 0)], sv[ks][wh == 1 ? 1 : (wh == 3 ? 2 : 0)], cin, 0, 0, 0);
+                    }
+                } else if constexpr (GEMM && HH) {
+                    if (t % 3 == 0) {                        // ah sh alone: one MFMA every third step, the epilogue pieces between them
+                        f32x16 cin = pc;
+                        if (t == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) cin[i] = 0.f;
+                        }
+                        pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[t / 3][0], sv[t / 3][0], cin, 0, 0, 0);
                     }
                 } else if constexpr (GEMM) {
                     const int ks = t / 3, wh = t % 3;        // al sh, ah sl, ah sh
@@ -726,15 +742,19 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false>
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
     constexpr int lds = R3 ? V7_LDS_BYTES : V8_LDS_BYTES;        // (three S terms: the split-bf16 kernel's 160 KB)
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
+    // r3 == 2 [r5]: the high x high residual whose missing terms arrive as a correction slab (<HH>; gradient passes only -- the loss-only pass
+    // has nowhere to put a correction and runs the third terms' instance)
+    if (a.r3 == 2 && a.W == nullptr && ((a.doA & 1) || a.doS))
+        return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, false, true>(a, stream);
     if (a.r3 && a.W == nullptr) {    // R3: the residual to fp32's class (unweighted instances; a weighted context keeps two terms)
         if (!(a.doA & 1) && !a.doS) return grad_launch_f16_v8_t<false, false, false, true, true>(a, stream);
         return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, true>(a, stream);

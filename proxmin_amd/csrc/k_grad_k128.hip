@@ -65,6 +65,7 @@ struct GradK128Args {
     DevStatus* wstatus;      // writable view of `status` (fault report)
     int chainInject;         // tests: report a fault from this launch
     float rangeRatio;        // [r4] f16_range_fault (k_grad_f16_v8.hip); 0: no check
+    int hh;                  // [r5] <.., HH>: the residual from the high x high product alone, the rest as a correction slab (k_gfix.hip; no weights)
 };
 
 struct SplitAArgs {
@@ -116,8 +117,11 @@ void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
 
 // HASW: weighted likelihood -- D = W (A S - Y), loss 1/2 sum W (Y - A S)^2: the producers fetch the W tile next to the Y tile
 // (they have the registers: the consumers bound this kernel) and scale R in the epilogue, as in k_grad_f16_v8<.., HASW>.
-template <bool HASW, bool CHAIN>
+// HH [r5]: k_grad_f16_v8<.., HH>'s residual (P0 = a0 s0: 8 MFMAs per block instead of 24; what it leaves out arrives as a correction slab, k_gfix.hip):
+// the mode-f16x2r instance of this kernel -- there is no LDS here for third terms, and none are needed.
+template <bool HASW, bool CHAIN, bool HH = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
+    static_assert(!(HH && HASW), "HH: unweighted contexts");
     constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
     constexpr int OFF_R = W8_OFF_R;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -311,12 +315,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                 for (int ks = 0; ks < 8; ++ks) {
                     const int so = (ks >> 2) * W8_S_HALF + (s_g1 ^ ((ks & 3) << 5));
                     sh[ks] = *reinterpret_cast<const f16x8*>(Slb + so);
-                    sl[ks] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
+                    if constexpr (!HH) sl[ks] = *reinterpret_cast<const f16x8*>(Slb + so + V5_S_TERM);
                 }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][1], sh[ks], pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sl[ks], pc, 0, 0, 0);
+                    if constexpr (!HH) {
+                        pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][1], sh[ks], pc, 0, 0, 0);
+                        pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sl[ks], pc, 0, 0, 0);
+                    }
                     pc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][0], sh[ks], pc, 0, 0, 0);
                     if constexpr (RELOAD) {
                         // pinned in program order (only VALU / SALU / LDS instructions may move across): behind the MFMAs
@@ -333,12 +339,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     // register limit) reads one S fragment pair, waits for it, issues its three MFMAs, reads the next pair
                     // into the same registers ... : eight exposed LDS latencies per slot.  Order imposed here: the reads
                     // run two fragment pairs (24 VGPRs) ahead of the MFMAs that use them.
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    constexpr int NR = HH ? 1 : 2, NM = HH ? 1 : 3;       // LDS reads / MFMAs per k step
+                    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        if (ks + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+                        if (ks + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
                         if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // the epilogue of block s-1 in the MFMAs' shadow
                     }
                 }
@@ -620,14 +627,16 @@ int grad_k128_chain_stride(const GradPlan& p, int chainL) {
     if (sg > want) sg = want;
     return sg < 1 ? 1 : sg;
 }
-template <bool HASW, bool CHAIN>
+template <bool HASW, bool CHAIN, bool HH = false>
 static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, CHAIN, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_k128<HASW, CHAIN>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_k128<HASW, CHAIN, HH>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
+    if (a.hh && a.W == nullptr && ((a.doA & 1) || a.doS))      // (the loss-only pass has nowhere to put a correction: two terms)
+        return a.chainL > 0 && (a.doA & 1) ? grad_launch_k128_t<false, true, true>(a, stream) : grad_launch_k128_t<false, false, true>(a, stream);
     if (a.chainL > 0 && (a.doA & 1))
         return a.W != nullptr ? grad_launch_k128_t<true, true>(a, stream) : grad_launch_k128_t<false, true>(a, stream);
     return a.W != nullptr ? grad_launch_k128_t<true, false>(a, stream) : grad_launch_k128_t<false, false>(a, stream);

@@ -268,6 +268,7 @@ struct SlabRef {
     int n;
     int64_t stride;      // floats between slabs: rows x K of K1's FRAME (the factor's rows, or more: zero-padded frame of a ragged shape)
     int ld;              // floats between rows of a slab: K, or K1's padded K (pmx_k1_frame: a K without a tuned kernel runs the next one's)
+    const float* extra = nullptr;   // [r5] one more slab outside the array (same row pitch), added LAST: the correction of a high x high residual (k_gfix.hip)
 };
 
 template <int NC>
@@ -310,6 +311,12 @@ __device__ __forceinline__ void load_grad(float (&g)[NC], const bool (&ok)[NC], 
         for (int c = 0; c < NC; ++c)
             if (ok[c]) g[c] += p[c * 32];
         p += stride;
+    }
+    if (s.extra != nullptr) {
+        const float* q = s.extra + r * s.ld + l32;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (ok[c]) g[c] += q[c * 32];
     }
 }
 
@@ -781,6 +788,46 @@ __global__ __launch_bounds__(EW_THREADS) void k_bb_step(BBStepArgs a) {
 }
 
 // single-block decision kernel shared by pgm and adaprox outer tests (algorithms.py:130-135,403-410)
+// ---- stand-alone Barzilai-Borwein sums of ONE block on caller arrays (utils.BarzilaiBorweinStepper.step called as a function,
+// proxmin/utils.py:216-241): s = X - X_prev, y = G - G_prev in the arrays' own type, products and sums in fp64, fixed order ----------
+constexpr int BBS_BLOCKS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void k_bb_sums(const T* X, const T* Xp, const T* G, const T* Gp, int64_t n, double* part) {
+    __shared__ double red[4][6];
+    double s2 = 0.0, sy = 0.0, y2 = 0.0, g2 = 0.0, mx = 0.0, mg = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)BBS_BLOCKS * 256) {
+        const T x = X[i], g = G[i];
+        const T s = Xp ? (T)(x - Xp[i]) : (T)0, y = Gp ? (T)(g - Gp[i]) : (T)0;
+        s2 += (double)s * (double)s;
+        sy += (double)s * (double)y;
+        y2 += (double)y * (double)y;
+        g2 += (double)g * (double)g;
+        mx = fmax(mx, fabs((double)x));
+        mg = fmax(mg, fabs((double)g));
+    }
+    double v[6] = {s2, sy, y2, g2, mx, mg};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v[q], o); v[q] = q < 4 ? v[q] + t : fmax(v[q], t); }
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 6; ++q) red[threadIdx.x >> 6][q] = v[q];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int q = threadIdx.x;
+        double r = red[0][q];
+        for (int w = 1; w < 4; ++w) r = q < 4 ? r + red[w][q] : fmax(r, red[w][q]);
+        part[blockIdx.x * 6 + q] = r;
+    }
+}
+__global__ void k_bb_sums_fold(const double* part, double* out) {
+    const int q = threadIdx.x;
+    if (q >= 6) return;
+    double r = part[q];
+    for (int b = 1; b < BBS_BLOCKS; ++b) r = q < 4 ? r + part[b * 6 + q] : fmax(r, part[b * 6 + q]);
+    out[q] = r;
+}
+
 struct DecideArgs {
     DevStatus* status;
     double* partials;

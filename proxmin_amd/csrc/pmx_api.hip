@@ -30,6 +30,7 @@
 #include "k_grad_f32pc.hip"
 #include "k_update.hip"
 #include "k_gram.hip"
+#include "k_gfix.hip"
 #include "k_small_f64.hip"
 
 // ------------------------------------------------------------------------------------------------
@@ -122,7 +123,12 @@ struct pmx_ctx {
     // k_grad_f16_v8.hip): the context then continues in exact fp32 on the same frame (k1_leave_f16).  PMX_F16_RANGE=n: ratio 2^n, 0: no check
     float rangeRatio = 65536.f;
     int rangeFaults = 0;
-    int f16_r3 = 0;                        // k_grad_f16_v8<.., R3>: the residual with three terms per operand and two accumulators (PMX_F16_R3=1; see the kernel)
+    int f16_r3 = 0;                        // 1: k_grad_f16_v8<.., R3>, the residual with three terms per operand and two accumulators; [r5] 2: <.., HH>, the residual from the
+                                           // high x high product and the rest as a correction slab (k_gfix.hip) where a kernel has that instance (K1's K = 64, 128; no weights), R3 elsewhere (PMX_F16_R3=0/1/2)
+    float* fixPart = nullptr;              // k_gfix_gram's partial matrices [2][GFIX_PARTS][2][Kk * Kk]
+    float* fixQ = nullptr;                 // [2][2][Kk * Kk]
+    float* fixSlab[2] = {nullptr, nullptr};   // the correction slabs (rowsK[j] x Kk)
+    bool fix_on = false;                   // the last gradient pass ran an <HH> kernel: the update kernels fold fixSlab behind K1's slabs (slab_ref)
     bool k1_sync_check = false;            // one-iteration-per-call paths (nothing to repeat into): every fp16 K1 launch is awaited and, refused, repeated in fp32 on the spot (enqueue_grad)
     int ncu = 0;
     _Float16* A16[2] = {nullptr, nullptr}; // k128: high / low fp16 terms of the scaled A (k_split_a_f16, once per K1 launch)
@@ -400,8 +406,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
     c->ncu = ncu;
-    c->f16_r3 = want_r3;
-    if (const char* e = getenv("PMX_F16_R3")) c->f16_r3 = atoi(e) != 0;        // (A/B switch: any f16x2 context)
+    c->f16_r3 = want_r3 ? 2 : 0;
+    if (const char* e = getenv("PMX_F16_R3")) c->f16_r3 = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));        // (A/B switch: any f16x2 context)
     if (const char* e = getenv("PMX_F16_RANGE")) c->rangeRatio = atoi(e) > 0 ? ldexpf(1.f, atoi(e)) : 0.f;
     c->Kk = K;
     if (!(getenv("PMX_FRAME") && atoi(getenv("PMX_FRAME")) == 0) && mode != PMX_MODE_F64 && !grad_small_applies(M, N, K)) {
@@ -468,6 +474,11 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     int rc = PMX_OK;
     if (c->chainL > 0) rc = dallocT(c, &c->chainFlags, (size_t)(c->plan.gridX * c->plan.gridY / c->chainL) * c->plan.RP * 4);
     if (c->f16_scales) rc = dallocT(c, &c->absmax, (size_t)3 * 256);
+    if (rc == PMX_OK && c->f16_r3 == 2 && (c->use_f16 || c->k128)) {          // <HH> instances: the correction's matrices and slabs
+        rc = dallocT(c, &c->fixPart, (size_t)2 * GFIX_PARTS * 2 * c->Kk * c->Kk, false);
+        if (rc == PMX_OK) rc = dallocT(c, &c->fixQ, (size_t)4 * c->Kk * c->Kk);
+        for (int j = 0; j < 2 && rc == PMX_OK; ++j) rc = dallocT(c, &c->fixSlab[j], (size_t)c->rowsK[j] * c->Kk);
+    }
     for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)Mk * c->Kk, c->framed || c->Kk != K);   // (framed: the rows behind M / the columns behind K stay zero)
     for (int j = 0; j < 2 && rc == PMX_OK && c->Kk != K; ++j) rc = dallocT(c, &c->Xk[j], (size_t)c->rowsK[j] * c->Kk);          // K1's zero-padded operands
     if (c->use_bf16) {
@@ -602,7 +613,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->f64 ? 7 : c->k32f16 ? (c->f16_r3 ? 10 : 8) : c->use_small ? 4 : (c->k128 ? 5 : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? 9 : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64 ? 7 : c->k32f16 ? (c->f16_r3 ? 10 : 8) : c->use_small ? 4 : (c->k128 ? (c->f16_r3 == 2 && !c->W && c->fixPart ? 12 : 5) : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? (c->f16_r3 == 2 && c->fixPart ? 11 : 9) : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -1026,6 +1037,21 @@ static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, doub
 }
 
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
+static int enqueue_gfix(pmx_ctx* c, const float* A, const float* St, int doA, int doS, hipStream_t stream) {
+    GfixArgs f{};
+    f.X[0] = A; f.X[1] = St;
+    f.rows[0] = c->M; f.rows[1] = c->N;
+    f.K = (int)c->Kk;
+    f.absmax = c->absmax;
+    f.part = c->fixPart; f.Q = c->fixQ;
+    f.out[0] = c->fixSlab[0]; f.out[1] = c->fixSlab[1];
+    f.ld = (int)c->Kk;
+    f.want[0] = (doA & 1) != 0; f.want[1] = doS != 0;
+    f.status = c->dstatus;
+    HIP_CHECK(launch_gfix(f, stream));
+    return PMX_OK;
+}
+
 static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int doA, int doS, bool absmax_fresh) {
     if (c->host_grad) return PMX_OK;       // a user `grad` callable: its result is already in G (see slab_ref)
     if (c->Kk != c->K) {                   // K1 runs the next tuned K: its operands are zero-padded copies of the factors
@@ -1039,6 +1065,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         A = c->Xk[0]; St = c->Xk[1];
     }
     const int64_t Kq = c->Kk;              // K as K1 sees it (rows of A / St are Kq floats apart)
+    bool fix_pending = false;              // an <HH> kernel was launched: its correction slab is owed (behind the timing events: they bracket K1 alone)
     const bool timed = c->timing && (c->timing_seq++ % (unsigned)c->timing_stride) == 0 && c->ev_used + 2 <= c->ev.size();
     if (c->k128) {
         AbsmaxArgs am{};
@@ -1072,6 +1099,8 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
             g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
+        g.hh = c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr && (doA | doS);
+        fix_pending = g.hh != 0;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -1139,6 +1168,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         bool took_f16 = false;
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss, &took_f16));
         c->f16_fell_back = c->use_f16 && !took_f16;      // (pmx_k1_info reports the kernel that ran)
+        if (doA | doS) fix_pending = c->use_f16 && took_f16 && c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr;
     } else {
         const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -1159,6 +1189,11 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         HIP_CHECK(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
     }
+    if (doA | doS) c->fix_on = fix_pending;
+    // what the high x high residual left out, as one more slab per block (k_gfix.hip).  In the launch stream: the three launches depend on the
+    // factors only, but nothing fits BESIDE K1 (its waves hold all 512 registers of every SIMD) -- measured on a stream of their own they sat
+    // behind K1's workgroups and the pass got 2 % slower (profiles/r05_a_gfix_side_stream.txt)
+    if (fix_pending) { const int rcf = enqueue_gfix(c, A, St, doA, doS, c->stream); if (rcf != PMX_OK) return rcf; }
     return PMX_OK;
 }
 
@@ -1188,6 +1223,7 @@ static SlabRef slab_ref(pmx_ctx* c, int j) {
     }
     s.base = c->slab[j];
     s.n = j == 0 ? c->nSlabA : c->nSlabS;
+    if (c->fix_on) s.extra = c->fixSlab[j];
     return s;
 }
 
@@ -1479,8 +1515,12 @@ extern "C" int pmx_loglike(pmx_ctx* c, double* out) {
 extern "C" int pmx_step_pgm(pmx_ctx* c, double out[2]) {
     if (!c || !out) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
+    int rc = PMX_OK;
+    // a context without a solver is a FUNCTION of its factors (nmf.step_pgm called by the caller's own code, on a context the host wrapper
+    // keeps between calls): the power iteration starts where a fresh context's does, not from the previous call's eigenvector
+    if (c->algo == ALG_NONE) { rc = reset_status(c); if (rc != PMX_OK) return rc; }
     HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, sizeof(int), c->stream));
-    int rc = c->f64 ? enqueue_front64(c, c->Xd[0], c->Xd[1], 0, 0, false, true, 1.0) : enqueue_steps(c, c->X[0], c->X[1], true, true, 1.0);
+    rc = c->f64 ? enqueue_front64(c, c->Xd[0], c->Xd[1], 0, 0, false, true, 1.0) : enqueue_steps(c, c->X[0], c->X[1], true, true, 1.0);
     if (rc != PMX_OK) return rc;
     rc = read_status(c);
     if (rc != PMX_OK) return rc;
@@ -1575,6 +1615,33 @@ extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const p
     }
     (void)hipFree(d);
     if (e != hipSuccess) FAIL(PMX_E_HIP, "prox_array: %s", hipGetErrorString(e));
+    return PMX_OK;
+}
+
+extern "C" int pmx_bb_sums(int device, int is_f64, const void* X, const void* Xprev, const void* G, const void* Gprev, int64_t count, double out[6]) {
+    if (!X || !G || !out) FAIL(PMX_E_INVALID, "NULL argument");
+    if (count <= 0) FAIL(PMX_E_INVALID, "bad count %lld", (long long)count);
+    if ((Xprev == nullptr) != (Gprev == nullptr)) FAIL(PMX_E_INVALID, "X_prev and G_prev come together");
+    HIP_CHECK(hipSetDevice(device));
+    const size_t es = is_f64 ? sizeof(double) : sizeof(float), bytes = ((size_t)count * es + 15) / 16 * 16;
+    const int narr = Xprev ? 4 : 2;
+    char* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, narr * bytes + (BBS_BLOCKS * 6 + 6) * sizeof(double)));
+    const void* src[4] = {X, G, Xprev, Gprev};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < narr && e == hipSuccess; ++i) e = hipMemcpy(d + i * bytes, src[i], (size_t)count * es, hipMemcpyHostToDevice);
+    double* part = reinterpret_cast<double*>(d + narr * bytes);
+    if (e == hipSuccess) {
+        const char* xp = Xprev ? d + 2 * bytes : nullptr;
+        const char* gp = Xprev ? d + 3 * bytes : nullptr;
+        if (is_f64) hipLaunchKernelGGL(k_bb_sums<double>, dim3(BBS_BLOCKS), dim3(256), 0, nullptr, (const double*)d, (const double*)xp, (const double*)(d + bytes), (const double*)gp, count, part);
+        else hipLaunchKernelGGL(k_bb_sums<float>, dim3(BBS_BLOCKS), dim3(256), 0, nullptr, (const float*)d, (const float*)xp, (const float*)(d + bytes), (const float*)gp, count, part);
+        hipLaunchKernelGGL(k_bb_sums_fold, dim3(1), dim3(64), 0, nullptr, part, part + BBS_BLOCKS * 6);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(out, part + BBS_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) FAIL(PMX_E_HIP, "bb_sums: %s", hipGetErrorString(e));
     return PMX_OK;
 }
 
@@ -1717,7 +1784,7 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         u.Xe[j] = p.accelerated ? c->Xe[j] : c->X[j];
         u.G[j] = c->G[j];
         u.slab[j] = slab_ref(c, j);
-        if (p.bb_type) { u.slab[j].base = c->G[j]; u.slab[j].n = 1; u.slab[j].ld = (int)c->K; }    // already folded by k_bb_reduce
+        if (p.bb_type) { u.slab[j].base = c->G[j]; u.slab[j].n = 1; u.slab[j].ld = (int)c->K; u.slab[j].extra = nullptr; }    // already folded by k_bb_reduce
         u.rows[j] = c->rows[j];
         u.prox[j] = to_dev(p.prox[j]);
     }
@@ -2279,7 +2346,7 @@ static int ada_enqueue_moment(pmx_ctx* c, int it, double b1t, double b1prev) {
     }
     if (c->shard_grad_from_comm) {   // row-sharded: gSt is the all-reduced sum sitting in the comm buffer (S-split: this rank's chunk of it)
         m.slab[1].base = c->ssplit ? c->comm_out : c->comm;
-        m.slab[1].n = 1; m.slab[1].ld = (int)c->K;
+        m.slab[1].n = 1; m.slab[1].ld = (int)c->K; m.slab[1].extra = nullptr;
     }
     m.K = (int)c->K;
     m.status = c->dstatus;
@@ -2310,7 +2377,7 @@ static int ada_enqueue_tail_fused(pmx_ctx* c, int it, double b1t, double b1prev)
         t.e_rel[j] = p.e_rel[j];
         t.slots[j] = (int)((upd_rows(c, j) + 8191) / 8192);
     }
-    if (c->shard_grad_from_comm) { m.slab[1].base = c->ssplit ? c->comm_out : c->comm; m.slab[1].n = 1; m.slab[1].ld = (int)c->K; }
+    if (c->shard_grad_from_comm) { m.slab[1].base = c->ssplit ? c->comm_out : c->comm; m.slab[1].n = 1; m.slab[1].ld = (int)c->K; m.slab[1].extra = nullptr; }
     m.K = (int)c->K;
     m.status = c->dstatus;
     m.partials = c->partials;
@@ -3032,7 +3099,7 @@ static int pgm_enqueue_update(pmx_ctx* c, bool gS_from_comm, int check) {
         u.rows[j] = upd_rows(c, j);
         u.prox[j] = to_dev(p.prox[j]);
     }
-    if (gS_from_comm) { u.slab[1].base = c->ssplit ? c->comm_out : c->comm; u.slab[1].n = 1; u.slab[1].ld = (int)c->K; }
+    if (gS_from_comm) { u.slab[1].base = c->ssplit ? c->comm_out : c->comm; u.slab[1].n = 1; u.slab[1].ld = (int)c->K; u.slab[1].extra = nullptr; }
     u.K = (int)c->K;
     u.status = c->dstatus;
     u.partials = c->partials;
@@ -3098,7 +3165,7 @@ static int bsdmm_enqueue_block(pmx_ctx* c, int j, bool gS_from_comm, const float
     BsdmmArgs u{};
     u.X = c->X[j];
     u.slab = slab_ref(c, j);
-    if (gS_from_comm) { u.slab.base = c->comm; u.slab.n = 1; u.slab.ld = (int)c->K; }
+    if (gS_from_comm) { u.slab.base = c->comm; u.slab.n = 1; u.slab.ld = (int)c->K; u.slab.extra = nullptr; }
     for (int i = 0; i < p.n_g[j]; ++i) { u.Z[i] = c->Zg[j][i]; u.U[i] = c->Ug[j][i]; u.prox_g[i] = to_dev(p.prox_g[j][i]); }
     u.rows = c->rows[j];
     u.K = (int)c->K;

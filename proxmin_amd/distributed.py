@@ -125,7 +125,9 @@ class NativeRccl:
     juggling, nothing of torch in the data path.  The drivers only need this interface (all_reduce, reduce_scatter_tensor,
     all_gather_into_tensor, get_rank, get_world_size, ReduceOp.SUM), so an instance goes where `torch.distributed` went.
     `bootstrap(dev, rank, world, broadcast)`: rank 0 draws the 128-byte id, `broadcast(bytes_or_None) -> bytes` hands it to
-    every rank (torch.distributed's broadcast_object_list, MPI, a file ...), every rank joins."""
+    every rank (torch.distributed's broadcast_object_list, MPI, a file ...), every rank joins.  Rank 0 takes part in the
+    broadcast WHATEVER happened to it: an id it could not draw (RCCL not loadable) travels as a marker, every rank raises
+    the same error without entering pmx_comm_init, and the caller's agreement step (see _collectives) is reached by all."""
 
     class ReduceOp:
         SUM = None
@@ -136,9 +138,17 @@ class NativeRccl:
     @classmethod
     def bootstrap(cls, dev, rank, world, broadcast):
         uid = C.create_string_buffer(128)
+        err = None
         if rank == 0:
-            _lib.check(dev.lib.pmx_comm_unique_id(uid))
-        raw = broadcast(bytes(uid.raw) if rank == 0 else None)
+            try:
+                _lib.check(dev.lib.pmx_comm_unique_id(uid))
+            except Exception as exc:     # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them
+                err = exc
+        raw = broadcast((bytes(uid.raw) if err is None else b"") if rank == 0 else None)
+        if err is not None:
+            raise err
+        if not raw:
+            raise _lib.PmxError("native RCCL collectives: rank 0 could not draw a communicator id")
         assert len(raw) == 128
         _lib.check(dev.lib.pmx_comm_init(dev.h, raw, int(rank), int(world)))
         return cls(dev, rank, world)
@@ -172,6 +182,7 @@ def default_comm(backend):
 def _collectives(comm, dev, rank, world, group):
     """`comm`: "torch" (torch.distributed on the current stream) | "native" (RCCL through the C ABI, bootstrapped over the
     process group that is there anyway) | None: $PMX_COMM, else default_comm(backend of the group) -- [r4] native on RCCL."""
+    _lib.require_torch()
     import torch.distributed as dist
     comm_arg = comm
     comm = comm or os.environ.get("PMX_COMM") or default_comm(dist.get_backend(group))
@@ -189,7 +200,7 @@ def _collectives(comm, dev, rank, world, group):
     # Join the communicator and prove it on a known answer before the solver depends on it; the ranks then AGREE (over the
     # process group that is there anyway) on whether every one of them succeeded.  Asked for explicitly, a failure raises;
     # chosen by default, the run goes on with torch.distributed's collectives and says so.
-    import torch
+    torch = _lib.require_torch()
     err, nat = None, None
     try:
         nat = NativeRccl.bootstrap(dev, rank, world, broadcast)
@@ -222,6 +233,7 @@ class ShardedAdaproxDriver:
 
     def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=16, dist_module=None):
         if dist_module is None:
+            _lib.require_torch()
             import torch.distributed as dist_module
         self.dist = dist_module
         self.eng = engine
@@ -305,6 +317,7 @@ class ShardedLoop:
 
     def __init__(self, engine, group=None, deferred_test=True, chunk=16, dist_module=None):
         if dist_module is None:
+            _lib.require_torch()
             import torch.distributed as dist_module
         self.dist, self.eng, self.group = dist_module, engine, group
         self.deferred = bool(deferred_test)
@@ -351,7 +364,7 @@ class ShardEngine:
 
     def __init__(self, dev, world, rank, M_global, algorithm="adaprox", s_split=False):
         self.algorithm = algorithm
-        import torch
+        torch = _lib.require_torch()
         self.dev = dev
         lib = dev.lib
         _lib.check(lib.pmx_set_world(dev.h, rank, world, int(M_global)))
@@ -428,7 +441,7 @@ class _DevArray:
 
 
 def _device_tensor(ptr, n, device):
-    import torch
+    torch = _lib.require_torch()
     return torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", device))
 
 
@@ -450,7 +463,8 @@ def nmf_adaprox_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None,
     Requires an initialised torch.distributed process group whose backend can reduce CUDA tensors
     (nccl = RCCL).  comm: "torch" (default) issues the collectives through torch.distributed, "native" through the C ABI's own
     RCCL entry points (pmx_comm_*; the process group only hands the communicator id around).  Returns (converged, iterations)."""
-    import torch
+    torch = _lib.require_torch()
+    _lib.require_torch()
     import torch.distributed as dist
     from . import operators
     from .engine import DeviceNMF
@@ -501,7 +515,8 @@ def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, acc
     partial Gram matrix and the stopping sums riding in every chunk), each rank updates its N / world columns (and, under
     FISTA, extrapolates them), all-gather of the next evaluation point; any device prox_S (pgm applies it once, row by row of
     S^T).  Returns (converged, iterations)."""
-    import torch
+    torch = _lib.require_torch()
+    _lib.require_torch()
     import torch.distributed as dist
     from . import operators
     from .engine import DeviceNMF
@@ -535,7 +550,8 @@ def nmf_pgm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, acc
 def nmf_bsdmm_sharded(Y_local, A_local, S, M_global, prox_A=None, prox_S=None, proxs_g=None, e_rel=1e-3, e_abs=0.0,
                       max_iter=1000, group=None, device=None, comm=None):
     """Row-sharded `nmf(Y, A, S, algorithm=bsdmm, proxs_g=...)` for one rank.  Returns (converged, iterations)."""
-    import torch
+    torch = _lib.require_torch()
+    _lib.require_torch()
     import torch.distributed as dist
     from . import operators
     from .engine import DeviceNMF

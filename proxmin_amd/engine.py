@@ -30,10 +30,9 @@ def _notice(key, msg):
 #   "f16x2"  as "bf16x3", but shapes with K = 64, M % 128 = 0, N % 256 = 0 run the two-term fp16 kernel (operands scaled
 #            by powers of two from the factor maxima: 9 instead of 12 MFMA products per multiply-add), and so do shapes
 #            with K = 128, M % 128 = 0, N % 128 = 0 (k_grad_f16_k128; no weights there)
-#   "f16x2r" "f16x2" with the RESIDUAL in exact fp32's class where k_grad_f16_v8 runs (K1's K = 64): the third fp16 terms of A and S in
-#            A@S and its small products in a second accumulator (11 instead of 9 products; include/pmx.h: PMX_MODE_F16X2R) -- the
-#            two-term product carries the operands' representation errors coherently into the gradients; K = 32 likewise (k_grad_f16_k32),
-#            K = 128 as "f16x2"
+#   "f16x2r" "f16x2" with the RESIDUAL in exact fp32's class (include/pmx.h: PMX_MODE_F16X2R).  K1's K = 64 / 128 without weights: the
+#            residual from the high x high fp16 product alone, the rest restored exactly through K x K matrices (k_gfix.hip) -- 7 instead
+#            of 9 MFMA products per multiply-add; K = 32: third fp16 terms of A and S in a second accumulator (11 products)
 _DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
 
 
@@ -85,7 +84,7 @@ class DeviceNMF:
         if mode not in ("f32", "f64"):
             k = self.k1_info()["kernel"]
             fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small"),
-                    "f16x2r": ("k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_small")}[mode]
+                    "f16x2r": ("k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_f16_v8_hh", "k_grad_f16_k128_hh", "k_grad_f16_k128", "k_grad_small")}[mode]
             generic_bf16 = k == "k_grad_bf16" and not (self.K == 64 and self.M % 128 == 0 and self.N % 256 == 0)
             if k not in fast or generic_bf16 or (mode in ("f16x2", "f16x2r") and k == "k_grad_bf16"):
                 _notice((mode, k, self.K, self.M % 128 == 0, self.N % 256 == 0),
@@ -98,8 +97,8 @@ class DeviceNMF:
             try:
                 if self.mode in ("f16x2", "f16x2r") and self.k1_info()["range_faults"]:
                     _notice(("range", self.M, self.N, self.K),
-                            "proxmin_amd: mode f16x2 at %d x %d x %d: the factors ran away from the data (K max|A| max|S| > 2^16 max|Y|: one fp16 "
-                            "scale cannot carry that residual); the run went on with the exact-fp32 kernel" % (self.M, self.N, self.K))
+                            "proxmin_amd: mode %s at %d x %d x %d: the factors ran away from the data (K max|A| max|S| > 2^16 max|Y|: one fp16 "
+                            "scale cannot carry that residual); the run went on with the exact-fp32 kernel" % (self.mode, self.M, self.N, self.K))
             except Exception:
                 pass
             self.lib.pmx_ctx_destroy(self.h)
@@ -222,7 +221,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3", "k_grad_f16_k32_r3")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_f16_v8_hh", "k_grad_f16_k128_hh")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool((v7 // 1000000) % 10)
         d["range_faults"] = v7 // 10000000   # 1: a two-term fp16 K1 refused the residual's range, the context went on in exact fp32 (f16_range_fault)

@@ -45,12 +45,37 @@ def _device_for(A, S, Y, W=None):
     return dev
 
 
+class _Borrowed:
+    """`with` wrapper that hands a cached context out and leaves it open."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        return self.dev
+
+    def __exit__(self, *exc):
+        return False
+
+
+_FACTOR_CTX = {}      # (M, N, K) -> the ONE factors-only context kept between calls
+
+
 def _factors_only(A, S):
-    """Context holding just the factors (the step rules never touch Y: nothing M x N is allocated or uploaded)."""
+    """Context holding just the factors (the step rules never touch Y: nothing M x N is allocated or uploaded).  [r5] The last one is
+    kept: the reference's FISTA idiom `step=lambda *X, it=None: tuple(.5 * s for s in step_pgm(*X))` calls this once per iteration,
+    and a context per call (allocations, a stream, two uploads) cost more than the rule itself.  One shape at a time; the result
+    is a function of (A, S) alone -- pmx_step_pgm restarts its power iteration on a context without a solver."""
     A, S = np.asarray(A), np.asarray(S)
-    dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
+    key = (A.shape[0], S.shape[1], A.shape[1])
+    dev = _FACTOR_CTX.get(key)
+    if dev is None or getattr(dev, "h", None) is None:
+        for old in _FACTOR_CTX.values():
+            old.close()
+        _FACTOR_CTX.clear()
+        dev = _FACTOR_CTX[key] = DeviceNMF(key[0], key[1], key[2], mode="f32")
     dev.set_factors(A, S)
-    return dev
+    return _Borrowed(dev)
 
 
 def log_likelihood(*X, Y=0, W=1):

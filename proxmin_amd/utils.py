@@ -45,14 +45,50 @@ class BarzilaiBorweinStepper:
     Pass the object (or its bound `.step`) as `step=` to `nmf(..., algorithm=pgm)`: the reductions
     (sum s^2, s.y, y^2, |G|^2, max|X|, max|G| with s = X - X_prev, y = G - G_prev) and the step formula run
     on the device each iteration, evaluated -- like the reference -- at the point the gradient was taken.
-    It has no host implementation: calling `.step` directly on ndarrays is not supported."""
+    [r5] Called directly on ndarrays -- `stepper.step(*X, it=it, grads=G)`, the reference's own signature and state
+    (`X_`, `G_`, `Delta`) -- the six sums of every block come from the device (pmx_bb_sums: the arrays go up, six numbers
+    come back); the scalar formula on them is the reference's.  Return types are the reference's: a tuple of
+    scalars at it == 0, an ndarray of N steps afterwards (utils.py:222,241)."""
 
     def __init__(self, type=1, init_r=0.1):
         assert type in [1, 2]
         self.r = init_r
         self.type = type
 
+    @staticmethod
+    def _sums(x, g, xp, gp):
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        lib = _lib.require_gpu()
+        f64 = all(np.asarray(a).dtype == np.float64 for a in (x, g))
+        dt = np.float64 if f64 else np.float32
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=dt) for a in (x, xp, g, gp)]
+        assert arrs[0].size == arrs[2].size and (arrs[1] is None or arrs[1].size == arrs[0].size == arrs[3].size)
+        out = (C.c_double * 6)()
+        ptr = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
+        _lib.check(lib.pmx_bb_sums(0, int(f64), ptr[0], ptr[1], ptr[2], ptr[3], arrs[0].size, out))
+        return list(out)
+
     def step(self, *X, it=None, grads=None):
-        raise NotImplementedError("BarzilaiBorweinStepper runs inside the device solver: pass it as step= to nmf(..., algorithm=pgm)")
+        import numpy as np
+        N = len(X)
+        assert grads is not None and len(grads) == N, "BarzilaiBorweinStepper.step needs grads= (algorithms.py:73-77 passes them)"
+        first = it == 0
+        sums = [self._sums(X[j], grads[j], None if first else self.X_[j], None if first else self.G_[j]) for j in range(N)]
+        self.X_ = tuple(np.array(x, copy=True) for x in X)       # utils.py:221,229 (_copy_tuple)
+        self.G_ = grads                                           # "no copy needed, created fresh every single iteration"
+        if first:
+            self.Delta = np.array([np.inf, ] * N)
+            return tuple(self.r * s[4] / s[5] for s in sums)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if self.type == 1:
+                A = tuple(np.float64(s[0]) / np.float64(s[1]) for s in sums)
+            else:
+                A = tuple(np.float64(s[1]) / np.float64(s[2]) for s in sums)
+            if it <= 3:
+                self.Delta = np.minimum(self.Delta, tuple(np.sqrt(s[0]) for s in sums))
+            Astab = tuple(self.Delta[j] / np.sqrt(np.float64(sums[j][3])) for j in range(N))
+            return np.minimum(np.abs(A), Astab)
 
     __call__ = step

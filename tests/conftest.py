@@ -5,6 +5,9 @@ import sys
 import numpy as np
 import pytest
 
+# the tests use torch next to the library (device arrays, torch.distributed): torch's HIP runtime must be in the process first
+# (proxmin_amd/_lib.py: load) -- the package itself does not import torch
+os.environ.setdefault("PMX_TORCH_PRELOAD", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -548,3 +548,21 @@ def test_backtracking_with_a_user_prox(pm, orc, accel):
            backtracking=True, f=f, e_rel=1e-9, max_iter=10)
     np.testing.assert_array_equal(A, runs["library"][0])
     np.testing.assert_array_equal(S, runs["library"][1])
+
+
+def test_barzilai_borwein_stepper_called_as_a_function(pm):
+    """[r5] utils.BarzilaiBorweinStepper.step(*X, it=, grads=) on ndarrays, as the reference allows (utils.py:216-241): the recorded
+    calls of the REAL reference (helpers.npz bb1 / bb2: six calls each on two fp64 blocks) -- same state, same return types, the
+    six sums per block from the device (pmx_bb_sums).  Then the same calls on fp32 copies against the fp64 results."""
+    from conftest import load_golden
+    z, _ = load_golden("helpers.npz")
+    for typ in (1, 2):
+        for dt, rtol in ((np.float64, 1e-10), (np.float32, 2e-5)):
+            bb = pm.utils.BarzilaiBorweinStepper(type=typ, init_r=0.1)
+            for it in range(6):
+                X = tuple(z["bb%d/X_%s_%d" % (typ, b, it)].astype(dt) for b in "AS")
+                G = tuple(z["bb%d/G_%s_%d" % (typ, b, it)].astype(dt) for b in "AS")
+                out = bb.step(*X, it=it, grads=G)
+                assert isinstance(out, tuple) if it == 0 else isinstance(out, np.ndarray)
+                np.testing.assert_allclose(np.asarray(out, dtype=np.float64), z["bb%d/steps" % typ][it], rtol=rtol, err_msg="type %d call %d %s" % (typ, it, dt.__name__))
+            assert bb.X_[0].dtype == dt and bb.G_ is G

@@ -555,21 +555,30 @@ def test_k32_two_term_fp16_kernel(eng, orc, M, N):
             assert dev.k1_info()["kernel"] == "k_grad_f16_k32" and dev.k1_info()["frame_K"] == 32
 
 
-@pytest.mark.parametrize("K", [64, 32])
-def test_third_terms_in_the_residual_remove_the_coherent_error(eng, orc, K):
-    """[r4] What mode f16x2r is for (k_grad_f16_v8<R3>).  With two fp16 terms per operand, P = A S carries the operands' representation
-    errors -- 2^-23 each, far below P's accumulation noise entry by entry, but the SAME dS[k][n] in every row of P: gS = A^T R picks up
-    A^T A dS, a sum that grows with M and not with sqrt(M).  On a problem with non-negative factors (every entry of A^T A positive) the
-    error of gS against fp64 is about twice exact fp32's in mode f16x2 and back at exact fp32's in mode f16x2r (NumPy emulation:
-    scratch/r4_emulate_modes.py -- 3.0e-7 / 1.5e-7 / 1.5e-7 of max|gS| at this size), gA alike through S S^T."""
+@pytest.mark.parametrize("K,variant", [(64, "hh"), (64, "r3"), (32, "r3"), (128, "hh")])
+def test_mode_f16x2r_removes_the_coherent_error(eng, orc, K, variant, monkeypatch):
+    """What mode f16x2r is for.  With two fp16 terms per operand, P = A S carries the operands' representation errors -- 2^-23 each, far
+    below P's accumulation noise entry by entry, but the SAME dS[k][n] in every row of P: gS = A^T R picks up A^T A dS, a sum that grows
+    with M and not with sqrt(M).  On a problem with non-negative factors (every entry of A^T A positive) the error of gS against fp64 is
+    about twice exact fp32's in mode f16x2 and back at exact fp32's in mode f16x2r, gA alike through S S^T -- whichever way the mode gets
+    there: [r5] "hh", the residual from the high x high product + the exact K x K correction slab (k_grad_f16_v8<HH> / k_grad_f16_k128<HH>
+    + k_gfix.hip; scratch/r5_gradient_error_table.py is its NumPy model), or [r4] "r3", third terms in a second accumulator (K = 32, and
+    K = 64 under PMX_F16_R3=1; scratch/r4_emulate_modes.py)."""
     M, N = 2048, 2048
     Y, A, S = orc.synthetic_problem(M, N, K, np.float32, unity_S=True, seed=4321)
     r64 = orc.residual_gradients(A.astype(np.float64), S.astype(np.float64), Y.astype(np.float64))
+    if variant == "r3" and K == 64:
+        monkeypatch.setenv("PMX_F16_R3", "1")
+    names = {64: ("k_grad_f32_pc", "k_grad_f16_v8", "k_grad_f16_v8_hh" if variant == "hh" else "k_grad_f16_v8_r3"),
+             32: ("k_grad_f32_pc", "k_grad_f16_k32", "k_grad_f16_k32_r3"), 128: ("k_grad_f32", "k_grad_f16_k128", "k_grad_f16_k128_hh")}[K]
     err = {}
-    for mode in ("f32", "f16x2", "f16x2r"):
+    for mode, name in zip(("f32", "f16x2", "f16x2r"), names):
+        if mode == "f16x2":
+            monkeypatch.delenv("PMX_F16_R3", raising=False)       # (the switch applies to any f16x2 context)
+        elif variant == "r3" and K == 64:
+            monkeypatch.setenv("PMX_F16_R3", "1")
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
-            assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32_pc", "f16x2": "k_grad_f16_v8" if K == 64 else "k_grad_f16_k32",
-                                               "f16x2r": "k_grad_f16_v8_r3" if K == 64 else "k_grad_f16_k32_r3"}[mode]
+            assert dev.k1_info()["kernel"] == name
             dev.set_Y(Y)
             dev.set_factors(A, S)
             g = dev.grad()

@@ -166,12 +166,12 @@ def test_medium_problems_at_rtol_1e4_in_split_modes(pm, orc, name, kw, M, N, K, 
     recorded next to the yardstick's -- the oracle itself in fp32 against the oracle in fp64 -- and held to a floor."""
     if mode == "bf16x3" and K == 128:
         pytest.skip("mode bf16x3 has no K = 128 kernel (the context runs the exact-fp32 kernel: covered by the f32 test)")
-    if mode == "f16x2r" and K == 128:
-        pytest.skip("mode f16x2r is mode f16x2 at K = 128 (its third terms live in k_grad_f16_v8 only)")
     from proxmin_amd.engine import DeviceNMF
     with DeviceNMF(M, N, K, mode=mode) as dev:
         kernel = dev.k1_info()["kernel"]
-    assert kernel == ("k_grad_f16_k128" if K == 128 else {"f16x2": "k_grad_f16_v8", "bf16x3": "k_grad_bf16", "f16x2r": "k_grad_f16_v8_r3"}[mode]), kernel
+    want = ({"f16x2": "k_grad_f16_k128", "f16x2r": "k_grad_f16_k128_hh"}[mode] if K == 128 else
+            {"f16x2": "k_grad_f16_v8", "bf16x3": "k_grad_bf16", "f16x2r": "k_grad_f16_v8_hh"}[mode])
+    assert kernel == want, kernel
     Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, unity_S=unity, seed=21)
     pm.set_default_mode(mode)
     try:
@@ -195,7 +195,11 @@ def test_medium_problems_at_rtol_1e4_in_split_modes(pm, orc, name, kw, M, N, K, 
     if name.startswith(SMOOTH):
         assert fA == 1.0 and fS == 1.0, "%s %s: %.6f / %.6f within rtol 1e-4 (worst %.1f x)" % (mode, name, fA, fS, max(wA, wS))
     else:
-        assert fA >= 0.9995 and fS >= 0.998, rec
+        if mode == "f16x2r":                 # the bench's arithmetic: tied to the yardstick (<= 2.5 x its out-of-tolerance count + 2 entries, <= 4 x its worst ratio)
+            assert (1.0 - fA) <= 2.5 * (1.0 - yA) + 2.0 / A.size and (1.0 - fS) <= 2.5 * (1.0 - yS) + 2.0 / S.size, rec
+            assert max(wA, wS) <= 4.0 * max(ywA, ywS, 1.0), rec
+        else:
+            assert fA >= 0.9995 and fS >= 0.998, rec
 
 
 def test_radam_early_iterates(pm, orc):
@@ -260,7 +264,7 @@ def _full_size(cfg, seed=4321):
     return M, N, K, backend, unity, Yd, A0, S0
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+@pytest.mark.parametrize("mode", ["f32", "f16x2", "f16x2r"])
 def test_full_size_cfg3_against_the_oracle(orc, mode):
     """BASELINE cfg3 at its full size (16384 x 16384, K = 64, adaprox / AMSGrad, prox_plus + prox_unity_plus on the
     columns of S): 3 iterations against the fp64 oracle on the very same Y (copied back from the GPU), both the library's
@@ -275,8 +279,9 @@ def test_full_size_cfg3_against_the_oracle(orc, mode):
         r = run(3)
         A, S = dev.get_factors()
         sub = [int(r.sub_iterations[0]), int(r.sub_iterations[1])]
-        if mode == "f16x2":
+        if mode != "f32":
             assert dev.k1_info()["chain"] == 16 and dev.k1_info()["tail_fused"]
+            assert dev.k1_info()["kernel"] == ("k_grad_f16_v8" if mode == "f16x2" else "k_grad_f16_v8_hh")
     Y64 = Yd.cpu().numpy().astype(np.float64)
     del Yd
     Ao, So = A0.astype(np.float64), S0.astype(np.float64)
@@ -285,19 +290,21 @@ def test_full_size_cfg3_against_the_oracle(orc, mode):
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
     REPORT["full cfg3 %s, 3 iterations vs fp64 oracle" % mode] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS), "sub_iterations": sub}
-    # measured (profiles/r02_parity_fractions.json): f32 0.999999 / 0.99985, f16x2 0.99989 / 0.99946 -- AMSGrad's eps clamp
-    floor = (0.9999, 0.9995) if mode == "f32" else (0.9995, 0.999)
+    # measured (profiles/r02_parity_fractions.json): f32 0.999999 / 0.99985, f16x2 0.99989 / 0.99946 -- AMSGrad's eps clamp.  The bench's mode
+    # (f16x2r) is held to exact fp32's floor here and to the yardstick rule in tests/test_gpu_parity_long.py
+    floor = (0.9999, 0.9995) if mode in ("f32", "f16x2r") else (0.9995, 0.999)
     assert fA >= floor[0] and fS >= floor[1], (fA, fS)
     np.testing.assert_allclose(S.sum(0), 1.0, rtol=1e-5)
 
 
-def test_full_size_cfg5_against_the_oracle(orc):
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2r"])
+def test_full_size_cfg5_against_the_oracle(orc, mode):
     """BASELINE cfg5 (16384 x 16384, K = 64, bSDMM, prox_plus + prox_soft per factor): 2 iterations against the fp64
-    oracle; smooth arithmetic: rtol 1e-4 on every entry, in the bench's arithmetic mode (f16x2)."""
+    oracle; smooth arithmetic: rtol 1e-4 on every entry, in the bench's arithmetic mode (f16x2r) and in f16x2."""
     import bench
     from proxmin_amd.engine import DeviceNMF
     M, N, K, backend, unity, Yd, A0, S0 = _full_size("cfg5")
-    with DeviceNMF(M, N, K, mode="f16x2") as dev:
+    with DeviceNMF(M, N, K, mode=mode) as dev:
         dev.set_Y_device(Yd.data_ptr(), ld=N, copy=False, keepalive=Yd)
         dev.set_factors(A0, S0)
         run = bench.begin_solver(dev, backend, unity)
@@ -309,14 +316,14 @@ def test_full_size_cfg5_against_the_oracle(orc):
     orc.bsdmm_nmf(Y64, Ao, So, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=2, e_rel=1e-12)
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
-    REPORT["full cfg5 f16x2, 2 iterations vs fp64 oracle"] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
+    REPORT["full cfg5 %s, 2 iterations vs fp64 oracle" % mode] = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS)}
     assert fA == 1.0 and fS == 1.0, (fA, fS, wA, wS)
 
 
 _CFG4_ORACLE = {}
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+@pytest.mark.parametrize("mode", ["f32", "f16x2", "f16x2r"])
 def test_full_size_cfg4_rows_of_one_rank_against_the_oracle(orc, mode):
     """BASELINE cfg4's per-GPU share (8192 of its 65536 rows x 16384, K = 128, adaprox / AMSGrad, prox_plus): 2 iterations
     on one GPU against the fp64 oracle, in the exact-fp32 mode and in the two-term fp16 mode (k_grad_f16_k128)."""
@@ -327,7 +334,7 @@ def test_full_size_cfg4_rows_of_one_rank_against_the_oracle(orc, mode):
     M = 8192
     Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 77, torch.device("cuda", 0))
     with DeviceNMF(M, N, K, mode=mode) as dev:
-        assert dev.k1_info()["kernel"] == ("k_grad_f32" if mode == "f32" else "k_grad_f16_k128")
+        assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32", "f16x2": "k_grad_f16_k128", "f16x2r": "k_grad_f16_k128_hh"}[mode]
         dev.set_Y_device(Yd.data_ptr(), ld=N, copy=False, keepalive=Yd)
         dev.set_factors(A0, S0)
         run = bench.begin_solver(dev, backend, unity)
