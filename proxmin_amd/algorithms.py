@@ -71,10 +71,14 @@ def _open_device(Y, A, S, W, f64=False):
     arrays are fp64 and the call is one the fp64 kernels cover (pgm / FISTA, small problem): compute in fp64 like the
     reference does for fp64 inputs (nmf.py:39-41)."""
     if f64:
-        dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64")
-        dev.set_Y(Y)
-        dev.set_factors(A, S)
-        return dev
+        try:
+            dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64")
+        except NotImplementedError:     # the library's own test (pmx_ctx_create) is the authority: compute in fp32 and cast back, as for any other fp64 call
+            dev = None
+        if dev is not None:
+            dev.set_Y(Y)
+            dev.set_factors(A, S)
+            return dev
     if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
         dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
         dev.set_host_grad(True)

@@ -56,7 +56,7 @@ __device__ __forceinline__ float gfix_scale(const float* absmax, int f, float* r
 // goes out before the scale's own round trip.
 template <int KT, int W>
 __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* red) {
-    constexpr int K = 32 * KT, TPW = KT * KT / 4, NB = KT == 2 ? 4 : 2;
+    constexpr int K = 32 * KT, TPW = KT * KT / 4, NB = KT == 2 ? 8 : 2;    // (K = 64: a 128-row share is ONE batch of loads)
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int64_t rows = a.rows[f];
     const int64_t per = 16 * ((rows + 16 * GFIX_PARTS - 1) / (16 * GFIX_PARTS));
@@ -180,22 +180,29 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
 #pragma unroll
         for (int ks = 0; ks < K / 16; ++ks) { x[ks][0] = xr[4 * ks]; x[ks][1] = xr[4 * ks + 1]; }
     }
-    constexpr int NL = K * K / 4 / 256;      // float4 per thread and matrix; entry 4 (i 256 + tid) .. + 3 = Q[k'][k .. k + 3], row-major
-    f32x4 tq[2][NL];                         // [0] = Q0, [1] = Qr (the order k_gfix_reduce leaves them in)
+    // The matrices, read so that the TRANSPOSED planes are written with one 16-byte store per eight k': thread t takes column k = t % K and the
+    // blocks of eight k' = 8 (t / K + (256 / K) i) .. -- 8 scalar loads per block, each coalesced across the lanes (consecutive k), one
+    // conflict-free ds_write_b128 per term.  (A float4-per-thread read with sixty-four 2-byte scattered stores, 16-way bank conflicts, was the
+    // kernel: 13 us of its 14.)
+    constexpr int TPK = 256 / K, NBLK = K / 8 / TPK;       // threads per column, blocks of eight k' per thread
+    const int kcol = tid % K, kb0 = tid / K;
+    float tq[2][NBLK][8];
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.Q + (int64_t)(1 - f) * 2 * K * K);
+        const float* src = a.Q + (int64_t)(1 - f) * 2 * K * K;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int i = 0; i < NL; ++i) tq[m][i] = src[(m * NL + i) * 256 + tid];
+            for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tq[m][i][e] = src[(size_t)m * K * K + (size_t)(8 * (kb0 + TPK * i) + e) * K + kcol];
     }
     float mx[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
+        for (int i = 0; i < NBLK; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx[m] = fmaxf(mx[m], fabsf(tq[m][i][e]));
+            for (int e = 0; e < 8; ++e) mx[m] = fmaxf(mx[m], fabsf(tq[m][i][e]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o)); }
     __shared__ float redq[2][4];
@@ -210,19 +217,21 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
         sq[m] = ldexpf(1.f, v > 0.f ? 14 - q : 0);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {            // plane (1 - m): Qr first
-        _Float16* ph = qpl + (size_t)((1 - m) * 2) * K * LDQ;
+    for (int m = 0; m < 2; ++m) {            // matrix m (0 = Q0, 1 = Qr) -> planes 2 (1 - m), + 1: Qr first
+        _Float16* ph = qpl + (size_t)((1 - m) * 2) * K * LDQ + (size_t)kcol * LDQ;
         _Float16* pl = ph + (size_t)K * LDQ;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int e0 = 4 * (i * 256 + tid), kp = e0 / K, k0 = e0 % K;
+        for (int i = 0; i < NBLK; ++i) {
+            gf16x8 h8, l8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 const float v = tq[m][i][e] * sq[m];
                 const _Float16 h = (_Float16)v;
-                ph[(k0 + e) * LDQ + kp] = h;
-                pl[(k0 + e) * LDQ + kp] = (_Float16)(v - (float)h);
+                h8[e] = h;
+                l8[e] = (_Float16)(v - (float)h);
             }
+            *reinterpret_cast<gf16x8*>(ph + 8 * (kb0 + TPK * i)) = h8;
+            *reinterpret_cast<gf16x8*>(pl + 8 * (kb0 + TPK * i)) = l8;
         }
     }
     __syncthreads();

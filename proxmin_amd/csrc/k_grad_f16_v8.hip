@@ -450,7 +450,10 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         lc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][wh == 0 ? 1 : (wh == 2 ? 2 : 0)], sv[ks][wh == 1 ? 1 : (wh == 3 ? 2 : 0)], cin, 0, 0, 0);
                     }
                 } else if constexpr (GEMM && HH) {
-                    if (t % 3 == 0) {                        // ah sh alone: one MFMA every third step, the epilogue pieces between them
+                    // ah sh alone: one MFMA every third step, the epilogue pieces between them.  (Measured and dropped: every k step from C = 0
+                    // with the partial sums added by the VALU, and the odd k steps with flipped sign -- the fp16 MFMA's adder is not IEEE
+                    // (scratch/r5_mfma_rounding2.hip), but neither changes the gradients' error: profiles/r05_b_mfma_accumulation.txt)
+                    if (t % 3 == 0) {
                         f32x16 cin = pc;
                         if (t == 0) {
 #pragma unroll

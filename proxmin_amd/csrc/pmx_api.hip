@@ -192,6 +192,8 @@ struct pmx_ctx {
     double nest_t = 1.0;                   // NesterovAccelerator.t (utils.py:195)
     double btT[2] = {1.0, 1.0};            // backtracking step multipliers T (algorithms.py:85), never reset inside a run
     double bt_fprev = 0.0, bt_fnow = 0.0;
+    bool bt_grad_fresh = false;            // line search: pmx_pgm_split(0) has just left this evaluation point's gradient in the slabs (a user `step` that takes
+                                           // `grads`): the pmx_pgm_bt_split(0) that follows does not run K1 again.  Cleared by anything that moves the factors.
     int bt_pending = 0;                    // line search: blocks (bit j) whose user prox the caller owes (pmx_pgm_bt_split)
     int bt_trial = 3;                      // blocks whose sums the current trial renews
     float* btBuf[2] = {nullptr, nullptr};  // argument / result of a user prox inside the line search (PMX_BUF_BT_A / _ST)
@@ -779,7 +781,7 @@ static int buf_lookup(pmx_ctx* c, int buf, float*** slot, int64_t* count, bool c
 }
 
 extern "C" int pmx_upload(pmx_ctx* c, int buf, const float* host, int64_t count) {
-    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; c->bt_grad_fresh = false; }
     if (!c || !host) FAIL(PMX_E_INVALID, "NULL argument");
     HIP_CHECK(hipSetDevice(c->device));
     float** slot; int64_t n;
@@ -942,6 +944,11 @@ static int one_iteration_per_call(pmx_ctx* c) {
 static int k1_leave_f16(pmx_ctx* c) {
     c->mode = PMX_MODE_F32;
     select_k1(c, c->Mk, c->Nk, c->ncu);
+    c->fix_on = false;
+    if (c->k1_sync_check) {                 // one-iteration-per-call paths run without chains (one_iteration_per_call: a chain fault could not be repaired by repeating the iteration)
+        c->chainL = 0;
+        c->nSlabA = c->plan.nSlabA;
+    }
     c->chainFlags = nullptr;
     c->chainSeq = 0;
     c->slab[0] = c->slab[1] = nullptr;
@@ -1649,7 +1656,7 @@ extern "C" int pmx_bb_sums(int device, int is_f64, const void* X, const void* Xp
 // PGM / FISTA                                             (proxmin/algorithms.py:12-144)
 // ------------------------------------------------------------------------------------------------
 extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
-    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; }
+    if (c) { c->absmax_by_finish = false; c->gram_by_update = false; c->bt_grad_fresh = false; }
     int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
@@ -1878,8 +1885,11 @@ static int bt_step(pmx_ctx* c, int phase, int* need, double eff[2]) {
             rc = enqueue_steps(c, c->Xe[0], c->Xe[1], true, true, (double)p.step_scale);
             if (rc != PMX_OK) return rc;
         }
-        rc = enqueue_grad(c, c->Xe[0], c->Xe[1], 1, 1);
-        if (rc != PMX_OK) return rc;
+        if (!c->bt_grad_fresh) {
+            rc = enqueue_grad(c, c->Xe[0], c->Xe[1], 1, 1);
+            if (rc != PMX_OK) return rc;
+        }
+        c->bt_grad_fresh = false;
         BtArgs u = bt_args(c);
         u.first = 1;
         for (int j = 0; j < 2; ++j) { u.do_block[j] = 1; u.mode[j] = p.host_prox[j] ? 1 : 0; }
@@ -2114,6 +2124,7 @@ extern "C" int pmx_pgm_split(pmx_ctx* c, int phase, const double* steps, pmx_res
             }
             rc = enqueue_grad(c, A, St, 1, 1);
             if (rc != PMX_OK) return rc;
+            c->bt_grad_fresh = p.backtracking != 0;      // (the line search's phase 0 evaluates the same point: Xe)
             if (p.bb_type) {             // the Barzilai-Borwein rule on the device (utils.py:216-241), exactly as a fused iteration
                 BBArgs b{};              // does it: k_bb_reduce folds the gradient as well
                 b.X[0] = A; b.X[1] = St;

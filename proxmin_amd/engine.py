@@ -54,7 +54,15 @@ def _f32(a):
 def f64_applies(M, N, K):
     """Shapes the fp64 kernels take (include/pmx.h: PMX_MODE_F64 -- the small-problem path: the reference's own examples
     and BASELINE cfg1); PMX_F64=0 switches the mode off (fp64 inputs are then computed in fp32 and cast back, as before)."""
-    if os.environ.get("PMX_F64", "1") == "0" or os.environ.get("PMX_K1_SMALL", "1") == "0":
+    def off(name):                      # the library reads these with atoi(): anything that is not a non-zero number switches off
+        v = os.environ.get(name)
+        if v is None:
+            return False
+        try:
+            return int(v.strip() or 0) == 0
+        except ValueError:
+            return True
+    if off("PMX_F64") or off("PMX_K1_SMALL"):
         return False
     return K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
 
@@ -135,6 +143,13 @@ class DeviceNMF:
         if keepalive is not None:
             self._keep.append(keepalive)
         _lib.check(self.lib.pmx_set_Y_device(self.h, C.c_void_p(int(dptr)), int(ld or self.N), int(bool(copy))))
+        if not copy and not self.f64:
+            fr = self.k1_info()["frame"]
+            if tuple(fr) != (self.M, self.N):
+                _notice(("frame-copy", self.M, self.N, self.K),
+                        "proxmin_amd: %d x %d x %d runs on the zero-padded frame %d x %d of its tuned kernel: the device array handed over with copy=False is "
+                        "COPIED into a frame-sized buffer (%.2f GiB more device memory; PMX_FRAME=0 keeps the caller's array and the guarded kernels)"
+                        % (self.M, self.N, self.K, fr[0], fr[1], fr[0] * fr[1] * 4 / 2.0 ** 30))
 
     def set_W(self, W):
         """Weights of the likelihood (nmf.py:13-41), an M x N array; None goes back to W == 1.  Mode "f32" takes any

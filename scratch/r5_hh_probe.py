@@ -51,3 +51,17 @@ with eng.DeviceNMF(M, N, K, mode="f16x2r") as dev:
     _lib.check(dev.lib.pmx_time_grad(dev.h, 1, 1, 30, C.byref(ms)))
     _lib.check(dev.lib.pmx_time_grad(dev.h, 1, 1, 100, C.byref(ms)))
     print("cfg3 HH, correction in the launch stream: %.4f ms" % ms.value, flush=True)
+# cfg4's share: K1 time at K = 128
+M, N, K = 8192, 16384, 128
+rng = np.random.default_rng(2)
+A0 = rng.random((M, K), dtype=np.float32); S0 = rng.random((K, N), dtype=np.float32) * np.float32(16.0 / K)
+Y = rng.random((M, N), dtype=np.float32) * 16
+for k in ("PMX_GFIX_SIDE", "PMX_F16_R3"):
+    os.environ.pop(k, None)
+for name, mode in (("f16x2", "f16x2"), ("HH", "f16x2r")) * 2:
+    with eng.DeviceNMF(M, N, K, mode=mode) as dev:
+        dev.set_Y(Y); dev.set_factors(A0, S0)
+        ms = C.c_double()
+        _lib.check(dev.lib.pmx_time_grad(dev.h, 1, 1, 30, C.byref(ms)))
+        _lib.check(dev.lib.pmx_time_grad(dev.h, 1, 1, 100, C.byref(ms)))
+        print("cfg4 share %s: gradient pass %.4f ms  [%s]" % (name, ms.value, dev.k1_info()["kernel"]), flush=True)

@@ -96,15 +96,17 @@ def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, 
         for b in ("A", "S"):
             out_dev, out_ref = 1.0 - got[b][0], 1.0 - yard[b][0]
             REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode]["out_of_tolerance_over_yardstick_%s" % b] = out_dev / max(out_ref, 1e-9)
+            # worst ratio: against the yardstick's worst over BOTH blocks (its own worst entry of A is a single one 2 % over the bound: no anchor)
+            yworst = max(yard["A"][1], yard["S"][1], 1.0)
             if mode == "f32":
                 assert out_dev <= 2.0 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
-                assert got[b][1] <= 3.0 * max(yard[b][1], 1.0), (mode, b, got[b][1], yard[b][1])
+                assert got[b][1] <= 3.0 * yworst, (mode, b, got[b][1], yworst)
             elif mode == "f16x2r":
                 # the headline's arithmetic, in exact fp32's class: [r4, <R3>] measured A 8 entries of 1 M (yardstick 1, mode f32 5), S 1.8 x the
                 # yardstick (mode f32 1.1 x, mode f16x2 4.2 x), worst entry 136 x the bound (82 x / 905 x); [r5, <HH>]: profiles/r05_*_parity_long.json
                 assert info["kernel"] == "k_grad_f16_v8_hh", info
                 assert out_dev <= 2.5 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
-                assert got[b][1] <= 4.0 * max(yard[b][1], 1.0), (mode, b, got[b][1], yard[b][1])
+                assert got[b][1] <= 4.0 * yworst, (mode, b, got[b][1], yworst)
             else:
                 assert out_dev <= (2.5e-4 if b == "A" else 1e-3), (mode, b, out_dev, out_ref)
                 assert got[b][1] <= 2000.0, (mode, b, got[b][1])
