@@ -56,7 +56,7 @@ __device__ __forceinline__ float gfix_scale(const float* absmax, int f, float* r
 // goes out before the scale's own round trip.
 template <int KT, int W>
 __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* red) {
-    constexpr int K = 32 * KT, TPW = KT * KT / 4, NB = KT == 2 ? 8 : 2;    // (K = 64: a 128-row share is ONE batch of loads)
+    constexpr int K = 32 * KT, TPW = KT * KT / 4, NB = KT == 2 ? 8 : 4;    // (K = 64: a 128-row share is ONE batch of loads, K = 128: two)
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int64_t rows = a.rows[f];
     const int64_t per = 16 * ((rows + 16 * GFIX_PARTS - 1) / (16 * GFIX_PARTS));
@@ -168,18 +168,8 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
     const int64_t rows = a.rows[f];
     const float* X = a.X[f];
     float* out = a.out[f];
-    const int64_t ntask = (rows + 31) / 32 * KT;          // the grid has a wave per task (launch_gfix)
-    const int64_t task = (int64_t)blockIdx.x * 4 + w;
+    const int64_t ntask = (rows + 31) / 32 * KT, stride = (int64_t)gridDim.x * 4;      // a wave per task and round (launch_gfix: <= 256 workgroups, the matrices staged once each)
     if ((int64_t)blockIdx.x * 4 >= ntask) return;
-    const int64_t rt = task / KT;
-    const int c = (int)(task % KT);
-    const bool live = task < ntask && rt * 32 + l31 < rows;
-    f32x4 x[K / 16][2];                      // this lane's row, components 16 ks + 8 hi .. + 7 (the MFMA's A operand: i = lane & 31, k = 8 (lane >> 5) ..)
-    {
-        const f32x4* xr = reinterpret_cast<const f32x4*>(X + (live ? rt * 32 + l31 : 0) * K + 8 * hi);
-#pragma unroll
-        for (int ks = 0; ks < K / 16; ++ks) { x[ks][0] = xr[4 * ks]; x[ks][1] = xr[4 * ks + 1]; }
-    }
     // The matrices, read so that the TRANSPOSED planes are written with one 16-byte store per eight k': thread t takes column k = t % K and the
     // blocks of eight k' = 8 (t / K + (256 / K) i) .. -- 8 scalar loads per block, each coalesced across the lanes (consecutive k), one
     // conflict-free ds_write_b128 per term.  (A float4-per-thread read with sixty-four 2-byte scattered stores, 16-way bank conflicts, was the
@@ -235,33 +225,42 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
         }
     }
     __syncthreads();
-    f32x16 acc1, acc2;
+    for (int64_t task = (int64_t)blockIdx.x * 4 + w; task < ntask; task += stride) {
+        const int64_t rt = task / KT;
+        const int c = (int)(task % KT);
+        const bool live = rt * 32 + l31 < rows;
+        f32x4 x[K / 16][2];                  // this lane's row, components 16 ks + 8 hi .. + 7 (the MFMA's A operand: i = lane & 31, k = 8 (lane >> 5) ..)
+        {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(X + (live ? rt * 32 + l31 : 0) * K + 8 * hi);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
-    const _Float16* qb = qpl + (size_t)(32 * c + l31) * LDQ + 8 * hi;
-#pragma unroll
-    for (int ks = 0; ks < K / 16; ++ks) {
-        gf16x8 xh, xl, xm;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = (live ? x[ks][e >> 2][e & 3] : 0.f) * sc;
-            const _Float16 h = (_Float16)v;
-            const float r1 = v - (float)h;
-            const _Float16 l = (_Float16)r1;
-            xh[e] = h; xl[e] = l; xm[e] = (_Float16)(r1 - (float)l);
+            for (int ks = 0; ks < K / 16; ++ks) { x[ks][0] = xr[4 * ks]; x[ks][1] = xr[4 * ks + 1]; }
         }
-        const gf16x8 qrh = *reinterpret_cast<const gf16x8*>(qb + 16 * ks);
-        const gf16x8 qrl = *reinterpret_cast<const gf16x8*>(qb + (size_t)K * LDQ + 16 * ks);
-        const gf16x8 q0h = *reinterpret_cast<const gf16x8*>(qb + (size_t)2 * K * LDQ + 16 * ks);
-        const gf16x8 q0l = *reinterpret_cast<const gf16x8*>(qb + (size_t)3 * K * LDQ + 16 * ks);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, qrh, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, q0h, acc2, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, qrl, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, q0l, acc2, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, qrh, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, q0h, acc2, 0, 0, 0);
-    }
-    if (task < ntask) {
+        f32x16 acc1, acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
+        const _Float16* qb = qpl + (size_t)(32 * c + l31) * LDQ + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) {
+            gf16x8 xh, xl, xm;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (live ? x[ks][e >> 2][e & 3] : 0.f) * sc;
+                const _Float16 h = (_Float16)v;
+                const float r1 = v - (float)h;
+                const _Float16 l = (_Float16)r1;
+                xh[e] = h; xl[e] = l; xm[e] = (_Float16)(r1 - (float)l);
+            }
+            const gf16x8 qrh = *reinterpret_cast<const gf16x8*>(qb + 16 * ks);
+            const gf16x8 qrl = *reinterpret_cast<const gf16x8*>(qb + (size_t)K * LDQ + 16 * ks);
+            const gf16x8 q0h = *reinterpret_cast<const gf16x8*>(qb + (size_t)2 * K * LDQ + 16 * ks);
+            const gf16x8 q0l = *reinterpret_cast<const gf16x8*>(qb + (size_t)3 * K * LDQ + 16 * ks);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, qrh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, q0h, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, qrl, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, q0l, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, qrh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, q0h, acc2, 0, 0, 0);
+        }
         const float u1 = 1.f / (sc * sq[1]), u2 = 1.f / (sc * sq[0]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -275,7 +274,8 @@ static hipError_t launch_gfix(const GfixArgs& a, hipStream_t s) {
     const int n = 2 * a.K * a.K;
     const size_t lds = (size_t)4 * a.K * (a.K + 8) * sizeof(_Float16);      // k_gfix_apply: two matrices x two fp16 terms, transposed
     const int64_t rmax = a.rows[0] > a.rows[1] ? a.rows[0] : a.rows[1];
-    const unsigned nb = (unsigned)(((rmax + 31) / 32 * (a.K / 32) + 3) / 4);      // k_gfix_apply: a wave per (32 rows, 32 columns)
+    unsigned nb = (unsigned)(((rmax + 31) / 32 * (a.K / 32) + 3) / 4);            // k_gfix_apply: a wave per (32 rows, 32 columns) and round
+    if (nb > 256) nb = 256;                                                          // (one staging of the matrices per workgroup: at most one workgroup per CU and block)
     if (a.K == 64) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gfix_apply<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
