@@ -148,7 +148,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(1000, 1500, 64, "f16x2"), (1000, 1500, 64, "f32"), (1100, 2000, 128, "f16x2"), (1000, 1400, 32, "f16x2")])
+@pytest.mark.parametrize("M,N,K,mode", [(1000, 1500, 64, "f16x2"), (1000, 1500, 64, "f32"), (1100, 2000, 128, "f16x2"), (1000, 1400, 32, "f16x2"),
+                                      (1000, 1500, 64, "f16x2r"), (1100, 2000, 128, "f16x2r")])      # [r5] <HH> + the correction slab on a frame
 @pytest.mark.parametrize("name,kw", CASES)
 def test_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
     """Six iterations of every back-end on a framed problem against the fp64 oracle on the real shape, from identical fp32 inputs:
@@ -226,7 +227,8 @@ def test_k_framed_gradient_matches_oracle(eng, orc, M, N, K, mode, Kk, kernel):
     np.testing.assert_allclose(gS, hS, rtol=4e-5, atol=4e-5 * np.abs(hS).max())
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(1024, 1536, 50, "f16x2"), (1000, 1500, 40, "f32"), (1100, 2000, 100, "f16x2"), (2048, 1024, 20, "f16x2")])
+@pytest.mark.parametrize("M,N,K,mode", [(1024, 1536, 50, "f16x2"), (1000, 1500, 40, "f32"), (1100, 2000, 100, "f16x2"), (2048, 1024, 20, "f16x2"),
+                                      (1000, 1500, 50, "f16x2r"), (1100, 2000, 100, "f16x2r")])      # [r5] rows, columns AND components padded under <HH>
 @pytest.mark.parametrize("name,kw", CASES)
 def test_k_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
     """six iterations of every back-end with an in-between K against the fp64 oracle: smooth back-ends every entry within the north

@@ -64,14 +64,22 @@ def _begin(dev, backend):
     return dev.bsdmm_run
 
 
+def _name(k16, mode):
+    """the kernel a mode-f16x2r context runs where a mode-f16x2 context runs k16 ([r5]: <HH> + the correction slab at K1's K = 64 / 128, <R3> at 32)"""
+    if mode == "f16x2":
+        return k16
+    return {"k_grad_f16_v8": "k_grad_f16_v8_hh", "k_grad_f16_k128": "k_grad_f16_k128_hh", "k_grad_f16_k32": "k_grad_f16_k32_r3"}[k16]
+
+
+@pytest.mark.parametrize("mode16", ["f16x2", "f16x2r"])
 @pytest.mark.parametrize("M,N,K,k16,k32", SHAPES)
-def test_faulting_gradient_is_the_fp32_kernels(eng, orc, M, N, K, k16, k32):
+def test_faulting_gradient_is_the_fp32_kernels(eng, orc, M, N, K, k16, k32, mode16):
     """pmx_grad / pmx_loglike: the first launch faults, the retry inside the same call runs the fp32 kernel of the frame; gradients
     bit for bit those of a mode-f32 context and within the K1 tolerance of the fp64 oracle; the loss-only pass never faults"""
     Y, A, S = _far_start(orc, M, N, K)
-    with eng.DeviceNMF(M, N, K, mode="f16x2") as dev:
+    with eng.DeviceNMF(M, N, K, mode=mode16) as dev:
         i0 = dev.k1_info()
-        assert i0["kernel"] == k16 and i0["range_faults"] == 0, i0
+        assert i0["kernel"] == _name(k16, mode16) and i0["range_faults"] == 0, i0
         dev.set_Y(Y)
         dev.set_factors(A, S)
         loss16 = dev.loglike()                       # (loss-only instance: fp32 residuals, no guard)
@@ -98,23 +106,24 @@ def test_faulting_gradient_is_the_fp32_kernels(eng, orc, M, N, K, k16, k32):
     np.testing.assert_allclose(gS, rS, rtol=2e-5, atol=2e-5 * np.abs(rS).max())
 
 
+@pytest.mark.parametrize("mode16", ["f16x2", "f16x2r"])
 @pytest.mark.parametrize("backend", ["adaprox", "pgm", "fista", "bsdmm"])
 @pytest.mark.parametrize("M,N,K,k16,k32", SHAPES[1:5])
-def test_faulting_first_iteration_equals_mode_f32(eng, orc, backend, M, N, K, k16, k32):
+def test_faulting_first_iteration_equals_mode_f32(eng, orc, backend, M, N, K, k16, k32, mode16):
     """every back-end from a start that trips the guard in its first K1 launch: the iteration is repeated with the fp32 kernel and the
     run is the run of a mode-f32 context (iteration count; factors bit for bit under adaprox)"""
     Y, A, S = _far_start(orc, M, N, K)
     out = {}
-    for mode in ("f16x2", "f32"):
+    for mode in (mode16, "f32"):
         with eng.DeviceNMF(M, N, K, mode=mode) as dev:
             dev.set_Y(Y)
             dev.set_factors(A, S)
             run = _begin(dev, backend)
             r = run(4)
             info = dev.k1_info()
-            assert r.iterations == 4 and info["kernel"] == k32 and info["range_faults"] == (1 if mode == "f16x2" else 0), (mode, r.iterations, info)
+            assert r.iterations == 4 and info["kernel"] == k32 and info["range_faults"] == (1 if mode == mode16 else 0), (mode, r.iterations, info)
             out[mode] = dev.get_factors()
-    for a, b in zip(out["f16x2"], out["f32"]):
+    for a, b in zip(out[mode16], out["f32"]):
         if backend == "adaprox":
             assert np.array_equal(a, b)
         else:      # (the step rule in front of the refused K1 ran twice: its power iteration restarts from the first attempt's vector)
