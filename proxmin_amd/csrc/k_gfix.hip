@@ -115,6 +115,71 @@ __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* 
         }
     }
 }
+// K = 128 (KT = 4): wave w owns tile row ti = w (its four tiles of both matrices) and needs ALL four 32-column chunks of every row.  Each wave
+// loads and splits ONE chunk (its own) and the four exchange the fp16 fragments through LDS: a quarter of the loads and conversions of the
+// scheme above, where every wave fetched and split whole rows (18.6 us at cfg4's share, most of it that).
+template <int W>
+__device__ __forceinline__ void gfix_gram_wave_k128(const GfixArgs& a, int f, float* red, gf16x8* frag) {
+    constexpr int K = 128, KT = 4, NB = 8;   // steps of sixteen rows per batch: frag[step][chunk][term][lane], 64 KB
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int64_t rows = a.rows[f];
+    const int64_t per = 16 * ((rows + 16 * GFIX_PARTS - 1) / (16 * GFIX_PARTS));
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const float* X = a.X[f] + 32 * W + l31;
+    f32x16 acc0[KT], accr[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[t][i] = 0.f; accr[t][i] = 0.f; }
+    float v[NB][8];
+#define GFIX_REQUEST(rb_)                                                                          \
+    _Pragma("unroll") for (int s = 0; s < NB; ++s)                                                 \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                \
+        const int64_t r = (rb_) + 16 * s + 8 * hi + q;                                             \
+        v[s][q] = r < r1 ? X[r * K] : 0.f;                                                         \
+    }
+    if (r0 < r1) { GFIX_REQUEST(r0) }
+    const float sc = gfix_scale(a.absmax, f, red), un = 1.f / (sc * sc);
+    for (int64_t rb = r0; rb < r1; rb += 16 * NB) {
+        gf16x8 h[NB], l[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float x = v[s][q] * sc;
+                const _Float16 t = (_Float16)x;
+                h[s][q] = t;
+                l[s][q] = (_Float16)(x - (float)t);
+            }
+            frag[((s * KT + W) * 2 + 0) * 64 + lane] = h[s];
+            frag[((s * KT + W) * 2 + 1) * 64 + lane] = l[s];
+        }
+        if (rb + 16 * NB < r1) { GFIX_REQUEST(rb + 16 * NB) }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NB; ++s)
+#pragma unroll
+            for (int tj = 0; tj < KT; ++tj) {
+                const gf16x8 hj = tj == W ? h[s] : frag[((s * KT + tj) * 2 + 0) * 64 + lane];
+                const gf16x8 lj = tj == W ? l[s] : frag[((s * KT + tj) * 2 + 1) * 64 + lane];
+                acc0[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[s], lj, acc0[tj], 0, 0, 0);
+                accr[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l[s], lj, accr[tj], 0, 0, 0);
+                acc0[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[s], hj, acc0[tj], 0, 0, 0);
+                accr[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l[s], hj, accr[tj], 0, 0, 0);
+            }
+        __syncthreads();                     // (the fragments are rewritten by the next batch)
+    }
+#undef GFIX_REQUEST
+    float* out = a.part + ((int64_t)f * GFIX_PARTS + blockIdx.x) * 2 * K * K;
+#pragma unroll
+    for (int tj = 0; tj < KT; ++tj)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kp = 32 * W + (i & 3) + 8 * (i >> 2) + 4 * hi, k = 32 * tj + l31;
+            out[kp * K + k] = acc0[tj][i] * un;
+            out[K * K + kp * K + k] = accr[tj][i] * un;
+        }
+}
 template <int KT>
 __global__ __launch_bounds__(256) void k_gfix_gram(GfixArgs a) {
     __shared__ float red[4];
@@ -122,10 +187,18 @@ __global__ __launch_bounds__(256) void k_gfix_gram(GfixArgs a) {
     const int f = blockIdx.y;
     if (!a.want[1 - f]) return;              // factor f's matrices correct the OTHER block's gradient
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w == 0) gfix_gram_wave<KT, 0>(a, f, red);
-    else if (w == 1) gfix_gram_wave<KT, 1>(a, f, red);
-    else if (w == 2) gfix_gram_wave<KT, 2>(a, f, red);
-    else gfix_gram_wave<KT, 3>(a, f, red);
+    if constexpr (KT == 4) {
+        extern __shared__ gf16x8 gfrag[];    // [8 steps][4 chunks][2 terms][64 lanes]: 64 KB
+        if (w == 0) gfix_gram_wave_k128<0>(a, f, red, gfrag);
+        else if (w == 1) gfix_gram_wave_k128<1>(a, f, red, gfrag);
+        else if (w == 2) gfix_gram_wave_k128<2>(a, f, red, gfrag);
+        else gfix_gram_wave_k128<3>(a, f, red, gfrag);
+    } else {
+        if (w == 0) gfix_gram_wave<KT, 0>(a, f, red);
+        else if (w == 1) gfix_gram_wave<KT, 1>(a, f, red);
+        else if (w == 2) gfix_gram_wave<KT, 2>(a, f, red);
+        else gfix_gram_wave<KT, 3>(a, f, red);
+    }
 }
 
 // entry e of Q[f][m]: four threads fold 32 partials each (all loads in flight), then the four sums in a fixed order
@@ -157,10 +230,11 @@ __global__ __launch_bounds__(256) void k_gfix_reduce(GfixArgs a) {
 // a0 / s0, xl + xm = x_r to 2^-22), each matrix as two terms scaled by a power of two from its own maximum, transposed in LDS so that a lane's
 // eight contraction indices are one 16-byte read;  X Qr ~ xh qh + xh ql + xl qh,  x_r Q0 ~ xl qh + xl ql + xm qh,  two accumulators (two scales).
 template <int KT>
-__global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
+__global__ __launch_bounds__(KT == 4 ? 512 : 256) void k_gfix_apply(GfixArgs a) {
     constexpr int K = 32 * KT, LDQ = K + 8;  // halves per row of a transposed plane (+ 16 bytes: the 16-byte reads of 32 rows spread over the banks)
+    constexpr int NT = KT == 4 ? 512 : 256, NW = NT / 64;      // K = 128: eight waves share one staging of the (4 x larger) matrices
     extern __shared__ _Float16 qpl[];        // [matrix: Qr, Q0][term][column k][k']
-    __shared__ float red[4];
+    __shared__ float red[8];
     if (chain_halted(a.status)) return;
     const int f = blockIdx.y;                // the block whose gradient is corrected
     if (!a.want[f]) return;
@@ -168,13 +242,13 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
     const int64_t rows = a.rows[f];
     const float* X = a.X[f];
     float* out = a.out[f];
-    const int64_t ntask = (rows + 31) / 32 * KT, stride = (int64_t)gridDim.x * 4;      // a wave per task and round (launch_gfix: <= 256 workgroups, the matrices staged once each)
-    if ((int64_t)blockIdx.x * 4 >= ntask) return;
+    const int64_t ntask = (rows + 31) / 32 * KT, stride = (int64_t)gridDim.x * NW;     // a wave per task and round (launch_gfix: <= 256 workgroups, the matrices staged once each)
+    if ((int64_t)blockIdx.x * NW >= ntask) return;
     // The matrices, read so that the TRANSPOSED planes are written with one 16-byte store per eight k': thread t takes column k = t % K and the
     // blocks of eight k' = 8 (t / K + (256 / K) i) .. -- 8 scalar loads per block, each coalesced across the lanes (consecutive k), one
     // conflict-free ds_write_b128 per term.  (A float4-per-thread read with sixty-four 2-byte scattered stores, 16-way bank conflicts, was the
     // kernel: 13 us of its 14.)
-    constexpr int TPK = 256 / K, NBLK = K / 8 / TPK;       // threads per column, blocks of eight k' per thread
+    constexpr int TPK = NT / K, NBLK = K / 8 / TPK;        // threads per column, blocks of eight k' per thread
     const int kcol = tid % K, kb0 = tid / K;
     float tq[2][NBLK][8];
     {
@@ -195,13 +269,15 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
             for (int e = 0; e < 8; ++e) mx[m] = fmaxf(mx[m], fabsf(tq[m][i][e]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o)); }
-    __shared__ float redq[2][4];
+    __shared__ float redq[2][NW];
     if (lane == 0) { redq[0][w] = mx[0]; redq[1][w] = mx[1]; }
     const float sc = gfix_scale(a.absmax, f, red);        // (its barrier publishes redq as well)
     float sq[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const float v = fmaxf(fmaxf(redq[m][0], redq[m][1]), fmaxf(redq[m][2], redq[m][3]));
+        float v = redq[m][0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v = fmaxf(v, redq[m][i]);
         int q = 0;
         (void)frexpf(v, &q);
         sq[m] = ldexpf(1.f, v > 0.f ? 14 - q : 0);
@@ -225,7 +301,7 @@ __global__ __launch_bounds__(256) void k_gfix_apply(GfixArgs a) {
         }
     }
     __syncthreads();
-    for (int64_t task = (int64_t)blockIdx.x * 4 + w; task < ntask; task += stride) {
+    for (int64_t task = (int64_t)blockIdx.x * NW + w; task < ntask; task += stride) {
         const int64_t rt = task / KT;
         const int c = (int)(task % KT);
         const bool live = rt * 32 + l31 < rows;
@@ -274,8 +350,10 @@ static hipError_t launch_gfix(const GfixArgs& a, hipStream_t s) {
     const int n = 2 * a.K * a.K;
     const size_t lds = (size_t)4 * a.K * (a.K + 8) * sizeof(_Float16);      // k_gfix_apply: two matrices x two fp16 terms, transposed
     const int64_t rmax = a.rows[0] > a.rows[1] ? a.rows[0] : a.rows[1];
-    unsigned nb = (unsigned)(((rmax + 31) / 32 * (a.K / 32) + 3) / 4);            // k_gfix_apply: a wave per (32 rows, 32 columns) and round
-    if (nb > 256) nb = 256;                                                          // (one staging of the matrices per workgroup: at most one workgroup per CU and block)
+    const int nw = a.K == 128 ? 8 : 4;                                               // waves per workgroup of k_gfix_apply
+    unsigned nb = (unsigned)(((rmax + 31) / 32 * (a.K / 32) + nw - 1) / nw);         // k_gfix_apply: a wave per (32 rows, 32 columns) and round
+    // one staging of the matrices per workgroup: at most as many workgroups as can be resident (K = 128: 139 KB of LDS = one per CU, two blocks: 128 each)
+    if (nb > (a.K == 128 ? 128u : 256u)) nb = a.K == 128 ? 128 : 256;
     if (a.K == 64) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gfix_apply<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -285,9 +363,11 @@ static hipError_t launch_gfix(const GfixArgs& a, hipStream_t s) {
     } else if (a.K == 128) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gfix_apply<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gfix_gram<4>, dim3(GFIX_PARTS, 2), dim3(256), 0, s, a);
+        e = hipFuncSetAttribute((const void*)k_gfix_gram<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gfix_gram<4>, dim3(GFIX_PARTS, 2), dim3(256), 64 * 1024, s, a);
         hipLaunchKernelGGL(k_gfix_reduce, dim3((n * 4 + 255) / 256, 2), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_gfix_apply<4>, dim3(nb, 2), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k_gfix_apply<4>, dim3(nb, 2), dim3(512), lds, s, a);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
