@@ -71,6 +71,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         return;
     }
 
+    // [r5] the region's S rows are REQUESTED first: they do not depend on the scales, and the launch opened with three dependent round trips to
+    // memory (factor maxima -> S rows -> A rows and the first Y tiles), ~1.5 us each -- a tenth of this kernel at cfg2's size
+    const int row64 = tid >> 3, f4 = tid & 7, r = row64 & 31;
+    float4 sr[NCB / 2];
+#pragma unroll
+    for (int c2 = 0; c2 < NCB / 2; ++c2)
+        sr[c2] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(2 * c2 + (row64 >> 5), r) * K)[f4];
     // ---- power-of-two operand scales from the factor maxima (k_absmax partials) and max|Y|; uniform (see k_grad_f16_v8) ----
     float scA, scS, scR, unP, unA, unS;
     {
@@ -94,12 +101,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         unP = ldexpf(1.f, -(eA + eS)); unA = ldexpf(1.f, -(eR + eS)); unS = ldexpf(1.f, -(eR + eA));
     }
     {   // ---- all S terms of the region, once: 512 threads = 64 image rows x 8 float4 = TWO blocks per pass (a row of S^T is 32 floats)
-        const int row64 = tid >> 3, f4 = tid & 7, r = row64 & 31;
         const int st_off = r * ROWB + ((((f4 >> 1) ^ v3_swz(r)) & 7) << 4) + 8 * (f4 & 1);
-        float4 sr[NCB / 2];
-#pragma unroll
-        for (int c2 = 0; c2 < NCB / 2; ++c2)
-            sr[c2] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(2 * c2 + (row64 >> 5), r) * K)[f4];
 #pragma unroll
         for (int c2 = 0; c2 < NCB / 2; ++c2) {
             unsigned char* d = smem + (2 * c2 + (row64 >> 5)) * SLB + st_off;

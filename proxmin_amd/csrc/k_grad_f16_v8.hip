@@ -217,6 +217,11 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         return;
     }
 
+    // [r5] the region's S rows are REQUESTED first (they do not depend on the scales): one dependent round trip less in front of the first block
+    float4 sr[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)            // image row tid >> 4 of block c = S^T row block_col(c, tid >> 4)
+        sr[c] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(c, tid >> 4) * K)[tid & 15];
     // ---- power-of-two operand scales from the factor maxima (k_absmax partials) and max|Y|; uniform ----------------
     float scA, scS, scR, unP, unA, unS;
     {
@@ -241,10 +246,6 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     }
     {   // ---- all S terms of the region, once: block cb -> Sl[cb] (all 512 threads, one float4 of each block) -------
         const int st_off = (tid >> 4) * ROWB + (((((tid & 15) >> 1) ^ v3_swz(tid >> 4)) & 7) << 4) + 8 * (tid & 1);
-        float4 sr[NCB];
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)        // image row tid >> 4 of block c = S^T row block_col(c, tid >> 4)
-            sr[c] = reinterpret_cast<const float4*>(a.St + (int64_t)block_col(c, tid >> 4) * K)[tid & 15];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             unsigned char* d = smem + c * SLB + st_off;
