@@ -448,6 +448,8 @@ def main():
         "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
                                    k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"]),
         "tail_ms": 1e3 * dt / args.steps - (2 if backend == "bsdmm" else 1) * k1_avg_ms,     # the step minus its K1 launches
+        "tail_note": "step minus K1: the update kernel(s) of the back-end (adaprox: k_ada_tail) and, in mode f16x2r at K1's K = 64 / 128, the three small launches of the "
+                     "K x K correction (k_gfix_gram / _reduce / _apply, ~23 us at cfg3: profiles/r05_c_timeline_cfg3_f16x2r.txt)",
     }
     info = dev.k1_info()
     if info["chain"]:

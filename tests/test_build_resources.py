@@ -21,6 +21,12 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb1E": 12,   # 8   chained
     "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb1E": 12,   # 9   slabs
     "13k_grad_f16_v8ILb0ELb0ELb0ELb1ELb1E": 24,   # 18  loss-only
+    # [r5] <.., HH> (mode f16x2r since round 5: the residual from the high x high product, the rest as a correction slab)
+    "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb0ELb1E": 8,   # 4   chained (the bench's kernel)
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0ELb1E": 8,   # 0   slabs
+    "11k_gfix_gram": 0,                   # 0   the correction's three kernels (k_gfix.hip)
+    "12k_gfix_apply": 0,
+    "13k_gfix_reduce": 0,
     "13k_grad_f16_v8ILb0ELb1ELb0E": 8,    # 0   weighted (5 in its loss-only instance)
     "13k_grad_f16_v8ILb0ELb1ELb1E": 8,    # 3   weighted, chained
     # two-term fp16 K1 at K = 128.  [r4] gSt re-split (one k tile per consumer wave, all 128 rows): 128 accumulator registers
