@@ -429,3 +429,52 @@ def test_sharded_pgm_bsdmm_match_unsharded_oracle(case):
         assert n == n_ref, (n, n_ref)
         assert stopped == all(conv)
     np.testing.assert_allclose(A, Ao, rtol=1e-8, atol=1e-11)
+
+
+def test_native_bootstrap_failure_reaches_every_rank():
+    """NativeRccl.bootstrap when rank 0 cannot draw a communicator id (RCCL not loadable).  Rank 0 must STILL take part in the
+    broadcast (the other ranks are waiting in it) and hand them a marker; every rank then raises without entering pmx_comm_init, so the
+    caller's agreement all-reduce (distributed._collectives) is reached by all of them instead of deadlocking."""
+    from proxmin_amd import _lib
+    from proxmin_amd.distributed import NativeRccl
+
+    class FakeLib:
+        def __init__(self, fail):
+            self.fail, self.init_calls = fail, 0
+
+        def pmx_comm_unique_id(self, buf):
+            return 3 if self.fail else 0
+
+        def pmx_comm_init(self, *a):
+            self.init_calls += 1
+            return 0
+
+    class FakeDev:
+        def __init__(self, fail):
+            self.lib, self.h = FakeLib(fail), None
+
+    sent = []
+
+    def bcast_rank0(raw):
+        sent.append(raw)
+        return raw
+
+    real_check = _lib.check
+    try:
+        def check(rc):                       # (no libpmx.so needed on this path: the fake reports its own failure)
+            if rc != 0:
+                raise _lib.PmxError("libpmx error %d: rccl not loadable" % rc)
+        _lib.check = check
+        dev0 = FakeDev(True)
+        with pytest.raises(_lib.PmxError):
+            NativeRccl.bootstrap(dev0, 0, 2, bcast_rank0)
+        assert sent == [b""] and dev0.lib.init_calls == 0          # the broadcast happened, with the marker; no communicator was entered
+        dev1 = FakeDev(False)
+        with pytest.raises(_lib.PmxError):
+            NativeRccl.bootstrap(dev1, 1, 2, lambda raw: sent[0])    # rank 1 receives the marker
+        assert dev1.lib.init_calls == 0
+        ok0 = FakeDev(False)
+        nat = NativeRccl.bootstrap(ok0, 0, 1, lambda raw: raw)       # the good path still joins
+        assert isinstance(nat, NativeRccl) and ok0.lib.init_calls == 1
+    finally:
+        _lib.check = real_check
