@@ -31,7 +31,9 @@ struct GfixArgs {
     int ld;
     int want[2];             // correct gA / gSt
     const DevStatus* status;
+    long long* prof;         // tuning (PMX_GFIX_PROF=1): 100 MHz time stamps of workgroup (0, 0): [0..3] gram, [4..5] reduce, [6..10] apply; else nullptr
 };
+#define GFIX_STAMP(i) do { if (a.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = wall_clock64(); } while (0)
 
 typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
 
@@ -74,8 +76,10 @@ __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* 
         const int64_t r = (rb_) + 16 * s + 8 * hi + q;                                             \
         _Pragma("unroll") for (int c = 0; c < KT; ++c) v[s][c][q] = r < r1 ? X[r * K + 32 * c] : 0.f; \
     }
+    GFIX_STAMP(0);
     if (r0 < r1) { GFIX_REQUEST(r0) }
     const float sc = gfix_scale(a.absmax, f, red), un = 1.f / (sc * sc);
+    GFIX_STAMP(1);
     for (int64_t rb = r0; rb < r1; rb += 16 * NB) {
         gf16x8 h[NB][KT], l[NB][KT];
 #pragma unroll
@@ -103,6 +107,7 @@ __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* 
             }
     }
 #undef GFIX_REQUEST
+    GFIX_STAMP(2);
     float* out = a.part + ((int64_t)f * GFIX_PARTS + blockIdx.x) * 2 * K * K;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -114,6 +119,7 @@ __device__ __forceinline__ void gfix_gram_wave(const GfixArgs& a, int f, float* 
             out[K * K + kp * K + k] = accr[t][i] * un;
         }
     }
+    GFIX_STAMP(3);
 }
 // K = 128 (KT = 4): wave w owns tile row ti = w (its four tiles of both matrices) and needs ALL four 32-column chunks of every row.  Each wave
 // loads and splits ONE chunk (its own) and the four exchange the fp16 fragments through LDS: a quarter of the loads and conversions of the
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(256) void k_gfix_reduce(GfixArgs a) {
     if (chain_halted(a.status)) return;
     const int f = blockIdx.y;
     if (!a.want[1 - f]) return;
+    GFIX_STAMP(4);
     const int n = 2 * a.K * a.K;
     const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 2, q = t & 3;
     static_assert(GFIX_PARTS == 128, "four threads x 32 partials");
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(256) void k_gfix_reduce(GfixArgs a) {
 #pragma unroll
     for (int i = 1; i < 4; ++i) tot += __shfl(s, base + i);
     if (e < n && q == 0) a.Q[(int64_t)f * n + e] = (float)tot;
+    GFIX_STAMP(5);
 }
 
 // C_X = X Qr(Z) + x_r Q0(Z): one wave per (32 rows, 32 output columns).  Split-fp16 MFMA like K1's own contractions (exact-fp32 MFMA runs at
@@ -244,6 +252,16 @@ __global__ __launch_bounds__(KT == 4 ? 512 : 256) void k_gfix_apply(GfixArgs a) 
     float* out = a.out[f];
     const int64_t ntask = (rows + 31) / 32 * KT, stride = (int64_t)gridDim.x * NW;     // a wave per task and round (launch_gfix: <= 256 workgroups, the matrices staged once each)
     if ((int64_t)blockIdx.x * NW >= ntask) return;
+    GFIX_STAMP(6);
+    f32x4 x[K / 16][2];                      // this lane's row, components 16 ks + 8 hi .. + 7 (the MFMA's A operand: i = lane & 31, k = 8 (lane >> 5) ..)
+#define GFIX_LOAD_X(t_)                                                                                                   \
+    {                                                                                                                     \
+        const int64_t row_ = ((t_) / KT) * 32 + l31;                                                                      \
+        const f32x4* xr = reinterpret_cast<const f32x4*>(X + (row_ < rows ? row_ : 0) * K + 8 * hi);                       \
+        _Pragma("unroll") for (int ks = 0; ks < K / 16; ++ks) { x[ks][0] = xr[4 * ks]; x[ks][1] = xr[4 * ks + 1]; }       \
+    }
+    const int64_t task0 = (int64_t)blockIdx.x * NW + w;
+    if (task0 < ntask) GFIX_LOAD_X(task0)
     // The matrices, read so that the TRANSPOSED planes are written with one 16-byte store per eight k': thread t takes column k = t % K and the
     // blocks of eight k' = 8 (t / K + (256 / K) i) .. -- 8 scalar loads per block, each coalesced across the lanes (consecutive k), one
     // conflict-free ds_write_b128 per term.  (A float4-per-thread read with sixty-four 2-byte scattered stores, 16-way bank conflicts, was the
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(KT == 4 ? 512 : 256) void k_gfix_apply(GfixArgs a) 
     __shared__ float redq[2][NW];
     if (lane == 0) { redq[0][w] = mx[0]; redq[1][w] = mx[1]; }
     const float sc = gfix_scale(a.absmax, f, red);        // (its barrier publishes redq as well)
+    GFIX_STAMP(7);
     float sq[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -301,16 +320,12 @@ __global__ __launch_bounds__(KT == 4 ? 512 : 256) void k_gfix_apply(GfixArgs a) 
         }
     }
     __syncthreads();
+    GFIX_STAMP(8);
     for (int64_t task = (int64_t)blockIdx.x * NW + w; task < ntask; task += stride) {
         const int64_t rt = task / KT;
         const int c = (int)(task % KT);
         const bool live = rt * 32 + l31 < rows;
-        f32x4 x[K / 16][2];                  // this lane's row, components 16 ks + 8 hi .. + 7 (the MFMA's A operand: i = lane & 31, k = 8 (lane >> 5) ..)
-        {
-            const f32x4* xr = reinterpret_cast<const f32x4*>(X + (live ? rt * 32 + l31 : 0) * K + 8 * hi);
-#pragma unroll
-            for (int ks = 0; ks < K / 16; ++ks) { x[ks][0] = xr[4 * ks]; x[ks][1] = xr[4 * ks + 1]; }
-        }
+        if (task != task0) GFIX_LOAD_X(task)   // (the first task's rows were requested before the matrices: one round trip less)
         f32x16 acc1, acc2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
@@ -343,7 +358,10 @@ __global__ __launch_bounds__(KT == 4 ? 512 : 256) void k_gfix_apply(GfixArgs a) 
             const int64_t r = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
             if (r < rows) out[r * a.ld + 32 * c + l31] = acc1[i] * u1 + acc2[i] * u2;
         }
+        GFIX_STAMP(9);
     }
+#undef GFIX_LOAD_X
+    GFIX_STAMP(10);
 }
 
 static hipError_t launch_gfix(const GfixArgs& a, hipStream_t s) {

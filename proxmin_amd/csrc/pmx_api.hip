@@ -128,6 +128,7 @@ struct pmx_ctx {
     float* fixPart = nullptr;              // k_gfix_gram's partial matrices [2][GFIX_PARTS][2][Kk * Kk]
     float* fixQ = nullptr;                 // [2][2][Kk * Kk]
     float* fixSlab[2] = {nullptr, nullptr};   // the correction slabs (rowsK[j] x Kk)
+    long long* fixProf = nullptr;          // PMX_GFIX_PROF=1: time stamps of the correction kernels' first workgroup (printed by pmx_time_grad)
     bool fix_on = false;                   // the last gradient pass ran an <HH> kernel: the update kernels fold fixSlab behind K1's slabs (slab_ref)
     bool k1_sync_check = false;            // one-iteration-per-call paths (nothing to repeat into): every fp16 K1 launch is awaited and, refused, repeated in fp32 on the spot (enqueue_grad)
     int ncu = 0;
@@ -480,6 +481,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         rc = dallocT(c, &c->fixPart, (size_t)2 * GFIX_PARTS * 2 * c->Kk * c->Kk, false);
         if (rc == PMX_OK) rc = dallocT(c, &c->fixQ, (size_t)4 * c->Kk * c->Kk);
         for (int j = 0; j < 2 && rc == PMX_OK; ++j) rc = dallocT(c, &c->fixSlab[j], (size_t)c->rowsK[j] * c->Kk);
+        if (rc == PMX_OK && getenv("PMX_GFIX_PROF")) rc = dallocT(c, &c->fixProf, 16);
     }
     for (int t = 0; t < 2 && rc == PMX_OK && c->k128; ++t) rc = dallocT(c, &c->A16[t], (size_t)Mk * c->Kk, c->framed || c->Kk != K);   // (framed: the rows behind M / the columns behind K stay zero)
     for (int j = 0; j < 2 && rc == PMX_OK && c->Kk != K; ++j) rc = dallocT(c, &c->Xk[j], (size_t)c->rowsK[j] * c->Kk);          // K1's zero-padded operands
@@ -1055,6 +1057,7 @@ static int enqueue_gfix(pmx_ctx* c, const float* A, const float* St, int doA, in
     f.ld = (int)c->Kk;
     f.want[0] = (doA & 1) != 0; f.want[1] = doS != 0;
     f.status = c->dstatus;
+    f.prof = c->fixProf;
     HIP_CHECK(launch_gfix(f, stream));
     return PMX_OK;
 }
@@ -1477,6 +1480,13 @@ extern "C" int pmx_time_grad(pmx_ctx* c, int do_A, int do_S, int reps, double* a
     (void)hipEventDestroy(e1);
     c->timing = was;
     *avg_ms = ms / reps;
+    if (c->fixProf && c->fix_on) {
+        long long h[16];
+        HIP_CHECK(hipMemcpy(h, c->fixProf, sizeof(h), hipMemcpyDeviceToHost));
+        auto us = [&](int i, int j) { return (double)(h[j] - h[i]) * 0.01; };
+        fprintf(stderr, "[gfixprof] workgroup 0, us: gram: start->scale %.2f, ->MFMAs done %.2f, ->stored %.2f | gram end -> reduce start %.2f | reduce %.2f | -> apply start %.2f | apply: ->scale %.2f, ->staged %.2f, ->task done %.2f, ->end %.2f | gram start -> apply end %.2f\n",
+                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(0, 10));
+    }
     if (c->k1prof) {
         unsigned long long h[16];
         HIP_CHECK(hipMemcpy(h, c->k1prof, sizeof(h), hipMemcpyDeviceToHost));
