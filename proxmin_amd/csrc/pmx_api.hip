@@ -1109,7 +1109,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             g.chainFlags = c->chainFlags; g.chainBase = (++c->chainSeq) * 64u; g.wstatus = c->dstatus;
             g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
-        g.hh = c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr && (doA | doS);
+        g.hh = c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr && ((doA & 1) || doS);     // (the launcher's own test: gradient passes only)
         fix_pending = g.hh != 0;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
@@ -1178,7 +1178,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         bool took_f16 = false;
         HIP_CHECK(grad_launch_bf16(c->plan, g, A, St, c->stream, &c->nloss, &took_f16));
         c->f16_fell_back = c->use_f16 && !took_f16;      // (pmx_k1_info reports the kernel that ran)
-        if (doA | doS) fix_pending = c->use_f16 && took_f16 && c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr;
+        if ((doA & 1) || doS) fix_pending = c->use_f16 && took_f16 && c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr;   // (grad_launch_f16_v8's own test)
     } else {
         const GradArgs g = small_grad_args(c, A, St, doA, doS);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
@@ -1199,7 +1199,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         HIP_CHECK(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
     }
-    if (doA | doS) c->fix_on = fix_pending;
+    if ((doA & 1) || doS) c->fix_on = fix_pending;
     // what the high x high residual left out, as one more slab per block (k_gfix.hip).  In the launch stream: the three launches depend on the
     // factors only, but nothing fits BESIDE K1 (its waves hold all 512 registers of every SIMD) -- measured on a stream of their own they sat
     // behind K1's workgroups and the pass got 2 % slower (profiles/r05_a_gfix_side_stream.txt)
