@@ -9,11 +9,11 @@
 // i.e. for either block X with the OTHER factor Z (both tall, rows x K):   C_X = X Qr(Z) + x_r Q0(Z),
 //     Qr(Z) = z_r^T Z,   Q0(Z) = z0^T Z              (K x K, Q[k'][k] = sum over rows of U[row][k'] Z[row][k]).
 // 4 (M + N) K^2 flops beside K1's 6 M N K: 0.1 % at 16384^2 x 64.  The correction is 2^-12 of the gradient's terms and needs 2^-12 of
-// relative accuracy to leave exact fp32's error class untouched; it is computed to ~2^-22.  Three launches in front of K1:
+// relative accuracy to leave exact fp32's error class untouched; it is computed to ~2^-22.  Three launches behind K1 (they depend on the factors only):
 //   k_gfix_gram    per-workgroup partial Q0 / Qr of both factors (fp16 MFMA on the very terms K1 uses: z0 exact, Z = z0 + z1, z_r ~ z1)
 //   k_gfix_reduce  fixed-order sum of the partials (deterministic: no float atomics)
-//   k_gfix_apply   C_X for every row of both blocks (exact-fp32 MFMA, Q in LDS) into the CORRECTION SLAB the update kernels fold
-//                  behind K1's own slabs (SlabRef::extra)
+//   k_gfix_apply   C_X for every row of both blocks (split-fp16 MFMA: the rows as three fp16 terms, the matrices as two, transposed in LDS) into the
+//                  CORRECTION SLAB the update kernels fold behind K1's own slabs (SlabRef::extra)
 // Unweighted likelihood only: with weights the missing term is W o (A s_r + a_r s0), which does not factor.
 // Row-sharded runs: every term is a sum over the rank's own rows (A's) or over replicated data (S's) -- nothing to exchange.
 #include "pmx_common.h"
