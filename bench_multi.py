@@ -69,7 +69,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     coll = OneRankOfMany() if fake > 1 else _collectives(None, dev, rank, world, None)
     if backend == "adaprox":
         dev.adaprox_begin([pA, pS], scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-3, 1e-3))
-        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, dist_module=coll)
+        drv = ShardedAdaproxDriver(eng, None, False, True, 1000, chunk=int(os.environ["PMX_BENCH_CHUNK"]) if "PMX_BENCH_CHUNK" in os.environ else None, dist_module=coll)
         b1 = np.full(total, 0.9)
         run = lambda n: drv.run(n, b1)
     elif backend == "pgm":
@@ -84,11 +84,13 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
         run = loop.run
     run(warm)
     dev.set_timing(True, every=4)   # HIP events around every 4th K1 launch of the timed region
-    dev.set_phase_timing(4)         # ... and at the phase boundaries of the same iterations (K1 / pack / collective / post / update)
+    if os.environ.get("PMX_BENCH_NO_PHASES", "0") != "1":
+        dev.set_phase_timing(4)     # ... and at the phase boundaries of the same iterations (K1 / pack / collective / post / update)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
+    t_enq = time.perf_counter()     # the host is done enqueueing (it waited for the device once per chunk of iterations)
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
@@ -110,7 +112,7 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     out = {
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_done_ms_per_step": 1e3 * (t_enq - t0) / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": getattr(args, "mode_dtype", {}).get(eff_mode, eff_mode), "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
                    "mode": getattr(args, "mode_desc", {}).get(eff_mode, eff_mode),

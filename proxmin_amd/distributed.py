@@ -231,7 +231,7 @@ class ShardedAdaproxDriver:
     """Iteration loop of the row-sharded adaprox back-end (algorithms.py:365-413 with one all-reduce
     per iteration).  `engine` provides phase(), chain_status(), more_subs() and the `comm` tensor."""
 
-    def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=16, dist_module=None):
+    def __init__(self, engine, group=None, check_convergence=True, any_prox=True, prox_max_iter=1000, chunk=None, dist_module=None):
         if dist_module is None:
             _lib.require_torch()
             import torch.distributed as dist_module
@@ -241,6 +241,12 @@ class ShardedAdaproxDriver:
         self.check = bool(check_convergence)
         self.any_prox = bool(any_prox)
         self.prox_max_iter = int(prox_max_iter)
+        if chunk is None:
+            # iterations enqueued between two reads of the device status (each read drains the stream: 8 us per iteration at 16, 2 us at
+            # 64, cfg4's share).  The fused tail decides its proximal loops on the device, so nothing is speculated on and the chunks may
+            # be as long as the single-GPU loop's (pmx_adaprox_run); the chain of tail kernels keeps 16 (its per-iteration records: 64 slots)
+            fused = getattr(engine, "tail_fused", None)
+            chunk = 64 if (fused() if callable(fused) else fused) else 16
         self.chunk = int(chunk)
         self.nsub = 2
         self.it = 0              # completed iterations
@@ -315,7 +321,7 @@ class ShardedLoop:
     and flushes it after the last iteration; bsdmm's all-reduce sits between its A step and its S step, so its
     test is exact without deferral."""
 
-    def __init__(self, engine, group=None, deferred_test=True, chunk=16, dist_module=None):
+    def __init__(self, engine, group=None, deferred_test=True, chunk=64, dist_module=None):
         if dist_module is None:
             _lib.require_torch()
             import torch.distributed as dist_module
@@ -413,6 +419,10 @@ class ShardEngine:
         ev = self._alias(_lib.BUF_EVAL_ST)
         if ev.data_ptr() != self.st_full.data_ptr():
             self.st_iterate, self.st_full = self.st_full, ev
+
+    def tail_fused(self):
+        """adaprox, after adaprox_begin: does the iteration tail run as ONE kernel (k_ada_tail)?"""
+        return self.algorithm == "adaprox" and bool(self.dev.k1_info().get("tail_fused"))
 
     def phase(self, phase, it, b1_it=0.0, b1_prev=0.0, nsub=0):
         lib, h = self.dev.lib, self.dev.h
