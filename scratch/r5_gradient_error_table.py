@@ -61,6 +61,12 @@ def grad(A, S, Y, prod="x2", cons="3", lowbits=4):
     elif cons == "1":
         gA = r[0] @ s[0].T
         gS = a[0].T @ r[0]
+    elif cons == "2r":      # the residual's low term dropped, the factors' kept
+        gA = r[0] @ s[0].T + r[0] @ s[1].T
+        gS = a[0].T @ r[0] + a[1].T @ r[0]
+    elif cons == "2f":      # the factors' low terms dropped, the residual's kept
+        gA = r[0] @ s[0].T + r[1] @ s[0].T
+        gS = a[0].T @ r[0] + a[0].T @ r[1]
     else:
         q = lambda x: rnd_bits(x, lowbits)
         gA = r[0] @ s[0].T + q(r[0]) @ q(s[1]).T + q(r[1]) @ q(s[0]).T
@@ -91,6 +97,8 @@ rows = [("numpy fp32 (the yardstick)", None, "-"),
         ("hh only, NO correction, gradients 3+3", dict(prod="hh_nofix", cons="3"), "28"),
         ("f16x2g  P hh + Gram correction, gradients 3+3", dict(prod="hh", cons="3"), "28"),
         ("f16x2g, gradients r0 s0 only", dict(prod="hh", cons="1"), "12"),
+        ("f16x2g, gradients r0 (s0 + s1): residual's low term dropped", dict(prod="hh", cons="2r"), "20"),
+        ("f16x2g, gradients (r0 + r1) s0: factors' low terms dropped", dict(prod="hh", cons="2f"), "20"),
         ("f16x2g, gradient cross terms with 4-bit operands", dict(prod="hh", cons="8", lowbits=4), "4 + 8 + (8 fp8 | 4 fp6)"),
         ("f16x2g, gradient cross terms with 3-bit operands", dict(prod="hh", cons="8", lowbits=3), ""),
         ("f16x2g, gradient cross terms with 6-bit operands", dict(prod="hh", cons="8", lowbits=6), ""),
