@@ -47,7 +47,8 @@ def bench_sharded(args, M, N, K, backend, unity, desc, rank, world, local):
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)          # collectives order against the current stream
-    dev = DeviceNMF(Ml, N, K, device=local, stream=tstream.cuda_stream, mode=getattr(args, "mode", None))
+    own = os.environ.get("PMX_BENCH_OWN_STREAM", "0") == "1"     # tuning only (one process playing one rank): the library's own stream, collectives unordered
+    dev = DeviceNMF(Ml, N, K, device=local, stream=None if own else tstream.cuda_stream, mode=getattr(args, "mode", None))
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
     # PMX_BENCH_FAKE_WORLD=W (single process): this GPU plays rank 0 of W -- M is the rank's share, the collectives are local
