@@ -145,9 +145,16 @@ static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 // one more gradient slab).  No representation error is left in P at all (mode f16x2r's third terms remove it to 2^-33), the residual's accumulation
 // noise is exact fp32's, and the producers issue a third / a fifth of the MFMAs.  The consumers (two-term R, A, S: 3 products) are unchanged.
 // scratch/r5_gradient_error_table.py: gradients 3.9e-8 / 1.5e-7 of max|g| against fp64 where NumPy fp32 has 3.6e-8 / 1.5e-7 and mode f16x2 4.0e-8 / 3.0e-7.
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false>
+// RS [r5]: the consumers' ROLES split by contraction instead of by rows (gradient passes that want BOTH gradients).  Before: wave j owned rows 32 j of gA (both k
+// tiles) and a quarter (row half x k tile) of gSt -- every wave read the block's S fragments (8 KB) AND its share of the panel's A fragments (8 KB) in every slot.
+// <RS>: waves 0, 1 contract gA for 64 rows each (four accumulator tiles: the S fragments are read twice per slot instead of four times), waves 2, 3 contract
+// gSt for one k tile each over ALL 128 rows of the panel -- with no gA tiles to hold, the panel's A fragments (64 registers) stay in registers for the eight
+// slots of a panel.  24 MFMAs per wave and slot as before; LDS reads per slot 64 KB instead of 112 KB (profiles/r05_c_lds_ablation.txt priced those bytes);
+// gSt needs no merge of row halves at the end.  Passes that want ONE gradient keep the row split (two of four waves would idle).
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     static_assert(!(R3 && HH) && !(HH && HASW), "HH: unweighted contexts, instead of the third terms");
+    static_assert(!RS || (HH && !PROF && !LOSS), "RS: an instance of the <HH> gradient pass");
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
     constexpr int NT = R3 ? 3 : 2;                       // fp16 terms of A and S in the residual's product (HH: the second term serves the consumers only)
     constexpr int SLB = NT * V5_S_TERM, OFF_A = NCB * SLB, OFF_R = OFF_A + V5_AIMG_BYTES;
@@ -535,6 +542,195 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         slot(nrp, c1{}, p1, p0, q1, q0, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt row halves)
+    } else if constexpr (RS) {
+        // ================================ consumers, roles split by contraction (see RS in the header) ==============
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();              // Sl published
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        if (j < 2) {
+            // ---- gA: rows 64 j .. 64 j + 63 of the panel (row tiles rt = 0, 1), both k tiles --------------------------------
+            f32x16 accA[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accA[rt][0][i] = 0.f; accA[rt][1][i] = 0.f; }
+            int r_t[2][2];                       // R as the A operand (transposing read), per row tile
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int m = (2 * j + rt) * 32 + 16 * (lq & 1) + 4 * (li & 3);
+                const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+                r_t[rt][0] = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+                r_t[rt][1] = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            }
+            const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);   // S as the B operand; k tile 1: ^ 64
+            const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+            auto gA_tile = [&](int prow, int rt) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + (2 * j + rt) * 32 + 4 * hi) * K + l31; };
+            auto flush_gA = [&](int prow) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float* p0_ = gA_tile(prow, rt);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float* ph_ = p0_ + half * 16 * K;
+                        asm volatile("" : "+v"(ph_));
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int i = half * 8 + q;        // tile_row(i) = (i & 3) + 8 * (i >> 2) + 4 * hi
+                            const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                            ph_[ro] = accA[rt][0][i] * unA;
+                            ph_[ro + 32] = accA[rt][1][i] * unA;
+                        }
+                    }
+                }
+            };
+            const float invUnA = scR * scS;
+            ChainLink link;
+            if constexpr (CHAIN) link.init(a.chainFlags, chainId, nrp, j, a.status, a.wstatus, lane);
+            if constexpr (CHAIN) {
+                if (a.chainInject && blockIdx.x == 0 && j == 0) link.fault(3);
+            }
+            sync();
+            sync();
+            int s = 2;
+#pragma nounroll
+            for (int rp = 0; rp < nrp; ++rp) {
+                const int pnl = panel_at(rp);
+                const int prow = row0 + pnl * V5_BM;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    if (cb == 0) {
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_s_barrier();
+                        if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, 1, nrp, a.chainBase, (a.doA & 1) != 0);
+                    }
+                    float pv[2][2][4];
+                    if constexpr (CHAIN) {
+                        if (cb == 3) link.look();
+                        if (cb >= 4 && link.cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) .. of all four tiles
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt) {
+                                const float* pb = gA_tile(prow, rt) + (8 * ((cb - 4) & 1) + 16 * ((cb - 4) >> 1)) * K;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    pv[rt][0][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                    pv[rt][1][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                }
+                            }
+                        }
+                    }
+                    {
+                        const unsigned char* Rb = smem + OFF_R + ((s - 2) & 1) * V5_R_BYTES;
+                        const unsigned char* Slb = smem + cb * SLB;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+                            const f16x8 s00 = v8_tr_pair(Slb, so0, so1);
+                            const f16x8 s01 = v8_tr_pair(Slb + V5_S_TERM, so0, so1);
+                            const f16x8 s10 = v8_tr_pair(Slb, so0 ^ 64, so1 ^ 64);
+                            const f16x8 s11 = v8_tr_pair(Slb + V5_S_TERM, so0 ^ 64, so1 ^ 64);
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt) {
+                                const f16x8 r0 = v8_tr_pair(Rb, r_t[rt][0] + ks * 4096, r_t[rt][1] + ks * 4096);
+                                const f16x8 r1 = v8_tr_pair(Rb + V5_R_TERM, r_t[rt][0] + ks * 4096, r_t[rt][1] + ks * 4096);
+                                accA[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s00, accA[rt][0], 0, 0, 0);
+                                accA[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, s10, accA[rt][1], 0, 0, 0);
+                                accA[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s01, accA[rt][0], 0, 0, 0);
+                                accA[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s11, accA[rt][1], 0, 0, 0);
+                                accA[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s00, accA[rt][0], 0, 0, 0);
+                                accA[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, s10, accA[rt][1], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if constexpr (CHAIN) {
+                        if (cb == 3) link.wait();
+                        if (cb >= 4 && link.cadd) {
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    accA[rt][0][4 * (cb - 4) + q] += pv[rt][0][q] * invUnA;
+                                    accA[rt][1][4 * (cb - 4) + q] += pv[rt][1][q] * invUnA;
+                                }
+                        }
+                    }
+                    if (cb + 1 == NCB) {
+                        flush_gA(prow);
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { accA[rt][0][i] = 0.f; accA[rt][1][i] = 0.f; }
+                        if constexpr (CHAIN) link.flushed();
+                    }
+                    sync();
+                    ++s;
+                }
+            }
+            if constexpr (CHAIN) link.publish();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();          // (the producers' last barrier)
+        } else {
+            // ---- gSt: k tile kt of every block of the region, ALL 128 rows of a panel (eight steps of sixteen) ------------------
+            const int kt = j - 2;
+            f32x16 accS[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accS[c][i] = 0.f;
+            const int r_g = l31 * 256 + ((hi ^ v4_swz(l31)) << 4);                                   // R^T rows n as the A operand, rows 16 ks ..: ^ (ks << 5)
+            const int a_t0 = tr_src(8 * hi + (li >> 2), kt * 32), a_t1 = tr_src(8 * hi + 4 + (li >> 2), kt * 32);   // A as the B operand, rows 16 ks ..: + ks * 16 * ROWB
+            f16x8 af[8][2];                      // the panel's A fragments (both terms), fetched once per panel
+            sync();
+            sync();
+            int s = 2;
+#pragma nounroll
+            for (int rp = 0; rp < nrp; ++rp) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    if (cb == 0) {               // block s-2 opens a row panel: the producers have just published its A terms
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_s_barrier();
+                        const unsigned char* Ab = smem + OFF_A;
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) {
+                            af[ks][0] = v8_tr_pair(Ab, a_t0 + ks * 16 * ROWB, a_t1 + ks * 16 * ROWB);
+                            af[ks][1] = v8_tr_pair(Ab + V5_A_TERM, a_t0 + ks * 16 * ROWB, a_t1 + ks * 16 * ROWB);
+                        }
+                    }
+                    const unsigned char* Rb = smem + OFF_R + ((s - 2) & 1) * V5_R_BYTES;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int ro = r_g ^ (ks << 5);
+                        const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
+                        const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
+                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, af[ks][0], accS[cb], 0, 0, 0);
+                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][1], accS[cb], 0, 0, 0);
+                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][0], accS[cb], 0, 0, 0);
+                    }
+                    sync();
+                    ++s;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();          // (the producers' last barrier)
+            {
+                float* dst = a.slabS + (int64_t)rowRegion * N * K;
+                const int kk = kt * 32 + l31;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int gn = block_col(cb, tile_row(i, lane));
+                        dst[(int64_t)gn * K + kk] = accS[cb][i] * unS;
+                    }
+            }
+        }
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -746,17 +942,19 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false>
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
     constexpr int lds = R3 ? V7_LDS_BYTES : V8_LDS_BYTES;        // (three S terms: the split-bf16 kernel's 160 KB)
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
     // r3 == 2 [r5]: the high x high residual whose missing terms arrive as a correction slab (<HH>; gradient passes only -- the loss-only pass
     // has nowhere to put a correction and runs the third terms' instance)
+    if (a.r3 == 2 && a.W == nullptr && (a.doA & 1) && a.doS && !a.prof && !(getenv("PMX_K1_ROLE_SPLIT") && atoi(getenv("PMX_K1_ROLE_SPLIT")) == 0))   // <RS>: both gradients wanted (PMX_K1_ROLE_SPLIT=0: A/B)
+        return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, false, true, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, false, true, true>(a, stream);
     if (a.r3 == 2 && a.W == nullptr && ((a.doA & 1) || a.doS))
         return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, false, true>(a, stream);
     if (a.r3 && a.W == nullptr) {    // R3: the residual to fp32's class (unweighted instances; a weighted context keeps two terms)
