@@ -119,9 +119,14 @@ void launch_split_a_f16(const SplitAArgs& a, hipStream_t s) {
 // (they have the registers: the consumers bound this kernel) and scale R in the epilogue, as in k_grad_f16_v8<.., HASW>.
 // HH [r5]: k_grad_f16_v8<.., HH>'s residual (P0 = a0 s0: 8 MFMAs per block instead of 24; what it leaves out arrives as a correction slab, k_gfix.hip):
 // the mode-f16x2r instance of this kernel -- there is no LDS here for third terms, and none are needed.
-template <bool HASW, bool CHAIN, bool HH = false>
+// RS [r5]: the consumers' roles split by contraction, as in k_grad_f16_v8<.., RS> (why: there): waves 0, 1 contract gA for 64 rows each (eight accumulator tiles;
+// the block's S fragments are read twice per slot instead of four times), waves 2, 3 contract gSt for TWO k tiles each over all 128 rows of the panel (the R^T
+// fragments are read twice per slot instead of four times; the high terms of the panel's A fragments stay in registers for the panel's four slots).  48 MFMAs
+// per wave and slot as before; LDS reads per slot 112 KB instead of 208 KB.  Gradient passes that want both gradients, <HH> only.
+template <bool HASW, bool CHAIN, bool HH = false, bool RS = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a) {
     static_assert(!(HH && HASW), "HH: unweighted contexts");
+    static_assert(!RS || HH, "RS: an instance of the <HH> gradient pass");
     constexpr int K = 128, ROWB = 128, NCB = W8_NCB, NKT = W8_NKT;
     constexpr int OFF_R = W8_OFF_R;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -398,6 +403,222 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         slot(T, nrp, c0{}, p0, p1, yO, wv1, no{}, yes{}, no{});
         slot(T + 1, nrp, c1{}, p1, p0, yE, wv1, no{}, no{}, no{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (RS) {
+        // ================================ consumers, roles split by contraction (see RS in the header) ==============
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();              // S images published
+        auto sync = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto tr_src = [&](int row, int k0) {
+            const int kk = k0 + 16 * (lq & 1) + 4 * (li & 3);
+            return row * ROWB + ((((kk >> 3) ^ v3_swz(row)) & 7) << 4) + 8 * ((kk >> 2) & 1);
+        };
+        using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>;
+        using c2 = std::integral_constant<int, 2>; using c3 = std::integral_constant<int, 3>;
+        if (j < 2) {
+            // ---- gA: rows 64 j .. 64 j + 63 of the panel (row tiles rt), all four k tiles (h * 64 + t * 32) ---------------------
+            f32x16 accA[2][NKT][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int h = 0; h < NKT; ++h)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { accA[rt][h][0][i] = 0.f; accA[rt][h][1][i] = 0.f; }
+            int r_t[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int m = (2 * j + rt) * 32 + 16 * (lq & 1) + 4 * (li & 3);
+                const int n0 = 8 * hi + (li >> 2), n1 = n0 + 4;
+                r_t[rt][0] = n0 * 256 + ((((m >> 3) ^ v4_swz(n0)) & 15) << 4) + 8 * ((m >> 2) & 1);
+                r_t[rt][1] = n1 * 256 + ((((m >> 3) ^ v4_swz(n1)) & 15) << 4) + 8 * ((m >> 2) & 1);
+            }
+            const int s_t0 = tr_src(8 * hi + (li >> 2), 0), s_t1 = tr_src(8 * hi + 4 + (li >> 2), 0);
+            const int slabIdxA = CHAIN ? colRegion / a.chainL : colRegion;
+            auto gA_tile = [&](int prow, int rt) { return a.slabA + (int64_t)slabIdxA * M * K + (int64_t)(prow + (2 * j + rt) * 32 + 4 * hi) * K + l31; };
+            auto flush_gA = [&](int prow) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h) {
+                        float* p0_ = gA_tile(prow, rt) + h * 64;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            float* ph_ = p0_ + half * 16 * K;
+                            asm volatile("" : "+v"(ph_));
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int i = half * 8 + q;
+                                const int ro = ((q & 3) + 8 * (q >> 2)) * K;
+                                ph_[ro] = accA[rt][h][0][i] * unA;
+                                ph_[ro + 32] = accA[rt][h][1][i] * unA;
+                            }
+                        }
+                    }
+            };
+            auto consumeA_ks = [&](int b, auto cb_c, auto ks_c) {      // one of the block's two steps of sixteen columns
+                constexpr int cb = decltype(cb_c)::value, ks = decltype(ks_c)::value;
+                const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+                const unsigned char* Slb = smem + cb * W8_SL_BYTES;
+                {
+                    f16x8 r0[2], r1[2];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        r0[rt] = v8_tr_pair(Rb, r_t[rt][0] + ks * 4096, r_t[rt][1] + ks * 4096);
+                        r1[rt] = v8_tr_pair(Rb + V5_R_TERM, r_t[rt][0] + ks * 4096, r_t[rt][1] + ks * 4096);
+                    }
+                    const int so0 = s_t0 + ks * 16 * ROWB, so1 = s_t1 + ks * 16 * ROWB;
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h) {
+                        const unsigned char* Sh = Slb + h * W8_S_HALF;
+                        const f16x8 s00 = v8_tr_pair(Sh, so0, so1);
+                        const f16x8 s01 = v8_tr_pair(Sh + V5_S_TERM, so0, so1);
+                        const f16x8 s10 = v8_tr_pair(Sh, so0 ^ 64, so1 ^ 64);
+                        const f16x8 s11 = v8_tr_pair(Sh + V5_S_TERM, so0 ^ 64, so1 ^ 64);
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            accA[rt][h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1[rt], s00, accA[rt][h][0], 0, 0, 0);
+                            accA[rt][h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1[rt], s10, accA[rt][h][1], 0, 0, 0);
+                            accA[rt][h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0[rt], s01, accA[rt][h][0], 0, 0, 0);
+                            accA[rt][h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0[rt], s11, accA[rt][h][1], 0, 0, 0);
+                            accA[rt][h][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0[rt], s00, accA[rt][h][0], 0, 0, 0);
+                            accA[rt][h][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0[rt], s10, accA[rt][h][1], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            auto consumeA = [&](int b, auto cb_c) { consumeA_ks(b, cb_c, c0{}); consumeA_ks(b, cb_c, c1{}); };
+            const float invUnA = scR * scS;
+            ChainLink link;
+            if constexpr (CHAIN) link.init(a.chainFlags, chainId, nrp, j, a.status, a.wstatus, lane);
+            // piece (rt, h) of the previous sum of this wave's rows (32 registers): requested in front of half a block's MFMAs, added behind them
+            auto chain_fetch = [&](int prow, int rt, int h, float (&pv)[32]) {
+                const float* pb = gA_tile(prow, rt) + h * 64;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float* q = pb + ((i & 3) + 8 * (i >> 2)) * K;
+                    pv[i] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    pv[16 + i] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(q + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+            };
+            auto chain_add = [&](int rt, int h, const float (&pv)[32]) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    accA[rt][h][0][i] += pv[i] * invUnA;
+                    accA[rt][h][1][i] += pv[16 + i] * invUnA;
+                }
+            };
+            if constexpr (CHAIN) {
+                if (a.chainInject && blockIdx.x == 0 && j == 0) link.fault(3);
+            }
+            sync();
+            sync();
+            int s = 2;
+#pragma nounroll
+            for (int rp = 0; rp < nrp; ++rp) {
+                const int pnl = panel_at(rp);
+                const int prow = row0 + pnl * V5_BM;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, a.chainStride, nrp, a.chainBase, (a.doA & 1) != 0);
+                consumeA(s - 2, c0{}); sync(); ++s;
+                if constexpr (CHAIN) link.look();
+                consumeA(s - 2, c1{});
+                if constexpr (CHAIN) link.wait();
+                sync(); ++s;
+                if constexpr (CHAIN) {
+                    float pv[32];
+                    if (link.cadd) chain_fetch(prow, 0, 0, pv);
+                    consumeA_ks(s - 2, c2{}, c0{});
+                    if (link.cadd) { chain_add(0, 0, pv); chain_fetch(prow, 0, 1, pv); }
+                    consumeA_ks(s - 2, c2{}, c1{});
+                    if (link.cadd) chain_add(0, 1, pv);
+                    sync(); ++s;
+                    if (link.cadd) chain_fetch(prow, 1, 0, pv);
+                    consumeA_ks(s - 2, c3{}, c0{});
+                    if (link.cadd) { chain_add(1, 0, pv); chain_fetch(prow, 1, 1, pv); }
+                    consumeA_ks(s - 2, c3{}, c1{});
+                    if (link.cadd) chain_add(1, 1, pv);
+                } else {
+                    consumeA(s - 2, c2{}); sync(); ++s;
+                    consumeA(s - 2, c3{});
+                }
+                flush_gA(prow);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int h = 0; h < NKT; ++h)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { accA[rt][h][0][i] = 0.f; accA[rt][h][1][i] = 0.f; }
+                if constexpr (CHAIN) link.flushed();
+                sync(); ++s;
+            }
+            if constexpr (CHAIN) link.publish();
+        } else {
+            // ---- gSt: k tiles 2 (j - 2) and 2 (j - 2) + 1 of every block of the region, all 128 rows of a panel ----------------------
+            const int kh = j - 2;                // the 64-wide half of the A images these two tiles live in
+            f32x16 accS[NCB][2];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accS[c][0][i] = 0.f; accS[c][1][i] = 0.f; }
+            const int r_g3 = l31 * 256 + ((hi ^ v4_swz(l31)) << 4);
+            int a_t[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { a_t[t][0] = tr_src(8 * hi + (li >> 2), t * 32); a_t[t][1] = tr_src(8 * hi + 4 + (li >> 2), t * 32); }
+            const unsigned char* Ab = smem + W8_OFF_A + kh * W8_A_HALF;
+            f16x8 af[8][2];                      // the panel's A fragments, HIGH terms (the low terms are read per slot: registers)
+            auto consumeS = [&](int b, auto cb_c) {
+                constexpr int cb = decltype(cb_c)::value;
+                const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int ro = r_g3 ^ (ks << 5);
+                    const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
+                    const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f16x8 a1 = v8_tr_pair(Ab + V5_A_TERM, a_t[t][0] + ks * 16 * ROWB, a_t[t][1] + ks * 16 * ROWB);
+                        accS[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, af[ks][t], accS[cb][t], 0, 0, 0);
+                        accS[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accS[cb][t], 0, 0, 0);
+                        accS[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][t], accS[cb][t], 0, 0, 0);
+                    }
+                }
+            };
+            sync();
+            sync();
+            int s = 2;
+#pragma nounroll
+            for (int rp = 0; rp < nrp; ++rp) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();          // the producers have published the panel's A terms
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) af[ks][t] = v8_tr_pair(Ab, a_t[t][0] + ks * 16 * ROWB, a_t[t][1] + ks * 16 * ROWB);
+                consumeS(s - 2, c0{}); sync(); ++s;
+                consumeS(s - 2, c1{}); sync(); ++s;
+                consumeS(s - 2, c2{}); sync(); ++s;
+                consumeS(s - 2, c3{}); sync(); ++s;
+            }
+            {
+                float* dst = a.slabS + (int64_t)rowRegion * N * K;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    const int bcol = col0 + c * V5_BN;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int kk = (2 * kh + t) * 32 + l31;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int gn = bcol + tile_row(i, lane);
+                            dst[(int64_t)gn * K + kk] = accS[c][t][i] * unS;
+                        }
+                    }
+                }
+            }
+        }
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -627,14 +848,16 @@ int grad_k128_chain_stride(const GradPlan& p, int chainL) {
     if (sg > want) sg = want;
     return sg < 1 ? 1 : sg;
 }
-template <bool HASW, bool CHAIN, bool HH = false>
+template <bool HASW, bool CHAIN, bool HH = false, bool RS = false>
 static hipError_t grad_launch_k128_t(const GradK128Args& a, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, CHAIN, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_k128<HASW, CHAIN, HH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_k128<HASW, CHAIN, HH>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_k128<HASW, CHAIN, HH, RS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), W8_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 hipError_t grad_launch_k128(const GradK128Args& a, hipStream_t stream) {
+    if (a.hh && a.W == nullptr && (a.doA & 1) && a.doS && !(getenv("PMX_K1_ROLE_SPLIT") && atoi(getenv("PMX_K1_ROLE_SPLIT")) == 0))    // <RS>: both gradients wanted (PMX_K1_ROLE_SPLIT=0: A/B)
+        return a.chainL > 0 ? grad_launch_k128_t<false, true, true, true>(a, stream) : grad_launch_k128_t<false, false, true, true>(a, stream);
     if (a.hh && a.W == nullptr && ((a.doA & 1) || a.doS))      // (the loss-only pass has nowhere to put a correction: two terms)
         return a.chainL > 0 && (a.doA & 1) ? grad_launch_k128_t<false, true, true>(a, stream) : grad_launch_k128_t<false, false, true>(a, stream);
     if (a.chainL > 0 && (a.doA & 1))
