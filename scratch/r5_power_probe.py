@@ -68,25 +68,34 @@ def phase(name, fn, secs=4.0):
     lines.append(line)
 
 
-M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
-Y, A0, S0 = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
 phase("idle", lambda: time.sleep(0.2) or "idle", 2.0)
-for mode, env in (("f16x2r", {}), ("f16x2", {}), ("f16x2r <R3>", {"PMX_F16_R3": "1"}), ("f32", {})):
+# [r5, later] specs on the command line: cfg:mode[:ENV=V,...]  (default: the four arithmetic modes at cfg3)
+specs = [a.split(":") for a in sys.argv[1:]] or [["cfg3", "f16x2r"], ["cfg3", "f16x2"], ["cfg3", "f16x2r", "PMX_F16_R3=1"], ["cfg3", "f32"]]
+cache = {}
+for sp in specs:
+    cfg, mode = sp[0], sp[1]
+    env = dict(kv.split("=") for kv in sp[2].split(",")) if len(sp) > 2 else {}
+    M, N, K, backend, unity, _ = bench.CONFIGS[cfg]
+    if cfg not in cache:
+        cache.clear()
+        cache[cfg] = bench.make_problem_device(M, N, K, unity, 1234, torch.device("cuda", 0))
+    Y, A0, S0 = cache[cfg]
     os.environ.update(env)
-    dev = DeviceNMF(M, N, K, device=0, mode=mode.split()[0])
+    dev = DeviceNMF(M, N, K, device=0, mode=mode)
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
     run = bench.begin_solver(dev, backend, unity)
     run(30)
+    nit = 200 if M * N >= (1 << 26) else 2000
 
     def chain():
         dev.set_timing(True, every=4)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        run(200)
+        run(nit)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         ms, n = dev.get_timing(); dev.set_timing(False)
-        return "iteration %.4f ms, K1 %.4f ms (%s)" % (dt / 200 * 1e3, ms / max(n, 1), dev.k1_info()["kernel"].replace("k_grad_", ""))
-    phase("cfg3 chain, mode " + mode, chain)
+        return "iteration %.4f ms, K1 %.4f ms (%s)" % (dt / nit * 1e3, ms / max(n, 1), dev.k1_info()["kernel"].replace("k_grad_", ""))
+    phase("%s chain, mode %s %s" % (cfg, mode, ",".join("%s=%s" % kv for kv in env.items())), chain)
     dev.close()
     for k in env:
         del os.environ[k]
