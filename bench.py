@@ -100,7 +100,7 @@ def effective_mode(dev):
     return "f32" if dev.k1_info()["kernel"] in ("k_grad_f32", "k_grad_f32_pc") else dev.mode
 
 
-def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kernel=None):
+def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kernel=None, both=True):
     """Dominant kernel = K1 (fused residual-gradient), priced on ALGORITHMIC work: 6 M N K flop and one pass over Y,
     M N 4 bytes, per launch.  Mode f32: the exact-fp32 MFMA peak bounds it.  Split modes: the algorithmic intensity 6 K / 4 flop per
     byte (48 / 96 / 192 at K = 32 / 64 / 128) times 8 TB/s is below the dense bf16 / fp16 MFMA peak at every K <= 128, so the pass
@@ -118,6 +118,8 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
              "k_grad_f16_k32": ("k_grad_f16_k32", "f16x2"), "k_grad_f16_k32_r3": ("k_grad_f16_k32<R3>", "f16x2r"),
              "k_grad_f16_k128": ("k_grad_f16_k128", "f16x2"), "k_grad_f16_k128_hh": ("k_grad_f16_k128<HH> + k_gfix", "f16x2g")}
     name, arith = names.get(kernel, ("k_grad_bf16_v7" if (K == 64 and M % 128 == 0 and N % 256 == 0) else "k_grad_bf16<%d>" % kp, "bf16x3"))
+    if both and kernel in ("k_grad_f16_v8_hh", "k_grad_f16_k128_hh") and os.environ.get("PMX_K1_ROLE_SPLIT", "1") != "0":
+        name = name.replace("<HH>", "<HH, RS>")      # passes that want both gradients: the consumers' roles split by contraction (k_grad_f16_v8.hip: RS)
     passes = MFMA_PASSES[arith]
     return {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
@@ -330,7 +332,7 @@ def other_configs(Y3, local):
             flop_launch = (8.0 if backend == "bsdmm" else 6.0) * M * N * K / nk1
             k1_avg = k1_ms / max(k1_n, 1)
             info = dev.k1_info()
-            roof = roofline_entry(effective_mode(dev), M, N, K, flop_launch, k1_avg, k1_n, k1_avg * nk1 * steps / (1e3 * dt), info["kernel"])
+            roof = roofline_entry(effective_mode(dev), M, N, K, flop_launch, k1_avg, k1_n, k1_avg * nk1 * steps / (1e3 * dt), info["kernel"], backend != "bsdmm")
             tr = pmc_traffic({"cfg4_share8192": "cfg4_rows8192", "cfg2_f16x2": "cfg2", "cfg2_f16x2r": "cfg2"}.get(name, name), effective_mode(dev))
             res[name] = {"value": steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
                          "mode": mode, "backend": backend, "shape": [M, N, K], "k1_kernel": roof["kernel"] + ("<chain %d>" % info["chain"] if info["chain"] else ""),
@@ -446,10 +448,10 @@ def main():
         "gflops": flop_per_it * its / 1e9,
         "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
         "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
-                                   k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"]),
+                                   k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"], backend != "bsdmm"),
         "tail_ms": 1e3 * dt / args.steps - (2 if backend == "bsdmm" else 1) * k1_avg_ms,     # the step minus its K1 launches
         "tail_note": "step minus K1: the update kernel(s) of the back-end (adaprox: k_ada_tail) and, in mode f16x2r at K1's K = 64 / 128, the three small launches of the "
-                     "K x K correction (k_gfix_gram / _reduce / _apply, ~23 us at cfg3: profiles/r05_c_timeline_cfg3_f16x2r.txt)",
+                     "K x K correction (k_gfix_gram / _reduce / _apply, ~24 us at cfg3: profiles/r05_i_timeline_cfg3_f16x2r.txt)",
     }
     info = dev.k1_info()
     if info["chain"]:
