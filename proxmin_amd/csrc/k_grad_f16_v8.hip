@@ -151,8 +151,11 @@ static_assert(V8_LDS_BYTES <= 160 * 1024, "");
 // gSt for one k tile each over ALL 128 rows of the panel -- with no gA tiles to hold, the panel's A fragments (64 registers) stay in registers for the eight
 // slots of a panel.  24 MFMAs per wave and slot as before; LDS reads per slot 64 KB instead of 112 KB (profiles/r05_c_lds_ablation.txt priced those bytes);
 // gSt needs no merge of row halves at the end.  Passes that want ONE gradient keep the row split (two of four waves would idle).
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false>
+// ONLYS [r5]: the pass wants gSt alone (bsdmm's S step).  The row split's consumers then hold no gA tiles, and the 32 registers they leave keep each wave's share
+// of the panel's A fragments for the panel's eight slots: 8 of the 16 KB a consumer reads per slot.
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false, bool ONLYS = false>
 __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
+    static_assert(!ONLYS || (HH && !RS && !CHAIN && !PROF && !LOSS), "ONLYS: an instance of the <HH> gradient pass without gA");
     static_assert(!(R3 && HH) && !(HH && HASW), "HH: unweighted contexts, instead of the third terms");
     static_assert(!RS || (HH && !PROF && !LOSS), "RS: an instance of the <HH> gradient pass");
     constexpr int K = 64, ROWB = 128, NCB = V5_NB;
@@ -782,11 +785,12 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             __builtin_amdgcn_s_barrier();
             PH(9)
         };
+        f16x8 afS[ONLYS ? 4 : 1][2];        // ONLYS: this wave's share (row half mh, k tile kt) of the panel's A fragments
         auto consume = [&](int b, int prow, int cb, f32x16& accSc) {     // block b: column block cb of the panel at row prow
             const unsigned char* Rb = smem + OFF_R + (b & 1) * V5_R_BYTES;
             const unsigned char* Slb = smem + cb * SLB;
             const unsigned char* Ab = smem + OFF_A;
-            if (a.doA & 1) {
+            if (!ONLYS && (a.doA & 1)) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const f16x8 r0 = v8_tr_pair(Rb, r_t0 + ks * 4096, r_t1 + ks * 4096);
@@ -812,14 +816,15 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                     const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
                     const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
                     const int ao0 = a_t0 + ks * 16 * ROWB, ao1 = a_t1 + ks * 16 * ROWB;
-                    const f16x8 a0 = v8_tr_pair(Ab, ao0, ao1);
-                    const f16x8 a1 = v8_tr_pair(Ab + V5_A_TERM, ao0, ao1);
+                    f16x8 a0, a1;
+                    if constexpr (ONLYS) { a0 = afS[ks][0]; a1 = afS[ks][1]; }
+                    else { a0 = v8_tr_pair(Ab, ao0, ao1); a1 = v8_tr_pair(Ab + V5_A_TERM, ao0, ao1); }
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, accSc, 0, 0, 0);
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, accSc, 0, 0, 0);
                     accSc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, accSc, 0, 0, 0);
                 }
             }
-            if (!CHAIN && (a.doA & 1) && cb + 1 == NCB) {
+            if (!ONLYS && !CHAIN && (a.doA & 1) && cb + 1 == NCB) {
                 flush_gA(prow);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { accA0[i] = 0.f; accA1[i] = 0.f; }
@@ -848,6 +853,13 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_s_barrier();
                     if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, 1, nrp, a.chainBase, (a.doA & 1) != 0);
+                    if constexpr (ONLYS) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            afS[ks][0] = v8_tr_pair(smem + OFF_A, a_t0 + ks * 16 * ROWB, a_t1 + ks * 16 * ROWB);
+                            afS[ks][1] = v8_tr_pair(smem + OFF_A + V5_A_TERM, a_t0 + ks * 16 * ROWB, a_t1 + ks * 16 * ROWB);
+                        }
+                    }
                 }
                 float pv0[4], pv1[4];
                 if constexpr (CHAIN) {
@@ -942,12 +954,12 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
 #undef PH
 }
 
-template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false>
+template <bool PROF, bool HASW, bool CHAIN, bool LOSS, bool R3 = false, bool HH = false, bool RS = false, bool ONLYS = false>
 static hipError_t grad_launch_f16_v8_t(const GradV4Args& a, hipStream_t stream) {
     constexpr int lds = R3 ? V7_LDS_BYTES : V8_LDS_BYTES;        // (three S terms: the split-bf16 kernel's 160 KB)
-    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS, ONLYS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((k_grad_f16_v8<PROF, HASW, CHAIN, LOSS, R3, HH, RS, ONLYS>), dim3(a.gridX * a.gridY), dim3(V5_THREADS), lds, stream, a);
     return hipGetLastError();
 }
 static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
@@ -955,6 +967,8 @@ static hipError_t grad_launch_f16_v8(const GradV4Args& a, hipStream_t stream) {
     // has nowhere to put a correction and runs the third terms' instance)
     if (a.r3 == 2 && a.W == nullptr && (a.doA & 1) && a.doS && !a.prof && !(getenv("PMX_K1_ROLE_SPLIT") && atoi(getenv("PMX_K1_ROLE_SPLIT")) == 0))   // <RS>: both gradients wanted (PMX_K1_ROLE_SPLIT=0: A/B)
         return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, false, true, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, false, true, true>(a, stream);
+    if (a.r3 == 2 && a.W == nullptr && !(a.doA & 1) && a.doS && !(getenv("PMX_K1_ROLE_SPLIT") && atoi(getenv("PMX_K1_ROLE_SPLIT")) == 0))      // <ONLYS>: gSt alone (same A/B switch)
+        return grad_launch_f16_v8_t<false, false, false, false, false, true, false, true>(a, stream);
     if (a.r3 == 2 && a.W == nullptr && ((a.doA & 1) || a.doS))
         return a.chainL > 0 ? grad_launch_f16_v8_t<false, false, true, false, false, true>(a, stream) : grad_launch_f16_v8_t<false, false, false, false, false, true>(a, stream);
     if (a.r3 && a.W == nullptr) {    // R3: the residual to fp32's class (unweighted instances; a weighted context keeps two terms)
