@@ -707,15 +707,23 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         }
                     }
                     const unsigned char* Rb = smem + OFF_R + ((s - 2) & 1) * V5_R_BYTES;
+                    // The panel's contribution is summed in a FRESH accumulator and added to the launch-long one with an IEEE fp32 add: the fp16 MFMA cuts its
+                    // addends three bits below the last place of the largest (profiles/r05_b_mfma_accumulation.txt) -- 24 truncating steps per slot on an
+                    // accumulator that has grown over the whole region drift downwards; on a small one they do not, and the add rounds to nearest once per slot.
+                    f32x16 tacc;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tacc[i] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
                         const int ro = r_g ^ (ks << 5);
                         const f16x8 r0 = *reinterpret_cast<const f16x8*>(Rb + ro);
                         const f16x8 r1 = *reinterpret_cast<const f16x8*>(Rb + V5_R_TERM + ro);
-                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, af[ks][0], accS[cb], 0, 0, 0);
-                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][1], accS[cb], 0, 0, 0);
-                        accS[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][0], accS[cb], 0, 0, 0);
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, af[ks][0], tacc, 0, 0, 0);
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][1], tacc, 0, 0, 0);
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, af[ks][0], tacc, 0, 0, 0);
                     }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) accS[cb][i] += tacc[i];
                     sync();
                     ++s;
                 }

@@ -25,8 +25,8 @@ LIMITS = {
     "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb0ELb1E": 8,   # 4   chained (the bench's kernel)
     "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0ELb1E": 8,   # 0   slabs
     # [r5] <.., HH, RS>: the consumers' roles split by contraction (the bench's kernel since then): gSt's waves hold the panel's A fragments in registers
-    "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb0ELb1ELb1E": 0,   # 0   chained, 240 VGPRs
-    "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0ELb1ELb1E": 0,   # 0   slabs
+    "13k_grad_f16_v8ILb0ELb0ELb1ELb0ELb0ELb1ELb1E": 4,   # 1   chained (256 VGPRs with the gSt waves' per-slot accumulator)
+    "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0ELb1ELb1E": 4,   # 2   slabs
     "13k_grad_f16_v8ILb0ELb0ELb0ELb0ELb0ELb1ELb0ELb1E": 0,   # 0   <ONLYS>: gSt alone, the wave's A fragments in registers (bsdmm's S step)
     "15k_grad_f16_k128ILb0ELb1ELb1ELb1E": 0,             # 0   K = 128, chained (the row split's chained instance spills 9)
     "15k_grad_f16_k128ILb0ELb0ELb1ELb1E": 0,             # 0   K = 128, slabs
