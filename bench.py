@@ -451,7 +451,7 @@ def main():
                                    k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"], backend != "bsdmm"),
         "tail_ms": 1e3 * dt / args.steps - (2 if backend == "bsdmm" else 1) * k1_avg_ms,     # the step minus its K1 launches
         "tail_note": "step minus K1: the update kernel(s) of the back-end (adaprox: k_ada_tail) and, in mode f16x2r at K1's K = 64 / 128, the three small launches of the "
-                     "K x K correction (k_gfix_gram / _reduce / _apply, ~24 us at cfg3: profiles/r05_k_timeline_cfg3_f16x2r.txt)",
+                     "K x K correction (k_gfix_gram / _reduce / _apply, ~24 us at cfg3: profiles/r05_l_timeline_cfg3_f16x2r.txt)",
     }
     info = dev.k1_info()
     if info["chain"]:
