@@ -76,7 +76,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "proxmin_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f != "bench_floor.hip":     # (the measurement skeleton is not a kernel of the product)
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -126,6 +126,59 @@ def roofline_entry(mode, M, N, K, flop_per_launch, k1_avg_ms, k1_n, share, kerne
             "algorithmic_tflops": tflops, "algorithmic_frac_of_bf16_mfma_peak": tflops / PEAK_BF16_MFMA_TFLOPS,
             "hbm_roof_tflops": 6.0 * K / 4.0 * PEAK_HBM_GBS / 1e3,      # what one pass over fp32 Y allows: 6K/4 flop/B x 8 TB/s
             "mfma_issued_tflops": passes * tflops, "mfma_products_per_3_contractions": round(3 * passes), "k1_share_of_step": share}
+
+
+def measured_on_this_box(local):
+    """[r6] SURVEY 8(d): "the measured (not nominal) peaks ... on the box", next to the nominal ones the roofline is priced against, and the ENERGY
+    FLOOR of K1's own job: the skeleton of k_grad_f16_v8<HH, RS> (its grid, its pass over a 16384 x 16384 fp32 Y, its 28 fp16 MFMAs per SIMD and
+    128 x 32 block, a barrier per block -- and nothing else) timed on this package under its power cap (proxmin_amd/csrc/bench_floor.hip, built by
+    __graft_entry__.build() into libpmx_floor.so).  All on random data: the package clocks to its power budget and zeros run up to 19 % faster
+    (MI355X_MICROARCH.md, DVFS)."""
+    import ctypes as C
+    path = os.path.join(ROOT, "proxmin_amd", "libpmx_floor.so")
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        return {"error": "libpmx_floor.so not loadable: %r" % (exc,)}
+    lib.pmxf_last_error.restype = C.c_char_p
+    lib.pmxf_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.pmxf_copy.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    lib.pmxf_mfma.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = {}
+
+    def call(fn, *a):
+        v = C.c_double()
+        rc = fn(*a, C.byref(v))
+        if rc != 0:
+            raise RuntimeError(lib.pmxf_last_error().decode("utf-8", "replace"))
+        return v.value
+    try:
+        M = N = 16384
+        gb = M * N * 4 / 1e9
+        out["hbm_copy_gbs"] = call(lib.pmxf_copy, local, 1 << 30, 10)                    # float4 copy kernel, bytes read + written per second
+        ms = {}
+        # variant = fetch (0: 4 B / lane, 1: 8 B / lane pairs = K1's fetch, 2: 16 B / lane, 3: none) + 10 ops (random fragments from LDS) + 100 epilogue + 1000 MFMAs
+        for name, var in (("stream_8B", 1), ("stream_16B", 2), ("mfma28_const", 1003), ("mfma28_random_lds", 1013),
+                          ("stream_8B+mfma28_const", 1001), ("stream_16B+mfma28_const", 1002),
+                          ("stream_8B+mfma28_random_lds", 1011), ("stream_16B+mfma28_random_lds", 1012),
+                          ("stream_8B+mfma28_random_lds+epilogue", 1111), ("stream_16B+mfma28_random_lds+epilogue", 1112),
+                          ("stream_8B+mfma36_const (round 3's arithmetic)", 2001)):
+            ms[name] = call(lib.pmxf_stream, local, var, M, N, 0, 20)
+        out["hbm_read_gbs"] = gb / (ms["stream_16B"] * 1e-3)                              # K1's grid reading Y once, 16 B per lane, nothing else
+        out["hbm_read_gbs_8B_per_lane"] = gb / (ms["stream_8B"] * 1e-3)
+        out["fp16_mfma_tflops_random"] = call(lib.pmxf_mfma, local, 1, 10)                # dense v_mfma_f32_32x32x16_f16 from registers, random operands
+        out["fp16_mfma_tflops_zeros"] = call(lib.pmxf_mfma, local, 0, 10)
+        out["skeleton_ms"] = ms
+        # the floor K1 is priced against: K1's own fetch shape and operands that toggle like real data, no epilogue (the epilogue variant is what a
+        # kernel that ALSO forms the residual cannot avoid; both are printed)
+        out["energy_floor_ms"] = ms["stream_8B+mfma28_random_lds"]
+        out["energy_floor_ms_16B_fetch"] = ms["stream_16B+mfma28_random_lds"]
+        out["energy_floor_with_epilogue_ms"] = ms["stream_8B+mfma28_random_lds+epilogue"]
+        out["note"] = ("measured on this GPU just before the headline, random data, 2 x 20 launches each after a warm pass; skeleton = K1's grid / region map / barrier per "
+                       "128 x 32 block / 4 + 24 MFMAs per producer + consumer wave and block, no gradient computed (proxmin_amd/csrc/bench_floor.hip)")
+    except Exception as exc:                      # a side measurement must never take the headline down
+        out["error"] = repr(exc)
+    return out
 
 
 def make_problem_device(M, N, K, unity, seed, device):
@@ -362,7 +415,10 @@ def main():
                          "bf16x3 = three-term bf16 split MFMA, f32 = exact fp32 MFMA (default for cfg2, which BASELINE quotes in fp32)")
     args = ap.parse_args()
     if args.mode is None:
-        args.mode = "f32" if args.config == "cfg2" else "f16x2r"
+        # [r6] the LIBRARY'S default arithmetic (proxmin_amd.engine.LIBRARY_DEFAULT_MODE = f16x2r): the headline needs no --mode; cfg2 is the one
+        # configuration BASELINE quotes in fp32, so its own line runs exact fp32 (its f16x2r number is in other_configs)
+        from proxmin_amd.engine import LIBRARY_DEFAULT_MODE
+        args.mode = "f32" if args.config == "cfg2" else LIBRARY_DEFAULT_MODE
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,8 +454,38 @@ def main():
         return
 
     from proxmin_amd.engine import DeviceNMF
+    import proxmin_amd
     Y, A0, S0 = make_problem_device(M, N, K, unity, 1234, device)
     torch.cuda.synchronize()
+
+    # [r6] Everything that is NOT the headline runs FIRST: the box's measured peaks and K1's energy floor, the same workload in the
+    # other arithmetic modes, the other BASELINE configurations, one nmf() call through the public entry point.  The timed region of the headline
+    # (20 steps = 8 ms with the driver's flags: inside one DVFS time constant) then starts on a package that has been busy for seconds.
+    side = {}
+    full = args.config == "cfg3" and not args.rows and not args.no_cpu
+    if full:
+        side["measured"] = measured_on_this_box(local)
+        for key, mode, warm_s, steps_s, note in (("value_f32_mode", "f32", 25, 20, "same workload in exact fp32 (mode f32: %s)"),
+                                                 ("value_f16x2_mode", "f16x2", 25, 40, "same workload in mode f16x2 (%s: two fp16 terms per operand in all three contractions; noisier than exact fp32: "
+                                                                                       "2-4 x its out-of-tolerance entries against the fp64 oracle, tests/test_gpu_parity_long.py)")):
+            try:
+                devs = DeviceNMF(M, N, K, device=local, mode=mode)
+                devs.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
+                devs.set_factors(A0, S0)
+                runs = begin_solver(devs, backend, unity)
+                runs(warm_s)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                runs(steps_s)
+                torch.cuda.synchronize()
+                side[key] = {"value": steps_s / (time.perf_counter() - t0), "unit": "it/s", "steps": steps_s, "warmup": warm_s, "note": note % devs.k1_info()["kernel"]}
+                devs.close()
+            except Exception as exc:
+                side[key] = {"error": repr(exc)}
+        side["other_configs"] = other_configs(Y, local)
+        side["nmf_call"] = nmf_call_leg(Y, A0, S0, unity)
+
+    assert proxmin_amd.get_default_mode() == proxmin_amd.LIBRARY_DEFAULT_MODE or os.environ.get("PMX_MODE"), "bench.py must not change the library's default mode"
     dev = DeviceNMF(M, N, K, device=local, mode=args.mode)
     dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
     dev.set_factors(A0, S0)
@@ -437,21 +523,21 @@ def main():
     its = args.steps / dt
     k1_avg_ms = k1_ms / max(k1_n, 1)
     flop_per_launch = flop_per_it / (2 if backend == "bsdmm" else 1)   # bsdmm: two K1 launches of 4MNK each
-    achieved_tflops = flop_per_launch / (k1_avg_ms * 1e-3) / 1e12
     out = {
         "metric": "NMF iterations/sec at Y=%dx%d, K=%d" % (M, N, K),
         "value": its, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_total,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": MODE_DTYPE[effective_mode(dev)], "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.config, desc), "M": M, "N": N, "K": K, "backend": backend,
-                   "mode": MODE_DESC[effective_mode(dev)], "parallelism": "1 GPU", "generator": GENERATOR},
+                   "mode": MODE_DESC[effective_mode(dev)], "mode_is_library_default": dev.mode == proxmin_amd.LIBRARY_DEFAULT_MODE,
+                   "parallelism": "1 GPU", "generator": GENERATOR},
         "gflops": flop_per_it * its / 1e9,
         "sub_iterations_per_step": sub_timed,     # proximal passes per iteration (A, S) inside the timed region only
         "roofline": roofline_entry(effective_mode(dev), M, N, K, flop_per_launch, k1_avg_ms, k1_n,
                                    k1_avg_ms * (2 if backend == "bsdmm" else 1) * args.steps / (1e3 * dt), dev.k1_info()["kernel"], backend != "bsdmm"),
         "tail_ms": 1e3 * dt / args.steps - (2 if backend == "bsdmm" else 1) * k1_avg_ms,     # the step minus its K1 launches
-        "tail_note": "step minus K1: the update kernel(s) of the back-end (adaprox: k_ada_tail) and, in mode f16x2r at K1's K = 64 / 128, the three small launches of the "
-                     "K x K correction (k_gfix_gram / _reduce / _apply, ~24 us at cfg3: profiles/r05_l_timeline_cfg3_f16x2r.txt)",
+        "tail_note": "step minus K1: the update kernel(s) of the back-end (adaprox: k_ada_tail) and, in mode f16x2r at K1's K = 64 / 128, the launches of the "
+                     "K x K correction (k_gfix_*)",
     }
     info = dev.k1_info()
     if info["chain"]:
@@ -462,42 +548,32 @@ def main():
         out["roofline"]["traffic"] = tr["bytes_per_launch"] if tr else None
         out["roofline"]["traffic_unit"] = "HBM bytes per K1 launch, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this build (%s); null: not measured for this build; algorithmic: %d" % (
             "fetch %d + write %d, %s" % (tr["fetch_bytes"], tr["write_bytes"], tr.get("when", "")) if tr else "profiles/k1_traffic.json has no entry for source hash %s" % kernel_source_hash(), M * N * 4)
+    meas = side.get("measured")
+    if meas and "error" not in meas:
+        # the nominal peak stays the denominator of `frac` (the contract's roofline); beside it: the same bytes against what THIS box streams, and
+        # K1 against the floor of its own job under this package's power cap
+        rl = out["roofline"]
+        rl["peak_nominal"] = rl["peak"]
+        rl["peak_measured_read_gbs"] = meas["hbm_read_gbs"]
+        rl["peak_measured_copy_gbs"] = meas["hbm_copy_gbs"]
+        rl["peak_measured_fp16_mfma_tflops_random_data"] = meas["fp16_mfma_tflops_random"]
+        rl["frac_of_measured_read_peak"] = (M * N * 4 / (k1_avg_ms * 1e-3) / 1e9) / meas["hbm_read_gbs"] if rl.get("bound") == "hbm" else None
+        if args.config == "cfg3" and M == 16384 and N == 16384 and effective_mode(dev) == "f16x2r":
+            rl["energy_floor_ms"] = meas["energy_floor_ms"]
+            rl["frac_of_energy_floor"] = meas["energy_floor_ms"] / k1_avg_ms
+            rl["energy_floor_with_epilogue_ms"] = meas["energy_floor_with_epilogue_ms"]
+            rl["energy_floor_note"] = ("K1's skeleton (its pass over Y with K1's own 8-byte requests + its 28 fp16 MFMAs per SIMD and block on operands that toggle like data, a barrier per "
+                                       "block, nothing else) on this GPU under its power cap: frac_of_energy_floor = floor / K1's launch time")
+    out.update({k: v for k, v in side.items() if k != "measured"})
+    if meas:
+        out["measured_on_this_box"] = meas
     if not args.no_cpu:
-        if args.config == "cfg3" and dev.mode == "f16x2r":
-            # the package default is the exact-fp32 MFMA mode: the same workload in that mode, short run, beside the headline
-            dev32 = DeviceNMF(M, N, K, device=local, mode="f32")
-            dev32.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
-            dev32.set_factors(A0, S0)
-            run32 = begin_solver(dev32, backend, unity)
-            run32(25)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run32(20)
-            torch.cuda.synchronize()
-            out["value_f32_mode"] = {"value": 20.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 20, "warmup": 25,
-                                     "note": "same workload with the library's default arithmetic (exact fp32 MFMA, %s)" % dev32.k1_info()["kernel"]}
-            dev32.close()
-            # ... and in mode f16x2 (two-term products everywhere: 9 MFMA products per 3 contractions, 2-4 x exact fp32's out-of-tolerance
-            # entries against the fp64 oracle -- NOT the headline's error class; tests/test_gpu_parity_long.py)
-            devr = DeviceNMF(M, N, K, device=local, mode="f16x2")
-            devr.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
-            devr.set_factors(A0, S0)
-            runr = begin_solver(devr, backend, unity)
-            runr(25)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            runr(40)
-            torch.cuda.synchronize()
-            out["value_f16x2_mode"] = {"value": 40.0 / (time.perf_counter() - t0), "unit": "it/s", "steps": 40, "warmup": 25,
-                                       "note": "same workload in mode f16x2 (%s: two fp16 terms per operand in all three contractions; noisier than exact fp32)" % devr.k1_info()["kernel"]}
-            devr.close()
         dev.close()
-        if args.config == "cfg3" and not args.rows:
-            # the other BASELINE configurations, short runs in the same process (same box, same build): driver-visible
-            out["other_configs"] = other_configs(Y, local)
         Yh = Y.cpu().numpy()
         del Y
         torch.cuda.empty_cache()
+        if full:
+            out["end_to_end"] = end_to_end_leg(Yh, A0, S0, unity)
         # the CPU leg is timed over the same steady state as the GPU: the last 5 warm-up iterations [warm_total - 5, warm_total)
         # of the GPU run against the same iteration indices of the oracle (its transient runs untimed)
         n_cpu = 5 if M * N <= 16384 * 16384 else 3
@@ -509,6 +585,46 @@ def main():
             rec["gpu_sub_iterations_same_window"] = sub_window
             rec["sub_iterations_equal"] = bool(sub_window is not None and all(abs(a - b) < 1e-9 for a, b in zip(cpu_sub, sub_window)))
     emit(out)
+
+
+def _cfg3_call(Yany, A, S, unity, n):
+    """one call of the PUBLIC entry point on cfg3's workload: `import proxmin_amd as proxmin; proxmin.nmf.nmf(...)`, library defaults"""
+    from functools import partial
+    import proxmin_amd as proxmin
+    t0 = time.perf_counter()
+    proxmin.nmf.nmf(Yany, A, S, prox_A=proxmin.operators.prox_plus,
+                    prox_S=partial(proxmin.operators.prox_unity_plus, axis=0) if unity else proxmin.operators.prox_plus,
+                    algorithm=proxmin.algorithms.adaprox, scheme="amsgrad", max_iter=n, e_rel=1e-3, check_convergence=False)
+    return time.perf_counter() - t0
+
+
+def nmf_call_leg(Yd, A0, S0, unity):
+    """[r6] The drop-in path itself: nmf() with Y ALREADY IN HBM (a torch tensor: adopted in place, engine.DeviceArrayRef), host factors, no
+    set_default_mode(), no DeviceNMF in sight.  Two calls (n1 and n2 iterations from the same start); the marginal rate (n2 - n1) / (t2 - t1)
+    is the iteration rate a user of the public entry point gets, free of the per-call fixed costs, which are printed as well."""
+    try:
+        n1, n2 = 60, 460
+        t1 = _cfg3_call(Yd, A0.copy(), S0.copy(), unity, n1)
+        t2 = _cfg3_call(Yd, A0.copy(), S0.copy(), unity, n2)
+        return {"iterations": [n1, n2], "seconds": [t1, t2], "value": (n2 - n1) / (t2 - t1), "unit": "it/s", "fixed_ms_per_call": 1e3 * (t1 - n1 * (t2 - t1) / (n2 - n1)),
+                "note": "proxmin_amd.nmf.nmf(Y_on_gpu, A, S, algorithm=adaprox, scheme='amsgrad', prox_S=partial(prox_unity_plus, axis=0), check_convergence=False) in the library's "
+                        "default mode: marginal iterations/s between a %d- and a %d-iteration call (iterations %d..%d of the problem; the headline times iterations ~60..160: K1's time "
+                        "drifts a few per cent along a run, DESIGN.md section 5); fixed part = context, factor upload / download, the cold start's proximal passes" % (n1, n2, n1, n2)}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
+def end_to_end_leg(Yh, A0, S0, unity):
+    """"D2H of A, S at exit included only in end-to-end nmf() latency, reported separately": nmf() called with HOST arrays (the
+    reference's own calling convention: Y in host RAM), 200 iterations: upload of the 1 GiB Y through the C ABI, context, solver, write-back.
+    PCIe-inclusive; never part of `value`."""
+    try:
+        n = 200
+        t = _cfg3_call(Yh, A0.copy(), S0.copy(), unity, n)
+        return {"iterations": n, "end_to_end_ms": 1e3 * t, "its_including_upload": n / t,
+                "note": "nmf() from host NumPy arrays (Y 1 GiB pageable memory -> HBM, factors back at exit), %d iterations, one call" % n}
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 if __name__ == "__main__":

@@ -12,6 +12,6 @@ Mirrors proxmin/__init__.py:1-4 (star-exports of algorithms and operators, submo
 from .algorithms import pgm, adaprox, bsdmm  # noqa: F401
 from .operators import *  # noqa: F401,F403
 from . import algorithms, operators, nmf, utils  # noqa: F401
-from .engine import set_default_mode, get_default_mode  # noqa: F401
+from .engine import set_default_mode, get_default_mode, LIBRARY_DEFAULT_MODE  # noqa: F401
 
 __version__ = "0.1.0"

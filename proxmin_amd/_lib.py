@@ -152,6 +152,19 @@ def load():
     # torch.distributed, goes through require_torch() below and says what is wrong instead of failing inside torch).
     if "torch" not in sys.modules and os.environ.get("PMX_TORCH_PRELOAD", "0") == "1":
         import torch  # noqa: F401
+    elif "torch" not in sys.modules and os.environ.get("PMX_TORCH_PRELOAD") is None:
+        # [r6] the silent failure mode: this process loads libpmx now and may import torch LATER -- torch would then see no GPU
+        # and say nothing.  If torch is installed, say so once, at the moment the order is decided (find_spec does not import it).
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import logging
+                logging.getLogger("proxmin").info(
+                    "proxmin_amd: libpmx.so is being loaded before torch.  If this process imports torch LATER, torch will see no GPU (PyTorch-ROCm "
+                    "brings its own HIP runtime): import torch first, or set PMX_TORCH_PRELOAD=1 (PMX_TORCH_PRELOAD=0 silences this note)")
+                _install_late_torch_guard()
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
@@ -166,6 +179,22 @@ def load():
         raise PmxError("struct layouts of libpmx.so %r differ from the ctypes mirrors %r; rebuild" % (list(sizes), mine))
     _lib = lib
     return lib
+
+
+class _LateTorchGuard:
+    """meta-path finder that does nothing but notice `import torch` after libpmx.so was loaded without it, and raise require_torch()'s
+    message there -- at the import, not at the first tensor that silently lands on the CPU"""
+
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" and _lib is not None and "torch" not in sys.modules and _lib.pmx_device_count() >= 1:     # (no GPU: nothing to lose)
+            raise ImportError("torch is being imported AFTER proxmin_amd loaded libpmx.so: PyTorch-ROCm brings its own HIP runtime and, loaded second, "
+                              "sees no GPU.  Import torch before the first proxmin_amd call, or set PMX_TORCH_PRELOAD=1")
+        return None
+
+
+def _install_late_torch_guard():
+    if not any(isinstance(f, _LateTorchGuard) for f in sys.meta_path):
+        sys.meta_path.insert(0, _LateTorchGuard())
 
 
 def require_torch():

@@ -25,7 +25,7 @@ from functools import partial
 import numpy as np
 
 from . import _lib, operators, utils
-from .engine import DeviceNMF, open_weighted
+from .engine import DeviceNMF, open_weighted, as_device_array, DeviceArrayRef
 
 logger = logging.getLogger("proxmin")
 
@@ -51,8 +51,10 @@ def _problem_from_grad(X, grad):
         _warn_host_path("grad (%r)" % (grad,))
         return None, A, S, None
     kw = grad.keywords
-    Y = np.asarray(kw["Y"])
-    assert Y.shape == (A.shape[0], S.shape[1]), "Y must be M x N"
+    Y = as_device_array(kw["Y"])          # [r6] a Y that already lives in HBM (torch / CuPy) is adopted in place, never copied to the host
+    if Y is None:
+        Y = np.asarray(kw["Y"])
+    assert tuple(Y.shape) == (A.shape[0], S.shape[1]), "Y must be M x N"
     return Y, A, S, _nmf._weights(kw.get("W", 1), Y.shape)
 
 
@@ -79,15 +81,32 @@ def _open_device(Y, A, S, W, f64=False):
             dev.set_Y(Y)
             dev.set_factors(A, S)
             return dev
+    _warn_f64_in_f32(Y, A, S)
     if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
         dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
         dev.set_host_grad(True)
         dev.set_factors(A, S)
         return dev
-    dev = open_weighted(A.shape[0], S.shape[1], A.shape[1], W)
+    dev = open_weighted(A.shape[0], S.shape[1], A.shape[1], W, device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
     dev.set_Y(Y)
     dev.set_factors(A, S)
     return dev
+
+
+_f64_warned = []
+
+
+def _warn_f64_in_f32(Y, A, S):
+    """[r6] The reference computes in the dtype of the caller's arrays (nmf.py:39-41: NumPy keeps fp64).  fp64 arrays that the fp64
+    kernels do not take (PMX_MODE_F64: K <= 16 and M N <= 2^20, all of the iteration on the device) are computed in fp32 on the
+    device and cast back: said ONCE, on logger "proxmin", so that nobody mistakes the result for an fp64 one."""
+    if _f64_warned:
+        return
+    if any(getattr(x, "dtype", None) == np.float64 for x in (Y, A, S) if x is not None):
+        _f64_warned.append(True)
+        logger.warning("proxmin_amd: float64 arrays at %d x %d x %d are computed in float32 on the GPU and cast back (the fp64 kernels take "
+                       "K <= 16 and M N <= 2^20 with library operators and step rules only); the reference would keep float64 here. "
+                       "Pass float32 arrays to silence this." % (A.shape[0], S.shape[1], A.shape[1]))
 
 
 def _prox_pair(prox, n=2):
@@ -251,7 +270,7 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     # [r4] fp64 inputs of a small problem, everything of the iteration on the device: fp64 arithmetic (PMX_MODE_F64)
     from .engine import f64_applies
     f64 = (not slow and not backtracking and bb is None and W is None and Y is not None
-           and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+           and all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
     with _open_device(Y, A, S, W, f64=f64) as dev:
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
                       e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
@@ -453,7 +472,7 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
 
     # [r4] fp64 inputs of a small problem: fp64 arithmetic on the device (k_small_f64.hip: k64_ada_iter), as the reference's own
     from .engine import f64_applies
-    f64 = (not slow and W is None and Y is not None and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S))
+    f64 = (not slow and W is None and Y is not None and all(x.dtype == np.float64 for x in (Y, A, S))
            and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
     with _open_device(Y, A, S, W, f64=f64) as dev:
         for j in range(2):
@@ -680,7 +699,7 @@ def _bsdmm_nmf(X, grad, prox, proxs_g=None, steps_g=None, Ls=None, update_order=
 
     # [r4] fp64 inputs of a small problem: fp64 arithmetic on the device (k_small_f64.hip: k64_bsdmm_block), as the reference's own
     from .engine import f64_applies
-    f64 = (not slow and Y is not None and all(np.asarray(x).dtype == np.float64 for x in (Y, A, S))
+    f64 = (not slow and Y is not None and all(x.dtype == np.float64 for x in (Y, A, S))
            and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
     with _open_device(Y, A, S, None, f64=f64) as dev:
         dev.bsdmm_begin(seq_f, seq_g, e_rel=er, e_abs=ea, update_order=order)

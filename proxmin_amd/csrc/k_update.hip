@@ -791,6 +791,8 @@ __global__ __launch_bounds__(EW_THREADS) void k_bb_step(BBStepArgs a) {
 // ---- stand-alone Barzilai-Borwein sums of ONE block on caller arrays (utils.BarzilaiBorweinStepper.step called as a function,
 // proxmin/utils.py:216-241): s = X - X_prev, y = G - G_prev in the arrays' own type, products and sums in fp64, fixed order ----------
 constexpr int BBS_BLOCKS = 256;
+// np.max propagates NaN (utils.py:222: a diverged run gets a NaN step in the reference); fmax() drops it
+__device__ __forceinline__ double bbs_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : fmax(a, b); }
 template <typename T>
 __global__ __launch_bounds__(256) void k_bb_sums(const T* X, const T* Xp, const T* G, const T* Gp, int64_t n, double* part) {
     __shared__ double red[4][6];
@@ -802,21 +804,21 @@ __global__ __launch_bounds__(256) void k_bb_sums(const T* X, const T* Xp, const 
         sy += (double)s * (double)y;
         y2 += (double)y * (double)y;
         g2 += (double)g * (double)g;
-        mx = fmax(mx, fabs((double)x));
-        mg = fmax(mg, fabs((double)g));
+        mx = bbs_max(mx, fabs((double)x));
+        mg = bbs_max(mg, fabs((double)g));
     }
     double v[6] = {s2, sy, y2, g2, mx, mg};
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v[q], o); v[q] = q < 4 ? v[q] + t : fmax(v[q], t); }
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v[q], o); v[q] = q < 4 ? v[q] + t : bbs_max(v[q], t); }
     if ((threadIdx.x & 63) == 0)
         for (int q = 0; q < 6; ++q) red[threadIdx.x >> 6][q] = v[q];
     __syncthreads();
     if (threadIdx.x < 6) {
         const int q = threadIdx.x;
         double r = red[0][q];
-        for (int w = 1; w < 4; ++w) r = q < 4 ? r + red[w][q] : fmax(r, red[w][q]);
+        for (int w = 1; w < 4; ++w) r = q < 4 ? r + red[w][q] : bbs_max(r, red[w][q]);
         part[blockIdx.x * 6 + q] = r;
     }
 }
@@ -824,7 +826,7 @@ __global__ void k_bb_sums_fold(const double* part, double* out) {
     const int q = threadIdx.x;
     if (q >= 6) return;
     double r = part[q];
-    for (int b = 1; b < BBS_BLOCKS; ++b) r = q < 4 ? r + part[b * 6 + q] : fmax(r, part[b * 6 + q]);
+    for (int b = 1; b < BBS_BLOCKS; ++b) r = q < 4 ? r + part[b * 6 + q] : bbs_max(r, part[b * 6 + q]);
     out[q] = r;
 }
 

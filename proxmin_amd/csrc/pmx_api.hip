@@ -15,6 +15,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <mutex>
 
 #include <fcntl.h>
 #include <sys/file.h>
@@ -1635,15 +1636,30 @@ extern "C" int pmx_prox_array(int device, float* X, int64_t rows, int K, const p
     return PMX_OK;
 }
 
+// [r6] scratch of pmx_bb_sums, one per device, kept between calls (the stepper calls this once per block and iteration: a hipMalloc / hipFree
+// pair each time cost more than the reduction); grows on demand, freed at process exit by the runtime
+struct BbScratch { char* d = nullptr; size_t bytes = 0; };
+static std::mutex g_bb_mu;
+static BbScratch g_bb_scratch[16];
 extern "C" int pmx_bb_sums(int device, int is_f64, const void* X, const void* Xprev, const void* G, const void* Gprev, int64_t count, double out[6]) {
     if (!X || !G || !out) FAIL(PMX_E_INVALID, "NULL argument");
     if (count <= 0) FAIL(PMX_E_INVALID, "bad count %lld", (long long)count);
     if ((Xprev == nullptr) != (Gprev == nullptr)) FAIL(PMX_E_INVALID, "X_prev and G_prev come together");
+    if (device < 0 || device >= 16) FAIL(PMX_E_INVALID, "bad device %d", device);
     HIP_CHECK(hipSetDevice(device));
     const size_t es = is_f64 ? sizeof(double) : sizeof(float), bytes = ((size_t)count * es + 15) / 16 * 16;
     const int narr = Xprev ? 4 : 2;
-    char* d = nullptr;
-    HIP_CHECK(hipMalloc((void**)&d, narr * bytes + (BBS_BLOCKS * 6 + 6) * sizeof(double)));
+    const size_t need = narr * bytes + (BBS_BLOCKS * 6 + 6) * sizeof(double);
+    std::lock_guard<std::mutex> lock(g_bb_mu);           // (also serialises the null-stream work of concurrent callers on the one scratch)
+    BbScratch& sc = g_bb_scratch[device];
+    if (sc.bytes < need) {
+        if (sc.d) (void)hipFree(sc.d);
+        sc.d = nullptr;
+        sc.bytes = 0;
+        HIP_CHECK(hipMalloc((void**)&sc.d, need));
+        sc.bytes = need;
+    }
+    char* d = sc.d;
     const void* src[4] = {X, G, Xprev, Gprev};
     hipError_t e = hipSuccess;
     for (int i = 0; i < narr && e == hipSuccess; ++i) e = hipMemcpy(d + i * bytes, src[i], (size_t)count * es, hipMemcpyHostToDevice);
@@ -1657,7 +1673,6 @@ extern "C" int pmx_bb_sums(int device, int is_f64, const void* X, const void* Xp
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(out, part + BBS_BLOCKS * 6, 6 * sizeof(double), hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d);
     if (e != hipSuccess) FAIL(PMX_E_HIP, "bb_sums: %s", hipGetErrorString(e));
     return PMX_OK;
 }

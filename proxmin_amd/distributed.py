@@ -245,12 +245,24 @@ class ShardedAdaproxDriver:
             # iterations enqueued between two reads of the device status (each read drains the stream: 8 us per iteration at 16, 2 us at
             # 64, cfg4's share).  The fused tail decides its proximal loops on the device, so nothing is speculated on and the chunks may
             # be as long as the single-GPU loop's (pmx_adaprox_run); the chain of tail kernels keeps 16 (its per-iteration records: 64 slots)
-            fused = getattr(engine, "tail_fused", None)
-            chunk = 64 if (fused() if callable(fused) else fused) else 16
-        self.chunk = int(chunk)
+            chunk = None
+        self._chunk_arg = None if chunk is None else int(chunk)
+        self.chunk = self._chunk()
         self.nsub = 2
         self.it = 0              # completed iterations
         self.stopped = False
+
+    SUB_REC_SLOTS = 64       # per-iteration records of the chain of tail kernels (k_update.hip: sub_rec[it & 63])
+
+    def _chunk(self):
+        """[r6] Re-evaluated at every chunk boundary: the fused tail can fault MID-RUN (pmx_adaprox_phase then clears tail_fused and
+        the chain of tail kernels takes over) -- a chunk of 64 fixed at construction would leave that chain with exactly as many iterations
+        in flight as it has record slots.  The chain keeps 16; an explicit chunk is clamped strictly below the slot count while it runs."""
+        fused = getattr(self.eng, "tail_fused", None)
+        fused = bool(fused() if callable(fused) else fused)
+        if self._chunk_arg is None:
+            return 64 if fused else 16
+        return self._chunk_arg if fused else min(self._chunk_arg, self.SUB_REC_SLOTS - 1)
 
     def _allreduce(self):
         if getattr(self.eng, "s_split", False):     # S-split: reduce-scatter here, the all-gather follows the update
@@ -270,6 +282,7 @@ class ShardedAdaproxDriver:
         """Advance up to n_iter iterations; b1 is the full per-iteration array (len >= it + n_iter)."""
         target = self.it + int(n_iter)
         while self.it < target and not self.stopped:
+            self.chunk = self._chunk()
             hi = min(target, self.it + self.chunk)
             first = self.it
             for it in range(first, hi):
@@ -321,7 +334,9 @@ class ShardedLoop:
     and flushes it after the last iteration; bsdmm's all-reduce sits between its A step and its S step, so its
     test is exact without deferral."""
 
-    def __init__(self, engine, group=None, deferred_test=True, chunk=64, dist_module=None):
+    def __init__(self, engine, group=None, deferred_test=True, chunk=32, dist_module=None):
+        # chunk: iterations enqueued between two reads of the device status.  After a mid-chunk convergence the rest of the chunk still runs
+        # (halted kernels return at once, the collectives are real): 32 bounds that tail at half of round 5's 64 for ~1 us more per iteration
         if dist_module is None:
             _lib.require_torch()
             import torch.distributed as dist_module

@@ -33,12 +33,20 @@ def _notice(key, msg):
 #   "f16x2r" "f16x2" with the RESIDUAL in exact fp32's class (include/pmx.h: PMX_MODE_F16X2R).  K1's K = 64 / 128 without weights: the
 #            residual from the high x high fp16 product alone, the rest restored exactly through K x K matrices (k_gfix.hip) -- 7 instead
 #            of 9 MFMA products per multiply-add; K = 32: third fp16 terms of A and S in a second accumulator (11 products)
-_DEFAULT_MODE = os.environ.get("PMX_MODE", "f32")
+# [r6] The library's default IS the benchmarked arithmetic: f16x2r is in exact fp32's error class, falls back to the
+# exact-fp32 kernel by itself where it has no kernel of its own (off-shape weighted contexts: open_weighted) or where one fp16 scale cannot
+# carry the residual (the range guard, tests/test_gpu_range.py), and runs the tuned kernels on zero-padded frames for ragged shapes.
+LIBRARY_DEFAULT_MODE = "f16x2r"
+_DEFAULT_MODE = os.environ.get("PMX_MODE", LIBRARY_DEFAULT_MODE)
+assert _DEFAULT_MODE in ("f32", "bf16x3", "f16x2", "f16x2r"), "PMX_MODE must be one of f32, bf16x3, f16x2, f16x2r"
 
 
-def set_default_mode(mode):
-    """Select the contraction arithmetic used by nmf() and friends ("f32", "bf16x3", "f16x2" or "f16x2r")."""
+def set_default_mode(mode=None):
+    """Select the contraction arithmetic used by nmf() and friends ("f32", "bf16x3", "f16x2" or "f16x2r"); None: back to the
+    library's default (LIBRARY_DEFAULT_MODE, or PMX_MODE from the environment)."""
     global _DEFAULT_MODE
+    if mode is None:
+        mode = os.environ.get("PMX_MODE", LIBRARY_DEFAULT_MODE)
     assert mode in ("f32", "bf16x3", "f16x2", "f16x2r")
     _DEFAULT_MODE = mode
 
@@ -69,6 +77,47 @@ def f64_applies(M, N, K):
 
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArrayRef:
+    """[r6] Y (or W) that is ALREADY in HBM: anything that speaks `__cuda_array_interface__` (a torch tensor on the GPU, a
+    CuPy array): float32, row-major, unit stride along the rows.  nmf() and the solvers adopt it zero-copy (pmx_set_Y_device)
+    instead of uploading a host array -- the reference's Y lives in host RAM (nmf.py:96), ours may live where the kernels read it.
+    The owner must keep its memory alive and unchanged for the duration of the call (the context holds a reference)."""
+
+    def __init__(self, obj):
+        cai = obj.__cuda_array_interface__
+        if cai.get("typestr") not in ("<f4", "=f4", "|f4"):
+            raise TypeError("a device-resident Y must be float32 (got %r)" % (cai.get("typestr"),))
+        shape = tuple(int(v) for v in cai["shape"])
+        if len(shape) != 2:
+            raise TypeError("a device-resident Y must be two-dimensional")
+        strides = cai.get("strides")
+        if strides is None:
+            ld = shape[1]
+        else:
+            if int(strides[1]) != 4 or int(strides[0]) % 4 or int(strides[0]) < 4 * shape[1]:
+                raise TypeError("a device-resident Y must be row-major with unit stride along its rows")
+            ld = int(strides[0]) // 4
+        self.ptr, self.shape, self.ld, self.owner = int(cai["data"][0]), shape, ld, obj
+        self.dtype = np.dtype(np.float32)
+        self.ndim = 2
+        dev = getattr(obj, "device", None)
+        self.device = int(getattr(dev, "index", None) or 0) if dev is not None and not isinstance(dev, int) else int(dev or 0)
+
+    def __array__(self, *a, **k):
+        raise TypeError("this array lives on the GPU; proxmin_amd adopts it in place")
+
+
+def as_device_array(obj):
+    """DeviceArrayRef for an object that lives on the GPU, None for host data"""
+    if isinstance(obj, DeviceArrayRef):
+        return obj
+    if isinstance(obj, np.ndarray) or not hasattr(obj, "__cuda_array_interface__"):
+        return None
+    if getattr(obj, "is_cuda", True) is False:       # a torch tensor on the host
+        return None
+    return DeviceArrayRef(obj)
 
 
 class DeviceNMF:
@@ -129,6 +178,11 @@ class DeviceNMF:
 
     # -- data -------------------------------------------------------------------------------
     def set_Y(self, Y):
+        ref = as_device_array(Y)
+        if ref is not None:               # already in HBM: adopted in place (fp64 contexts: copied and widened by the library)
+            assert ref.shape == (self.M, self.N), "Y must be M x N"
+            self.set_Y_device(ref.ptr, ld=ref.ld, copy=self.f64, keepalive=ref.owner)
+            return
         Y = np.asarray(Y)
         assert Y.shape == (self.M, self.N), "Y must be M x N"
         if self.f64:

@@ -11,13 +11,16 @@ and run the same device kernels on the arrays they are given.
 """
 from __future__ import annotations
 
+import atexit
 import logging
+import os
+import threading
 from functools import partial
 
 import numpy as np
 
 from . import algorithms, operators
-from .engine import DeviceNMF, open_weighted
+from .engine import DeviceNMF, open_weighted, as_device_array, DeviceArrayRef
 
 logger = logging.getLogger("proxmin")
 
@@ -36,17 +39,40 @@ def _weights(W, shape):
     return W
 
 
+def _shape_of(Y):
+    ref = as_device_array(Y)
+    return ref.shape if ref is not None else np.shape(Y)
+
+
 def _device_for(A, S, Y, W=None):
     """Context with Y (and W) and the factors on the device (weights: engine.open_weighted picks the kernel)."""
-    A, S, Y = np.asarray(A), np.asarray(S), np.asarray(Y)
-    dev = open_weighted(Y.shape[0], Y.shape[1], A.shape[1], W)
+    A, S = np.asarray(A), np.asarray(S)
+    Y = as_device_array(Y) or np.asarray(Y)      # a Y that lives in HBM is adopted in place (engine.DeviceArrayRef)
+    dev = open_weighted(Y.shape[0], Y.shape[1], A.shape[1], W, device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
     dev.set_Y(Y)
     dev.set_factors(A, S)
     return dev
 
 
-class _Borrowed:
-    """`with` wrapper that hands a cached context out and leaves it open."""
+_FACTOR_CTX = {}      # (device, M, N, K) -> the ONE factors-only context kept between calls
+_FACTOR_LOCK = threading.RLock()
+
+
+def _close_factor_ctx():
+    """at interpreter exit, BEFORE libpmx can be unloaded under a context's __del__ (atexit runs ahead of module teardown)"""
+    with _FACTOR_LOCK:
+        for old in _FACTOR_CTX.values():
+            old.close()
+        _FACTOR_CTX.clear()
+
+
+atexit.register(_close_factor_ctx)
+
+
+class _Locked:
+    """`with` wrapper around the cached factors-only context: holds the cache's lock from set_factors() to the result (two threads
+    calling step_pgm / step_adaprox on the same shape used to race on the uploads and the status buffer: ADVICE r5) and leaves the
+    context open."""
 
     def __init__(self, dev):
         self.dev = dev
@@ -55,33 +81,39 @@ class _Borrowed:
         return self.dev
 
     def __exit__(self, *exc):
+        _FACTOR_LOCK.release()
         return False
-
-
-_FACTOR_CTX = {}      # (M, N, K) -> the ONE factors-only context kept between calls
 
 
 def _factors_only(A, S):
     """Context holding just the factors (the step rules never touch Y: nothing M x N is allocated or uploaded).  [r5] The last one is
     kept: the reference's FISTA idiom `step=lambda *X, it=None: tuple(.5 * s for s in step_pgm(*X))` calls this once per iteration,
-    and a context per call (allocations, a stream, two uploads) cost more than the rule itself.  One shape at a time; the result
-    is a function of (A, S) alone -- pmx_step_pgm restarts its power iteration on a context without a solver."""
+    and a context per call (allocations, a stream, two uploads) cost more than the rule itself.  One shape and device at a time; the
+    result is a function of (A, S) alone -- pmx_step_pgm restarts its power iteration on a context without a solver.  [r6] The cache is
+    guarded by a lock held for the whole call (the reference's step_pgm is a pure, thread-safe function), keyed by the device
+    (PMX_DEVICE, default 0) as well, and closed by an atexit hook."""
     A, S = np.asarray(A), np.asarray(S)
-    key = (A.shape[0], S.shape[1], A.shape[1])
-    dev = _FACTOR_CTX.get(key)
-    if dev is None or getattr(dev, "h", None) is None:
-        for old in _FACTOR_CTX.values():
-            old.close()
-        _FACTOR_CTX.clear()
-        dev = _FACTOR_CTX[key] = DeviceNMF(key[0], key[1], key[2], mode="f32")
-    dev.set_factors(A, S)
-    return _Borrowed(dev)
+    device = int(os.environ.get("PMX_DEVICE", "0"))
+    key = (device, A.shape[0], S.shape[1], A.shape[1])
+    _FACTOR_LOCK.acquire()
+    try:
+        dev = _FACTOR_CTX.get(key)
+        if dev is None or getattr(dev, "h", None) is None:
+            for old in _FACTOR_CTX.values():
+                old.close()
+            _FACTOR_CTX.clear()
+            dev = _FACTOR_CTX[key] = DeviceNMF(key[1], key[2], key[3], device=device, mode="f32")
+        dev.set_factors(A, S)
+    except BaseException:
+        _FACTOR_LOCK.release()
+        raise
+    return _Locked(dev)
 
 
 def log_likelihood(*X, Y=0, W=1):
     """1/2 sum W (Y - A S)^2 (nmf.py:13-25), reduced inside the fused residual kernel."""
     A, S = X
-    with _device_for(A, S, Y, _weights(W, np.shape(Y))) as dev:
+    with _device_for(A, S, Y, _weights(W, _shape_of(Y))) as dev:
         return dev.loglike()
 
 
@@ -89,7 +121,7 @@ def grad_likelihood(*X, Y=0, W=1):
     """(D S^T, A^T D) with D = W (A S - Y) (nmf.py:28-41): one launch of the fused residual-gradient
     kernel.  Returns arrays in the dtype of A."""
     A, S = X
-    with _device_for(A, S, Y, _weights(W, np.shape(Y))) as dev:
+    with _device_for(A, S, Y, _weights(W, _shape_of(Y))) as dev:
         gA, gS = dev.grad()
     dt = np.asarray(A).dtype
     return gA.astype(dt), np.ascontiguousarray(gS).astype(dt)

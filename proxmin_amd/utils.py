@@ -50,24 +50,27 @@ class BarzilaiBorweinStepper:
     come back); the scalar formula on them is the reference's.  Return types are the reference's: a tuple of
     scalars at it == 0, an ndarray of N steps afterwards (utils.py:222,241)."""
 
+    device = None       # GPU the stand-alone sums run on: None = PMX_DEVICE from the environment, else device 0 (set the attribute to choose)
+
     def __init__(self, type=1, init_r=0.1):
         assert type in [1, 2]
         self.r = init_r
         self.type = type
 
-    @staticmethod
-    def _sums(x, g, xp, gp):
+    def _sums(self, x, g, xp, gp):
         import ctypes as C
+        import os
         import numpy as np
         from . import _lib
         lib = _lib.require_gpu()
+        device = int(os.environ.get("PMX_DEVICE", "0")) if self.device is None else int(self.device)
         f64 = all(np.asarray(a).dtype == np.float64 for a in (x, g))
         dt = np.float64 if f64 else np.float32
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=dt) for a in (x, xp, g, gp)]
         assert arrs[0].size == arrs[2].size and (arrs[1] is None or arrs[1].size == arrs[0].size == arrs[3].size)
         out = (C.c_double * 6)()
         ptr = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
-        _lib.check(lib.pmx_bb_sums(0, int(f64), ptr[0], ptr[1], ptr[2], ptr[3], arrs[0].size, out))
+        _lib.check(lib.pmx_bb_sums(device, int(f64), ptr[0], ptr[1], ptr[2], ptr[3], arrs[0].size, out))
         return list(out)
 
     def step(self, *X, it=None, grads=None):

@@ -126,7 +126,7 @@ def run(seed, n_cases, only=None, F64=False, log=print):
             ok = False; worst = float("nan"); fr = float("nan"); log("EXC", type(e).__name__, str(e)[:300])
         log("%s case %d %s: frac %.5f worst %.1f" % ("ok  " if ok else "FAIL", case, desc, fr, worst))
         bad += not ok
-    pm.set_default_mode("f32")
+    pm.set_default_mode(None)
     return bad
 
 
@@ -261,5 +261,5 @@ def run_options(seed, n_cases, only=None, log=print):
             log("EXC %s %s" % (type(e).__name__, str(e)[:300]))
         log("%s case %d %s: callbacks %d / %d frac %.5f worst %.1f" % ("ok  " if ok else "FAIL", case, desc, counts["dev"], counts["orc"], fr, worst))
         bad += not ok
-    pm.set_default_mode("f32")
+    pm.set_default_mode(None)
     return bad

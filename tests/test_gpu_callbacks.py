@@ -14,13 +14,18 @@ from conftest import as_spec, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def pm():
+@pytest.fixture(scope="module", params=["library-default", "f32"])
+def pm(request):
+    """[r6] the callback / user-callable surface in the LIBRARY'S default arithmetic (f16x2r: what a user who swaps the import gets)
+    and in exact fp32"""
     import __graft_entry__ as g
     g.build()
     import proxmin_amd
-    proxmin_amd.set_default_mode("f32")
-    return proxmin_amd
+    proxmin_amd.set_default_mode(None if request.param == "library-default" else request.param)
+    if request.param == "library-default":
+        assert proxmin_amd.get_default_mode() == proxmin_amd.LIBRARY_DEFAULT_MODE == "f16x2r"
+    yield proxmin_amd
+    proxmin_amd.set_default_mode(None)
 
 
 @pytest.fixture(scope="module")

@@ -134,7 +134,7 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, name, mode):
             pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
             pm.nmf.nmf(Y, A1, S1, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=c["its"], e_rel=1e-9, callback=tb)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     import time
     import warnings
     ctx = mp.get_context("spawn")

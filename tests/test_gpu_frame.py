@@ -45,7 +45,7 @@ def pm():
     import proxmin_amd
     proxmin_amd.set_default_mode("f32")
     yield proxmin_amd
-    proxmin_amd.set_default_mode("f32")
+    proxmin_amd.set_default_mode(None)
 
 
 @pytest.fixture(scope="module")
@@ -167,7 +167,7 @@ def test_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
     try:
         A, S, Ao, So = _solve_pair(pm, orc, name, kw, Y, A0, S0, unity, np.float64)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
     if name.startswith(SMOOTH):
@@ -245,7 +245,7 @@ def test_k_framed_solvers_at_rtol_1e4(pm, orc, name, kw, M, N, K, mode):
     try:
         A, S, Ao, So = _solve_pair(pm, orc, name, kw, Y, A0, S0, unity, np.float64)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
     if name.startswith(SMOOTH):

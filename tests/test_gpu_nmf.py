@@ -58,8 +58,8 @@ def pm(request):
     proxmin_amd.set_default_mode(request.param)
     MODE["name"] = request.param
     yield proxmin_amd
-    proxmin_amd.set_default_mode("f32")
-    MODE["name"] = "f32"
+    proxmin_amd.set_default_mode(None)
+    MODE["name"] = proxmin_amd.get_default_mode()
 
 
 @pytest.fixture(scope="module")
@@ -589,7 +589,7 @@ def test_chained_k1_fault_falls_back_to_slabs(orc, monkeypatch, backend, kmode):
             info = dev.k1_info()
             assert r.iterations == 6 and info["chain"] == 0 and info["chain_faults"] == 1, (r.iterations, info)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     # different summation orders of gA (chains / slabs) from the faulting iteration on: the module's trajectory policy
     MODE["name"] = kmode
     try:

@@ -59,57 +59,108 @@ def _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, its, ld=None):
 
 
 def test_cfg3_full_size_device_error_against_the_references_own_fp32_error(eng, orc):
-    """The AMSGrad eps-clamp story as a test.  Full cfg3, 3 iterations from a cold start: the fp64 oracle is the truth; the
-    oracle run in fp32 (NumPy fp32 GEMMs: the reference's own arithmetic for fp32 inputs, nmf.py:39-41) is the yardstick.
-    * The library's default arithmetic (mode f32, exact fp32 MFMA) must stay within 2 x the yardstick's out-of-tolerance
-      fraction (plus 2e-5 of slack for the quantisation of the count) and 3 x its worst ratio: measured A 4.8e-6 against
-      9.5e-7, S 1.42e-4 against 1.28e-4, worst entry 82 x the bound against 62 x.
-    * [r5] The bench's arithmetic (mode f16x2r: the residual from the high x high fp16 product + the exact K x K correction,
-      k_grad_f16_v8<HH> + k_gfix.hip) is held to the SAME kind of rule: <= 2.5 x the yardstick's out-of-tolerance fraction
-      (+ 2e-5) and <= 4 x its worst ratio, on both blocks.
-    * Mode f16x2 (NOT the bench's since round 5; bench.py prints it as value_f16x2_mode) carries the operands' 2^-23
-      representation errors coherently into the gradients.  On entries whose second moment sits at AMSGrad's eps clamp that
-      shows: measured A 1.08e-4 / S 5.4e-4 out of tolerance (4 x the yardstick on S, ~100 x on A, where the yardstick is almost
-      zero), worst entry 883 x the bound.  Asserted for it and for bf16x3: absolute floors and the pass counts only -- they are
-      NOT claimed to meet the yardstick."""
+    """The AMSGrad eps-clamp story as a test.  Full cfg3 from a cold start, [r6] EIGHT iterations of both oracles with a snapshot
+    after three: the fp64 oracle is the truth; the oracle run in fp32 (NumPy fp32 GEMMs: the reference's own arithmetic for fp32
+    inputs, nmf.py:39-41) is the yardstick.
+    After 3 iterations (the round-2..5 bars, unchanged except for the anchors):
+    * mode f32 (exact fp32 MFMA): <= 2 x the yardstick's out-of-tolerance fraction (+ 2e-5) per block; worst entry <= 3 x the
+      yardstick's worst OF THE SAME BLOCK with an absolute floor of 100 x the bound ([r6] ADVICE r5: the anchor used to be the
+      larger block's worst, behind which a regression in A could hide; A's own yardstick worst is a single entry 2 % over the
+      bound, hence the floor): measured A 82 / S 62.
+    * [r5] the library's default and the bench's arithmetic (mode f16x2r: k_grad_f16_v8<HH> + k_gfix.hip): <= 2.5 x the yardstick's
+      fraction (+ 2e-5), worst <= 4 x the block's yardstick worst (floor 200 x the bound); [r6] and in ENTRIES of A, where the
+      yardstick has one: <= 3 x mode f32's count + 4.  The out-of-tolerance entries of A are listed (index, error over bound, the
+      oracle's second moment V and gradient-scale there) for modes f32 and f16x2r: they are eps-clamp entries (V at AMSGrad's
+      eps floor: Psi = sqrt(max(V, eps)) amplifies any rounding difference of a near-zero gradient entry by up to 1e4).
+    * modes f16x2 / bf16x3: absolute floors only -- they are NOT claimed to meet the yardstick.
+    After 8 iterations: the same comparison recorded, modes f32 and f16x2r asserted at <= 3 x the yardstick's fraction (+ 5e-5)
+    and the same pass counts as one of the two oracles."""
     import torch
     import bench
     M, N, K, backend, unity, _ = bench.CONFIGS["cfg3"]
     Yd, A0, S0 = bench.make_problem_device(M, N, K, unity, 4321, torch.device("cuda", 0))
-    dev_out = {}
+    dev_out, dev_out8 = {}, {}
     for mode in ("f32", "f16x2", "bf16x3", "f16x2r"):     # (bf16x3: recorded beside the others -- three bf16 terms in A S, two in the gradient products)
         dev_out[mode] = _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, 3)
+    for mode in ("f32", "f16x2r"):
+        dev_out8[mode] = _run_device(eng, mode, M, N, K, backend, unity, Yd, A0, S0, 8)
     Y32 = Yd.cpu().numpy()
     del Yd
-    A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
-    ret64 = orc.adaprox_nmf(Y32.astype(np.float64), A64, S64, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=3, e_rel=1e-3, check_convergence=False)
-    A32, S32 = A0.copy(), S0.copy()
-    ret32 = orc.adaprox_nmf(Y32, A32, S32, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=3, e_rel=1e-3, check_convergence=False)
+
+    def oracle_run(dtype):
+        A, S = A0.astype(dtype), S0.astype(dtype)
+        Mm, Vv = [np.zeros_like(A), np.zeros_like(S)], [np.zeros_like(A), np.zeros_like(S)]
+        snap = {}
+
+        def cb(A_, S_, it=None):
+            if it == 3:
+                snap.update(A=A_.copy(), S=S_.copy(), V_A=Vv[0].copy(), M_A=Mm[0].copy())
+
+        ret = orc.adaprox_nmf(Y32.astype(dtype) if dtype != np.float32 else Y32, A, S, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=8,
+                              e_rel=1e-3, check_convergence=False, M=Mm, V=Vv, callback=cb, sub_trace=True)
+        per = ret[6]
+        return snap, (A, S), [int(sum(p[j] for p in per[:3])) for j in range(2)], [int(sum(p[j] for p in per)) for j in range(2)]
+
+    snap64, fin64, sub64_3, sub64_8 = oracle_run(np.float64)
+    snap32, fin32, sub32_3, sub32_8 = oracle_run(np.float32)
     del Y32
-    yard = {"A": frac_within(A32, A64), "S": frac_within(S32, S64)}
+    A64, S64 = snap64["A"], snap64["S"]
+    yard = {"A": frac_within(snap32["A"], A64), "S": frac_within(snap32["S"], S64)}
     REPORT["cfg3 full, 3 its: oracle fp32 vs oracle fp64 (yardstick)"] = {"frac_A": yard["A"][0], "frac_S": yard["S"][0], "worst_ratio": max(yard["A"][1], yard["S"][1]),
-                                                                        "sub_iterations_fp32": [int(ret32[5][0]), int(ret32[5][1])], "sub_iterations_fp64": [int(ret64[5][0]), int(ret64[5][1])]}
+                                                                        "worst_ratio_A": yard["A"][1], "worst_ratio_S": yard["S"][1],
+                                                                        "sub_iterations_fp32": sub32_3, "sub_iterations_fp64": sub64_3}
+
+    def bad_entries_of_A(A):
+        err = np.abs(np.asarray(A, dtype=np.float64) - A64)
+        bound = ATOL + RTOL * np.abs(A64)
+        idx = np.argwhere(err > bound)
+        return [[int(i), int(k), float(err[i, k] / bound[i, k]), float(snap64["V_A"][i, k]), float(snap64["M_A"][i, k]), float(A64[i, k])] for i, k in idx]
+
+    listing = {"yardstick (oracle fp32)": bad_entries_of_A(snap32["A"]), "columns": ["row", "k", "error / bound", "V (fp64 oracle, after 3 its)", "M (same)", "A (same)"]}
+    counts_A = {}
     for mode, (A, S, sub, info) in dev_out.items():
-        assert sub == [int(ret64[5][0]), int(ret64[5][1])], (mode, sub, ret64[5])
+        assert sub == sub64_3, (mode, sub, sub64_3)
         got = {"A": frac_within(A, A64), "S": frac_within(S, S64)}
-        REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode] = {"frac_A": got["A"][0], "frac_S": got["S"][0], "worst_ratio": max(got["A"][1], got["S"][1])}
+        rec = REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode] = {"frac_A": got["A"][0], "frac_S": got["S"][0], "worst_ratio": max(got["A"][1], got["S"][1]),
+                                                                           "worst_ratio_A": got["A"][1], "worst_ratio_S": got["S"][1]}
+        if mode in ("f32", "f16x2r"):
+            listing[mode] = bad_entries_of_A(A)
+            counts_A[mode] = len(listing[mode])
         for b in ("A", "S"):
             out_dev, out_ref = 1.0 - got[b][0], 1.0 - yard[b][0]
-            REPORT["cfg3 full, 3 its: device %s vs oracle fp64" % mode]["out_of_tolerance_over_yardstick_%s" % b] = out_dev / max(out_ref, 1e-9)
-            # worst ratio: against the yardstick's worst over BOTH blocks (its own worst entry of A is a single one 2 % over the bound: no anchor)
-            yworst = max(yard["A"][1], yard["S"][1], 1.0)
+            rec["out_of_tolerance_over_yardstick_%s" % b] = out_dev / max(out_ref, 1e-9)
             if mode == "f32":
                 assert out_dev <= 2.0 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
-                assert got[b][1] <= 3.0 * yworst, (mode, b, got[b][1], yworst)
+                assert got[b][1] <= 3.0 * max(yard[b][1], 100.0 / 3.0), (mode, b, got[b][1], yard[b][1])
             elif mode == "f16x2r":
                 # the headline's arithmetic, in exact fp32's class: [r4, <R3>] measured A 8 entries of 1 M (yardstick 1, mode f32 5), S 1.8 x the
                 # yardstick (mode f32 1.1 x, mode f16x2 4.2 x), worst entry 136 x the bound (82 x / 905 x); [r5, <HH>]: profiles/r05_*_parity_long.json
                 assert info["kernel"] == "k_grad_f16_v8_hh", info
                 assert out_dev <= 2.5 * out_ref + 2e-5, (mode, b, out_dev, out_ref)
-                assert got[b][1] <= 4.0 * yworst, (mode, b, got[b][1], yworst)
+                assert got[b][1] <= 4.0 * max(yard[b][1], 50.0), (mode, b, got[b][1], yard[b][1])
             else:
                 assert out_dev <= (2.5e-4 if b == "A" else 1e-3), (mode, b, out_dev, out_ref)
                 assert got[b][1] <= 2000.0, (mode, b, got[b][1])
+    # [r6] A in ENTRIES (1 048 576 of them; the yardstick has ~1 out of tolerance): the bench's arithmetic tied to exact fp32's count
+    n_yard = len(listing["yardstick (oracle fp32)"])
+    assert counts_A["f16x2r"] <= max(3 * counts_A["f32"], 3 * n_yard) + 4, (counts_A, n_yard)
+    eps_floor = 1e-8                          # AMSGrad's eps (algorithms.py:176-177: Psi = sqrt(max(V, eps)) in the reference's cold-start semantics)
+    listing["shared f16x2r / f32"] = len({(e[0], e[1]) for e in listing["f16x2r"]} & {(e[0], e[1]) for e in listing["f32"]})
+    listing["fraction of the listed entries with V below 100 eps"] = {m: (float(np.mean([e[3] < 100 * eps_floor for e in listing[m]])) if listing[m] else None) for m in ("f32", "f16x2r")}
+    REPORT["cfg3 full, 3 its: out-of-tolerance entries of A"] = listing
+    # ---- 8 iterations ---------------------------------------------------------------------------------------------------------------------------
+    A64, S64 = fin64
+    yard8 = {"A": frac_within(fin32[0], A64), "S": frac_within(fin32[1], S64)}
+    REPORT["cfg3 full, 8 its: oracle fp32 vs oracle fp64 (yardstick)"] = {"frac_A": yard8["A"][0], "frac_S": yard8["S"][0], "worst_ratio_A": yard8["A"][1], "worst_ratio_S": yard8["S"][1],
+                                                                        "sub_iterations_fp32": sub32_8, "sub_iterations_fp64": sub64_8}
+    for mode, (A, S, sub, info) in dev_out8.items():
+        got = {"A": frac_within(A, A64), "S": frac_within(S, S64)}
+        rec = REPORT["cfg3 full, 8 its: device %s vs oracle fp64" % mode] = {"frac_A": got["A"][0], "frac_S": got["S"][0], "worst_ratio_A": got["A"][1], "worst_ratio_S": got["S"][1], "sub_iterations": sub}
+        assert sub in (sub64_8, sub32_8), (mode, sub, sub64_8, sub32_8)
+        for b in ("A", "S"):
+            out_dev, out_ref = 1.0 - got[b][0], 1.0 - yard8[b][0]
+            rec["out_of_tolerance_over_yardstick_%s" % b] = out_dev / max(out_ref, 1e-9)
+            assert out_dev <= 3.0 * out_ref + 5e-5, (mode, b, out_dev, out_ref)
 
 
 def test_cfg3_twenty_iterations_bench_mode_against_default_mode(eng):
@@ -192,7 +243,7 @@ def test_k128_kernel_thirty_iterations_against_exact_fp32(eng, backend, mode):
     assert rel < 5e-6, rel
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+@pytest.mark.parametrize("mode", ["f32", "f16x2", "f16x2r"])
 @pytest.mark.parametrize("fista", [False, True])
 def test_cfg2_end_to_end_at_full_size(eng, orc, fista, mode):
     """BASELINE cfg2 (4096 x 4096, K = 32, prox_plus, fp32): PGM and damped FISTA (step = 0.5 step_pgm),
@@ -206,14 +257,14 @@ def test_cfg2_end_to_end_at_full_size(eng, orc, fista, mode):
     Y = Yd.cpu().numpy()
     del Yd
     with eng.DeviceNMF(M, N, K, mode=mode) as dev:
-        assert dev.k1_info()["kernel"] == ("k_grad_f32_pc" if mode == "f32" else "k_grad_f16_k32")
-    pm.set_default_mode(mode)
+        assert dev.k1_info()["kernel"] == {"f32": "k_grad_f32_pc", "f16x2": "k_grad_f16_k32", "f16x2r": "k_grad_f16_k32_r3"}[mode]
+    pm.set_default_mode(mode)          # (f16x2r: the LIBRARY'S default since round 6 and the arithmetic bench.py quotes cfg2_f16x2r in)
     A, S = A0.copy(), S0.copy()
     kw = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if fista else {}
     try:
         pm.nmf.nmf(Y, A, S, max_iter=10, e_rel=1e-12, **kw)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
     step = (lambda A_, S_, it, grads: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_))) if fista else None
     orc.pgm_nmf(Y.astype(np.float64), A64, S64, max_iter=10, e_rel=1e-12, accelerated=fista, step=step)

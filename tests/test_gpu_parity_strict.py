@@ -37,7 +37,7 @@ def pm():
     import proxmin_amd
     proxmin_amd.set_default_mode("f32")
     yield proxmin_amd
-    proxmin_amd.set_default_mode("f32")
+    proxmin_amd.set_default_mode(None)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_fractions.json"), "w") as f:
@@ -177,7 +177,7 @@ def test_medium_problems_at_rtol_1e4_in_split_modes(pm, orc, name, kw, M, N, K, 
     try:
         A, S, Ao, So = _solve_pair(pm, orc, name, kw, Y, A0, S0, unity, np.float64)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     fA, wA = frac_within(A, Ao)
     fS, wS = frac_within(S, So)
     rec = {"frac_A": fA, "frac_S": fS, "worst_ratio": max(wA, wS), "kernel": kernel}

@@ -153,7 +153,7 @@ def test_radam_runaway_meets_the_oracle(orc, M, N, K):
                 f.append(float((np.abs(a - b) <= 2e-5 + 2e-4 * np.abs(b)).mean()))
             frac[mode] = min(f)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     assert frac["f32"] >= 0.999 and frac["f16x2"] >= 0.999, frac
 
 
@@ -232,7 +232,7 @@ def test_one_iteration_per_call_paths_switch_on_the_spot(orc, case):
                 pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, prox_A=my_plus, proxs_g=[[pm.operators.prox_plus], None], max_iter=3, e_rel=1e-12)
             out[mode] = (A, S)
     finally:
-        pm.set_default_mode("f32")
+        pm.set_default_mode(None)
     for a, b in zip(out["f16x2"], out["f32"]):
         assert np.isfinite(a).all()
         if case in ("user_prox_adaprox",):
