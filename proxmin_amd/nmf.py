@@ -201,6 +201,62 @@ def bsdmm_closures(Y, prox, W=1):
     return prox_f, step_f
 
 
+def _nmf_sharded(Y, A, S, W, prox_A, prox_S, algorithm, step, max_iter, e_rel, callback, kw):
+    """nmf(Y_local, A_local, S, ..., M_global=M[, group=pg, comm="torch"|"native", s_split="auto"]) -> the sharded drivers.
+    What the sharded protocol does not carry raises here instead of silently running something else: weights, user callables (prox, step,
+    callback: they would see one rank's rows), Barzilai-Borwein / backtracking.  Returns the reference's shapes with None where a
+    gathered array would be needed (pgm's gradient, adaprox's moments): (converged, None, None) / (converged, None, None, None) / converged."""
+    from . import distributed
+    M_global = int(kw.pop("M_global"))
+    group, comm, s_split = kw.pop("group", None), kw.pop("comm", None), kw.pop("s_split", "auto")
+    if not (np.isscalar(W) and W == 1):
+        raise NotImplementedError("row-sharded nmf(): a weighted likelihood is not carried by the sharded protocol")
+    if callback is not None and not isinstance(callback, utils_NullCallback()):
+        raise NotImplementedError("row-sharded nmf(): a callback would see one rank's rows of A only")
+    assert np.asarray(A).shape[0] <= M_global
+    if algorithm is algorithms.pgm:
+        scale, fixed = 1.0, None
+        if isinstance(step, scaled_step_pgm):
+            scale = step.scale
+        elif isinstance(step, constant_step):
+            fixed = step.steps
+        elif not (step is None or step is step_pgm or (isinstance(step, partial) and step.func is step_pgm)):
+            raise NotImplementedError("row-sharded pgm: the Lipschitz rule (default, scaled_step_pgm) or constant_step only")
+        if kw.pop("backtracking", False):
+            raise NotImplementedError("row-sharded pgm: no line search")
+        acc = bool(kw.pop("accelerated", False))
+        if kw:
+            raise TypeError("unexpected arguments for row-sharded pgm: %r" % sorted(kw))
+        conv, _ = distributed.nmf_pgm_sharded(Y, A, S, M_global, prox_A=prox_A, prox_S=prox_S, accelerated=acc, step_scale=scale, fixed_steps=fixed,
+                                              e_rel=e_rel, max_iter=max_iter, group=group, comm=comm, s_split=s_split)
+        return conv, None, None
+    if algorithm is algorithms.adaprox:
+        if not (step is None or step is step_adaprox):
+            raise NotImplementedError("row-sharded adaprox: the default step rule (nmf.step_adaprox) only")
+        for bad in ("M", "V", "Vhat"):
+            if kw.pop(bad, None) is not None:
+                raise NotImplementedError("row-sharded adaprox: no warm start of the moments")
+        conv, _ = distributed.nmf_adaprox_sharded(Y, A, S, M_global, prox_A=prox_A, prox_S=prox_S, e_rel=e_rel, max_iter=max_iter, group=group, comm=comm,
+                                                  s_split=s_split, **kw)
+        return conv, None, None, None
+    if step is not None:
+        raise NotImplementedError("a user `step` is not supported with bsdmm (it crashes in the reference too)")
+    for bad in ("Ls", "update_order", "steps_g", "steps_g_update"):
+        if kw.get(bad) is not None and bad != "steps_g_update":
+            raise NotImplementedError("row-sharded bsdmm: %s is not carried by the sharded protocol" % bad)
+        kw.pop(bad, None)
+    conv, _ = distributed.nmf_bsdmm_sharded(Y, A, S, M_global, prox_A=prox_A, prox_S=prox_S, proxs_g=kw.pop("proxs_g", None), e_rel=e_rel,
+                                            e_abs=kw.pop("e_abs", 0.0), max_iter=max_iter, group=group, comm=comm)
+    if kw:
+        raise TypeError("unexpected arguments for row-sharded bsdmm: %r" % sorted(kw))
+    return conv
+
+
+def utils_NullCallback():
+    from .utils import NullCallback
+    return NullCallback
+
+
 def nmf(
     Y,
     A,
@@ -221,8 +277,18 @@ def nmf(
     return value is that of the chosen algorithm (pgm: (converged, grads, steps); adaprox:
     (converged, M, V, Vhat); bsdmm: converged).  `algorithm` must be one of THIS package's
     `algorithms.pgm / adaprox / bsdmm` (identity test, nmf.py:141).
+
+    Beyond the reference: Y may already live in HBM (anything with `__cuda_array_interface__`, float32: adopted in place); and with
+    `M_global=<rows of the whole problem>` (plus optional `group=`, `comm=`, `s_split=`) the arrays are one rank's rows of a row-sharded
+    run over a torch.distributed process group (see _nmf_sharded).
     """
     assert algorithm in [algorithms.pgm, algorithms.adaprox, algorithms.bsdmm]
+
+    # [r6] Row-sharded runs through the SAME entry point: with `M_global=<rows of the whole problem>` the arrays are THIS RANK'S rows of Y
+    # and A (S is replicated) and the call runs on the process group `group` (default: the world) with one packed collective per
+    # iteration (proxmin_amd/distributed.py; SURVEY 8(e)).  Without M_global the call is the reference's: one process, one GPU.
+    if "M_global" in algorithm_args:
+        return _nmf_sharded(Y, A, S, W, prox_A, prox_S, algorithm, step, max_iter, e_rel, callback, dict(algorithm_args))
 
     grad = partial(grad_likelihood, Y=Y, W=W)
     X = [A, S]

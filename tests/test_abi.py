@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,3 +102,54 @@ def test_weighted_step_rule_dispatch_mirrors_step_pgms_own_argument():
             pm.pgm([A.copy(), S.copy()], grad, step, prox=[pm.operators.prox_plus] * 2, max_iter=1)
         except _lib.PmxError:
             pass                       # (no GPU in this container: the call got past the step-rule dispatch)
+
+
+def test_default_mode_and_its_reset():
+    """[r6] the library's default arithmetic is the benchmarked one; set_default_mode(None) goes back to it"""
+    import proxmin_amd as pm
+    assert pm.LIBRARY_DEFAULT_MODE == "f16x2r"
+    before = pm.get_default_mode()
+    try:
+        pm.set_default_mode("f32")
+        assert pm.get_default_mode() == "f32"
+        pm.set_default_mode(None)
+        assert pm.get_default_mode() == os.environ.get("PMX_MODE", "f16x2r")
+        with pytest.raises(AssertionError):
+            pm.set_default_mode("fp8")
+    finally:
+        pm.set_default_mode(before)
+
+
+def test_device_array_detection_is_host_only_logic():
+    """engine.as_device_array: NumPy arrays and host objects are host data; an object with __cuda_array_interface__ is adopted with its pitch"""
+    from proxmin_amd.engine import as_device_array, DeviceArrayRef
+    assert as_device_array(np.zeros((3, 4), np.float32)) is None
+    assert as_device_array([[1.0, 2.0]]) is None
+
+    class Fake:
+        def __init__(self, typestr="<f4", shape=(6, 8), strides=None):
+            self.__cuda_array_interface__ = {"typestr": typestr, "shape": shape, "strides": strides, "data": (4096, False), "version": 3}
+    r = as_device_array(Fake())
+    assert isinstance(r, DeviceArrayRef) and r.shape == (6, 8) and r.ld == 8 and r.ptr == 4096 and r.dtype == np.float32
+    assert as_device_array(Fake(strides=(48, 4))).ld == 12          # rows of a wider array
+    for bad in (Fake(typestr="<f8"), Fake(shape=(6,)), Fake(strides=(32, 8)), Fake(strides=(16, 4))):
+        with pytest.raises(TypeError):
+            as_device_array(bad)
+    with pytest.raises(TypeError):
+        np.asarray(r)                                                # never silently copied to the host
+
+
+def test_sharded_dispatch_refuses_what_the_protocol_does_not_carry():
+    """nmf(..., M_global=M): weights, user callables and warm starts raise before anything touches a GPU or a process group"""
+    import proxmin_amd as pm
+    Y, A, S = np.ones((4, 6), np.float32), np.ones((4, 2), np.float32), np.ones((2, 6), np.float32)
+    with pytest.raises(NotImplementedError):
+        pm.nmf.nmf(Y, A, S, W=np.ones((4, 6)), M_global=8)
+    with pytest.raises(NotImplementedError):
+        pm.nmf.nmf(Y, A, S, step=lambda *X, it=None: (1.0, 1.0), M_global=8)
+    with pytest.raises(NotImplementedError):
+        pm.nmf.nmf(Y, A, S, callback=lambda *X, it=None: None, M_global=8)
+    with pytest.raises(NotImplementedError):
+        pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, M=(A, S), M_global=8)
+    with pytest.raises(NotImplementedError):
+        pm.nmf.nmf(Y, A, S, backtracking=True, f=lambda *X: 0.0, M_global=8)

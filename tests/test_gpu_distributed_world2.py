@@ -88,7 +88,24 @@ def _worker(rank, world, port, name, mode, out_dir):
         r0, r1 = pdist.shard_rows(M, world)[rank]
         A_l, S = A0[r0:r1].copy(), S0.copy()
         ops = pm.operators
-        if name.startswith("adaprox"):
+        # [r6] some cases enter through the PUBLIC front door -- nmf(Y_local, A_local, S, ..., M_global=M) dispatches to the same drivers
+        front = name in ("pgm", "bsdmm", "adaprox_k64_split", "fista_split")
+        if front and name.startswith("adaprox"):
+            ret = pm.nmf.nmf(Y[r0:r1], A_l, S, algorithm=pm.adaprox, scheme=c.get("scheme", "amsgrad"), max_iter=c["its"], e_rel=1e-3,
+                             check_convergence=False, M_global=M, s_split=c.get("s_split", False))
+            assert len(ret) == 4 and ret[0] == (None, None)
+            n = c["its"]
+        elif front and name.startswith(("pgm", "fista")):
+            kwp = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if c.get("accelerated") else {}
+            ret = pm.nmf.nmf(Y[r0:r1], A_l, S, max_iter=c["its"], e_rel=1e-9, M_global=M, s_split=c.get("s_split", False), **kwp)
+            assert len(ret) == 3
+            n = c["its"]
+        elif front:
+            pgl = [[ops.prox_plus, partial(ops.prox_soft, thresh=0.01)]] * 2
+            ret = pm.nmf.nmf(Y[r0:r1], A_l, S, algorithm=pm.bsdmm, proxs_g=pgl, max_iter=c["its"], e_rel=1e-9, M_global=M)
+            assert len(ret) == 2
+            n = c["its"]
+        elif name.startswith("adaprox"):
             pS = partial(ops.prox_unity_plus, axis=0) if c.get("unity") else ops.prox_plus
             conv, n = pdist.nmf_adaprox_sharded(Y[r0:r1], A_l, S, M, prox_A=ops.prox_plus, prox_S=pS, scheme=c.get("scheme", "amsgrad"),
                                                 check_convergence=False, e_rel=1e-3, max_iter=c["its"], s_split=c.get("s_split", False))
