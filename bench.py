@@ -407,7 +407,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="the headline alone: no CPU baseline and none of the side legs (peaks, other configurations, nmf() leg)")
+    ap.add_argument("--skip-cpu-baseline", action="store_true", help="everything but the CPU leg (tuning: A/B runs that want other_configs)")
     ap.add_argument("--rows", type=int, default=0, help="override M (debug)")
     ap.add_argument("--mode", default=None, choices=["f32", "bf16x3", "f16x2", "f16x2r"],
                     help="contraction arithmetic: f16x2r = fp16 split MFMA in exact fp32's error class (default for cfg3 / cfg4 / cfg5: the headline), "
@@ -572,15 +573,16 @@ def main():
         Yh = Y.cpu().numpy()
         del Y
         torch.cuda.empty_cache()
-        if full:
+        if full and not args.skip_cpu_baseline:
             out["end_to_end"] = end_to_end_leg(Yh, A0, S0, unity)
         # the CPU leg is timed over the same steady state as the GPU: the last 5 warm-up iterations [warm_total - 5, warm_total)
         # of the GPU run against the same iteration indices of the oracle (its transient runs untimed)
         n_cpu = 5 if M * N <= 16384 * 16384 else 3
         trans = max(warm_total - n_cpu, 1) if backend == "adaprox" else 1
-        rec, cpu_sub = cpu_baseline(Yh, A0, S0, backend, unity, n_iter=n_cpu, transient=trans)
-        out["cpu_baseline"] = rec
-        if backend == "adaprox" and cpu_sub is not None:
+        rec, cpu_sub = (None, None) if args.skip_cpu_baseline else cpu_baseline(Yh, A0, S0, backend, unity, n_iter=n_cpu, transient=trans)
+        if rec is not None:
+            out["cpu_baseline"] = rec
+        if rec is not None and backend == "adaprox" and cpu_sub is not None:
             rec["sub_iterations_per_step"] = cpu_sub
             rec["gpu_sub_iterations_same_window"] = sub_window
             rec["sub_iterations_equal"] = bool(sub_window is not None and all(abs(a - b) < 1e-9 for a, b in zip(cpu_sub, sub_window)))

@@ -117,6 +117,7 @@ struct GradBfArgs {
     int chainInject;
     float rangeRatio;    // (see GradV4Args)
     int r3;
+    int consPrio;        // (see GradV4Args)
 };
 
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -868,6 +869,7 @@ struct GradV4Args {
     int chainInject;     // tests: report a fault from this launch (exercises the host's fall-back)
     float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 4 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
     int r3;              // [r4] k_grad_f16_v8<.., R3>: third terms of A and S in the residual's product, two accumulators
+    int consPrio;        // [r6] s_setprio level of the CONSUMER waves for the launch (0: none): the consumers are the pole of every slot, the producers wait ~30 % of it at the barrier
 };
 
 // (k_grad_bf16_v4's kernel was removed in round 4 together with k_grad_bf16_v5's: with K1's zero-padded frame -- pmx_k1_frame -- the
@@ -1490,7 +1492,7 @@ hipError_t grad_launch_bf16(const GradPlan& p, const GradBfArgs& a_, const float
         g.gridX = p.gridX; g.gridY = p.gridY; g.prof = a.prof;
         g.W = a.W; g.ldW = a.ldW;
         g.absmax = a.absmax; g.ymax = a.ymax; g.wmax = a.wmax;
-        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio; g.r3 = a.r3;
+        g.chainL = a.chainL; g.chainFlags = a.chainFlags; g.chainBase = a.chainBase; g.wstatus = a.wstatus; g.chainInject = a.chainInject; g.rangeRatio = a.rangeRatio; g.r3 = a.r3; g.consPrio = a.consPrio;
         // fp16 two-term mode; its producers fetch Y (and W) eight bytes at a time: even pitch, 8-byte-aligned base (anything
         // else runs the split-bf16 kernel of the same frame below)
         const bool pairs_ok = (a.ldY % 2) == 0 && (((uintptr_t)a.Y) & 7) == 0 && (a.W == nullptr || (a.ldW == a.ldY && (((uintptr_t)a.W) & 7) == 0));   // (the weights share Y's per-lane offsets)

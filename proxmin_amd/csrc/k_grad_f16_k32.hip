@@ -123,6 +123,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
     }
 
     if (producer) {
+        k1_set_priority(-a.consPrio);      // (PMX_K1_PRIO < 0: the producers instead -- A/B only)
         // ================================ producers: P = A S and R ================================================
         f32x16 p0, p1;
         f32x16 q0, q1;                       // R3: the small products' accumulators
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
+        k1_set_priority(a.consPrio);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // Sl published
 

@@ -65,6 +65,15 @@ __device__ __forceinline__ bool f16_range_fault(float boundP, float ymax, float 
     return true;
 }
 
+// [r6] static priority for one role of the workgroup (MI355X_MICROARCH.md "two waves per SIMD", item 4): each SIMD hosts one producer and one consumer wave;
+// the consumers (24 MFMAs + their LDS operand reads per slot) are the pole, the producers wait at the barrier.  Arbitration is by priority, then age --
+// and the consumers are the YOUNGER half.  One s_setprio for the launch, no per-slot flips.  Level from the launch arguments (PMX_K1_PRIO: A/B).
+__device__ __forceinline__ void k1_set_priority(int level) {
+    if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else if (level >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 // absmax[f * V8_NPART + b] = max |X_f| over workgroup b's share (f = 0: A, M x 64; f = 1: St, N x 64)
 struct AbsmaxArgs {
     const float* X[2];
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
     }
 
     if (producer) {
+        k1_set_priority(-a.consPrio);      // (PMX_K1_PRIO < 0: the producers instead -- A/B only)
         // ================================ producers: GEMM1 and R =================================================
         f32x16 p0, p1;
         f32x16 q0, q1;                       // R3: the small products' accumulators (see the kernel's header)
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         __builtin_amdgcn_s_barrier();              // (pairs with the consumers' barrier between parking and merging their gSt row halves)
     } else if constexpr (RS) {
         // ================================ consumers, roles split by contraction (see RS in the header) ==============
+        k1_set_priority(a.consPrio);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // Sl published
         auto sync = [&]() {
@@ -744,6 +755,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
         }
     } else {
         // ================================ consumers: GEMM2 and GEMM3 of block s-2 =================================
+        k1_set_priority(a.consPrio);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // Sl published
 

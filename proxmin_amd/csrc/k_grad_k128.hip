@@ -66,6 +66,7 @@ struct GradK128Args {
     int chainInject;         // tests: report a fault from this launch
     float rangeRatio;        // [r4] f16_range_fault (k_grad_f16_v8.hip); 0: no check
     int hh;                  // [r5] <.., HH>: the residual from the high x high product alone, the rest as a correction slab (k_gfix.hip; no weights)
+    int consPrio;            // [r6] s_setprio level of the consumer waves (k1_set_priority, k_grad_f16_v8.hip)
 };
 
 struct SplitAArgs {
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
     if (producer) {
+        k1_set_priority(-a.consPrio);      // (PMX_K1_PRIO < 0: the producers instead -- A/B only)
         // ================================ producers: P = A S and R ================================================
         f32x16 p0, p1;
         float yE[16], yO[16];
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if constexpr (RS) {
         // ================================ consumers, roles split by contraction (see RS in the header) ==============
+        k1_set_priority(a.consPrio);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // S images published
         auto sync = [&]() {
@@ -621,6 +624,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
         }
     } else {
         // ================================ consumers: gA and gSt of block s-2 ======================================
+        k1_set_priority(a.consPrio);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();              // S images published
 

@@ -161,6 +161,7 @@ struct pmx_ctx {
     int chainFaults = 0;                   // times the chained mode was left after a fault
     // test hooks, read from the environment ONCE when the context is created (never on a launch path):
     int hook_inject_k1 = 0;                //   PMX_INJECT_K1_FAULT=n: the n-th chained K1 launch reports a fault
+    int k1_prio = 0;                       // [r6] s_setprio level of K1's consumer waves (PMX_K1_PRIO; k1_set_priority)
     std::string hook_tail_lockfile;        //   PMX_TAIL_LOCKFILE: several processes on ONE GPU take turns with the persistent tail
     bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
     GridBar* gridbar = nullptr;            // its barrier state
@@ -406,6 +407,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     }
     if (const char* e = getenv("PMX_GRAM_IN_UPDATE")) c->gram_in_update = atoi(e) != 0;
     if (const char* e = getenv("PMX_INJECT_K1_FAULT")) c->hook_inject_k1 = atoi(e);
+    if (const char* e = getenv("PMX_K1_PRIO")) c->k1_prio = atoi(e);
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 0;
@@ -1111,6 +1113,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
         g.hh = c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr && ((doA & 1) || doS);     // (the launcher's own test: gradient passes only)
+        g.consPrio = c->k1_prio;
         fix_pending = g.hh != 0;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
@@ -1135,6 +1138,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = 1.f;
         g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         g.r3 = c->f16_r3;
+        g.consPrio = c->k1_prio;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -1165,7 +1169,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
-            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio; g.r3 = c->f16_r3;
+            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio; g.r3 = c->f16_r3; g.consPrio = c->k1_prio;
         }
         if (c->chainL > 0) {                 // k_grad_f16_v8<.., CHAIN> / k_grad_bf16_v7<.., CHAIN>
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
