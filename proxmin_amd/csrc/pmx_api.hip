@@ -161,7 +161,7 @@ struct pmx_ctx {
     int chainFaults = 0;                   // times the chained mode was left after a fault
     // test hooks, read from the environment ONCE when the context is created (never on a launch path):
     int hook_inject_k1 = 0;                //   PMX_INJECT_K1_FAULT=n: the n-th chained K1 launch reports a fault
-    int k1_prio = 0;                       // [r6] s_setprio level of K1's consumer waves (PMX_K1_PRIO; k1_set_priority)
+    int k1_prio = -999;                    // [r6] s_setprio level of K1's consumer waves (k1_set_priority); -999: the kernel's own default (k1_prio_for), PMX_K1_PRIO overrides
     std::string hook_tail_lockfile;        //   PMX_TAIL_LOCKFILE: several processes on ONE GPU take turns with the persistent tail
     bool tail_fused = false;               // adaprox: the iteration tail runs as one persistent kernel (k_ada_tail)
     GridBar* gridbar = nullptr;            // its barrier state
@@ -1048,6 +1048,13 @@ static int enqueue_small_front(pmx_ctx* c, const float* A, const float* St, doub
     return PMX_OK;
 }
 
+// [r6] Consumer-wave priority per tuned K1 (same-box A/B, profiles/r06_b_setprio_ab.txt): K = 128 and K = 32 gain 1-2.5 % at level 1 (the consumers
+// are the pole of the slot and the younger half of the workgroup), K = 64 shows nothing outside the noise and keeps 0.
+static int k1_prio_for(const pmx_ctx* c, int kk) {
+    if (c->k1_prio != -999) return c->k1_prio;
+    return kk == 64 ? 0 : 1;
+}
+
 // absmax_fresh: the factor maxima in c->absmax were written by the kernel that produced A and St (k_ada_finish)
 static int enqueue_gfix(pmx_ctx* c, const float* A, const float* St, int doA, int doS, hipStream_t stream) {
     GfixArgs f{};
@@ -1113,7 +1120,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             g.chainInject = c->hook_inject_k1 > 0 && (int)c->chainSeq == c->hook_inject_k1;   // tests (read once, at pmx_ctx_create)
         }
         g.hh = c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr && ((doA & 1) || doS);     // (the launcher's own test: gradient passes only)
-        g.consPrio = c->k1_prio;
+        g.consPrio = k1_prio_for(c, 128);
         fix_pending = g.hh != 0;
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_k128(g, c->stream));
@@ -1138,7 +1145,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = 1.f;
         g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         g.r3 = c->f16_r3;
-        g.consPrio = c->k1_prio;
+        g.consPrio = k1_prio_for(c, 32);
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -1169,7 +1176,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
             am.status = c->dstatus;
             if (!absmax_fresh) launch_absmax(am, c->stream);
             g.absmax = c->absmax; g.ymax = c->ymax; g.wmax = c->wmax;
-            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio; g.r3 = c->f16_r3; g.consPrio = c->k1_prio;
+            g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio; g.r3 = c->f16_r3; g.consPrio = k1_prio_for(c, 64);
         }
         if (c->chainL > 0) {                 // k_grad_f16_v8<.., CHAIN> / k_grad_bf16_v7<.., CHAIN>
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
