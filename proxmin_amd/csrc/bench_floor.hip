@@ -173,6 +173,85 @@ __global__ __launch_bounds__(512, 2) void kf_mfma(int iters, unsigned seed, floa
     if (s == 123.456f) out[0] = s;
 }
 
+// [r6] How the matrix pipe takes a slot's worth of DEPENDENT MFMAs (the gSt waves of k_grad_f16_v8<RS> sum a slot in one accumulator):
+//   mode 0  24 MFMAs on ONE accumulator, back to back
+//   mode 1  the same with the operand reads of the next k step (two 16-byte LDS reads) between every three of them -- the kernel's shape
+//   mode 2  as mode 1, the 24 MFMAs alternating between TWO accumulators
+//   mode 3  as mode 1, FOUR accumulators (independent: the pipe's own rate with these reads)
+// One wave per SIMD and launch (waves = 1) or two (waves = 2: 512 threads); `slots` slots per wave; out: nothing (timing only).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void kf_chain(int slots, float* out) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    f16x8* frag = reinterpret_cast<f16x8*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int e = tid; e < 2048; e += blockDim.x) {
+        f16x8 v;
+        for (int i = 0; i < 8; ++i) v[i] = (_Float16)(((float)((((unsigned)(e * 8 + i) * 2654435761u) >> 16) & 1023) - 512.f) * 0.03f);
+        frag[e] = v;
+    }
+    __syncthreads();
+    const f16x8* fw = frag + lane;
+    f32x16 c[4] = {};
+    f16x8 a0 = fw[0], a1 = fw[64];
+    for (int s = 0; s < slots; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            f16x8 r0 = a0, r1 = a1;
+            if constexpr (MODE != 0) { r0 = fw[64 * ((2 * ks + s) & 31)]; r1 = fw[64 * ((2 * ks + 1 + s) & 31)]; }
+            if constexpr (MODE <= 1) {
+                c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, c[0], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, c[0], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, c[0], 0, 0, 0);
+            } else if constexpr (MODE == 2) {
+                const int e = ks & 1;
+                c[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, c[e], 0, 0, 0);
+                c[e ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, c[e ^ 1], 0, 0, 0);
+                c[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, c[e], 0, 0, 0);
+            } else {
+                c[(3 * ks) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, a0, c[(3 * ks) & 3], 0, 0, 0);
+                c[(3 * ks + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a1, c[(3 * ks + 1) & 3], 0, 0, 0);
+                c[(3 * ks + 2) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r0, a0, c[(3 * ks + 2) & 3], 0, 0, 0);
+            }
+        }
+    }
+    float sum = 0.f;
+    for (int q = 0; q < 4; ++q) sum += c[q][0] + c[q][9];
+    if (sum == 123.456f) out[0] = sum;
+}
+
+// cycles-equivalent: average ns per MFMA of one wave (24 per slot), `waves` = 1 or 2 waves per SIMD
+extern "C" int pmxf_chain(int device, int mode, int waves, int reps, double* ns_per_mfma) {
+    if (!ns_per_mfma || reps <= 0 || (waves != 1 && waves != 2)) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+    FCHECK(hipSetDevice(device));
+    float* out = nullptr;
+    FCHECK(hipMalloc(&out, 64));
+    hipEvent_t e0, e1;
+    FCHECK(hipEventCreate(&e0));
+    FCHECK(hipEventCreate(&e1));
+    const int slots = 512;
+    double tot = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+        FCHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) {
+            if (mode == 0) hipLaunchKernelGGL(kf_chain<0>, dim3(256), dim3(256 * waves), 32768, 0, slots, out);
+            else if (mode == 1) hipLaunchKernelGGL(kf_chain<1>, dim3(256), dim3(256 * waves), 32768, 0, slots, out);
+            else if (mode == 2) hipLaunchKernelGGL(kf_chain<2>, dim3(256), dim3(256 * waves), 32768, 0, slots, out);
+            else hipLaunchKernelGGL(kf_chain<3>, dim3(256), dim3(256 * waves), 32768, 0, slots, out);
+        }
+        FCHECK(hipEventRecord(e1, 0));
+        FCHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        FCHECK(hipEventElapsedTime(&t, e0, e1));
+        if (pass) tot += t / reps;
+    }
+    FCHECK(hipGetLastError());
+    *ns_per_mfma = tot / 2 * 1e6 / ((double)slots * 24.0);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return 0;
+}
+
 template <typename Kern>
 static int time_launches(Kern kern, int lds, int grid, int reps, const float* Y, int64_t ld, int M, int N, int RP, int gridX, float* out, double* ms) {
     FCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

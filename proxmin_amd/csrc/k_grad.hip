@@ -45,6 +45,7 @@ struct GradArgs {
     unsigned chainBase;
     DevStatus* wstatus;
     int chainInject;
+    K1GramFold fold;     // [r6] k_grad_f32_pc: the step rule's Gram fold riding in the first workgroups (pmx_common.h)
 };
 
 template <int KP> struct GradCfg;

@@ -870,6 +870,7 @@ struct GradV4Args {
     float rangeRatio;    // [r4] two-term fp16 kernels: report k1_fault 4 when K max|A| max|S| > rangeRatio max|Y| (0: no check; f16_range_fault)
     int r3;              // [r4] k_grad_f16_v8<.., R3>: third terms of A and S in the residual's product, two accumulators
     int consPrio;        // [r6] s_setprio level of the CONSUMER waves for the launch (0: none): the consumers are the pole of every slot, the producers wait ~30 % of it at the barrier
+    K1GramFold fold;     // [r6] k_grad_f16_k32: the step rule's Gram fold riding in the first workgroups (pmx_common.h)
 };
 
 // (k_grad_bf16_v4's kernel was removed in round 4 together with k_grad_bf16_v5's: with K1's zero-padded frame -- pmx_k1_frame -- the

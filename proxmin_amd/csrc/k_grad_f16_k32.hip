@@ -30,6 +30,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k32(GradV4Args a) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     if (chain_halted(a.status)) return;
+    k1_gram_fold(a.fold);                    // [r6] the step rule's Gram fold of THIS iteration, in the first workgroups (pmx_common.h)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int li = lane & 15, lq = lane >> 4;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(512, 2) void k_grad_f32_pc(GradArgs a, int gridX, i
     float* Rimg = fsm + C::OFF_R;
 
     if (chain_halted(a.status)) return;
+    k1_gram_fold(a.fold);                    // [r6] the step rule's Gram fold of THIS iteration, in the first workgroups (pmx_common.h)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int M = a.M, N = a.N;
     int rowRegion, colRegion;

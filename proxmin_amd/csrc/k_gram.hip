@@ -100,7 +100,6 @@ struct GramReduceArgs {
     // bsdmm: the Boyd test of the block whose update kernel ran just before (utils.py:349-391), likewise (dec_bsdmm.status != nullptr)
     BsdmmDecideArgs dec_bsdmm;
 };
-__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt);
 // Entry e of factor f: EIGHT threads fold up to 32 partials each (two batches of 16 loads in flight: the partials come from other
 // XCDs, a load-add-load-add loop pays one memory round trip per term), then the eight sums are added in a fixed order.
 // (Round 3: one thread per entry, eight batches: 5.2 us at K = 32; now two round trips.)
@@ -117,26 +116,8 @@ __global__ __launch_bounds__(256) void k_gram_reduce(GramReduceArgs a) {
     }
     const int f = blockIdx.y;
     if (!a.want[f]) return;
-    const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 3, q = t & 7;
     static_assert(GRAM_BLOCKS == 256, "eight threads x 32 partials");
-    const int np = a.nparts[f];
-    double s = 0.0;
-    if (e < n) {
-        const float* p = a.part + (int64_t)f * GRAM_BLOCKS * n + (int64_t)(q * 32) * n + e;
-        const int mine = np - q * 32 < 32 ? np - q * 32 : 32;          // partials of this thread (<= 0: none)
-        for (int b0 = 0; b0 < mine; b0 += 16) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i < mine ? b0 + i : mine - 1) * n];   // (unconditional loads: all 16 in flight)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += b0 + i < mine ? (double)v[i] : 0.0;
-        }
-    }
-    const int base = threadIdx.x & 56;       // (an octet never straddles a wave; every lane takes part in the shuffles)
-    double tot = __shfl(s, base);
-#pragma unroll
-    for (int i = 1; i < 8; ++i) tot += __shfl(s, base + i);
-    if (e < n && q == 0) a.G[(int64_t)f * n + e] = tot;
+    gram_fold_octet(a.part, a.G, a.KP, a.nparts[f], f, blockIdx.x * 256 + threadIdx.x);      // (pmx_common.h: shared with K1's prologue, k1_gram_fold)
 }
 
 

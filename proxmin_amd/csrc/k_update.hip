@@ -445,7 +445,6 @@ struct PgmArgs {
     float* gramPart;         // [2][GRAM_BLOCKS][KP*KP]
     int KP;
 };
-__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt = false);
 template <int NC>
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_update(PgmArgs a) {
     __shared__ double scratch[2 * EW_WAVES];
@@ -876,7 +875,7 @@ __device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials,
 }
 __global__ __launch_bounds__(EW_THREADS) void k_pgm_decide(DecideArgs a) {
     if (chain_halted(a.status)) return;
-    pgm_decide_body(a.status, a.partials, a.e_rel, a.check);
+    pgm_decide_body(a.status, a.partials, a.e_rel, a.check, false);
 }
 
 // ------------------------------------------------------------------------------------------------

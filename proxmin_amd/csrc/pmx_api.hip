@@ -147,6 +147,8 @@ struct pmx_ctx {
     BsdmmDecideArgs bsd_decide{};
     bool gram_fresh[2] = {false, false};   // bsdmm: gramPart[f] holds the partial Gram matrices of the CURRENT factor f (left by k_bsdmm_update)
     bool gram_in_update = true;            // PMX_GRAM_IN_UPDATE=0 (read at context creation): off
+    bool fold_in_k1 = true;                // [r6] pgm: the step rule's Gram fold rides in K1's first workgroups where it can (PMX_FOLD_IN_K1=0: off, A/B)
+    K1GramFold k1_fold{};                  //   what the NEXT K1 launch carries (part == nullptr: nothing); set by pgm_enqueue_iteration, consumed by enqueue_grad_once
     bool decide_pending = false;           // pgm: the stopping test of the last enqueued iteration has not been enqueued yet (it rides in the
                                            // next k_gram_reduce launch, or pgm_flush_decide() launches it at the end of a chunk)
     __bf16* Bp[2] = {nullptr, nullptr};    // presplit terms, row-major   [3][rowsPad][KP]
@@ -407,6 +409,7 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     }
     if (const char* e = getenv("PMX_GRAM_IN_UPDATE")) c->gram_in_update = atoi(e) != 0;
     if (const char* e = getenv("PMX_INJECT_K1_FAULT")) c->hook_inject_k1 = atoi(e);
+    if (const char* e = getenv("PMX_FOLD_IN_K1")) c->fold_in_k1 = atoi(e) != 0;
     if (const char* e = getenv("PMX_K1_PRIO")) c->k1_prio = atoi(e);
     if (const char* e = getenv("PMX_TAIL_LOCKFILE")) c->hook_tail_lockfile = e;
     int ncu = 0;
@@ -1146,6 +1149,7 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         g.wstatus = c->dstatus; g.rangeRatio = c->rangeRatio;
         g.r3 = c->f16_r3;
         g.consPrio = k1_prio_for(c, 32);
+        g.fold = c->k1_fold; c->k1_fold = K1GramFold{};
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         HIP_CHECK(grad_launch_f16_k32(g, c->stream));
         c->nloss = c->plan.gridX * c->plan.gridY;
@@ -1192,7 +1196,8 @@ static int enqueue_grad_once(pmx_ctx* c, const float* A, const float* St, int do
         c->f16_fell_back = c->use_f16 && !took_f16;      // (pmx_k1_info reports the kernel that ran)
         if ((doA & 1) || doS) fix_pending = c->use_f16 && took_f16 && c->f16_r3 == 2 && c->W == nullptr && c->fixPart != nullptr;   // (grad_launch_f16_v8's own test)
     } else {
-        const GradArgs g = small_grad_args(c, A, St, doA, doS);
+        GradArgs g = small_grad_args(c, A, St, doA, doS);
+        if (c->f32pc && !c->use_small) { g.fold = c->k1_fold; c->k1_fold = K1GramFold{}; }     // (k_grad_f32_pc carries the fold; pgm_enqueue_iteration arms it for that kernel only)
         if (timed) HIP_CHECK(hipEventRecord(c->ev[c->ev_used], c->stream));
         if (c->f32pc && c->chainL > 0) {
             if (c->chainSeq >= (1u << 21)) {   // arrival words would run out of bits: start over
@@ -1798,13 +1803,40 @@ static int pgm_enqueue_iteration(pmx_ctx* c) {
         rc = enqueue_small_front(c, A, St, (double)p.step_scale);          // algorithms.py:105-106, one launch
         if (rc != PMX_OK) return rc;
     } else {
-        if (!p.use_fixed_steps && !p.bb_type) {
+        // [r6] Where the partial Gram matrices of this iterate were left by the previous update kernel and K1 is one of the producer / consumer kernels of
+        // K = 32 (cfg2's: k_grad_f16_k32, k_grad_f32_pc<32>), their fold (and the previous iteration's stopping test) ride in K1's first workgroups and
+        // k_eig follows K1: three launches per iteration instead of four (k_gram_reduce was 5.5 us of cfg2's 50; pmx_common.h: k1_gram_fold).
+        const bool fold_here = !p.use_fixed_steps && !p.bb_type && c->gram_by_update && c->fold_in_k1 && !c->host_grad && !eig_small_applies(c) && c->KP == 32 && c->Kk == 32 &&
+                               (c->k32f16 || (c->f32pc && !c->use_small && !c->use_bf16)) && !c->bsd_decide_pending &&
+                               c->plan.gridX * c->plan.gridY >= k1_gram_fold_wgs(c->KP, 512);
+        if (fold_here) {
+            K1GramFold gf{};
+            gf.part = c->gramPart; gf.G = c->gramG; gf.KP = c->KP;
+            gf.nparts[0] = gram_nparts(c->M); gf.nparts[1] = gram_nparts(c->N);
+            if (c->decide_pending) { gf.dec_partials = c->partials; gf.dec_status = c->dstatus; gf.dec_e_rel[0] = p.e_rel[0]; gf.dec_e_rel[1] = p.e_rel[1]; }
+            c->k1_fold = gf;
+            c->decide_pending = false;
+        } else if (!p.use_fixed_steps && !p.bb_type) {
             rc = enqueue_steps(c, A, St, true, true, (double)p.step_scale, c->gram_by_update, c->decide_pending);   // algorithms.py:106
             if (rc != PMX_OK) return rc;
             c->decide_pending = false;
         }
         rc = enqueue_grad(c, A, St, 1, 1, c->absmax_by_finish);               // algorithms.py:105
         if (rc != PMX_OK) return rc;
+        if (fold_here) {
+            if (c->k1_fold.part != nullptr) {    // the launch that ran is not one that carries the fold (a fall-back inside enqueue_grad): the stand-alone kernel, behind K1
+                GramReduceArgs r{};
+                r.part = c->k1_fold.part; r.G = c->gramG; r.KP = c->KP; r.status = c->dstatus;
+                r.want[0] = r.want[1] = 1;
+                r.nparts[0] = c->k1_fold.nparts[0]; r.nparts[1] = c->k1_fold.nparts[1];
+                r.dec_partials = c->k1_fold.dec_partials; r.dec_status = c->k1_fold.dec_status;
+                r.dec_e_rel[0] = c->k1_fold.dec_e_rel[0]; r.dec_e_rel[1] = c->k1_fold.dec_e_rel[1];
+                c->k1_fold = K1GramFold{};
+                launch_gram_reduce(r, c->stream);
+            }
+            rc = enqueue_eig_only(c, true, true, (double)p.step_scale);     // algorithms.py:106, behind K1: the update kernel is its only reader
+            if (rc != PMX_OK) return rc;
+        }
     }
     if (p.bb_type) {                                                      // step(*_X, it, grads=G): utils.py:216-241
         BBArgs b{};

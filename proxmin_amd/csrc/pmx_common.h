@@ -87,6 +87,60 @@ __device__ __forceinline__ bool chain_halted(const DevStatus* st) {
     return __builtin_nontemporal_load(&st->halt) != 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// [r6] The step rule's Gram fold (k_gram_reduce's work) riding in the first workgroups of the NEXT K1 launch.
+// pgm: Gram(X_t) is needed by the update kernel of iteration t only (step = 1 / lmax), not by K1; its partials are left by the update
+// kernel of iteration t - 1.  As a launch of its own the fold is 5.5 us of a 50 us iteration at 4096 x 4096 x 32 (pure latency: two
+// round trips to memory); K1's workgroups open with round trips of their own that the fold's ride along with.  Same arithmetic, same
+// order as k_gram_reduce (eight threads fold up to 32 partials each, two batches of 16 loads in flight; the eight sums in a fixed
+// order): the step rule is the same number bit for bit whichever kernel folded.  The stopping test of iteration t - 1 rides in one
+// more workgroup, as it does in k_gram_reduce.
+// ------------------------------------------------------------------------------------------
+struct K1GramFold {
+    const float* part;       // [2][GRAM_BLOCKS][KP*KP]; nullptr: nothing rides in this launch
+    double* G;               // [2][KP*KP]
+    int KP;
+    int nparts[2];
+    double* dec_partials;    // the previous iteration's stopping test (nullptr: none)
+    DevStatus* dec_status;
+    double dec_e_rel[2];
+};
+__device__ __forceinline__ void pgm_decide_body(DevStatus* st, double* partials, const double (&e_rel)[2], int check, bool wt);   // k_update.hip
+// t: index of the calling thread among the 8 * KP * KP threads that fold factor f (octet e = t >> 3 owns entry e)
+__device__ __forceinline__ void gram_fold_octet(const float* part, double* G, int KP, int np, int f, int t) {
+    const int n = KP * KP, e = t >> 3, q = t & 7;
+    double s = 0.0;
+    if (e < n) {
+        const float* p = part + (int64_t)f * GRAM_BLOCKS * n + (int64_t)(q * 32) * n + e;
+        const int mine = np - q * 32 < 32 ? np - q * 32 : 32;          // partials of this thread (<= 0: none)
+        for (int b0 = 0; b0 < mine; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(b0 + i < mine ? b0 + i : mine - 1) * n];   // (unconditional loads: all 16 in flight)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += b0 + i < mine ? (double)v[i] : 0.0;
+        }
+    }
+    const int base = threadIdx.x & 56;       // (an octet never straddles a wave; every lane takes part in the shuffles)
+    double tot = __shfl(s, base);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) tot += __shfl(s, base + i);
+    if (e < n && q == 0) G[(int64_t)f * n + e] = tot;
+}
+// workgroups the fold occupies in a launch of `threads`-thread workgroups (+ 1 for the stopping test)
+__host__ __device__ inline int k1_gram_fold_wgs(int KP, int threads) { return 2 * ((8 * KP * KP + threads - 1) / threads) + 1; }
+// called by every workgroup of K1 before anything else (uniform per workgroup); the workgroup then goes on with its region
+__device__ __forceinline__ void k1_gram_fold(const K1GramFold& g) {
+    if (g.part == nullptr) return;
+    const int per = (8 * g.KP * g.KP + (int)blockDim.x - 1) / (int)blockDim.x, b = blockIdx.x;
+    if (b < 2 * per) {
+        const int f = b / per;
+        gram_fold_octet(g.part, g.G, g.KP, g.nparts[f], f, (b - f * per) * (int)blockDim.x + (int)threadIdx.x);
+    } else if (b == 2 * per && g.dec_partials != nullptr) {
+        pgm_decide_body(g.dec_status, g.dec_partials, g.dec_e_rel, 1, false);
+    }
+}
+
 // tall factor descriptor: X is rows x K, row-major, K contiguous
 struct Tall {
     float* p;
