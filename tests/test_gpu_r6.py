@@ -125,3 +125,46 @@ def test_the_measurement_skeleton_loads_and_measures(pm):
     assert lib.pmxf_stream(0, 77, 4096, 4096, 0, 3, C.byref(v)) != 0  # an unknown variant is refused
     assert lib.pmxf_mfma(0, 1, 2, C.byref(v)) == 0, lib.pmxf_last_error()
     assert 300.0 < v.value < 2600.0, v.value                          # TFLOP/s
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x2r"])
+@pytest.mark.parametrize("accelerated", [False, True])
+def test_the_gram_fold_riding_in_k1_is_bit_identical_to_the_reduce_launch(pm, orc, mode, accelerated):
+    """pgm at K = 32 (cfg2's kernels: k_grad_f32_pc<32>, k_grad_f16_k32): the step rule's Gram fold and the previous iteration's stopping test ride in K1's first
+    workgroups (pmx_common.h: k1_gram_fold; PMX_FOLD_IN_K1, read at context creation) -- same arithmetic in the same order as k_gram_reduce: identical factors,
+    gradients, steps and stopping iteration, also when the stopping test fires inside the run."""
+    from proxmin_amd.engine import DeviceNMF
+    M, N, K = 2048, 4096, 32
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float32, seed=21)
+    with DeviceNMF(M, N, K, mode=mode) as dev:
+        assert dev.k1_info()["kernel"] == ("k_grad_f32_pc" if mode == "f32" else "k_grad_f16_k32_r3")
+    kw = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if accelerated else {}
+    out = {}
+    pm.set_default_mode(mode)
+    try:
+        for fold in ("1", "0"):
+            os.environ["PMX_FOLD_IN_K1"] = fold
+            for e_rel, its in ((1e-12, 17), (3e-2, 300)):          # a fixed count / a run the stopping test ends
+                A, S = A0.copy(), S0.copy()
+                conv, G, steps = pm.nmf.nmf(Y, A, S, max_iter=its, e_rel=e_rel, **kw)            # chunks of iterations enqueued ahead: the ride's home
+                Ac, Sc = A0.copy(), S0.copy()
+                tb = pm.utils.Traceback()
+                pm.nmf.nmf(Y, Ac, Sc, max_iter=its, e_rel=e_rel, callback=tb, **kw)              # one iteration per call (the callback wants every iterate)
+                assert np.array_equal(A, Ac) and np.array_equal(S, Sc), "chained and per-iteration runs differ (fold %s, e_rel %g)" % (fold, e_rel)
+                out[(fold, e_rel)] = (A, S, G, steps, conv, len(tb.trace))
+    finally:
+        os.environ.pop("PMX_FOLD_IN_K1", None)
+        pm.set_default_mode(None)
+    for e_rel in (1e-12, 3e-2):
+        a, b = out[("1", e_rel)], out[("0", e_rel)]
+        assert a[5] == b[5] and a[4] == b[4], (a[4:], b[4:])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+        assert tuple(a[3]) == tuple(b[3])
+    assert 1 < out[("1", 3e-2)][5] < 300, "the second run is meant to stop on its test (%d iterations)" % out[("1", 3e-2)][5]
+    # and against the oracle (the module's usual bound)
+    A64, S64 = A0.astype(np.float64), S0.astype(np.float64)
+    step = (lambda A_, S_, it, grads: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_))) if accelerated else None
+    orc.pgm_nmf(Y.astype(np.float64), A64, S64, max_iter=17, e_rel=1e-12, accelerated=accelerated, step=step)
+    np.testing.assert_allclose(out[("1", 1e-12)][0], A64, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out[("1", 1e-12)][1], S64, rtol=1e-4, atol=1e-5)
