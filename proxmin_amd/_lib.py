@@ -182,13 +182,23 @@ def load():
 
 
 class _LateTorchGuard:
-    """meta-path finder that does nothing but notice `import torch` after libpmx.so was loaded without it, and raise require_torch()'s
-    message there -- at the import, not at the first tensor that silently lands on the CPU"""
+    """meta-path finder that imports nothing: it notices `torch` being looked up after libpmx.so was loaded without it on a box with a GPU and says
+    what will go wrong -- once, as a WARNING on logger "proxmin", at the import instead of at the first tensor that silently lands on the CPU.
+    (It does not raise: libraries probe for torch with importlib.util.find_spec, and a probe is not an import.)"""
+    warned = False
 
     def find_spec(self, name, path=None, target=None):
-        if name == "torch" and _lib is not None and "torch" not in sys.modules and _lib.pmx_device_count() >= 1:     # (no GPU: nothing to lose)
-            raise ImportError("torch is being imported AFTER proxmin_amd loaded libpmx.so: PyTorch-ROCm brings its own HIP runtime and, loaded second, "
-                              "sees no GPU.  Import torch before the first proxmin_amd call, or set PMX_TORCH_PRELOAD=1")
+        if name == "torch" and not _LateTorchGuard.warned and _lib is not None and "torch" not in sys.modules:
+            try:
+                has_gpu = _lib.pmx_device_count() >= 1
+            except Exception:
+                has_gpu = False
+            if has_gpu:
+                _LateTorchGuard.warned = True
+                import logging
+                logging.getLogger("proxmin").warning(
+                    "proxmin_amd: torch is being imported AFTER libpmx.so was loaded: PyTorch-ROCm brings its own HIP runtime and, loaded second, sees no "
+                    "GPU.  Import torch before the first proxmin_amd call, or set PMX_TORCH_PRELOAD=1")
         return None
 
 
