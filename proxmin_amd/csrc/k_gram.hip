@@ -370,14 +370,14 @@ __device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, c
 // Called by the 64 lanes of wave 0 after g[] (fp32 copy of G, zero beyond K) is complete; returns true when the result was
 // accepted and stored, false when the exact solver (eig_solve_block from the top) has to be run.
 // ------------------------------------------------------------------------------------------------
+// [r6] The solve in two halves that do not depend on each other until the verdict: eig_wave_main (warm-started power iteration, fp64 Rayleigh quotient, residual)
+// and eig_wave_probe (the dominance probe: largest column norm + three power steps from a fixed sign-mixed vector).  eig_wave_solve runs them one after the other in
+// ONE wave (k_eig_small, k_small_front, k64_front: the callers that have one wave to spare); k_eig gives each its own wave (the probe was ~40 % of the solve's time).
+// Same operations in the same order either way: bit-identical eigenvalues.
 template <int KM>
-__device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, const double* G, const int GS, const float* g,
-                                               const int ld, const int K, const double ev0) {
-    DevStatus* st = a.status;
-    const int t = threadIdx.x;
-    const bool in = t < K;
-    const int tt = in ? t : 0;
-    auto wsum = [&](double v) {
+struct EigWaveOps {
+    // sums over the wave by DPP row_shr shifts inside the rows of 16 lanes (+ the rows' totals by v_readlane), broadcasts by v_readlane
+    static __device__ __forceinline__ double wsum(double v) {
 #define PMX_ROW_SHR(n)                                                                                         \
         {                                                                                              \
             const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + n, 0xf, 0xf, true); \
@@ -394,21 +394,29 @@ __device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, co
             tot += __hiloint2double(__builtin_amdgcn_readlane(hi_, 63), __builtin_amdgcn_readlane(lo_, 63));
         }
         return tot;
-    };
-    auto bcast = [&](double v, int k) {                   // k uniform
+    }
+    static __device__ __forceinline__ double bcast(double v, int k) {                   // k uniform
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
-    };
+    }
+};
+struct EigWaveMain { double l, lam, vr, resid; int it; };
+// t: lane (0 .. 63)
+template <int KM>
+__device__ __forceinline__ EigWaveMain eig_wave_main(const EigArgs& a, const int t, const double* G, const int GS, const float* g, const int ld, const int K, const double ev0) {
+    using O = EigWaveOps<KM>;
+    const bool in = t < K;
+    const int tt = in ? t : 0;
     const double v0 = in ? ev0 : 0.0;
-    const double n0 = sqrt(wsum(v0 * v0));
+    const double n0 = sqrt(O::wsum(v0 * v0));
     double vr = in ? ((n0 > 0.0 && n0 == n0 && n0 < 1e300) ? v0 / n0 : 1.0 / sqrt((double)K)) : 0.0;
     double lam_prev = -1.0, lam = 0.0;
     int it = 0, calm = 0;
     for (; it < a.max_iter; ++it) {
         float sacc = 0.f;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) sacc += g[tt * ld + k] * (float)bcast(vr, k);    // (entries >= K: exact zeros; unrolled so that the LDS reads go out together)
+        for (int k = 0; k < KM; ++k) sacc += g[tt * ld + k] * (float)O::bcast(vr, k);    // (entries >= K: exact zeros; unrolled so that the LDS reads go out together)
         const double w = in ? (double)sacc : 0.0;
-        const double nrm = sqrt(wsum(w * w));
+        const double nrm = sqrt(O::wsum(w * w));
         lam = nrm;
         if (nrm == 0.0 || !(nrm == nrm)) break;
         vr = in ? w / nrm : 0.0;
@@ -419,13 +427,20 @@ __device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, co
     }
     double gv = 0.0;
 #pragma unroll
-    for (int k = 0; k < KM; ++k) gv += G[tt * GS + k] * bcast(vr, k);
+    for (int k = 0; k < KM; ++k) gv += G[tt * GS + k] * O::bcast(vr, k);
     if (!in) gv = 0.0;
-    const double rq_n = wsum(gv * vr), rq_d = wsum(vr * vr);
+    const double rq_n = O::wsum(gv * vr), rq_d = O::wsum(vr * vr);
     double l = (rq_d > 0.0) ? rq_n / rq_d : lam;
     if (!(lam == lam)) l = lam;
     const double r1 = in ? gv - l * vr : 0.0;
-    const double resid = sqrt(wsum(r1 * r1) / (rq_d > 0.0 ? rq_d : 1.0));
+    const double resid = sqrt(O::wsum(r1 * r1) / (rq_d > 0.0 ? rq_d : 1.0));
+    return EigWaveMain{l, lam, vr, resid, it};
+}
+template <int KM>
+__device__ __forceinline__ double eig_wave_probe(const int t, const float* g, const int ld, const int K) {
+    using O = EigWaveOps<KM>;
+    const bool in = t < K;
+    const int tt = in ? t : 0;
     double cn = 0.0;
     if (in) {
 #pragma unroll
@@ -434,31 +449,44 @@ __device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, co
     }
     double probe = 0.0;
 #pragma unroll
-    for (int k = 0; k < KM; ++k) probe = fmax(probe, bcast(cn, k));
+    for (int k = 0; k < KM; ++k) probe = fmax(probe, O::bcast(cn, k));
     double w2 = in ? 1.0 + 0.37 * (double)((t * 7) % 5) - 0.61 * (double)(t & 1) : 0.0;
     double un = 0.0, ud = 1.0;
     for (int stepi = 0; stepi < 3; ++stepi) {
         double s2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) s2 += (double)g[k * ld + tt] * bcast(w2, k);
+        for (int k = 0; k < KM; ++k) s2 += (double)g[k * ld + tt] * O::bcast(w2, k);
         if (!in) s2 = 0.0;
-        un = wsum(s2 * w2);
-        ud = wsum(w2 * w2);
-        const double nn = sqrt(wsum(s2 * s2));
+        un = O::wsum(s2 * w2);
+        ud = O::wsum(w2 * w2);
+        const double nn = sqrt(O::wsum(s2 * s2));
         w2 = in ? (nn > 0.0 ? s2 / nn : 0.0) : 0.0;
     }
     if (ud > 0.0) probe = fmax(probe, un / ud);
-    const bool not_dominant = probe > l * (1.0 + 1e-5);
-    const bool need_exact = l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant || a.force_exact);
+    return probe;
+}
+// the verdict, by the lanes of the wave that ran eig_wave_main: accepted -> stored, else the caller runs the exact solver
+__device__ __forceinline__ bool eig_wave_verdict(const EigArgs& a, const int f, const int t, const int K, const EigWaveMain& m, const double probe) {
+    DevStatus* st = a.status;
+    const bool not_dominant = probe > m.l * (1.0 + 1e-5);
+    const bool need_exact = m.l > 0.0 && m.l == m.l && m.l < 1e300 && (!(m.resid <= 1e-6 * m.l) || not_dominant || a.force_exact);
     if (!need_exact) {
         if (t == 0) {
-            st->lam[f] = l;
-            st->step[1 - f] = a.scale / l;
-            st->eig_iters[f] = it;
+            st->lam[f] = m.l;
+            st->step[1 - f] = a.scale / m.l;
+            st->eig_iters[f] = m.it;
         }
-        if (in) st->eigvec[f][t] = (lam > 0.0 && lam == lam) ? vr : 1.0;
+        if (t < K) st->eigvec[f][t] = (m.lam > 0.0 && m.lam == m.lam) ? m.vr : 1.0;
     }
     return !need_exact;
+}
+template <int KM>
+__device__ __forceinline__ bool eig_wave_solve(const EigArgs& a, const int f, const double* G, const int GS, const float* g,
+                                               const int ld, const int K, const double ev0) {
+    const int t = threadIdx.x;
+    const EigWaveMain m = eig_wave_main<KM>(a, t, G, GS, g, ld, K, ev0);
+    const double probe = eig_wave_probe<KM>(t, g, ld, K);
+    return eig_wave_verdict(a, f, t, K, m, probe);
 }
 
 __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
@@ -470,13 +498,23 @@ __global__ __launch_bounds__(256) void k_eig(EigArgs a) {
     const double* G = a.G + (int64_t)f * KP * KP;
     const double ev0 = (int)threadIdx.x < a.K ? a.status->eigvec[f][threadIdx.x] : 0.0;      // (requested with G)
     for (int e = threadIdx.x; e < KP * KP; e += 256) g[(e / KP) * ld + (e % KP)] = (float)G[e];
-    if (KP <= 64) {                          // one wave does the whole solve; the exact solver, if needed, is the block version
+    if (KP <= 64) {                          // [r6] wave 0 the solve, wave 1 the dominance probe beside it (eig_wave_main / _probe); the exact solver, if needed, is the block version
         __shared__ int s_accepted;
+        __shared__ double s_probe;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
-        if (threadIdx.x < 64) {
-            const bool ok = KP == 32 ? eig_wave_solve<32>(a, f, G, KP, g, ld, a.K, ev0) : eig_wave_solve<64>(a, f, G, KP, g, ld, a.K, ev0);
-            if (threadIdx.x == 0) s_accepted = ok;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        EigWaveMain m{};
+        if (w == 0) m = KP == 32 ? eig_wave_main<32>(a, lane, G, KP, g, ld, a.K, ev0) : eig_wave_main<64>(a, lane, G, KP, g, ld, a.K, ev0);
+        else if (w == 1) {
+            const double p = KP == 32 ? eig_wave_probe<32>(lane, g, ld, a.K) : eig_wave_probe<64>(lane, g, ld, a.K);
+            if (lane == 0) s_probe = p;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (w == 0) {
+            const bool ok = eig_wave_verdict(a, f, lane, a.K, m, s_probe);
+            if (lane == 0) s_accepted = ok;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # [r6] k_eig's wave solve with LDS broadcasts instead of v_readlane pairs (+ the fp64 matrix in LDS): bit-identity against the previous build (scratch/libpmx_base.so), then timing
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6h; mkdir -p $O
+O=gpurun_out/r6q; mkdir -p $O
 cat > /tmp/eig_hash.py <<'PY'
 import sys, os, hashlib
 from functools import partial
@@ -36,7 +36,7 @@ for L in new base; do
 if [ $L = base ]; then export PMX_LIB=$GRAFT_REPO_ROOT/scratch/libpmx_base.so; else unset PMX_LIB; fi
 echo -n "$L cfg2 f16x2r "; python bench.py --config cfg2 --mode f16x2r --steps 400 --warmup 40 --no-cpu 2>/dev/null | line
 echo -n "$L cfg2 f32    "; python bench.py --config cfg2 --steps 400 --warmup 40 --no-cpu 2>/dev/null | line
-echo -n "$L cfg5        "; python bench.py --config cfg5 --steps 40 --warmup 10 --no-cpu 2>/dev/null | line
+echo -n "$L cfg5        "; python bench.py --config cfg5 --steps 40 --warmup 10 --no-cpu 2>/dev/null | line; echo "$L mediums:"; python scratch/r6_pgm_k64_probe.py 2>/dev/null | grep f16x2r
 done
 done | tee $O/eig_ab.txt
 unset PMX_LIB
