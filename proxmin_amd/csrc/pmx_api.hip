@@ -33,6 +33,7 @@
 #include "k_gram.hip"
 #include "k_gfix.hip"
 #include "k_small_f64.hip"
+#include "k_big_f64.hip"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -106,6 +107,12 @@ struct pmx_ctx {
     double* Zd[2][PMX_MAX_G] = {};         // [r4] bsdmm in fp64 (k64_bsdmm_block)
     double* Ud[2][PMX_MAX_G] = {};
     int t64x = 0, t64y = 0;                // K1 tiles: column tiles (-> gA slabs), row tiles (-> gSt slabs)
+    // [r6] fp64 at any size (k_big_f64.hip): the same context, other launches
+    bool f64big = false;
+    double* gramPart64 = nullptr;          // [2][G64_BLOCKS][KP*KP]
+    double* colpart64 = nullptr;           // [2][EW_BLOCKS][MAXK]
+    int nsplit64[2] = {1, 1}, bps64[2] = {1, 1};   // sweep plan of the gradient pass of block j (0: gA, fixed factor A; 1: gSt, fixed factor St)
+    int nsub64 = 4;                        // adaprox: proximal passes enqueued per iteration (follows the loops' lengths)
 
     // K1
     bool host_grad = false;                // pmx_set_host_grad: the gradient is whatever the caller uploaded into PMX_BUF_GA / GST (user `grad` callable)
@@ -387,9 +394,11 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     const bool want_r3 = mode == PMX_MODE_F16X2R;
     if (want_r3) mode = PMX_MODE_F16X2;          // the same kernels, frames and fall-backs; k_grad_f16_v8 runs its <R3> instance
     if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2 && mode != PMX_MODE_F64) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
-    if (mode == PMX_MODE_F64 && !(grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192))
-        FAIL(PMX_E_UNSUPPORTED, "fp64 arithmetic is implemented for small problems only (K <= 16, M N <= 2^20, M, N <= 8192); %lld x %lld x %lld runs in fp32",
-             (long long)M, (long long)N, (long long)K);
+    const bool f64_small = grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192;
+    const bool f64_big_off = getenv("PMX_F64_BIG") && atoi(getenv("PMX_F64_BIG")) == 0;      // (A/B, and the way back to the fp32 computation of large fp64 problems)
+    if (mode == PMX_MODE_F64 && !f64_small && (f64_big_off || (double)M * (double)N * 8.0 > 160e9))
+        FAIL(PMX_E_UNSUPPORTED, "fp64 arithmetic is not available for %lld x %lld x %lld (%s); it runs in fp32",
+             (long long)M, (long long)N, (long long)K, f64_big_off ? "PMX_F64_BIG=0: small problems only" : "Y does not fit");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) FAIL(PMX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -453,13 +462,23 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     const int64_t Mk = c->Mk, Nk = c->Nk;
     if (mode == PMX_MODE_F64) {              // fp64 context: its own arrays and kernels (k_small_f64.hip), nothing of the fp32 state
         c->f64 = true;
-        c->use_small = true;
+        c->f64big = !f64_small;
+        c->use_small = f64_small;
         c->use_bf16 = c->use_f16 = c->k128 = c->f32pc = c->f16_scales = false;
         c->chainL = 0;
-        c->t64x = (int)((N + SG_COLS - 1) / SG_COLS);
-        c->t64y = (int)((M + S64_ROWS - 1) / S64_ROWS);
-        c->nSlabA = c->t64x; c->nSlabS = c->t64y;
-        c->plan.gridX = c->t64y; c->plan.gridY = c->t64x; c->plan.RP = 1;
+        if (c->f64big) {                     // k_big_f64.hip: one MFMA pass per gradient, a few slabs each
+            pass64_plan(M, N, (int)K, &c->nsplit64[0], &c->bps64[0]);
+            pass64_plan(N, M, (int)K, &c->nsplit64[1], &c->bps64[1]);
+            c->nSlabA = c->nsplit64[0]; c->nSlabS = c->nsplit64[1];
+            c->t64x = (int)((M + 63) / 64) * c->nsplit64[0];       // workgroups of the pass (-> loss partials)
+            c->t64y = (int)((N + 63) / 64) * c->nsplit64[1];
+            c->plan.gridX = c->t64y; c->plan.gridY = 1; c->plan.RP = 1;
+        } else {
+            c->t64x = (int)((N + SG_COLS - 1) / SG_COLS);
+            c->t64y = (int)((M + S64_ROWS - 1) / S64_ROWS);
+            c->nSlabA = c->t64x; c->nSlabS = c->t64y;
+            c->plan.gridX = c->t64y; c->plan.gridY = c->t64x; c->plan.RP = 1;
+        }
         int rc64 = dallocT(c, &c->Yd, (size_t)M * N, false);
         for (int j = 0; j < 2 && rc64 == PMX_OK; ++j) {
             rc64 = dallocT(c, &c->Xd[j], (size_t)c->rows[j] * K);
@@ -467,7 +486,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         }
         if (rc64 == PMX_OK) rc64 = dallocT(c, &c->slabd[0], (size_t)c->nSlabA * M * K, false);
         if (rc64 == PMX_OK) rc64 = dallocT(c, &c->slabd[1], (size_t)c->nSlabS * N * K, false);
-        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->lossPart, (size_t)c->t64x * c->t64y);
+        if (rc64 == PMX_OK) rc64 = dallocT(c, &c->lossPart, c->f64big ? (size_t)std::max(c->t64x, c->t64y) : (size_t)c->t64x * c->t64y);
+        if (rc64 == PMX_OK && c->f64big) rc64 = dallocT(c, &c->gramPart64, (size_t)2 * G64_BLOCKS * c->KP * c->KP, false);
         if (rc64 == PMX_OK) rc64 = dallocT(c, &c->partials, (size_t)SL_COUNT * 2 * EW_BLOCKS);
         if (rc64 == PMX_OK) rc64 = dallocT(c, &c->gramG, (size_t)2 * c->KP * c->KP);
         if (rc64 == PMX_OK) rc64 = dallocT(c, &c->eigQ, (size_t)2 * c->KP * c->KP);
@@ -623,7 +643,7 @@ extern "C" int pmx_get_phase_timing(pmx_ctx* c, double ms[6], int* iterations) {
 
 extern "C" int pmx_k1_info(pmx_ctx* c, int info[8]) {
     if (!c || !info) FAIL(PMX_E_INVALID, "NULL argument");
-    info[0] = c->f64 ? 7 : c->k32f16 ? (c->f16_r3 ? 10 : 8) : c->use_small ? 4 : (c->k128 ? (c->f16_r3 == 2 && !c->W && c->fixPart ? 12 : 5) : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? (c->f16_r3 == 2 && c->fixPart ? 11 : 9) : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
+    info[0] = c->f64big ? 13 : c->f64 ? 7 : c->k32f16 ? (c->f16_r3 ? 10 : 8) : c->use_small ? 4 : (c->k128 ? (c->f16_r3 == 2 && !c->W && c->fixPart ? 12 : 5) : (c->use_f16 && !c->f16_fell_back ? (c->f16_r3 && !c->W ? (c->f16_r3 == 2 && c->fixPart ? 11 : 9) : 2) : (c->use_bf16 ? 1 : (c->f32pc ? 6 : 0))));
     info[1] = c->chainL;
     info[2] = c->nSlabA;
     info[3] = c->nSlabS;
@@ -1369,7 +1389,51 @@ static void fill_result(pmx_ctx* c, pmx_result* r, int it_before) {
 // ------------------------------------------------------------------------------------------------
 // PMX_MODE_F64: K1 (+ the step rule) and the pgm iteration of an fp64 context
 // ------------------------------------------------------------------------------------------------
+// [r6] k_big_f64.hip: one MFMA pass per gradient wanted (gSt first: it carries the loss), then the step rule in three launches
+static int enqueue_front64_big(pmx_ctx* c, const double* A, const double* St, int doA, int doS, bool tiles, bool steps, double scale) {
+    if (tiles) {
+        const bool loss_only = !doA && !doS;
+        for (int j = 1; j >= 0; --j) {
+            const bool want = j ? (doS || loss_only) : (doA != 0);
+            if (!want) continue;
+            Pass64Args p{};
+            p.Y = c->Yd; p.ldY = c->N;
+            p.F = j ? St : A; p.W = j ? A : St;
+            p.rowsF = (int)c->rows[j]; p.rowsW = (int)c->rows[1 - j];
+            p.K = (int)c->K;
+            p.slab = c->slabd[j];
+            p.status = c->dstatus;
+            p.nsplit = c->nsplit64[j]; p.bps = c->bps64[j];
+            p.store = !loss_only;
+            const bool with_loss = j == 1 || !doS;           // (the loss rides in gSt's pass, or in gA's when that is the only one)
+            p.lossPart = with_loss ? c->lossPart : nullptr;
+            HIP_CHECK(launch_grad64_pass(p, c->KP, j == 0, c->stream));
+            if (with_loss) c->nloss = j ? c->t64y : c->t64x;
+        }
+    }
+    if (steps) {
+        Gram64Args g{};
+        g.X[0] = A; g.X[1] = St;
+        g.rows[0] = c->M; g.rows[1] = c->N;
+        g.K = (int)c->K;
+        g.part = c->gramPart64; g.G = c->gramG;
+        g.status = c->dstatus;
+        g.want[0] = 1; g.want[1] = 1;
+        launch_gram64(g, c->KP, c->stream);
+        EigArgs e{};
+        e.G = c->gramG; e.Gw = c->gramG; e.KP = c->KP; e.K = (int)c->K; e.status = c->dstatus;
+        e.want[0] = 1; e.want[1] = 1;                // factor 0 (A) -> step of block 1 (S), factor 1 (St) -> step of block 0 (A)
+        e.scale = scale;
+        e.max_iter = 200;
+        e.Q = c->eigQ;
+        e.force_exact = 1;
+        HIP_CHECK(launch_eig(e, c->stream));
+    }
+    HIP_CHECK(hipGetLastError());
+    return PMX_OK;
+}
 static int enqueue_front64(pmx_ctx* c, const double* A, const double* St, int doA, int doS, bool tiles, bool steps, double scale) {
+    if (c->f64big) return enqueue_front64_big(c, A, St, doA, doS, tiles, steps, scale);
     Grad64Args g{};
     g.Y = c->Yd; g.ldY = c->N;
     g.A = A; g.St = St;
@@ -1422,7 +1486,8 @@ static int pgm64_enqueue_iteration(pmx_ctx* c) {
     }
     const int64_t rmax = c->rows[0] > c->rows[1] ? c->rows[0] : c->rows[1];
     const int nbx = (int)((rmax + EW_THREADS / 32 - 1) / (EW_THREADS / 32));      // <= 256: M, N <= 8192
-    launch_pgm64_update(u, nbx, c->stream);                                        // algorithms.py:107-108
+    if (c->f64big) launch_pgm64b_update(u, c->stream);
+    else launch_pgm64_update(u, nbx, c->stream);                                   // algorithms.py:107-108
     DecideArgs d{};
     d.status = c->dstatus; d.partials = c->partials;
     d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
@@ -1445,7 +1510,8 @@ extern "C" int pmx_grad(pmx_ctx* c) {
         if (rc != PMX_OK) return rc;
         Fold64Args f{};
         for (int j = 0; j < 2; ++j) { f.slab[j] = c->slabd[j]; f.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS; f.G[j] = c->Gd[j]; f.count[j] = c->rows[j] * c->K; }
-        launch_fold64(f, c->stream);
+        if (c->f64big) launch_fold64b(f, c->stream);
+        else launch_fold64(f, c->stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return PMX_OK;
@@ -2290,8 +2356,10 @@ extern "C" int pmx_adaprox_begin(pmx_ctx* c, const pmx_adaprox_params* p, int wa
             }
             if (rc != PMX_OK) return rc;
         }
-        rc = dallocT(c, &c->alpha64, 32);
+        rc = dallocT(c, &c->alpha64, c->f64big ? 2 * MAXK : 32);
+        if (rc == PMX_OK && c->f64big) rc = dallocT(c, &c->colpart64, (size_t)2 * EW_BLOCKS * MAXK);
         if (rc != PMX_OK) return rc;
+        c->nsub64 = 4;
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return PMX_OK;
     }
@@ -2515,6 +2583,76 @@ extern "C" int pmx_adaprox_run(pmx_ctx* c, int n_iter, const double* b1, double 
     const pmx_adaprox_params& p = c->ada;
     const bool any_prox = p.prox[0].n > 0 || p.prox[1].n > 0;
     const int it0 = c->hstatus->it_done;
+    if (c->f64big) {         // [r6] k_big_f64.hip: two MFMA passes, then the tail as a chain of launches; the proximal loops' lengths are guessed
+        auto args_of = [&](int gi) {
+            Ada64bArgs b{};
+            Ada64Args& a = b.a;
+            for (int j = 0; j < 2; ++j) {
+                a.X[j] = c->Xd[j]; a.Xp[j] = c->Xpd[j]; a.Mm[j] = c->Md[j]; a.Vv[j] = c->Vd[j];
+                a.Vh[j] = p.warm_vhat ? c->Vhd[j] : nullptr;
+                a.Psi[j] = c->Psid[j]; a.z[j] = c->zd[j];
+                a.slab[j] = c->slabd[j];
+                a.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS;
+                a.rows[j] = c->rows[j];
+                a.prox[j] = to_dev(p.prox[j]);
+                a.has_prox[j] = p.prox[j].n > 0;
+                a.e_rel[j] = p.e_rel[j];
+                a.fixed[j] = p.fixed_alpha[j];
+            }
+            a.K = (int)c->K;
+            a.status = c->dstatus;
+            a.scheme = p.scheme;
+            a.it = it0 + gi;
+            a.b1t = b1[gi]; a.b1prev = gi == 0 ? b1_prev : b1[gi - 1];
+            a.b2 = p.b2; a.eps = p.eps; a.p = p.p;
+            a.check_convergence = p.check_convergence;
+            a.prox_max_iter = p.prox_max_iter;
+            a.use_fixed = p.use_fixed_steps;
+            a.alpha_out = c->alpha64;
+            b.partials = c->partials;
+            b.colpart = c->colpart64;
+            return b;
+        };
+        int gi = 0;
+        while (gi < n_iter && !c->hstatus->stopped) {
+            const int chunk = std::min(n_iter - gi, 16);
+            const int nsub = any_prox ? std::max(1, std::min(c->nsub64, p.prox_max_iter)) : 0;
+            for (int i = 0; i < chunk; ++i) {
+                rc = enqueue_front64(c, c->Xd[0], c->Xd[1], 1, 1, true, false, 1.0);       // algorithms.py:369
+                if (rc != PMX_OK) return rc;
+                Ada64bArgs b = args_of(gi + i);
+                launch_ada64b_head(b, c->stream);                                          // :370-378
+                for (int t = 1; t <= nsub; ++t) { b.t = t; launch_ada64b_sub(b, c->stream); }   // :386-392
+                b.t = nsub;
+                launch_ada64b_close(b, c->stream);                                         // :400-410
+                HIP_CHECK(hipGetLastError());
+            }
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+            if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
+            int done = c->hstatus->it_done - it0;                // iterations of this call completed
+            int passes = nsub;
+            while (c->hstatus->halt && c->hstatus->reason == HALT_NEED_SUB) {      // iteration `done` stands in front of its verdict: more passes
+                const int more = std::min(p.prox_max_iter - passes, std::max(passes, 4));
+                if (more <= 0) FAIL(PMX_E_STATE, "adaprox (fp64): the proximal loop asks for passes beyond prox_max_iter");
+                HIP_CHECK(hipMemsetAsync(&c->dstatus->halt, 0, 2 * sizeof(int), c->stream));      // halt, reason
+                Ada64bArgs b = args_of(done);
+                for (int t = passes + 1; t <= passes + more; ++t) { b.t = t; launch_ada64b_sub(b, c->stream); }
+                passes += more;
+                b.t = passes;
+                launch_ada64b_close(b, c->stream);
+                HIP_CHECK(hipGetLastError());
+                rc = read_status(c);
+                if (rc != PMX_OK) return rc;
+                if (c->hstatus->halt && c->hstatus->reason == HALT_ERROR) FAIL(PMX_E_HIP, "%s", chain_error_text(c));
+                done = c->hstatus->it_done - it0;
+            }
+            if (any_prox) c->nsub64 = std::max(c->hstatus->last_tau[0], c->hstatus->last_tau[1]) + 2;
+            gi = done;
+        }
+        fill_result(c, res, it0);
+        return PMX_OK;
+    }
     if (c->f64) {            // K1 tiles (k64_front without its step-rule workgroups) + the whole tail by one workgroup (k64_ada_iter)
         for (int left = n_iter, gi = 0; left > 0 && !c->hstatus->stopped; left -= 16) {
             for (int i = 0; i < std::min(left, 16); ++i, ++gi) {
@@ -2772,7 +2910,16 @@ static int bsdmm_enqueue_iteration(pmx_ctx* c) {
             u.e_rel = p.e_rel[j];
             u.e_abs = p.e_abs[j];
             u.last_block = o == n_order - 1;
-            launch_bsdmm64_block(u, c->stream);
+            if (c->f64big) {             // [r6] the update over the grid, its sums folded by the fp32 path's decide kernel (it only ever saw fp64 sums)
+                launch_bsdmm64b_update(u, c->partials, c->stream);
+                BsdmmDecideArgs d{};
+                d.status = c->dstatus; d.partials = c->partials;
+                d.j = j; d.n_g = p.n_g[j];
+                d.size = c->rows[j] * c->K;
+                d.e_rel = p.e_rel[j]; d.e_abs = p.e_abs[j];
+                d.last_block = u.last_block;
+                launch_bsdmm_decide(d, c->stream);
+            } else launch_bsdmm64_block(u, c->stream);
             HIP_CHECK(hipGetLastError());
             continue;
         }

@@ -60,8 +60,9 @@ def _f32(a):
 
 
 def f64_applies(M, N, K):
-    """Shapes the fp64 kernels take (include/pmx.h: PMX_MODE_F64 -- the small-problem path: the reference's own examples
-    and BASELINE cfg1); PMX_F64=0 switches the mode off (fp64 inputs are then computed in fp32 and cast back, as before)."""
+    """Shapes the fp64 kernels take (include/pmx.h: PMX_MODE_F64 -- the fused small-problem kernels for the reference's own examples
+    and BASELINE cfg1, the MFMA passes of k_big_f64.hip for the rest up to K = 128); PMX_F64=0 switches the mode off (fp64 inputs are
+    then computed in fp32 and cast back, with a warning)."""
     def off(name):                      # the library reads these with atoi(): anything that is not a non-zero number switches off
         v = os.environ.get(name)
         if v is None:
@@ -70,9 +71,11 @@ def f64_applies(M, N, K):
             return int(v.strip() or 0) == 0
         except ValueError:
             return True
-    if off("PMX_F64") or off("PMX_K1_SMALL"):
+    if off("PMX_F64"):
         return False
-    return K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
+    small = not off("PMX_K1_SMALL") and K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
+    # [r6] everything else up to K = 128: one MFMA pass per gradient (k_big_f64.hip); PMX_F64_BIG=0 keeps the small kernels only
+    return small or (not off("PMX_F64_BIG") and K <= 128 and 8.0 * M * N <= 160e9)
 
 
 def _vp(a):
@@ -290,7 +293,7 @@ class DeviceNMF:
         _lib.check(self.lib.pmx_k1_info(self.h, v))
         keys = ("kernel", "chain", "slabs_A", "slabs_S", "row_regions", "col_regions", "panels_per_region", "chain_faults")
         d = dict(zip(keys, list(v)))
-        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_f16_v8_hh", "k_grad_f16_k128_hh")[d["kernel"]]
+        d["kernel"] = ("k_grad_f32", "k_grad_bf16", "k_grad_f16_v8", "k_grad_f16_v9", "k_grad_small", "k_grad_f16_k128", "k_grad_f32_pc", "k64_front", "k_grad_f16_k32", "k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_f16_v8_hh", "k_grad_f16_k128_hh", "k64_grad_pass")[d["kernel"]]
         v7 = d.pop("chain_faults")
         d["chain_faults"], d["tail_faults"], d["tail_fused"] = v7 % 1000, (v7 // 1000) % 1000, bool((v7 // 1000000) % 10)
         d["range_faults"] = v7 // 10000000   # 1: a two-term fp16 K1 refused the residual's range, the context went on in exact fp32 (f16_range_fault)

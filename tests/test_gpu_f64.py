@@ -294,11 +294,13 @@ def test_fp64_operators_and_convergence(pm, orc):
         assert tuple(conv) == tuple(oret[0])
 
 
-def test_fp64_mode_says_what_it_does_not_cover(pm, orc):
+def test_fp64_mode_says_what_it_does_not_cover(pm, orc, monkeypatch):
     from proxmin_amd import _lib
     from proxmin_amd.engine import DeviceNMF
-    with pytest.raises(NotImplementedError):                 # not a small problem (PMX_E_UNSUPPORTED)
-        DeviceNMF(4096, 4096, 32, mode="f64")
+    with monkeypatch.context() as mp:                        # [r6] larger problems have their own fp64 kernels (tests/test_gpu_f64_big.py); without them:
+        mp.setenv("PMX_F64_BIG", "0")
+        with pytest.raises(NotImplementedError):             # not a small problem (PMX_E_UNSUPPORTED)
+            DeviceNMF(4096, 4096, 32, mode="f64")
     Y, A, S = orc.synthetic_problem(64, 96, 4, np.float64, seed=1)
     with DeviceNMF(64, 96, 4, mode="f64") as dev:
         dev.set_Y(Y)

@@ -1,0 +1,293 @@
+"""GPU: fp64 arithmetic for fp64 inputs at ANY size up to K = 128 (PMX_MODE_F64 outside the small-problem kernels:
+proxmin_amd/csrc/k_big_f64.hip -- one v_mfma_f64_16x16x4_f64 pass per gradient, the step rule from fp64 Gram matrices, the three
+back-ends' updates as plain launches).
+
+The reference keeps the dtype of its inputs (nmf.py:39-41); until round 6 fp64 callers above K = 16 / M N = 2^20 were computed in
+fp32 and cast back.  Everything here is held against the fp64 oracle: gradient, likelihood and step rule to round-off, the three
+back-ends end to end to rtol 1e-9 (the sums run in another order than NumPy's; nothing else differs), stopping iterations and
+proximal pass counts equal."""
+from functools import partial
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+SHAPES = [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (1500, 2000, 5), (65, 70, 17), (2048, 1024, 32), (130, 9000, 100), (64, 64, 33)]
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import __graft_entry__ as g
+    g.build()
+    import proxmin_amd
+    return proxmin_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import nmf_oracle
+    return nmf_oracle
+
+
+def _close(got, want, rtol=RTOL, name=""):
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * np.abs(want).max(), err_msg=name)
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gradient_likelihood_and_step_rule(pm, orc, M, N, K):
+    from proxmin_amd.engine import DeviceNMF, f64_applies
+    assert f64_applies(M, N, K)
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float64, seed=M + N + K)
+    with DeviceNMF(M, N, K, mode="f64") as dev:
+        assert dev.k1_info()["kernel"] == "k64_grad_pass"
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+        sA, sS = dev.step_pgm()
+        A2, S2 = dev.get_factors()
+    assert gA.dtype == np.float64 and gS.dtype == np.float64
+    np.testing.assert_array_equal(A2, A)
+    np.testing.assert_array_equal(S2, S)
+    rA, rS = orc.residual_gradients(A, S, Y)
+    np.testing.assert_allclose(gA, rA, rtol=1e-12, atol=1e-12 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=1e-12, atol=1e-12 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(A, S, Y), rel=1e-12)
+    LA, LS = orc.lipschitz_steps(A, S)
+    assert sA == pytest.approx(LA, rel=1e-11) and sS == pytest.approx(LS, rel=1e-11)
+
+
+def test_gradient_of_an_asymmetric_problem_catches_a_transposed_tile(pm, orc):
+    """Y with a structure no transposition leaves alone (rows and columns scaled differently, K components of distinct size)"""
+    from proxmin_amd.engine import DeviceNMF
+    M, N, K = 200, 333, 40
+    rng = np.random.default_rng(2)
+    A = rng.random((M, K)) * np.arange(1, K + 1)[None, :]
+    S = rng.random((K, N)) * np.linspace(0.1, 3.0, N)[None, :]
+    Y = rng.random((M, N)) * np.arange(1, M + 1)[:, None]
+    with DeviceNMF(M, N, K, mode="f64") as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A, S)
+        gA, gS = dev.grad()
+    rA, rS = orc.residual_gradients(A, S, Y)
+    np.testing.assert_allclose(gA, rA, rtol=1e-12, atol=1e-12 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=1e-12, atol=1e-12 * np.abs(rS).max())
+
+
+def _spy(monkeypatch):
+    from proxmin_amd import algorithms, engine
+    seen = []
+    real = engine.DeviceNMF
+
+    class Spy(real):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            seen.append((self.mode, self.k1_info()["kernel"]))
+    monkeypatch.setattr(algorithms, "DeviceNMF", Spy)
+    return seen
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (1500, 2000, 5)])
+@pytest.mark.parametrize("accelerated", [False, True])
+def test_pgm_and_fista(pm, orc, monkeypatch, M, N, K, accelerated):
+    seen = _spy(monkeypatch)
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=7)
+    kw = dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)) if accelerated else {}
+    step = (lambda A_, S_, it, grads: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_))) if accelerated else None
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv, G, steps = pm.nmf.nmf(Y, A, S, prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=10, e_rel=1e-9, callback=tb, **kw)
+    assert seen == [("f64", "k64_grad_pass")], seen
+    Ac, Sc = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, Ac, Sc, prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=10, e_rel=1e-9, **kw)      # chained: the same bits
+    assert np.array_equal(A, Ac) and np.array_equal(S, Sc)
+    Ao, So = A0.copy(), S0.copy()
+    trace = []
+    oret = orc.pgm_nmf(Y, Ao, So, prox_S=("unity_plus", 0), max_iter=10, e_rel=1e-9, accelerated=accelerated, step=step, trace=trace)
+    assert A.dtype == np.float64
+    _close(A, Ao, name="A")
+    _close(S, So, name="S")
+    assert tuple(conv) == tuple(oret[0])
+    _close(tb.trace[3][0], trace[3][0], name="iterate 3")
+    _close(G[0], oret[1][0], rtol=1e-8, name="returned gradient")
+
+
+def test_pgm_operators_and_stopping_iteration(pm, orc):
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(300, 700, 24, np.float64, seed=9)
+    cases = [
+        (dict(prox_A=partial(ops.prox_soft, thresh=0.01), prox_S=partial(ops.prox_hard, thresh=1e-3, type="absolute")),
+         dict(prox_A=("soft", 0.01, "relative"), prox_S=("hard", 1e-3, "absolute")), 12, 1e-9),
+        (dict(prox_A=partial(ops.prox_unity, axis=1), prox_S=partial(ops.prox_soft_plus, thresh=0.02)),
+         dict(prox_A=("unity", 1), prox_S=("soft_plus", 0.02, "relative")), 8, 1e-9),
+        (dict(), dict(), 400, 2e-2),                         # converges: the stopping test stops both at the same iteration
+    ]
+    for kw, okw, its, e_rel in cases:
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        conv, G, steps = pm.nmf.nmf(Y, A, S, max_iter=its, e_rel=e_rel, callback=tb, **kw)
+        Ao, So = A0.copy(), S0.copy()
+        trace = []
+        oret = orc.pgm_nmf(Y, Ao, So, max_iter=its, e_rel=e_rel, trace=trace, **okw)
+        _close(A, Ao)
+        _close(S, So)
+        assert tuple(conv) == tuple(oret[0]) and len(tb.trace) == len(trace)
+    assert len(trace) < 400
+
+
+@pytest.mark.parametrize("scheme", ["adam", "nadam", "amsgrad", "padam", "adamx", "radam"])
+def test_adaprox_schemes(pm, orc, monkeypatch, scheme):
+    seen = _spy(monkeypatch)
+    ops = pm.operators
+    M, N, K = 320, 448, 48
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=3)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme=scheme, prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=8, e_rel=1e-4, check_convergence=False)
+    assert seen == [("f64", "k64_grad_pass")], seen
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme=scheme, max_iter=8, e_rel=1e-4, check_convergence=False)
+    _close(A, Ao, name=scheme + " A")
+    _close(S, So, name=scheme + " S")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1500, 50), (256, 300, 128), (1500, 2000, 5)])
+def test_adaprox_shapes_pass_counts_warm_start_and_constant_steps(pm, orc, M, N, K):
+    from proxmin_amd.engine import DeviceNMF
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=11)
+    # (1) the proximal loops end after the oracle's number of passes (a tight e_rel: more passes than the first guess -- the chain is
+    #     halted in front of the verdict and resumed, pmx_api.hip: HALT_NEED_SUB)
+    its = 6
+    with DeviceNMF(M, N, K, mode="f64") as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A0, S0)
+        dev.adaprox_begin([ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_unity_plus, axis=0), 1)],
+                          scheme="amsgrad", check_convergence=False, prox_max_iter=1000, e_rel=(1e-7, 1e-7))
+        res = dev.adaprox_run(np.full(its, 0.9), 0.9)
+        got = [int(res.sub_iterations[0]), int(res.sub_iterations[1])]
+        A, S = dev.get_factors()
+    Ao, So = A0.copy(), S0.copy()
+    out = orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=its, e_rel=1e-7, check_convergence=False)
+    assert res.iterations == its and got == [int(out[5][0]), int(out[5][1])], (got, out[5])
+    assert got[1] > 4 * its, "the case is meant to need more passes than the first guess (%r)" % (got,)
+    _close(A, Ao)
+    _close(S, So)
+    # (2) prox_max_iter cuts the loop short
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=4, e_rel=1e-7, prox_max_iter=3, check_convergence=False)
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme="adam", max_iter=4, e_rel=1e-7, prox_max_iter=3, check_convergence=False)
+    _close(A, Ao)
+    _close(S, So)
+    # (3) warm start with M / V / Vhat, b1 array
+    rng = np.random.default_rng(3)
+    b1 = np.linspace(0.9, 0.5, 7)
+    M0 = [rng.normal(size=A0.shape) * 0.01, rng.normal(size=S0.shape) * 0.01]
+    V0 = [rng.random(A0.shape) * 1e-3, rng.random(S0.shape) * 1e-3]
+    Vh0 = [v * 1.5 for v in V0]
+    A, S = A0.copy(), S0.copy()
+    Mm, V, Vh = [m.copy() for m in M0], [v.copy() for v in V0], [v.copy() for v in Vh0]
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adamx", prox_S=partial(ops.prox_unity_plus, axis=0), b1=b1, max_iter=7, e_rel=1e-4,
+               M=Mm, V=V, Vhat=Vh, check_convergence=False)
+    Ao, So = A0.copy(), S0.copy()
+    Mo, Vo, Vho = [m.copy() for m in M0], [v.copy() for v in V0], [v.copy() for v in Vh0]
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme="adamx", b1=b1, max_iter=7, e_rel=1e-4, M=Mo, V=Vo, Vhat=Vho, check_convergence=False)
+    for got_, want in ((A, Ao), (S, So), (Mm[0], Mo[0]), (V[1], Vo[1]), (Vh[0], Vho[0]), (Vh[1], Vho[1])):
+        _close(got_, want)
+    # (4) constant steps, no prox on A
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", step=pm.nmf.constant_step(0.01, 0.002), max_iter=5, e_rel=1e-4, check_convergence=False)
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, step=lambda a, s, it: (0.01, 0.002), scheme="adam", max_iter=5, e_rel=1e-4, check_convergence=False)
+    _close(A, Ao)
+    _close(S, So)
+
+
+def test_adaprox_outer_convergence(pm, orc):
+    Y, A0, S0 = orc.synthetic_problem(300, 500, 20, np.float64, seed=9)
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv, _, _, _ = pm.nmf.nmf(Y, A, S, algorithm=pm.adaprox, scheme="adam", max_iter=400, e_rel=2e-3, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    oret = orc.adaprox_nmf(Y, Ao, So, scheme="adam", max_iter=400, e_rel=2e-3)
+    assert tuple(conv) == tuple(oret[0]) and len(tb.trace) == oret[4] and oret[4] < 400
+    _close(A, Ao, rtol=1e-8)
+    _close(S, So, rtol=1e-8)
+    # chained: the same iteration count and bits as one iteration per call
+    Ac, Sc = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, Ac, Sc, algorithm=pm.adaprox, scheme="adam", max_iter=400, e_rel=2e-3)
+    assert np.array_equal(A, Ac) and np.array_equal(S, Sc)
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (1500, 2000, 5)])
+def test_bsdmm(pm, orc, monkeypatch, M, N, K):
+    from proxmin_amd import _lib
+    from proxmin_amd.engine import DeviceNMF
+    seen = _spy(monkeypatch)
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, seed=5)
+    # through nmf(): plus + soft on both blocks
+    A, S = A0.copy(), S0.copy()
+    conv = pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, proxs_g=[[ops.prox_plus, partial(ops.prox_soft, thresh=1e-3)]] * 2, max_iter=8, e_rel=1e-9)
+    assert seen == [("f64", "k64_grad_pass")], seen
+    Ao, So = A0.copy(), S0.copy()
+    oconv, oit = orc.bsdmm_nmf(Y, Ao, So, proxs_g=[[("plus",), ("soft", 1e-3, "relative")]] * 2, max_iter=8, e_rel=1e-9)
+    _close(A, Ao)
+    _close(S, So)
+    assert list(conv) == list(oconv)
+    # the constraint variables against the oracle's (the reference drops them)
+    pA, pS = ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(ops.prox_plus, 1)
+    gA = [ops.device_proxseq(ops.prox_plus, 0), ops.device_proxseq(partial(ops.prox_soft, thresh=0.02), 0)]
+    gS = [ops.device_proxseq(partial(ops.prox_soft_plus, thresh=0.01), 1)]
+    with DeviceNMF(M, N, K, mode="f64") as dev:
+        dev.set_Y(Y)
+        dev.set_factors(A0, S0)
+        dev.bsdmm_begin([pA, pS], [gA, gS], e_rel=(1e-9, 1e-9), e_abs=(0.0, 0.0))
+        dev.bsdmm_run(6)
+        A, S = dev.get_factors()
+        Z = [[dev._download(_lib.BUF_Z0 + j * _lib.MAX_G + i, (M, N)[j]) for i in range((2, 1)[j])] for j in range(2)]
+        U = [[dev._download(_lib.BUF_U0 + j * _lib.MAX_G + i, (M, N)[j]) for i in range((2, 1)[j])] for j in range(2)]
+    Ao, So = A0.copy(), S0.copy()
+    state = {}
+    orc.bsdmm_nmf(Y, Ao, So, proxs_g=[[("plus",), ("soft", 0.02, "relative")], [("soft_plus", 0.01, "relative")]], max_iter=6, e_rel=1e-9, state=state)
+    _close(A, Ao)
+    _close(S, So)
+    for i in range(2):
+        _close(Z[0][i], state["Z"][0][i])
+        _close(U[0][i], state["U"][0][i], rtol=1e-7)
+    _close(Z[1][0].T, state["Z"][1][0])
+    _close(U[1][0].T, state["U"][1][0], rtol=1e-7)
+
+
+def test_bsdmm_stops_by_boyds_test_at_the_oracles_iteration(pm, orc):
+    """(this noisy problem meets Boyd's criteria only with an absolute tolerance: e_abs = 1 stops the oracle at iteration 232)"""
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(200, 400, 24, np.float64, seed=5)
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv = pm.nmf.nmf(Y, A, S, algorithm=pm.bsdmm, proxs_g=[[ops.prox_plus], [ops.prox_plus]], max_iter=400, e_rel=1e-3, e_abs=1.0, callback=tb)
+    Ao, So = A0.copy(), S0.copy()
+    oconv, oit = orc.bsdmm_nmf(Y, Ao, So, proxs_g=[[("plus",)], [("plus",)]], max_iter=400, e_rel=1e-3, e_abs=1.0)
+    assert list(conv) == list(oconv) == [True, True] and len(tb.trace) == oit and oit < 400
+    _close(A, Ao, rtol=1e-8)
+    _close(S, So, rtol=1e-8)
+
+
+def test_switching_the_large_path_off_restores_the_fp32_computation_and_its_warning(pm, orc, monkeypatch, caplog):
+    import logging
+    from proxmin_amd import algorithms
+    from proxmin_amd.engine import DeviceNMF, f64_applies
+    monkeypatch.setenv("PMX_F64_BIG", "0")
+    assert not f64_applies(256, 512, 64) and f64_applies(200, 1000, 5)
+    with pytest.raises(NotImplementedError):
+        DeviceNMF(256, 512, 64, mode="f64")
+    algorithms._f64_warned.clear()
+    Y, A0, S0 = orc.synthetic_problem(256, 512, 64, np.float64, seed=5)
+    with caplog.at_level(logging.WARNING, logger="proxmin"):
+        A, S = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A, S, max_iter=2)
+    assert [r for r in caplog.records if "float64 arrays" in r.getMessage()]
+    assert A.dtype == np.float64

@@ -76,10 +76,11 @@ def test_nmf_adopts_a_device_resident_Y_in_place(pm, orc, backend):
         pm.nmf.nmf(Yd.double(), A0.copy(), S0.copy(), max_iter=1)          # a device Y must be float32
 
 
-def test_float64_arrays_computed_in_float32_are_announced_once(pm, orc, caplog):
+def test_float64_arrays_computed_in_float32_are_announced_once(pm, orc, caplog, monkeypatch):
     from proxmin_amd import algorithms
+    monkeypatch.setenv("PMX_F64_BIG", "0")          # (with the large fp64 kernels on, this problem is computed in fp64: tests/test_gpu_f64_big.py)
     algorithms._f64_warned.clear()
-    Y, A0, S0 = orc.synthetic_problem(256, 512, 64, np.float64, seed=5)     # K = 64: outside the fp64 kernels (K <= 16)
+    Y, A0, S0 = orc.synthetic_problem(256, 512, 64, np.float64, seed=5)     # K = 64: outside the small fp64 kernels (K <= 16)
     with caplog.at_level(logging.WARNING, logger="proxmin"):
         A, S = A0.copy(), S0.copy()
         pm.nmf.nmf(Y, A, S, max_iter=2)
