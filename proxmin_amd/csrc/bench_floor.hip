@@ -173,6 +173,26 @@ __global__ __launch_bounds__(512, 2) void kf_mfma(int iters, unsigned seed, floa
     if (s == 123.456f) out[0] = s;
 }
 
+// dense fp64 MFMA (v_mfma_f64_16x16x4_f64): `waves` waves per SIMD, eight independent accumulators per wave, operands in registers -- the roof of k64_grad_pass
+typedef double kf_v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void kf_mfma_f64(int iters, unsigned seed, double* out) {
+    double a[4], b[2];
+    for (int j = 0; j < 4; ++j) {
+        unsigned x = (threadIdx.x * 16u + j + blockIdx.x * 8192u) * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+        a[j] = seed ? ((double)(x & 1023) - 512.0) * 0.01 : 0.0;
+        if (j < 2) b[j] = seed ? ((double)((x >> 10) & 1023) - 512.0) * 0.01 : 0.0;
+    }
+    kf_v4d c[8] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q & 3], b[q >> 2], c[q], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int q = 0; q < 8; ++q) s += c[q][0] + c[q][3];
+    if (s == 123.456) out[0] = s;
+}
+
 // [r6] How the matrix pipe takes a slot's worth of DEPENDENT MFMAs (the gSt waves of k_grad_f16_v8<RS> sum a slot in one accumulator):
 //   mode 0  24 MFMAs on ONE accumulator, back to back
 //   mode 1  the same with the operand reads of the next k step (two 16-byte LDS reads) between every three of them -- the kernel's shape
@@ -368,6 +388,35 @@ extern "C" int pmxf_mfma(int device, int random_data, int reps, double* tflops) 
     }
     FCHECK(hipGetLastError());
     const double flop = 256.0 * 8.0 * (double)iters * 16.0 * 2.0 * 32 * 32 * 16;
+    *tflops = flop / (tot / 2 * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return 0;
+}
+
+// fp64 matrix-core rate on this box: `waves` (1 or 2) waves per SIMD
+extern "C" int pmxf_mfma_f64(int device, int random_data, int waves, int reps, double* tflops) {
+    if (!tflops || reps <= 0 || (waves != 1 && waves != 2)) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+    FCHECK(hipSetDevice(device));
+    double* out = nullptr;
+    FCHECK(hipMalloc(&out, 64));
+    hipEvent_t e0, e1;
+    FCHECK(hipEventCreate(&e0));
+    FCHECK(hipEventCreate(&e1));
+    const int iters = 4096;      // x 8 MFMAs per wave
+    double tot = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+        FCHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kf_mfma_f64, dim3(256), dim3(256 * waves), 0, 0, iters, random_data ? 4242u : 0u, out);
+        FCHECK(hipEventRecord(e1, 0));
+        FCHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        FCHECK(hipEventElapsedTime(&t, e0, e1));
+        if (pass) tot += t / reps;
+    }
+    FCHECK(hipGetLastError());
+    const double flop = 256.0 * 4.0 * waves * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
     *tflops = flop / (tot / 2 * 1e-3) / 1e12;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -139,6 +139,8 @@ struct EigArgs {
                            // round-off).  The power iteration runs on the fp32 copy of G and is accepted at a residual of 1e-6
                            // lambda, i.e. lambda to ~1e-12 / (relative gap) -- plenty for fp32 factors, 8e-10 in fp64 ones after
                            // 25 iterations (measured against the reference's fixture)
+                           // [r6] 2: the same accuracy from power steps on the fp64 matrix after the fp32 ones (eig_solve_block); the exact
+                           // solver only when those do not settle (k_big_f64.hip: K up to 128, where the exact solver costs milliseconds)
 };
 // one workgroup per factor.  Factor f's eigenvalue sets the step of the OTHER block:
 // lmax(A^T A) -> step_S (block 1), lmax(S S^T) -> step_A (block 0)   (nmf.py:44-49)
@@ -215,8 +217,50 @@ __device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, c
     for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
     if ((t & 63) == 0) red[t >> 6] = rr;
     __syncthreads();
-    const double resid = sqrt((red[0] + red[1] + red[2] + red[3]) / (rq_d > 0.0 ? rq_d : 1.0));
+    double resid = sqrt((red[0] + red[1] + red[2] + red[3]) / (rq_d > 0.0 ? rq_d : 1.0));
     __syncthreads();
+    // ---- [r6] force_exact == 2 (fp64 contexts at size, k_big_f64.hip): the exact solver below is O(K^3) dependent steps through memory
+    //      (0.9 ms at K = 64, 3.5 ms at K = 128 -- more than K1).  Instead: power steps ON THE fp64 MATRIX from the converged fp32 vector
+    //      until the residual is at 1e-11 l; the Rayleigh quotient's error is quadratic in it, i.e. l is at fp64 round-off.  A dominant
+    //      eigenvalue (the Perron root of a non-negative Gram matrix) gets there in a handful of steps; a cluster does not and ends in the
+    //      exact solver as before. ----------------------------------------------------------------------------------------------------
+    if (a.force_exact == 2 && l > 0.0 && l == l && l < 1e300) {
+        for (int r = 0; r < 200 && !(resid <= 1e-11 * l); ++r) {
+            double p2 = (t < K) ? wv[t] * wv[t] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) p2 += __shfl_xor(p2, o);
+            if ((t & 63) == 0) red[t >> 6] = p2;
+            __syncthreads();
+            const double nrm2 = sqrt(red[0] + red[1] + red[2] + red[3]);
+            __syncthreads();
+            if (!(nrm2 > 0.0)) break;
+            if (t < K) vec[t] = wv[t] / nrm2;
+            __syncthreads();
+            if (t < K) {
+                double s2 = 0.0;
+                for (int k = 0; k < K; ++k) s2 += G[(int64_t)k * GS + t] * vec[k];      // (symmetric: column t, coalesced over t)
+                wv[t] = s2;
+            }
+            __syncthreads();
+            double n3 = (t < K) ? wv[t] * vec[t] : 0.0, d3 = (t < K) ? vec[t] * vec[t] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { n3 += __shfl_xor(n3, o); d3 += __shfl_xor(d3, o); }
+            if ((t & 63) == 0) { red[t >> 6] = n3; red[4 + (t >> 6)] = d3; }
+            __syncthreads();
+            const double qn = red[0] + red[1] + red[2] + red[3], qd = red[4] + red[5] + red[6] + red[7];
+            __syncthreads();
+            l = qd > 0.0 ? qn / qd : l;
+            double r3 = (t < K) ? (wv[t] - l * vec[t]) : 0.0;
+            r3 *= r3;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r3 += __shfl_xor(r3, o);
+            if ((t & 63) == 0) red[t >> 6] = r3;
+            __syncthreads();
+            resid = sqrt((red[0] + red[1] + red[2] + red[3]) / (qd > 0.0 ? qd : 1.0));
+            __syncthreads();
+            ++it;
+        }
+    }
     // ---- a small residual says l is AN eigenvalue, not that it is the largest: the iteration is warm-started from the
     //      previous call's vector, and when two eigenvalues cross (factors with mixed signs under prox_id / soft / hard: no
     //      Perron argument) the iterate can sit on the pair that has just become second.  Two lower bounds on lmax of the
@@ -261,7 +305,7 @@ __device__ __forceinline__ void eig_solve_block(const EigArgs& a, const int f, c
     }
     const bool not_dominant = probe > l * (1.0 + 1e-5);
     int used_exact = 0;
-    if (l > 0.0 && l == l && l < 1e300 && (!(resid <= 1e-6 * l) || not_dominant || a.force_exact)) {
+    if (l > 0.0 && l == l && l < 1e300 && (!(resid <= (a.force_exact == 2 ? 1e-9 : 1e-6) * l) || not_dominant || a.force_exact == 1)) {
         // ---- Lanczos tridiagonalisation with full re-orthogonalisation (fp64), K steps = exact ---------
         __shared__ double al[MAXK], be[MAXK + 1], cdot[MAXK];
         __shared__ int nT;

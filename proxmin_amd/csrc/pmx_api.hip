@@ -33,6 +33,7 @@
 #include "k_gram.hip"
 #include "k_gfix.hip"
 #include "k_small_f64.hip"
+#include "k_grad_f64.hip"
 #include "k_big_f64.hip"
 
 // ------------------------------------------------------------------------------------------------
@@ -1426,7 +1427,7 @@ static int enqueue_front64_big(pmx_ctx* c, const double* A, const double* St, in
         e.scale = scale;
         e.max_iter = 200;
         e.Q = c->eigQ;
-        e.force_exact = 1;
+        e.force_exact = 2;                           // lambda_max to fp64 round-off by power steps on the fp64 matrix (k_gram.hip: EigArgs::force_exact)
         HIP_CHECK(launch_eig(e, c->stream));
     }
     HIP_CHECK(hipGetLastError());
