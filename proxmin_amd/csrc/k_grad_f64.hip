@@ -2,6 +2,7 @@
 // depends on pmx_common.h alone so that scratch/f64pass_bench.hip can time the kernel by itself).
 #include "pmx_common.h"
 #include <algorithm>
+#include <type_traits>
 
 __device__ __forceinline__ double p64_wave_sum(double v) {
 #pragma unroll
@@ -18,7 +19,7 @@ struct Pass64Args {
     double* slab;            // [nsplit][rowsF][K]
     double* lossPart;        // [gridDim.x] sum of T^2 over this workgroup's blocks, or nullptr
     const DevStatus* status;
-    int rowsF, rowsW, K;
+    int rowsF, rowsW, K;     // the REAL extents (slab rows, components stored)
     int nsplit, bps;         // splits of the sweep (-> slabs), 64-row blocks of W per split
     int store;               // 0: the loss alone (pmx_loglike)
 };
@@ -35,29 +36,24 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int strip = blockIdx.x / a.nsplit, split = blockIdx.x - strip * a.nsplit;
     const int K = a.K;
-    const int nblk = (a.rowsW + 63) / 64;
+    const int nblk = (a.rowsW + 63) / 64;       // (the padding makes the last one whole)
     const int b0 = split * a.bps, b1 = b0 + a.bps < nblk ? b0 + a.bps : nblk;
     const int fcol = strip * 64 + 16 * wv + l15;               // this lane's row of F (GEMM1's B operand) == its column of T
-    const bool fok = fcol < a.rowsF;
     double ff[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = 4 * s + q;
-        ff[s] = (fok && k < K) ? a.F[(int64_t)fcol * K + k] : 0.0;
-    }
+    for (int s = 0; s < KS; ++s) ff[s] = a.F[(int64_t)fcol * KP + 4 * s + q];
     v4d gacc[KJ];
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) gacc[kj] = (v4d){0.0, 0.0, 0.0, 0.0};
     double loss = 0.0;
     double wreg[NLD];
     v4d yv[4];
+    // F, W and Y are PADDED by the caller: rows to multiples of 64, K to KP (row pitch KP), zeros behind the real extents (pad64 below) --
+    // no test on any load; a block's rows of W are one scalar base + an offset per lane
     auto w_load = [&](int b) {
+        const double* wb = a.W + (int64_t)b * 64 * KP;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 256 * i, r = e / KP, k = e - r * KP;
-            const int64_t w = (int64_t)b * 64 + r;
-            wreg[i] = (w < a.rowsW && k < K) ? a.W[w * K + k] : 0.0;
-        }
+        for (int i = 0; i < NLD; ++i) wreg[i] = wb[tid + 256 * i];
     };
     auto w_store = [&](double* buf) {
 #pragma unroll
@@ -66,15 +62,13 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
             buf[r * KP + (k ^ b64_swz(r))] = wreg[i];
         }
     };
+    const double* ylane = TRANS ? a.Y + (int64_t)fcol * a.ldY + q : a.Y + (int64_t)q * a.ldY + fcol;      // this lane's corner of a tile
     auto y_load = [&](int b) {       // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t w = (int64_t)b * 64 + 16 * mi + q + 4 * r;
-                const bool ok = fok && w < a.rowsW;
-                yv[mi][r] = ok ? (TRANS ? a.Y[(int64_t)fcol * a.ldY + w] : a.Y[w * a.ldY + fcol]) : 0.0;
-            }
+            for (int r = 0; r < 4; ++r)
+                yv[mi][r] = TRANS ? ylane[(int64_t)b * 64 + 16 * mi + 4 * r] : ylane[((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY];
     };
     if (b0 < b1) {
         w_load(b0);
@@ -93,30 +87,53 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
             w_load(b + 1);
             y_load(b + 1);
         }
+        // 2 KP MFMAs in chunks of CH: the LDS operands of chunk c + 1 are requested before the MFMAs of chunk c are issued (two register
+        // sets); the scheduler is held to that order -- left alone it hoists every read of the block and spills
+        {
+            constexpr int CH = 8, N1 = 4 * KS / CH, NCH = (4 * KS + 16 * KJ) / CH;
+            static_assert((4 * KS) % CH == 0 && (16 * KJ) % CH == 0, "chunking");
+            double op[2][CH];
+            auto opl = [&](auto cc, int buf) {
+                constexpr int c = decltype(cc)::value;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const double aop = cur[(16 * mi + l15) * KP + ((4 * s + q) ^ ga)];
-                t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, ff[s], t[mi], 0, 0, 0);
-            }
-        if (a.lossPart != nullptr) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) loss += t[mi][r] * t[mi][r];
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mi + 4 * r + q, gb = b64_swz(4 * r + q);
-#pragma unroll
-                for (int kj = 0; kj < KJ; ++kj) {
-                    const double bop = cur[row * KP + ((16 * kj + l15) ^ gb)];
-                    gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], bop, gacc[kj], 0, 0, 0);
+                for (int i = 0; i < CH; ++i) {
+                    if constexpr (c < N1) {
+                        const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
+                        op[buf][i] = cur[(16 * mi + l15) * KP + ((4 * s1 + q) ^ ga)];
+                    } else {
+                        const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
+                        op[buf][i] = cur[(16 * mi + 4 * r + q) * KP + ((16 * kj + l15) ^ b64_swz(4 * r + q))];
+                    }
                 }
-            }
+            };
+            auto run = [&](auto self, auto cc) -> void {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c + 1 < NCH) opl(std::integral_constant<int, c + 1>{}, (c + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if constexpr (c < N1) {
+                        const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
+                        t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
+                    } else {
+                        const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
+                        gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], op[c & 1][i], gacc[kj], 0, 0, 0);
+                    }
+                }
+                if constexpr (c == N1 - 1) {
+                    if (a.lossPart != nullptr) {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) loss += t[mi][r] * t[mi][r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c + 1 < NCH) self(self, std::integral_constant<int, c + 1>{});
+            };
+            opl(std::integral_constant<int, 0>{}, 0);
+            run(run, std::integral_constant<int, 0>{});
+        }
         if (more) w_store(wl + (((b - b0) & 1) ^ 1) * 64 * KP);
         __syncthreads();
     }
@@ -136,6 +153,27 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
         if (tid == 0) a.lossPart[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
     }
 }
+// a factor (rows x K, row-major) into its padded copy for K1: ceil64(rows) x KP, zeros behind the real extents
+struct Pad64Args {
+    const double* X[2];
+    double* P[2];
+    int64_t rows[2];
+    int K, KP;
+    const DevStatus* status;
+};
+__global__ __launch_bounds__(256) void k64_pad_factors(Pad64Args a) {
+    if (chain_halted(a.status)) return;
+    const int j = blockIdx.y;
+    const int64_t rp = (a.rows[j] + 63) / 64 * 64, n = rp * a.KP;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / a.KP;
+        const int k = (int)(e - r * a.KP);
+        a.P[j][e] = (r < a.rows[j] && k < a.K) ? a.X[j][r * a.K + k] : 0.0;
+    }
+}
+inline void launch_pad64(const Pad64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64_pad_factors, dim3(512, 2), dim3(256), 0, s, a); }
+inline bool pad64_needed(int64_t rows, int K, int KP) { return rows % 64 != 0 || K != KP; }
+
 // splits of a sweep over rowsW rows for a fixed factor of rowsF rows: enough workgroups for four per CU, slabs that stay a
 // small fraction of Y's bytes (nsplit K / rowsW <= ~1/10), no empty split
 inline void pass64_plan(int64_t rowsF, int64_t rowsW, int K, int* nsplit, int* bps) {

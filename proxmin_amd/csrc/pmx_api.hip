@@ -114,6 +114,8 @@ struct pmx_ctx {
     double* colpart64 = nullptr;           // [2][EW_BLOCKS][MAXK]
     int nsplit64[2] = {1, 1}, bps64[2] = {1, 1};   // sweep plan of the gradient pass of block j (0: gA, fixed factor A; 1: gSt, fixed factor St)
     int nsub64 = 4;                        // adaprox: proximal passes enqueued per iteration (follows the loops' lengths)
+    double* Xk64[2] = {nullptr, nullptr};  // K1's padded operands (ceil64(rows) x KP), when the factors are not already that shape
+    int64_t ldY64 = 0;                     // row pitch of Yd (ceil64(N): K1 loads without tests)
 
     // K1
     bool host_grad = false;                // pmx_set_host_grad: the gradient is whatever the caller uploaded into PMX_BUF_GA / GST (user `grad` callable)
@@ -480,7 +482,11 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
             c->nSlabA = c->t64x; c->nSlabS = c->t64y;
             c->plan.gridX = c->t64y; c->plan.gridY = c->t64x; c->plan.RP = 1;
         }
-        int rc64 = dallocT(c, &c->Yd, (size_t)M * N, false);
+        const int64_t Mp64 = (M + 63) / 64 * 64, Np64 = (N + 63) / 64 * 64;
+        c->ldY64 = c->f64big ? Np64 : N;
+        int rc64 = dallocT(c, &c->Yd, c->f64big ? (size_t)Mp64 * Np64 : (size_t)M * N, c->f64big && (Mp64 != M || Np64 != N));
+        for (int j = 0; j < 2 && rc64 == PMX_OK && c->f64big; ++j)
+            if (pad64_needed(c->rows[j], (int)K, c->KP)) rc64 = dallocT(c, &c->Xk64[j], (size_t)((c->rows[j] + 63) / 64 * 64) * c->KP);
         for (int j = 0; j < 2 && rc64 == PMX_OK; ++j) {
             rc64 = dallocT(c, &c->Xd[j], (size_t)c->rows[j] * K);
             if (rc64 == PMX_OK) rc64 = dallocT(c, &c->Gd[j], (size_t)c->rows[j] * K);
@@ -853,7 +859,7 @@ extern "C" int pmx_set_Y_host_f64(pmx_ctx* c, const double* Y, int64_t ld) {
     if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_Y_host_f64 needs a PMX_MODE_F64 context");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
-    HIP_CHECK(hipMemcpy2DAsync(c->Yd, c->N * sizeof(double), Y, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpy2DAsync(c->Yd, (c->f64big ? c->ldY64 : c->N) * sizeof(double), Y, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->haveY = true;
     return PMX_OK;
@@ -1394,12 +1400,20 @@ static void fill_result(pmx_ctx* c, pmx_result* r, int it_before) {
 static int enqueue_front64_big(pmx_ctx* c, const double* A, const double* St, int doA, int doS, bool tiles, bool steps, double scale) {
     if (tiles) {
         const bool loss_only = !doA && !doS;
+        const double* X[2] = {A, St};
+        if (c->Xk64[0] || c->Xk64[1]) {              // the padded copies K1 reads (rows to 64, K to KP)
+            Pad64Args pa{};
+            for (int j = 0; j < 2; ++j) { pa.X[j] = X[j]; pa.P[j] = c->Xk64[j]; pa.rows[j] = c->Xk64[j] ? c->rows[j] : 0; }
+            pa.K = (int)c->K; pa.KP = c->KP; pa.status = c->dstatus;
+            launch_pad64(pa, c->stream);
+            for (int j = 0; j < 2; ++j) if (c->Xk64[j]) X[j] = c->Xk64[j];
+        }
         for (int j = 1; j >= 0; --j) {
             const bool want = j ? (doS || loss_only) : (doA != 0);
             if (!want) continue;
             Pass64Args p{};
-            p.Y = c->Yd; p.ldY = c->N;
-            p.F = j ? St : A; p.W = j ? A : St;
+            p.Y = c->Yd; p.ldY = c->ldY64;
+            p.F = X[j]; p.W = X[1 - j];
             p.rowsF = (int)c->rows[j]; p.rowsW = (int)c->rows[1 - j];
             p.K = (int)c->K;
             p.slab = c->slabd[j];

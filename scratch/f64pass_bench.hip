@@ -19,10 +19,13 @@ int main(int argc, char** argv) {
     for (auto& v : hA) v = rnd();
     for (auto& v : hS) v = rnd() / K;
     for (auto& v : hY) v = rnd();
-    double *A, *S, *Y, *slab[2], *loss; DevStatus* st;
-    CK(hipMalloc(&A, M * K * 8)); CK(hipMalloc(&S, N * K * 8)); CK(hipMalloc(&Y, M * N * 8)); CK(hipMalloc(&st, sizeof(DevStatus)));
-    CK(hipMemset(st, 0, sizeof(DevStatus)));
-    CK(hipMemcpy(A, hA.data(), M * K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(S, hS.data(), N * K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(Y, hY.data(), M * N * 8, hipMemcpyHostToDevice));
+    double *A0, *S0, *A, *S, *Y, *slab[2], *loss; DevStatus* st;
+    const int64_t Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64;
+    CK(hipMalloc(&A0, M * K * 8)); CK(hipMalloc(&S0, N * K * 8)); CK(hipMalloc(&A, Mp * KP * 8)); CK(hipMalloc(&S, Np * KP * 8)); CK(hipMalloc(&Y, Mp * Np * 8)); CK(hipMalloc(&st, sizeof(DevStatus)));
+    CK(hipMemset(st, 0, sizeof(DevStatus))); CK(hipMemset(Y, 0, Mp * Np * 8));
+    CK(hipMemcpy(A0, hA.data(), M * K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(S0, hS.data(), N * K * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy2D(Y, Np * 8, hY.data(), N * 8, N * 8, M, hipMemcpyHostToDevice));
+    { Pad64Args pa{}; pa.X[0] = A0; pa.X[1] = S0; pa.P[0] = A; pa.P[1] = S; pa.rows[0] = M; pa.rows[1] = N; pa.K = K; pa.KP = KP; pa.status = st; launch_pad64(pa, nullptr); CK(hipDeviceSynchronize()); }
     int ns[2], bps[2];
     pass64_plan(M, N, K, &ns[0], &bps[0]); pass64_plan(N, M, K, &ns[1], &bps[1]);
     const int64_t rows[2] = {M, N};
@@ -31,7 +34,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int j = 1; j >= 0; --j) {
         Pass64Args p{};
-        p.Y = Y; p.ldY = N; p.F = j ? S : A; p.W = j ? A : S; p.rowsF = (int)rows[j]; p.rowsW = (int)rows[1 - j]; p.K = K;
+        p.Y = Y; p.ldY = Np; p.F = j ? S : A; p.W = j ? A : S; p.rowsF = (int)rows[j]; p.rowsW = (int)rows[1 - j]; p.K = K;
         p.slab = slab[j]; p.status = st; p.nsplit = ns[j]; p.bps = bps[j]; p.store = 1; p.lossPart = j ? loss : nullptr;
         CK(launch_grad64_pass(p, KP, j == 0, nullptr));
         CK(hipDeviceSynchronize());
