@@ -28,8 +28,18 @@ struct Pass64Args {
 __device__ __forceinline__ int b64_swz(int row) { return ((row & 1) << 4) | (row & 14); }
 
 template <int KP, bool TRANS>
-__global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
+__global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64Args a) {
     constexpr int KS = KP / 4, KJ = KP / 16, NLD = KP / 4;     // contraction steps, output tiles along K, doubles staged per thread and block
+    // A block is 2 KP MFMAs per wave, issued in chunks of CH; everything else of the step hangs on that sequence (the scheduler is held to
+    // it: left alone it hoists every LDS read of the block and spills, and a burst of 32 global loads in front of the first MFMA keeps the
+    // wave from issuing anything else for ~2000 cycles):
+    //   chunk c        requests the LDS operands of chunk c + 1 (two register sets), then issues its MFMAs
+    //   chunks 0..YC-1 request this block's tile of Y (subtracted when GEMM1 is complete: T = W F^T - Y)
+    //   chunks LC0..   request the NEXT block's rows of W, a group of GS per chunk, and store them to the other LDS buffer two chunks later
+    constexpr int CH = 8, N1 = 4 * KS / CH, NCH = (4 * KS + 16 * KJ) / CH;
+    constexpr int YC = N1 >= 8 ? 4 : 2, YPC = 16 / YC;
+    constexpr int GS = 4, NG = NLD / GS, LC0 = YC;
+    static_assert((4 * KS) % CH == 0 && (16 * KJ) % CH == 0 && LC0 + NG + 2 <= NCH && YC < N1, "chunk plan");
     extern __shared__ __attribute__((aligned(16))) double wl[];   // [2][64][KP]
     __shared__ double lred[4];
     if (chain_halted(a.status)) return;
@@ -39,6 +49,8 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
     const int nblk = (a.rowsW + 63) / 64;       // (the padding makes the last one whole)
     const int b0 = split * a.bps, b1 = b0 + a.bps < nblk ? b0 + a.bps : nblk;
     const int fcol = strip * 64 + 16 * wv + l15;               // this lane's row of F (GEMM1's B operand) == its column of T
+    // F, W and Y are PADDED by the caller: rows to multiples of 64, K to KP (row pitch KP), zeros behind the real extents (k64_pad_factors
+    // below) -- no test on any load
     double ff[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) ff[s] = a.F[(int64_t)fcol * KP + 4 * s + q];
@@ -46,95 +58,96 @@ __global__ __launch_bounds__(256) void k64_grad_pass(Pass64Args a) {
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) gacc[kj] = (v4d){0.0, 0.0, 0.0, 0.0};
     double loss = 0.0;
-    double wreg[NLD];
-    v4d yv[4];
-    // F, W and Y are PADDED by the caller: rows to multiples of 64, K to KP (row pitch KP), zeros behind the real extents (pad64 below) --
-    // no test on any load; a block's rows of W are one scalar base + an offset per lane
-    auto w_load = [&](int b) {
-        const double* wb = a.W + (int64_t)b * 64 * KP;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) wreg[i] = wb[tid + 256 * i];
-    };
-    auto w_store = [&](double* buf) {
+    const double* ylane = TRANS ? a.Y + (int64_t)fcol * a.ldY + q : a.Y + (int64_t)q * a.ldY + fcol;      // this lane's corner of a tile
+    if (b0 < b1) {                   // the first block's rows of W
+        const double* wb = a.W + (int64_t)b0 * 64 * KP;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i, r = e / KP, k = e - r * KP;
-            buf[r * KP + (k ^ b64_swz(r))] = wreg[i];
+            wl[r * KP + (k ^ b64_swz(r))] = wb[e];
         }
-    };
-    const double* ylane = TRANS ? a.Y + (int64_t)fcol * a.ldY + q : a.Y + (int64_t)q * a.ldY + fcol;      // this lane's corner of a tile
-    auto y_load = [&](int b) {       // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                yv[mi][r] = TRANS ? ylane[(int64_t)b * 64 + 16 * mi + 4 * r] : ylane[((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY];
-    };
-    if (b0 < b1) {
-        w_load(b0);
-        y_load(b0);
-        w_store(wl);
     }
     __syncthreads();
-    const int ga = b64_swz(l15);
+    const int lcA = q ^ b64_swz(l15), lcB = l15 ^ b64_swz(q), rowA = l15 * KP, rowB = q * KP;
     for (int b = b0; b < b1; ++b) {
         const double* cur = wl + ((b - b0) & 1) * 64 * KP;
-        v4d t[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) t[mi] = -yv[mi];
+        double* nxt = wl + (((b - b0) & 1) ^ 1) * 64 * KP;
         const bool more = b + 1 < b1;
-        if (more) {                  // the next block's rows of W and tile of Y: in flight under this block's MFMAs
-            w_load(b + 1);
-            y_load(b + 1);
-        }
-        // 2 KP MFMAs in chunks of CH: the LDS operands of chunk c + 1 are requested before the MFMAs of chunk c are issued (two register
-        // sets); the scheduler is held to that order -- left alone it hoists every read of the block and spills
-        {
-            constexpr int CH = 8, N1 = 4 * KS / CH, NCH = (4 * KS + 16 * KJ) / CH;
-            static_assert((4 * KS) % CH == 0 && (16 * KJ) % CH == 0, "chunking");
-            double op[2][CH];
-            auto opl = [&](auto cc, int buf) {
-                constexpr int c = decltype(cc)::value;
+        const double* wb = a.W + (int64_t)(b + 1) * 64 * KP;
+        v4d t[4], yv[4];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if constexpr (c < N1) {
-                        const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
-                        op[buf][i] = cur[(16 * mi + l15) * KP + ((4 * s1 + q) ^ ga)];
-                    } else {
-                        const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
-                        op[buf][i] = cur[(16 * mi + 4 * r + q) * KP + ((16 * kj + l15) ^ b64_swz(4 * r + q))];
+        for (int mi = 0; mi < 4; ++mi) t[mi] = (v4d){0.0, 0.0, 0.0, 0.0};
+        double op[2][CH], wtmp[NG][GS];
+        // operand addresses: column k of row r sits at k ^ b64_swz(r).  GEMM1's A operand: row 16 mi + l15, column 4 s + q  ->  l15 KP +
+        // ((q ^ swz(l15)) ^ 4 s) + 16 mi KP; the second product's B operand: row 16 mi + 4 r + q, column 16 kj + l15  ->  q KP + ((l15 ^ sq) ^
+        // (16 kj ^ 4 r)) + (16 mi + 4 r) KP with sq = swz(q) (swz(4 r + q) = sq ^ 4 r).  One lane constant XOR a compile-time constant each --
+        // recomputed per chunk (the asm keeps the compiler from hoisting 32 of them out of the loop, which is what spilled)
+        auto opl = [&](auto cc, int buf) {
+            constexpr int c = decltype(cc)::value;
+            int la = lcA, lb = lcB;
+            asm volatile("" : "+v"(la), "+v"(lb));
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if constexpr (c < N1) {
+                    const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
+                    op[buf][i] = cur[rowA + (la ^ (4 * s1)) + 16 * mi * KP];
+                } else {
+                    const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
+                    op[buf][i] = cur[rowB + (lb ^ ((16 * kj) ^ (4 * r))) + (16 * mi + 4 * r) * KP];
+                }
+            }
+        };
+        auto run = [&](auto self, auto cc) -> void {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c < YC) {          // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
+#pragma unroll
+                for (int i = 0; i < YPC; ++i) {
+                    const int idx = c * YPC + i, mi = idx >> 2, r = idx & 3;
+                    yv[mi][r] = TRANS ? ylane[(int64_t)b * 64 + 16 * mi + 4 * r] : ylane[((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY];
+                }
+            }
+            if constexpr (c >= LC0 && c < LC0 + NG) {
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < GS; ++i) wtmp[c - LC0][i] = wb[tid + 256 * ((c - LC0) * GS + i)];
+                }
+            }
+            if constexpr (c >= LC0 + 2 && c < LC0 + 2 + NG) {
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < GS; ++i) {
+                        const int e = tid + 256 * ((c - LC0 - 2) * GS + i), r = e / KP, k = e - r * KP;
+                        nxt[r * KP + (k ^ b64_swz(r))] = wtmp[c - LC0 - 2][i];
                     }
                 }
-            };
-            auto run = [&](auto self, auto cc) -> void {
-                constexpr int c = decltype(cc)::value;
-                if constexpr (c + 1 < NCH) opl(std::integral_constant<int, c + 1>{}, (c + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (c + 1 < NCH) opl(std::integral_constant<int, c + 1>{}, (c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if constexpr (c < N1) {
-                        const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
-                        t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
-                    } else {
-                        const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
-                        gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], op[c & 1][i], gacc[kj], 0, 0, 0);
-                    }
+            for (int i = 0; i < CH; ++i) {
+                if constexpr (c < N1) {
+                    const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
+                    t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
+                } else {
+                    const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
+                    gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], op[c & 1][i], gacc[kj], 0, 0, 0);
                 }
-                if constexpr (c == N1 - 1) {
-                    if (a.lossPart != nullptr) {
+            }
+            if constexpr (c == N1 - 1) {     // the residual (nmf.py:39), and its square for the likelihood
 #pragma unroll
-                        for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi) t[mi] -= yv[mi];
+                if (a.lossPart != nullptr) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) loss += t[mi][r] * t[mi][r];
-                    }
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) loss += t[mi][r] * t[mi][r];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (c + 1 < NCH) self(self, std::integral_constant<int, c + 1>{});
-            };
-            opl(std::integral_constant<int, 0>{}, 0);
-            run(run, std::integral_constant<int, 0>{});
-        }
-        if (more) w_store(wl + (((b - b0) & 1) ^ 1) * 64 * KP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c + 1 < NCH) self(self, std::integral_constant<int, c + 1>{});
+        };
+        opl(std::integral_constant<int, 0>{}, 0);
+        run(run, std::integral_constant<int, 0>{});
         __syncthreads();
     }
     if (a.store) {
