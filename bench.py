@@ -144,6 +144,7 @@ def measured_on_this_box(local):
     lib.pmxf_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.pmxf_copy.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     lib.pmxf_mfma.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.pmxf_mfma_f64.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     out = {}
 
     def call(fn, *a):
@@ -168,6 +169,8 @@ def measured_on_this_box(local):
         out["hbm_read_gbs_8B_per_lane"] = gb / (ms["stream_8B"] * 1e-3)
         out["fp16_mfma_tflops_random"] = call(lib.pmxf_mfma, local, 1, 10)                # dense v_mfma_f32_32x32x16_f16 from registers, random operands
         out["fp16_mfma_tflops_zeros"] = call(lib.pmxf_mfma, local, 0, 10)
+        out["fp64_mfma_tflops_random"] = call(lib.pmxf_mfma_f64, local, 1, 2, 5)          # dense v_mfma_f64_16x16x4_f64, two waves per SIMD (the fp64 path's roof: fp64_inputs)
+        out["fp64_mfma_tflops_random_one_wave_per_simd"] = call(lib.pmxf_mfma_f64, local, 1, 1, 5)
         out["skeleton_ms"] = ms
         # the floor K1 is priced against: K1's own fetch shape and operands that toggle like real data, no epilogue (the epilogue variant is what a
         # kernel that ALSO forms the residual cannot avoid; both are printed)
@@ -485,6 +488,7 @@ def main():
                 side[key] = {"error": repr(exc)}
         side["other_configs"] = other_configs(Y, local)
         side["nmf_call"] = nmf_call_leg(Y, A0, S0, unity)
+        side["fp64_inputs"] = fp64_inputs_leg(Y, A0, S0, backend, unity, local, side["measured"].get("fp64_mfma_tflops_random"))
 
     assert proxmin_amd.get_default_mode() == proxmin_amd.LIBRARY_DEFAULT_MODE or os.environ.get("PMX_MODE"), "bench.py must not change the library's default mode"
     dev = DeviceNMF(M, N, K, device=local, mode=args.mode)
@@ -612,6 +616,40 @@ def nmf_call_leg(Yd, A0, S0, unity):
                 "note": "proxmin_amd.nmf.nmf(Y_on_gpu, A, S, algorithm=adaprox, scheme='amsgrad', prox_S=partial(prox_unity_plus, axis=0), check_convergence=False) in the library's "
                         "default mode: marginal iterations/s between a %d- and a %d-iteration call (iterations %d..%d of the problem; the headline times iterations ~60..160: K1's time "
                         "drifts a few per cent along a run, DESIGN.md section 5); fixed part = context, factor upload / download, the cold start's proximal passes" % (n1, n2, n1, n2)}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
+def fp64_inputs_leg(Yd, A0, S0, backend, unity, local, peak_tf):
+    """[r6] The reference computes in the dtype of its arrays (nmf.py:39-41) and its own examples are fp64.  The same workload handed over as
+    float64 arrays runs the fp64 kernels (PMX_MODE_F64 at size: proxmin_amd/csrc/k_grad_f64.hip -- one v_mfma_f64_16x16x4_f64 pass per
+    gradient, 8 M N K FLOPs per iteration -- and k_big_f64.hip): iterations/s, and the fraction of the fp64 matrix-core rate MEASURED on this
+    box just before (measured_on_this_box).  MFMA-bound, not HBM-bound: Y (2 GiB in fp64) is streamed twice per iteration at ~1.5 TB/s each."""
+    try:
+        from proxmin_amd.engine import DeviceNMF
+        M, N = Yd.shape
+        K = A0.shape[1]
+        Yh = Yd.double().cpu().numpy()
+        with DeviceNMF(M, N, K, device=local, mode="f64") as dev:
+            dev.set_Y(Yh)
+            del Yh
+            dev.set_factors(A0.astype(np.float64), S0.astype(np.float64))
+            kernel = dev.k1_info()["kernel"]
+            run = begin_solver(dev, backend, unity)
+            warm, steps = 30, 20
+            run(warm)
+            t0 = time.perf_counter()
+            run(steps)
+            dt = time.perf_counter() - t0
+        flops = 8.0 * M * N * K
+        out = {"value": steps / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm, "dtype": "f64", "kernel": kernel,
+               "k1_tflops_achieved_whole_iteration": flops / (dt / steps) / 1e12,
+               "note": "the headline's workload and solver with float64 arrays (Y uploaded from the host: 2 GiB): fp64 operands, products and sums; K1 = two MFMA passes "
+                       "(8 M N K FLOPs), the rate is the whole iteration's"}
+        if peak_tf:
+            out["peak_tflops_measured"] = peak_tf
+            out["frac_of_measured_fp64_mfma_peak"] = out["k1_tflops_achieved_whole_iteration"] / peak_tf
+        return out
     except Exception as exc:
         return {"error": repr(exc)}
 
