@@ -10,6 +10,7 @@ __device__ __forceinline__ double p64_wave_sum(double v) {
     return v;
 }
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct Pass64Args {
     const double* Y;
@@ -33,13 +34,16 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
     // A block is 2 KP MFMAs per wave, issued in chunks of CH; everything else of the step hangs on that sequence (the scheduler is held to
     // it: left alone it hoists every LDS read of the block and spills, and a burst of 32 global loads in front of the first MFMA keeps the
     // wave from issuing anything else for ~2000 cycles):
-    //   chunk c        requests the LDS operands of chunk c + 1 (two register sets), then issues its MFMAs
-    //   chunks 0..YC-1 request this block's tile of Y (subtracted when GEMM1 is complete: T = W F^T - Y)
-    //   chunks LC0..   request the NEXT block's rows of W, a group of GS per chunk, and store them to the other LDS buffer two chunks later
+    //   chunk c          requests the LDS operands of chunk c + 1 (two register sets), then issues its MFMAs
+    //   chunks 0..NG-1   request the NEXT block's rows of W (L2-resident: every workgroup sweeps them), a group of GS per chunk, and store them
+    //                    to the other LDS buffer WD chunks later
+    //   chunk N1-1       GEMM1 is complete: T = W F^T - Y (nmf.py:39) with the tile of Y requested during the PREVIOUS block
+    //   chunks N1..      request the NEXT block's tile of Y (HBM: ~2 us away; it has the rest of this block and the next GEMM1 to arrive.
+    //                    Requested at the head of its own block it was not back when GEMM1 ended: 0.2 ms of a 1.4 ms pass at cfg3)
     constexpr int CH = 8, N1 = 4 * KS / CH, NCH = (4 * KS + 16 * KJ) / CH;
     constexpr int YC = N1 >= 8 ? 4 : 2, YPC = 16 / YC;
-    constexpr int GS = 4, NG = NLD / GS, LC0 = YC;
-    static_assert((4 * KS) % CH == 0 && (16 * KJ) % CH == 0 && LC0 + NG + 2 <= NCH && YC < N1, "chunk plan");
+    constexpr int GS = 4, NG = NLD / GS, WD = 3;
+    static_assert((4 * KS) % CH == 0 && (16 * KJ) % CH == 0 && NG + WD <= NCH && N1 + YC <= NCH, "chunk plan");
     extern __shared__ __attribute__((aligned(16))) double wl[];   // [2][64][KP]
     __shared__ double lred[4];
     if (chain_halted(a.status)) return;
@@ -53,33 +57,42 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
     // below) -- no test on any load
     double ff[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) ff[s] = a.F[(int64_t)fcol * KP + 4 * s + q];
+    for (int s = 0; s < KS; ++s) ff[s] = a.F[(int64_t)fcol * KP + 8 * (s >> 1) + 2 * q + (s & 1)];      // contraction step s takes k = 8 (s >> 1) + 2 q + (s & 1): steps 2 c, 2 c + 1 are ONE 16-byte LDS read of W
     v4d gacc[KJ];
 #pragma unroll
     for (int kj = 0; kj < KJ; ++kj) gacc[kj] = (v4d){0.0, 0.0, 0.0, 0.0};
     double loss = 0.0;
-    const double* ylane = TRANS ? a.Y + (int64_t)fcol * a.ldY + q : a.Y + (int64_t)q * a.ldY + fcol;      // this lane's corner of a tile
-    if (b0 < b1) {                   // the first block's rows of W
+    const double* ylane = a.Y + (int64_t)fcol * a.ldY + q;      // TRANS: this lane's corner of a tile
+    const int64_t yoff = (int64_t)q * a.ldY + fcol;             // else: its offset from a tile's first row
+    v4d yv[4];
+    auto y_req = [&](int b, int idx) {      // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
+        const int mi = idx >> 2, r = idx & 3;
+        if (TRANS) yv[mi][r] = ylane[(int64_t)b * 64 + 16 * mi + 4 * r];                 // one address per lane + immediates
+        else yv[mi][r] = (a.Y + ((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY)[yoff];      // a scalar row base + one offset per lane
+    };
+    if (b0 < b1) {                   // the first block's rows of W and tile of Y
         const double* wb = a.W + (int64_t)b0 * 64 * KP;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i, r = e / KP, k = e - r * KP;
             wl[r * KP + (k ^ b64_swz(r))] = wb[e];
         }
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) y_req(b0, idx);
     }
     __syncthreads();
-    const int lcA = q ^ b64_swz(l15), lcB = l15 ^ b64_swz(q), rowA = l15 * KP, rowB = q * KP;
+    const int lcA = (2 * q) ^ b64_swz(l15), lcB = l15 ^ b64_swz(q), rowA = l15 * KP, rowB = q * KP;
     for (int b = b0; b < b1; ++b) {
         const double* cur = wl + ((b - b0) & 1) * 64 * KP;
         double* nxt = wl + (((b - b0) & 1) ^ 1) * 64 * KP;
         const bool more = b + 1 < b1;
         const double* wb = a.W + (int64_t)(b + 1) * 64 * KP;
-        v4d t[4], yv[4];
+        v4d t[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) t[mi] = (v4d){0.0, 0.0, 0.0, 0.0};
         double op[2][CH], wtmp[NG][GS];
-        // operand addresses: column k of row r sits at k ^ b64_swz(r).  GEMM1's A operand: row 16 mi + l15, column 4 s + q  ->  l15 KP +
-        // ((q ^ swz(l15)) ^ 4 s) + 16 mi KP; the second product's B operand: row 16 mi + 4 r + q, column 16 kj + l15  ->  q KP + ((l15 ^ sq) ^
+        // operand addresses: column k of row r sits at k ^ b64_swz(r).  GEMM1's A operand: row 16 mi + l15, columns 8 c + 2 q + {0, 1}  ->  l15 KP +
+        // ((2 q ^ swz(l15)) ^ 8 c) + 16 mi KP (swz is even: the pair stays adjacent and 16-byte aligned); the second product's B operand: row 16 mi + 4 r + q, column 16 kj + l15  ->  q KP + ((l15 ^ sq) ^
         // (16 kj ^ 4 r)) + (16 mi + 4 r) KP with sq = swz(q) (swz(4 r + q) = sq ^ 4 r).  One lane constant XOR a compile-time constant each --
         // recomputed per chunk (the asm keeps the compiler from hoisting 32 of them out of the loop, which is what spilled)
         auto opl = [&](auto cc, int buf) {
@@ -88,9 +101,12 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
             asm volatile("" : "+v"(la), "+v"(lb));
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                if constexpr (c < N1) {
-                    const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
-                    op[buf][i] = cur[rowA + (la ^ (4 * s1)) + 16 * mi * KP];
+                if constexpr (c < N1) {              // chunk c of GEMM1 = contraction steps 2 c and 2 c + 1 of the four tiles: op[h * 4 + mi]
+                    if (i < 4) {
+                        const v2d pr = *reinterpret_cast<const v2d*>(cur + rowA + (la ^ (8 * c)) + 16 * i * KP);
+                        op[buf][i] = pr[0];
+                        op[buf][4 + i] = pr[1];
+                    }
                 } else {
                     const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
                     op[buf][i] = cur[rowB + (lb ^ ((16 * kj) ^ (4 * r))) + (16 * mi + 4 * r) * KP];
@@ -99,26 +115,25 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
         };
         auto run = [&](auto self, auto cc) -> void {
             constexpr int c = decltype(cc)::value;
-            if constexpr (c < YC) {          // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
-#pragma unroll
-                for (int i = 0; i < YPC; ++i) {
-                    const int idx = c * YPC + i, mi = idx >> 2, r = idx & 3;
-                    yv[mi][r] = TRANS ? ylane[(int64_t)b * 64 + 16 * mi + 4 * r] : ylane[((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY];
-                }
-            }
-            if constexpr (c >= LC0 && c < LC0 + NG) {
+            if constexpr (c < NG) {
                 if (more) {
 #pragma unroll
-                    for (int i = 0; i < GS; ++i) wtmp[c - LC0][i] = wb[tid + 256 * ((c - LC0) * GS + i)];
+                    for (int i = 0; i < GS; ++i) wtmp[c][i] = wb[tid + 256 * (c * GS + i)];
                 }
             }
-            if constexpr (c >= LC0 + 2 && c < LC0 + 2 + NG) {
+            if constexpr (c >= WD && c < WD + NG) {
                 if (more) {
 #pragma unroll
                     for (int i = 0; i < GS; ++i) {
-                        const int e = tid + 256 * ((c - LC0 - 2) * GS + i), r = e / KP, k = e - r * KP;
-                        nxt[r * KP + (k ^ b64_swz(r))] = wtmp[c - LC0 - 2][i];
+                        const int e = tid + 256 * ((c - WD) * GS + i), r = e / KP, k = e - r * KP;
+                        nxt[r * KP + (k ^ b64_swz(r))] = wtmp[c - WD][i];
                     }
+                }
+            }
+            if constexpr (c >= N1 && c < N1 + YC) {
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < YPC; ++i) y_req(b + 1, (c - N1) * YPC + i);
                 }
             }
             if constexpr (c + 1 < NCH) opl(std::integral_constant<int, c + 1>{}, (c + 1) & 1);
