@@ -14,7 +14,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
-SHAPES = [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (1500, 2000, 5), (65, 70, 17), (2048, 1024, 32), (130, 9000, 100), (64, 64, 33)]
+SHAPES = [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (1500, 2000, 5), (65, 70, 17), (2048, 1024, 32), (130, 9000, 100), (64, 64, 33),
+          (3, 400000, 2), (20000, 7, 3), (1, 70, 128), (129, 63, 65), (4097, 300, 1)]
 
 
 @pytest.fixture(scope="module")
