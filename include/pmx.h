@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 4
+#define PMX_ABI_VERSION 5
 
 /* ---- status codes -------------------------------------------------------------------- */
 enum {
@@ -64,7 +64,7 @@ enum {
                             kernel 9): A S takes the third fp16 terms of A and S (ah s3 + a3 sh beside ah sl + al sh) and keeps everything
                             but ah sh in a second accumulator, R = (P_hh - Y) + P_lo -- 5 instead of 3 products in that contraction.
                             Weighted contexts: the kernels of PMX_MODE_F16X2 (the missing term W o (A s_r + a_r s0) does not factor). */
-    PMX_MODE_F64 = 4     /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
+    PMX_MODE_F64 = 4,    /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  The fused loops of the three back-ends with this
                             library's operators and step rules: pmx_set_Y_host_f64, pmx_upload_f64 / pmx_download_f64,
                             pmx_pgm_begin / _run (pgm, FISTA), pmx_adaprox_begin / _run (all six schemes, warm start, constant
@@ -75,7 +75,10 @@ enum {
                             M N <= 2^20, M, N <= 8192: the reference's own examples and BASELINE cfg1) run fused launches of
                             plain fp64 FMAs (k_small_f64.hip); everything else up to K = 128 -- [r6] -- runs one
                             v_mfma_f64_16x16x4_f64 pass per gradient and the updates as plain launches (k_grad_f64.hip,
-                            k_big_f64.hip; PMX_F64_BIG=0 in the environment restores the fp32 computation of those shapes) */
+                            k_big_f64.hip; PMX_F64_BIG=0 in the environment restores the fp32 computation of those shapes),
+                            which also take WEIGHTS (pmx_set_W_host_f64) */
+    PMX_MODE_F64_MFMA = 6 /* [ABI v5] PMX_MODE_F64 on the matrix-core kernels whatever the shape (a weighted likelihood on a small
+                            problem; tests) */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */
@@ -194,6 +197,11 @@ int pmx_download(pmx_ctx* ctx, int buf, float* host, int64_t count);
  * PMX_BUF_MA .. _VHST (both directions), PMX_BUF_GA / _GST (download: the gradient pgm returns, algorithms.py:144) and bsdmm's
  * PMX_BUF_Z0 / _U0 + .. (download) */
 int pmx_set_Y_host_f64(pmx_ctx* ctx, const double* Y, int64_t ld);
+/* [ABI v5] the same from a float64 device buffer (row-major, pitch ld elements; copied: the context keeps its own padded array), and the
+ * weights of the likelihood (nmf.py:13-41: M x N, float64, host) of an fp64 context that runs the matrix-core kernels (NULL: back to W == 1;
+ * PMX_E_UNSUPPORTED in a context on the small-problem kernels: create it with PMX_MODE_F64_MFMA) */
+int pmx_set_Y_device_f64(pmx_ctx* ctx, const double* dY, int64_t ld);
+int pmx_set_W_host_f64(pmx_ctx* ctx, const double* W, int64_t ld);
 int pmx_upload_f64(pmx_ctx* ctx, int buf, const double* host, int64_t count);
 int pmx_download_f64(pmx_ctx* ctx, int buf, double* host, int64_t count);
 /* device address of a buffer (for zero-copy interop, e.g. torch.distributed on the comm buffer) */
@@ -228,7 +236,7 @@ int pmx_time_grad(pmx_ctx* ctx, int do_A, int do_S, int reps, double* avg_ms);
  * to tell which implementation produced a number: info[0] = kernel (0 exact-fp32 MFMA k_grad_f32, 1 split-bf16
  * k_grad_bf16*, 2 two-term fp16 k_grad_f16_v8, 4 the small-problem fp32 kernel k_grad_small, 5 two-term fp16 at K = 128
  * k_grad_f16_k128, 6 exact fp32 with producer / consumer wavefronts k_grad_f32_pc, 7 the fp64 small-problem kernels, 8 two-term fp16 at K = 32
- * k_grad_f16_k32, 9 / 10 k_grad_f16_v8<R3> / k_grad_f16_k32<R3>, 11 / 12 k_grad_f16_v8<HH> / k_grad_f16_k128<HH> + the correction slab of k_gfix.hip: PMX_MODE_F16X2R), info[1] = workgroups per gA chain (0: one gA slab per column region,
+ * k_grad_f16_k32, 9 / 10 k_grad_f16_v8<R3> / k_grad_f16_k32<R3>, 11 / 12 k_grad_f16_v8<HH> / k_grad_f16_k128<HH> + the correction slab of k_gfix.hip: PMX_MODE_F16X2R, 13 the fp64 matrix-core passes k64_grad_pass), info[1] = workgroups per gA chain (0: one gA slab per column region,
  * no chains), info[2] / info[3] = gA / gSt slabs the update kernels fold, info[4] x info[5] = row x column regions
  * (= workgroups), info[6] = row panels per region, info[7] = times this context left the chained mode after a fault
  * + 1000 x times it left the fused adaprox tail (k_ada_tail) + 1000000 if that tail is in use now + 10000000 if a two-term fp16 kernel

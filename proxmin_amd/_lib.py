@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get("PMX_LIB") or os.path.join(_HERE, "libpmx.so")   # PMX
 MAX_SEQ = 4
 MAX_G = 4
 MAXK = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums (include/pmx.h)
-MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64, MODE_F16X2R = 0, 2, 3, 4, 5
+MODE_F32, MODE_BF16X3, MODE_F16X2, MODE_F64, MODE_F16X2R, MODE_F64_MFMA = 0, 2, 3, 4, 5, 6
 PROX = {"id": 0, "zero": 1, "plus": 2, "unity": 3, "unity_plus": 4, "min": 5, "max": 6,
         "hard": 7, "hard_plus": 8, "soft": 9, "soft_plus": 10}
 SCHEME = {"adam": 0, "nadam": 1, "amsgrad": 2, "padam": 3, "adamx": 4, "radam": 5}
@@ -78,6 +78,8 @@ _SIGNATURES = {
     "pmx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pmx_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pmx_set_Y_host_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_set_Y_device_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pmx_set_W_host_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pmx_upload_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_download_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pmx_set_phase_timing": (C.c_int, [C.c_void_p, C.c_int]),

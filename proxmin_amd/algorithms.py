@@ -73,14 +73,19 @@ def _open_device(Y, A, S, W, f64=False):
     arrays are fp64 and the call is one the fp64 kernels cover (pgm / FISTA, small problem): compute in fp64 like the
     reference does for fp64 inputs (nmf.py:39-41)."""
     if f64:
-        try:
-            dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64")
+        try:                            # (a weighted likelihood: the matrix-core kernels whatever the shape -- the small-problem ones take no weights)
+            dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64" if W is None else "f64mfma", device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
         except NotImplementedError:     # the library's own test (pmx_ctx_create) is the authority: compute in fp32 and cast back, as for any other fp64 call
             dev = None
         if dev is not None:
             dev.set_Y(Y)
+            if W is not None:
+                dev.set_W(W)
             dev.set_factors(A, S)
             return dev
+    if isinstance(Y, DeviceArrayRef) and Y.dtype == np.float64:
+        raise NotImplementedError("a float64 device-resident Y is taken by the fp64 kernels only (library operators and step rules, no line search / "
+                                  "Barzilai-Borwein / user callables, K <= 128); hand this call a float32 array")
     _warn_f64_in_f32(Y, A, S)
     if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
         dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f32")
@@ -269,8 +274,8 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     # unweighted Lipschitz rule -- also when the likelihood carries weights)
     # [r4] fp64 inputs of a small problem, everything of the iteration on the device: fp64 arithmetic (PMX_MODE_F64)
     from .engine import f64_applies
-    f64 = (not slow and not backtracking and bb is None and W is None and Y is not None
-           and all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+    f64 = (not slow and not backtracking and bb is None and Y is not None and not isinstance(W, DeviceArrayRef)
+           and all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1], weighted=W is not None))
     with _open_device(Y, A, S, W, f64=f64) as dev:
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
                       e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
@@ -472,8 +477,8 @@ def adaprox(X, grad, step, prox=None, scheme="adam", b1=0.9, b2=0.999, eps=1e-8,
 
     # [r4] fp64 inputs of a small problem: fp64 arithmetic on the device (k_small_f64.hip: k64_ada_iter), as the reference's own
     from .engine import f64_applies
-    f64 = (not slow and W is None and Y is not None and all(x.dtype == np.float64 for x in (Y, A, S))
-           and f64_applies(A.shape[0], S.shape[1], A.shape[1]))
+    f64 = (not slow and Y is not None and not isinstance(W, DeviceArrayRef) and all(x.dtype == np.float64 for x in (Y, A, S))
+           and f64_applies(A.shape[0], S.shape[1], A.shape[1], weighted=W is not None))
     with _open_device(Y, A, S, W, f64=f64) as dev:
         for j in range(2):
             if warm:

@@ -15,6 +15,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 struct Pass64Args {
     const double* Y;
     int64_t ldY;
+    const double* Wt;        // weights of the likelihood (nmf.py:13-41), Y's shape and pitch; nullptr: W == 1 (the <HASW = false> instances)
     const double* F;         // fixed factor: rowsF x K (the gradient is taken with respect to it)
     const double* W;         // swept factor: rowsW x K
     double* slab;            // [nsplit][rowsF][K]
@@ -28,8 +29,8 @@ struct Pass64Args {
 // and 4 rows x 16 columns (the second product's B operand) -- then touch every pair of banks once per half-wave
 __device__ __forceinline__ int b64_swz(int row) { return ((row & 1) << 4) | (row & 14); }
 
-template <int KP, bool TRANS>
-__global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64Args a) {
+template <int KP, bool TRANS, bool HASW>
+__global__ __launch_bounds__(256, (KP <= 64 && !HASW ? 2 : 1)) void k64_grad_pass(Pass64Args a) {
     constexpr int KS = KP / 4, KJ = KP / 16, NLD = KP / 4;     // contraction steps, output tiles along K, doubles staged per thread and block
     // A block is 2 KP MFMAs per wave, issued in chunks of CH; everything else of the step hangs on that sequence (the scheduler is held to
     // it: left alone it hoists every LDS read of the block and spills, and a burst of 32 global loads in front of the first MFMA keeps the
@@ -64,11 +65,16 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
     double loss = 0.0;
     const double* ylane = a.Y + (int64_t)fcol * a.ldY + q;      // TRANS: this lane's corner of a tile
     const int64_t yoff = (int64_t)q * a.ldY + fcol;             // else: its offset from a tile's first row
-    v4d yv[4];
+    v4d yv[4], wv4[HASW ? 4 : 1];
+    const double* wlane = HASW ? a.Wt + (int64_t)fcol * a.ldY + q : nullptr;
     auto y_req = [&](int b, int idx) {      // T's accumulator layout: register r of tile mi = row 16 mi + q + 4 r, column l15
         const int mi = idx >> 2, r = idx & 3;
         if (TRANS) yv[mi][r] = ylane[(int64_t)b * 64 + 16 * mi + 4 * r];                 // one address per lane + immediates
         else yv[mi][r] = (a.Y + ((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY)[yoff];      // a scalar row base + one offset per lane
+        if constexpr (HASW) {
+            if (TRANS) wv4[mi][r] = wlane[(int64_t)b * 64 + 16 * mi + 4 * r];
+            else wv4[mi][r] = (a.Wt + ((int64_t)b * 64 + 16 * mi + 4 * r) * a.ldY)[yoff];
+        }
     };
     if (b0 < b1) {                   // the first block's rows of W and tile of Y
         const double* wb = a.W + (int64_t)b0 * 64 * KP;
@@ -148,14 +154,18 @@ __global__ __launch_bounds__(256, (KP <= 64 ? 2 : 1)) void k64_grad_pass(Pass64A
                     gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], op[c & 1][i], gacc[kj], 0, 0, 0);
                 }
             }
-            if constexpr (c == N1 - 1) {     // the residual (nmf.py:39), and its square for the likelihood
+            if constexpr (c == N1 - 1) {     // the residual D = W (A S - Y) (nmf.py:39), and sum W (A S - Y)^2 for the likelihood (nmf.py:25)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) t[mi] -= yv[mi];
                 if (a.lossPart != nullptr) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) loss += t[mi][r] * t[mi][r];
+                        for (int r = 0; r < 4; ++r) loss += HASW ? wv4[mi][r] * (t[mi][r] * t[mi][r]) : t[mi][r] * t[mi][r];
+                }
+                if constexpr (HASW) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) t[mi] *= wv4[mi];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -218,15 +228,21 @@ hipError_t launch_grad64_pass(const Pass64Args& a, int KP, bool trans, hipStream
     const int strips = (a.rowsF + 63) / 64;
     const size_t lds = (size_t)2 * 64 * KP * sizeof(double);
     const dim3 grid(strips * a.nsplit), block(256);
-#define PMX_PASS64(KPV, TR)                                                                                                              \
-    do {                                                                                                                                 \
-        hipError_t e_ = hipFuncSetAttribute((const void*)k64_grad_pass<KPV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        if (e_ != hipSuccess) return e_;                                                                                                 \
-        hipLaunchKernelGGL((k64_grad_pass<KPV, TR>), grid, block, lds, s, a);                                                            \
+#define PMX_PASS64(KPV, TR, HW)                                                                                                              \
+    do {                                                                                                                                     \
+        hipError_t e_ = hipFuncSetAttribute((const void*)k64_grad_pass<KPV, TR, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        if (e_ != hipSuccess) return e_;                                                                                                     \
+        hipLaunchKernelGGL((k64_grad_pass<KPV, TR, HW>), grid, block, lds, s, a);                                                            \
     } while (0)
-    if (KP == 32) { if (trans) PMX_PASS64(32, true); else PMX_PASS64(32, false); }
-    else if (KP == 64) { if (trans) PMX_PASS64(64, true); else PMX_PASS64(64, false); }
-    else { if (trans) PMX_PASS64(128, true); else PMX_PASS64(128, false); }
+#define PMX_PASS64_T(KPV)                                                                                         \
+    do {                                                                                                          \
+        if (a.Wt != nullptr) { if (trans) PMX_PASS64(KPV, true, true); else PMX_PASS64(KPV, false, true); }       \
+        else { if (trans) PMX_PASS64(KPV, true, false); else PMX_PASS64(KPV, false, false); }                     \
+    } while (0)
+    if (KP == 32) PMX_PASS64_T(32);
+    else if (KP == 64) PMX_PASS64_T(64);
+    else PMX_PASS64_T(128);
+#undef PMX_PASS64_T
 #undef PMX_PASS64
     return hipGetLastError();
 }

@@ -114,6 +114,8 @@ struct pmx_ctx {
     double* colpart64 = nullptr;           // [2][EW_BLOCKS][MAXK]
     int nsplit64[2] = {1, 1}, bps64[2] = {1, 1};   // sweep plan of the gradient pass of block j (0: gA, fixed factor A; 1: gSt, fixed factor St)
     int nsub64 = 4;                        // adaprox: proximal passes enqueued per iteration (follows the loops' lengths)
+    bool Wd_on = false;
+    double* Wd = nullptr;                  // weights of the likelihood (pmx_set_W_host_f64), Yd's shape and pitch; nullptr: W == 1
     double* Xk64[2] = {nullptr, nullptr};  // K1's padded operands (ceil64(rows) x KP), when the factors are not already that shape
     int64_t ldY64 = 0;                     // row pitch of Yd (ceil64(N): K1 loads without tests)
 
@@ -394,10 +396,12 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
     if (M <= 0 || N <= 0 || K <= 0) FAIL(PMX_E_INVALID, "bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     if (K > MAXK) FAIL(PMX_E_UNSUPPORTED, "K=%lld > %d components is not supported", (long long)K, MAXK);
     if (M > (1ll << 30) || N > (1ll << 30)) FAIL(PMX_E_UNSUPPORTED, "dimension too large");
+    const bool f64_mfma = mode == PMX_MODE_F64_MFMA;
+    if (f64_mfma) mode = PMX_MODE_F64;           // the matrix-core kernels whatever the shape
     const bool want_r3 = mode == PMX_MODE_F16X2R;
     if (want_r3) mode = PMX_MODE_F16X2;          // the same kernels, frames and fall-backs; k_grad_f16_v8 runs its <R3> instance
     if (mode != PMX_MODE_F32 && mode != PMX_MODE_BF16X3 && mode != PMX_MODE_F16X2 && mode != PMX_MODE_F64) FAIL(PMX_E_UNSUPPORTED, "compute mode %d is not built into this library", mode);
-    const bool f64_small = grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192;
+    const bool f64_small = !f64_mfma && grad_small_applies(M, N, K) && K <= 16 && M <= 8192 && N <= 8192;
     const bool f64_big_off = getenv("PMX_F64_BIG") && atoi(getenv("PMX_F64_BIG")) == 0;      // (A/B, and the way back to the fp32 computation of large fp64 problems)
     if (mode == PMX_MODE_F64 && !f64_small && (f64_big_off || (double)M * (double)N * 8.0 > 160e9))
         FAIL(PMX_E_UNSUPPORTED, "fp64 arithmetic is not available for %lld x %lld x %lld (%s); it runs in fp32",
@@ -862,6 +866,31 @@ extern "C" int pmx_set_Y_host_f64(pmx_ctx* c, const double* Y, int64_t ld) {
     HIP_CHECK(hipMemcpy2DAsync(c->Yd, (c->f64big ? c->ldY64 : c->N) * sizeof(double), Y, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->haveY = true;
+    return PMX_OK;
+}
+extern "C" int pmx_set_Y_device_f64(pmx_ctx* c, const double* dY, int64_t ld) {
+    if (!c || !dY) FAIL(PMX_E_INVALID, "NULL argument");
+    if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_Y_device_f64 needs a PMX_MODE_F64 context");
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemcpy2DAsync(c->Yd, (c->f64big ? c->ldY64 : c->N) * sizeof(double), dY, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyDeviceToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->haveY = true;
+    return PMX_OK;
+}
+extern "C" int pmx_set_W_host_f64(pmx_ctx* c, const double* W, int64_t ld) {
+    if (!c) FAIL(PMX_E_INVALID, "ctx is NULL");
+    if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_W_host_f64 needs a PMX_MODE_F64 context");
+    if (!W) { c->Wd_on = false; return PMX_OK; }
+    if (!c->f64big) FAIL(PMX_E_UNSUPPORTED, "the small-problem fp64 kernels take no weights; create the context with PMX_MODE_F64_MFMA");
+    if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
+    HIP_CHECK(hipSetDevice(c->device));
+    const int64_t Mp = (c->M + 63) / 64 * 64;
+    int rc = dallocT(c, &c->Wd, (size_t)Mp * c->ldY64);       // (zeroed once: the padding stays zero)
+    if (rc != PMX_OK) return rc;
+    HIP_CHECK(hipMemcpy2DAsync(c->Wd, c->ldY64 * sizeof(double), W, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->Wd_on = true;
     return PMX_OK;
 }
 static int buf_lookup_f64(pmx_ctx* c, int buf, bool writable, double** p, int64_t* count) {
@@ -1413,6 +1442,7 @@ static int enqueue_front64_big(pmx_ctx* c, const double* A, const double* St, in
             if (!want) continue;
             Pass64Args p{};
             p.Y = c->Yd; p.ldY = c->ldY64;
+            p.Wt = c->Wd_on ? c->Wd : nullptr;
             p.F = X[j]; p.W = X[1 - j];
             p.rowsF = (int)c->rows[j]; p.rowsW = (int)c->rows[1 - j];
             p.K = (int)c->K;
@@ -1787,6 +1817,8 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
         if (rc != PMX_OK) return rc;
     }
     if (c->f64) {                                // PMX_MODE_F64: plain pgm / FISTA with device operators and a device or fixed step
+        if (c->Wd_on && !p->use_fixed_steps && !p->unweighted_rule)     // nmf.step_pgm with an array W raises (nmf.py:63)
+            FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
         if (p->backtracking || p->bb_type || p->host_prox[0] || p->host_prox[1])
             FAIL(PMX_E_UNSUPPORTED, "fp64 contexts run pgm / FISTA with this library's operators and step rules (no line search, Barzilai-Borwein or user prox)");
         c->pgm = *p;
@@ -2853,7 +2885,7 @@ extern "C" int pmx_bsdmm_begin(pmx_ctx* c, const pmx_bsdmm_params* p) {
     int rc = require_ready(c, true);
     if (rc != PMX_OK) return rc;
     if (!p) FAIL(PMX_E_INVALID, "params is NULL");
-    if (c->W)                                          // bsdmm's steps come from nmf.step_pgm (nmf.py:187-193)
+    if (c->W || c->Wd_on)                              // bsdmm's steps come from nmf.step_pgm (nmf.py:187-193)
         FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
     for (int j = 0; j < 2; ++j) {
         rc = check_prox(p->prox_f[j], j ? "prox_S" : "prox_A");

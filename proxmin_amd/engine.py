@@ -59,7 +59,7 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def f64_applies(M, N, K):
+def f64_applies(M, N, K, weighted=False):
     """Shapes the fp64 kernels take (include/pmx.h: PMX_MODE_F64 -- the fused small-problem kernels for the reference's own examples
     and BASELINE cfg1, the MFMA passes of k_big_f64.hip for the rest up to K = 128); PMX_F64=0 switches the mode off (fp64 inputs are
     then computed in fp32 and cast back, with a warning)."""
@@ -73,9 +73,10 @@ def f64_applies(M, N, K):
             return True
     if off("PMX_F64"):
         return False
-    small = not off("PMX_K1_SMALL") and K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
-    # [r6] everything else up to K = 128: one MFMA pass per gradient (k_big_f64.hip); PMX_F64_BIG=0 keeps the small kernels only
-    return small or (not off("PMX_F64_BIG") and K <= 128 and 8.0 * M * N <= 160e9)
+    small = not weighted and not off("PMX_K1_SMALL") and K <= 16 and M <= 4096 and N <= 8192 and M * N <= (1 << 20)
+    # [r6] everything else up to K = 128 -- and every weighted likelihood -- : one MFMA pass per gradient (k_big_f64.hip);
+    # PMX_F64_BIG=0 keeps the small kernels only
+    return small or (not off("PMX_F64_BIG") and K <= 128 and 8.0 * M * N * (2 if weighted else 1) <= 160e9)
 
 
 def _vp(a):
@@ -84,14 +85,16 @@ def _vp(a):
 
 class DeviceArrayRef:
     """[r6] Y (or W) that is ALREADY in HBM: anything that speaks `__cuda_array_interface__` (a torch tensor on the GPU, a
-    CuPy array): float32, row-major, unit stride along the rows.  nmf() and the solvers adopt it zero-copy (pmx_set_Y_device)
+    CuPy array): float32 (or float64: [r6] copied into the fp64 context's own array), row-major, unit stride along the rows.  nmf() and the solvers adopt float32 zero-copy (pmx_set_Y_device)
     instead of uploading a host array -- the reference's Y lives in host RAM (nmf.py:96), ours may live where the kernels read it.
     The owner must keep its memory alive and unchanged for the duration of the call (the context holds a reference)."""
 
     def __init__(self, obj):
         cai = obj.__cuda_array_interface__
-        if cai.get("typestr") not in ("<f4", "=f4", "|f4"):
-            raise TypeError("a device-resident Y must be float32 (got %r)" % (cai.get("typestr"),))
+        ts = cai.get("typestr")
+        if ts not in ("<f4", "=f4", "|f4", "<f8", "=f8", "|f8"):
+            raise TypeError("a device-resident Y must be float32 or float64 (got %r)" % (ts,))
+        es = 8 if ts.endswith("8") else 4
         shape = tuple(int(v) for v in cai["shape"])
         if len(shape) != 2:
             raise TypeError("a device-resident Y must be two-dimensional")
@@ -99,11 +102,11 @@ class DeviceArrayRef:
         if strides is None:
             ld = shape[1]
         else:
-            if int(strides[1]) != 4 or int(strides[0]) % 4 or int(strides[0]) < 4 * shape[1]:
+            if int(strides[1]) != es or int(strides[0]) % es or int(strides[0]) < es * shape[1]:
                 raise TypeError("a device-resident Y must be row-major with unit stride along its rows")
-            ld = int(strides[0]) // 4
+            ld = int(strides[0]) // es
         self.ptr, self.shape, self.ld, self.owner = int(cai["data"][0]), shape, ld, obj
-        self.dtype = np.dtype(np.float32)
+        self.dtype = np.dtype(np.float64 if es == 8 else np.float32)
         self.ndim = 2
         dev = getattr(obj, "device", None)
         self.device = int(getattr(dev, "index", None) or 0) if dev is not None and not isinstance(dev, int) else int(dev or 0)
@@ -132,8 +135,8 @@ class DeviceNMF:
         self.device = device
         mode = mode or _DEFAULT_MODE
         self.mode = mode
-        self.f64 = mode == "f64"          # fp64 operands, products and sums (small problems, the fused loops of the three back-ends: k_small_f64.hip)
-        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f16x2r": _lib.MODE_F16X2R, "f64": _lib.MODE_F64}[mode]
+        self.f64 = mode in ("f64", "f64mfma")          # fp64 operands, products and sums (small problems, the fused loops of the three back-ends: k_small_f64.hip)
+        mode_id = {"f32": _lib.MODE_F32, "bf16x3": _lib.MODE_BF16X3, "f16x2": _lib.MODE_F16X2, "f16x2r": _lib.MODE_F16X2R, "f64": _lib.MODE_F64, "f64mfma": _lib.MODE_F64_MFMA}[mode]
         h = C.c_void_p()
         _lib.check(self.lib.pmx_ctx_create(C.byref(h), device, self.M, self.N, self.K, mode_id,
                                            C.c_void_p(stream) if stream else None))
@@ -141,7 +144,7 @@ class DeviceNMF:
         self._keep = []
         # a split-precision context that fell off its fast kernel says so once (pmx_k1_info knows): ragged shapes and
         # K outside {64, 128} run the generic split-bf16 kernels or the exact-fp32 one, 1.5-3 x slower per pass
-        if mode not in ("f32", "f64"):
+        if mode not in ("f32", "f64", "f64mfma"):
             k = self.k1_info()["kernel"]
             fast = {"f16x2": ("k_grad_f16_v8", "k_grad_f16_k128", "k_grad_f16_k32", "k_grad_small"), "bf16x3": ("k_grad_bf16", "k_grad_small"),
                     "f16x2r": ("k_grad_f16_v8_r3", "k_grad_f16_k32_r3", "k_grad_f16_v8_hh", "k_grad_f16_k128_hh", "k_grad_f16_k128", "k_grad_small")}[mode]
@@ -182,9 +185,17 @@ class DeviceNMF:
     # -- data -------------------------------------------------------------------------------
     def set_Y(self, Y):
         ref = as_device_array(Y)
-        if ref is not None:               # already in HBM: adopted in place (fp64 contexts: copied and widened by the library)
+        if ref is not None:               # already in HBM: float32 adopted in place; float64 copied into the fp64 context's own (padded) array
             assert ref.shape == (self.M, self.N), "Y must be M x N"
-            self.set_Y_device(ref.ptr, ld=ref.ld, copy=self.f64, keepalive=ref.owner)
+            if ref.dtype == np.float64:
+                if not self.f64:
+                    raise NotImplementedError("a float64 device-resident Y is taken by the fp64 kernels only (library operators and step rules, K <= 128); "
+                                              "this call computes in float32: hand it a float32 array")
+                _lib.check(self.lib.pmx_set_Y_device_f64(self.h, C.c_void_p(int(ref.ptr)), int(ref.ld)))
+                return
+            if self.f64:
+                raise NotImplementedError("an fp64 context takes a float64 Y")
+            self.set_Y_device(ref.ptr, ld=ref.ld, copy=False, keepalive=ref.owner)
             return
         Y = np.asarray(Y)
         assert Y.shape == (self.M, self.N), "Y must be M x N"
@@ -213,10 +224,14 @@ class DeviceNMF:
         shape; the split-bf16 mode only those of its default kernel (K = 64, M % 128 = 0, N % 256 = 0) and raises
         NotImplementedError otherwise -- see open_weighted()."""
         if W is None:
-            _lib.check(self.lib.pmx_set_W_host(self.h, None, 0))
+            _lib.check((self.lib.pmx_set_W_host_f64 if self.f64 else self.lib.pmx_set_W_host)(self.h, None, 0))
             return
         W = np.asarray(W)
         assert W.shape == (self.M, self.N), "W must be M x N"
+        if self.f64:                     # [r6] the fp64 matrix-core kernels take weights (mode "f64mfma" forces them on a small problem)
+            Wd = np.ascontiguousarray(W, dtype=np.float64)
+            _lib.check(self.lib.pmx_set_W_host_f64(self.h, _vp(Wd), self.N))
+            return
         Wf = _f32(W)
         _lib.check(self.lib.pmx_set_W_host(self.h, _vp(Wf), self.N))
 

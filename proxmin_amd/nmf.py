@@ -29,11 +29,11 @@ _AMBIGUOUS = "The truth value of an array with more than one element is ambiguou
 
 
 def _weights(W, shape):
-    """None for the reference's default W == 1, else the M x N float32 weight array (a scalar is broadcast)."""
+    """None for the reference's default W == 1, else the M x N weight array (a scalar is broadcast)."""
     if np.isscalar(W):
         if W == 1:
             return None
-        return np.full(shape, W, dtype=np.float32)
+        return np.full(shape, W, dtype=np.float64)      # (fp32 contexts round it to float32 as before; fp64 ones keep the caller's number)
     W = np.asarray(W)
     assert W.shape == tuple(shape), "W must be M x N"
     return W

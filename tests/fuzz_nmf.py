@@ -65,14 +65,15 @@ def run(seed, n_cases, only=None, F64=False, log=print):
         sd = int(crng.integers(1 << 30))
         DT = np.float64 if F64 else np.float32
         if F64:
-            weighted = bt = False
+            weighted = weighted and F64 == "big"       # (the matrix-core kernels take weights)
+            bt = False
             mode = "f32"                     # (the default mode: fp64 inputs of a small problem take the fp64 path by themselves)
         Y, A0, S0 = orc.synthetic_problem(M, N, K, DT, unity_S=(sS[0] == "unity_plus"), seed=sd)
         if sA[0] == "unity_plus":
             A0 = (A0 / A0.sum(axis=1, keepdims=True)).astype(DT)
         W = None
         if weighted:
-            W = (0.1 + 2.0 * crng.random((M, N))).astype(np.float32)
+            W = (0.1 + 2.0 * crng.random((M, N))).astype(DT)
             W[crng.random((M, N)) < 0.2] = 0
         desc = "%dx%dx%d %s %s its=%d W=%d accel=%d bt=%d proxA=%s proxS=%s%s" % (M, N, K, algo, mode, its, weighted, accel, bt, sA[0], sS[0], " " + scheme if algo == "adaprox" else "")
         pm.set_default_mode(mode)

@@ -132,7 +132,9 @@ def test_device_array_detection_is_host_only_logic():
     r = as_device_array(Fake())
     assert isinstance(r, DeviceArrayRef) and r.shape == (6, 8) and r.ld == 8 and r.ptr == 4096 and r.dtype == np.float32
     assert as_device_array(Fake(strides=(48, 4))).ld == 12          # rows of a wider array
-    for bad in (Fake(typestr="<f8"), Fake(shape=(6,)), Fake(strides=(32, 8)), Fake(strides=(16, 4))):
+    r8 = as_device_array(Fake(typestr="<f8", strides=(96, 8)))      # [r6] float64: taken by the fp64 kernels (copied into the context's own array)
+    assert r8.dtype == np.float64 and r8.ld == 12
+    for bad in (Fake(typestr="<f2"), Fake(typestr="<i4"), Fake(shape=(6,)), Fake(strides=(32, 8)), Fake(strides=(16, 4)), Fake(typestr="<f8", strides=(48, 4))):
         with pytest.raises(TypeError):
             as_device_array(bad)
     with pytest.raises(TypeError):

@@ -277,6 +277,78 @@ def test_bsdmm_stops_by_boyds_test_at_the_oracles_iteration(pm, orc):
     _close(S, So, rtol=1e-8)
 
 
+@pytest.mark.parametrize("M,N,K", [(384, 512, 64), (1000, 1500, 50), (256, 300, 128), (90, 210, 7), (65, 70, 17)])
+def test_weighted_likelihood(pm, orc, monkeypatch, M, N, K):
+    """nmf.py:13-41 with an M x N weight array, fp64: D = W (A S - Y), 1/2 sum W (A S - Y)^2 -- kernel level, then adaprox and pgm (with an
+    explicit step: the reference's default rule raises on a weight array, nmf.py:63) end to end.  Small shapes run the matrix-core kernels as
+    well (mode "f64mfma": the fused small-problem kernels take no weights)."""
+    from proxmin_amd.engine import DeviceNMF
+    ops = pm.operators
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=M + K)
+    rng = np.random.default_rng(17)
+    W = 0.2 + rng.random((M, N))
+    W[rng.random((M, N)) < 0.1] = 0
+    with DeviceNMF(M, N, K, mode="f64mfma") as dev:
+        assert dev.k1_info()["kernel"] == "k64_grad_pass"
+        dev.set_Y(Y)
+        dev.set_W(W)
+        dev.set_factors(A0, S0)
+        gA, gS = dev.grad()
+        loss = dev.loglike()
+        dev.set_W(None)
+        gA1, gS1 = dev.grad()
+    rA, rS = orc.residual_gradients(A0, S0, Y, W)
+    np.testing.assert_allclose(gA, rA, rtol=1e-12, atol=1e-12 * np.abs(rA).max())
+    np.testing.assert_allclose(gS, rS, rtol=1e-12, atol=1e-12 * np.abs(rS).max())
+    assert loss == pytest.approx(orc.half_sq_residual(A0, S0, Y, W), rel=1e-12)
+    uA, uS = orc.residual_gradients(A0, S0, Y)
+    np.testing.assert_allclose(gA1, uA, rtol=1e-12, atol=1e-12 * np.abs(uA).max())      # (weights taken away again)
+    seen = _spy(monkeypatch)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, W=W, algorithm=pm.adaprox, scheme="amsgrad", prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=6, e_rel=1e-4, check_convergence=False)
+    assert seen == [("f64mfma", "k64_grad_pass")], seen
+    Ao, So = A0.copy(), S0.copy()
+    orc.adaprox_nmf(Y, Ao, So, ("plus",), ("unity_plus", 0), scheme="amsgrad", max_iter=6, e_rel=1e-4, check_convergence=False, W=W)
+    _close(A, Ao)
+    _close(S, So)
+    A, S = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, A, S, W=W, step=pm.nmf.scaled_step_pgm(0.5), accelerated=True, max_iter=6, e_rel=1e-9)
+    Ao, So = A0.copy(), S0.copy()
+    orc.pgm_nmf(Y, Ao, So, step=lambda A_, S_, it=None, grads=None: tuple(0.5 * s_ for s_ in orc.lipschitz_steps(A_, S_)), accelerated=True, max_iter=6, e_rel=1e-9, W=W)
+    _close(A, Ao)
+    _close(S, So)
+    with pytest.raises(ValueError):          # the reference's own failure: `if W == 1` on an array (nmf.py:63)
+        pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
+
+
+def test_a_float64_Y_that_lives_on_the_gpu(pm, orc):
+    """a torch float64 tensor (or a pitched view of one) as Y: copied into the fp64 context's array on the device -- the same bits as the host array"""
+    import torch
+    ops = pm.operators
+    M, N, K = 500, 700, 40
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=4)
+    kw = dict(algorithm=pm.adaprox, scheme="adam", prox_S=partial(ops.prox_unity_plus, axis=0), max_iter=5, e_rel=1e-4, check_convergence=False)
+    Ah, Sh = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, Ah, Sh, **kw)
+    Yd = torch.from_numpy(Y).to("cuda:0")
+    Ad, Sd = A0.copy(), S0.copy()
+    pm.nmf.nmf(Yd, Ad, Sd, **kw)
+    assert Ad.dtype == np.float64 and np.array_equal(Ah, Ad) and np.array_equal(Sh, Sd)
+    wide = torch.zeros((M, N + 24), device="cuda:0", dtype=torch.float64)
+    wide[:, :N] = Yd
+    Ap, Sp = A0.copy(), S0.copy()
+    pm.nmf.nmf(wide[:, :N], Ap, Sp, **kw)
+    assert np.array_equal(Ah, Ap) and np.array_equal(Sh, Sp)
+    Y2, A2, S2 = orc.synthetic_problem(120, 200, 4, np.float64, seed=4)                   # a small problem: the fused small-problem kernels, same entry
+    Ah, Sh = A2.copy(), S2.copy()
+    pm.nmf.nmf(Y2, Ah, Sh, max_iter=5)
+    Ad, Sd = A2.copy(), S2.copy()
+    pm.nmf.nmf(torch.from_numpy(Y2).to("cuda:0"), Ad, Sd, max_iter=5)
+    assert np.array_equal(Ah, Ad) and np.array_equal(Sh, Sd)
+    with pytest.raises(NotImplementedError):                                               # what the fp64 kernels do not cover has no float64 device path
+        pm.nmf.nmf(Yd, A0.copy(), S0.copy(), backtracking=True, f=partial(pm.nmf.log_likelihood, Y=Y), max_iter=2)
+
+
 def test_switching_the_large_path_off_restores_the_fp32_computation_and_its_warning(pm, orc, monkeypatch, caplog):
     import logging
     from proxmin_amd import algorithms
