@@ -103,14 +103,14 @@ _f64_warned = []
 
 def _warn_f64_in_f32(Y, A, S):
     """[r6] The reference computes in the dtype of the caller's arrays (nmf.py:39-41: NumPy keeps fp64).  fp64 arrays that the fp64
-    kernels do not take (PMX_MODE_F64: all of the iteration on the device with library operators and step rules, no weights; PMX_F64_BIG=0) are computed in fp32 on the
+    kernels do not take (PMX_MODE_F64: all of the iteration on the device with library operators and step rules; PMX_F64_BIG=0) are computed in fp32 on the
     device and cast back: said ONCE, on logger "proxmin", so that nobody mistakes the result for an fp64 one."""
     if _f64_warned:
         return
     if any(getattr(x, "dtype", None) == np.float64 for x in (Y, A, S) if x is not None):
         _f64_warned.append(True)
         logger.warning("proxmin_amd: float64 arrays at %d x %d x %d are computed in float32 on the GPU and cast back (the fp64 kernels take "
-                       "library operators and step rules only: no weights, line search, Barzilai-Borwein or user callables); the reference would keep float64 here. "
+                       "library operators and step rules only: no line search, Barzilai-Borwein or user callables); the reference would keep float64 here. "
                        "Pass float32 arrays to silence this." % (A.shape[0], S.shape[1], A.shape[1]))
 
 

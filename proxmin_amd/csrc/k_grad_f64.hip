@@ -87,35 +87,42 @@ __global__ __launch_bounds__(256, (KP <= 64 && !HASW ? 2 : 1)) void k64_grad_pas
         for (int idx = 0; idx < 16; ++idx) y_req(b0, idx);
     }
     __syncthreads();
-    const int lcA = (2 * q) ^ b64_swz(l15), lcB = l15 ^ b64_swz(q), rowA = l15 * KP, rowB = q * KP;
+    const unsigned wS = (unsigned)(8 * ((tid / KP) * KP + ((tid % KP) ^ b64_swz(tid / KP))));       // this thread's slot of a staged block, rows tid / KP + (256 / KP) jj
+    const unsigned laR = (unsigned)(8 * (l15 * KP + ((2 * q) ^ b64_swz(l15)))), lbR = (unsigned)(8 * (q * KP + (l15 ^ b64_swz(q))));
     for (int b = b0; b < b1; ++b) {
-        const double* cur = wl + ((b - b0) & 1) * 64 * KP;
-        double* nxt = wl + (((b - b0) & 1) ^ 1) * 64 * KP;
+        const unsigned nxtB = (unsigned)((((b - b0) & 1) ^ 1) * 64 * KP * 8);
         const bool more = b + 1 < b1;
         const double* wb = a.W + (int64_t)(b + 1) * 64 * KP;
         v4d t[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) t[mi] = (v4d){0.0, 0.0, 0.0, 0.0};
         double op[2][CH], wtmp[NG][GS];
-        // operand addresses: column k of row r sits at k ^ b64_swz(r).  GEMM1's A operand: row 16 mi + l15, columns 8 c + 2 q + {0, 1}  ->  l15 KP +
-        // ((2 q ^ swz(l15)) ^ 8 c) + 16 mi KP (swz is even: the pair stays adjacent and 16-byte aligned); the second product's B operand: row 16 mi + 4 r + q, column 16 kj + l15  ->  q KP + ((l15 ^ sq) ^
-        // (16 kj ^ 4 r)) + (16 mi + 4 r) KP with sq = swz(q) (swz(4 r + q) = sq ^ 4 r).  One lane constant XOR a compile-time constant each --
-        // recomputed per chunk (the asm keeps the compiler from hoisting 32 of them out of the loop, which is what spilled)
+        // operand addresses (bytes): column k of row r sits at k ^ b64_swz(r).
+        //   GEMM1's A operand: row 16 mi + l15, columns 8 c + 2 q + {0, 1}  ->  [l15 KP + (2 q ^ swz(l15))] ^ 8 (c & 3), + 32 (c >> 2) + 16 mi KP
+        //   (swz is even: the pair stays adjacent and 16-byte aligned);
+        //   the second product's B operand: row 16 mi + 4 r + q, column 16 kj + l15  ->  [q KP + (l15 ^ swz(q))] ^ (16 (kj & 1) ^ 4 r), + 32 (kj >> 1) +
+        //   (16 mi + 4 r) KP   (swz(4 r + q) = swz(q) ^ 4 r).
+        // The bracket is one lane constant per product (+ this block's buffer); what is XORed touches bits 2..4 of the column only, everything else is
+        // an immediate offset of the read: one v_xor per variant and chunk (the asm keeps the compiler from hoisting all twelve variants out of the
+        // chunks -- that spilled --, per-operand address arithmetic cost 3.8 VALU instructions per MFMA)
+        const unsigned curB = (unsigned)(((b - b0) & 1) * 64 * KP * 8);
+        const char* ldsb = reinterpret_cast<const char*>(wl);
         auto opl = [&](auto cc, int buf) {
             constexpr int c = decltype(cc)::value;
-            int la = lcA, lb = lcB;
+            unsigned la = laR + curB, lb = lbR + curB;
             asm volatile("" : "+v"(la), "+v"(lb));
+            if constexpr (c < N1) {                  // chunk c of GEMM1 = contraction steps 2 c and 2 c + 1 of the four tiles: op[h * 4 + mi]
+                const unsigned base = la ^ (unsigned)(64 * (c & 3));
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if constexpr (c < N1) {              // chunk c of GEMM1 = contraction steps 2 c and 2 c + 1 of the four tiles: op[h * 4 + mi]
-                    if (i < 4) {
-                        const v2d pr = *reinterpret_cast<const v2d*>(cur + rowA + (la ^ (8 * c)) + 16 * i * KP);
-                        op[buf][i] = pr[0];
-                        op[buf][4 + i] = pr[1];
-                    }
-                } else {
+                for (int mi = 0; mi < 4; ++mi) {
+                    const v2d pr = *reinterpret_cast<const v2d*>(ldsb + base + (256 * (c >> 2) + 16 * mi * KP * 8));
+                    op[buf][mi] = pr[0];
+                    op[buf][4 + mi] = pr[1];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
                     const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
-                    op[buf][i] = cur[rowB + (lb ^ ((16 * kj) ^ (4 * r))) + (16 * mi + 4 * r) * KP];
+                    const unsigned base = lb ^ (unsigned)(8 * ((16 * (kj & 1)) ^ (4 * r)));
+                    op[buf][i] = *reinterpret_cast<const double*>(ldsb + base + (256 * (kj >> 1) + (16 * mi + 4 * r) * KP * 8));
                 }
             }
         };
@@ -130,9 +137,10 @@ __global__ __launch_bounds__(256, (KP <= 64 && !HASW ? 2 : 1)) void k64_grad_pas
             if constexpr (c >= WD && c < WD + NG) {
                 if (more) {
 #pragma unroll
-                    for (int i = 0; i < GS; ++i) {
-                        const int e = tid + 256 * ((c - WD) * GS + i), r = e / KP, k = e - r * KP;
-                        nxt[r * KP + (k ^ b64_swz(r))] = wtmp[c - WD][i];
+                    for (int i = 0; i < GS; ++i) {       // element tid + 256 jj of the block: row r0 + (256 / KP) jj, column tid % KP  ->  wS ^ 8 (rj & 14), + 8 rj KP
+                        constexpr int rj = (256 / KP) * ((c - WD) * GS);
+                        const int rji = rj + (256 / KP) * i;
+                        *reinterpret_cast<double*>(reinterpret_cast<char*>(wl) + ((wS + nxtB) ^ (unsigned)(8 * (rji & 14))) + 8 * rji * KP) = wtmp[c - WD][i];
                     }
                 }
             }
@@ -148,7 +156,10 @@ __global__ __launch_bounds__(256, (KP <= 64 && !HASW ? 2 : 1)) void k64_grad_pas
             for (int i = 0; i < CH; ++i) {
                 if constexpr (c < N1) {
                     const int g = c * CH + i, s1 = g >> 2, mi = g & 3;
-                    t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
+                    if constexpr (c == 0) {
+                        if (i < 4) t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);      // (the block's first product of a tile: C = 0 inline)
+                        else t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
+                    } else t[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[c & 1][i], ff[s1], t[mi], 0, 0, 0);
                 } else {
                     const int h = (c - N1) * CH + i, kj = h % KJ, mr = h / KJ, mi = mr >> 2, r = mr & 3;
                     gacc[kj] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[mi][r], op[c & 1][i], gacc[kj], 0, 0, 0);
