@@ -488,7 +488,8 @@ extern "C" int pmx_ctx_create(pmx_ctx** out, int device, int64_t M, int64_t N, i
         }
         const int64_t Mp64 = (M + 63) / 64 * 64, Np64 = (N + 63) / 64 * 64;
         c->ldY64 = c->f64big ? Np64 : N;
-        int rc64 = dallocT(c, &c->Yd, c->f64big ? (size_t)Mp64 * Np64 : (size_t)M * N, c->f64big && (Mp64 != M || Np64 != N));
+        // (the matrix-core path allocates Y when it arrives: a context that only evaluates the step rule -- nmf.step_pgm on fp64 factors -- holds nothing M x N)
+        int rc64 = c->f64big ? PMX_OK : dallocT(c, &c->Yd, (size_t)M * N, false);
         for (int j = 0; j < 2 && rc64 == PMX_OK && c->f64big; ++j)
             if (pad64_needed(c->rows[j], (int)K, c->KP)) rc64 = dallocT(c, &c->Xk64[j], (size_t)((c->rows[j] + 63) / 64 * 64) * c->KP);
         for (int j = 0; j < 2 && rc64 == PMX_OK; ++j) {
@@ -858,11 +859,19 @@ extern "C" int pmx_buffer_ptr(pmx_ctx* c, int buf, void** dptr, int64_t* count) 
 // ------------------------------------------------------------------------------------------------
 // PMX_MODE_F64: transfers of an fp64 context (k_small_f64.hip)
 // ------------------------------------------------------------------------------------------------
+// the matrix-core path's Y: ceil64(M) x ceil64(N), zero behind the real extents (allocated on first use)
+static int alloc_Y64(pmx_ctx* c) {
+    if (c->Yd || !c->f64big) return PMX_OK;
+    const int64_t Mp = (c->M + 63) / 64 * 64;
+    return dallocT(c, &c->Yd, (size_t)Mp * c->ldY64, Mp != c->M || c->ldY64 != c->N);
+}
 extern "C" int pmx_set_Y_host_f64(pmx_ctx* c, const double* Y, int64_t ld) {
     if (!c || !Y) FAIL(PMX_E_INVALID, "NULL argument");
     if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_Y_host_f64 needs a PMX_MODE_F64 context");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
+    int rcy = alloc_Y64(c);
+    if (rcy != PMX_OK) return rcy;
     HIP_CHECK(hipMemcpy2DAsync(c->Yd, (c->f64big ? c->ldY64 : c->N) * sizeof(double), Y, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->haveY = true;
@@ -873,6 +882,8 @@ extern "C" int pmx_set_Y_device_f64(pmx_ctx* c, const double* dY, int64_t ld) {
     if (!c->f64) FAIL(PMX_E_STATE, "pmx_set_Y_device_f64 needs a PMX_MODE_F64 context");
     if (ld < c->N) FAIL(PMX_E_INVALID, "ld %lld < N", (long long)ld);
     HIP_CHECK(hipSetDevice(c->device));
+    int rcy = alloc_Y64(c);
+    if (rcy != PMX_OK) return rcy;
     HIP_CHECK(hipMemcpy2DAsync(c->Yd, (c->f64big ? c->ldY64 : c->N) * sizeof(double), dY, ld * sizeof(double), c->N * sizeof(double), c->M, hipMemcpyDeviceToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->haveY = true;

@@ -48,7 +48,23 @@ def _device_for(A, S, Y, W=None):
     """Context with Y (and W) and the factors on the device (weights: engine.open_weighted picks the kernel)."""
     A, S = np.asarray(A), np.asarray(S)
     Y = as_device_array(Y) or np.asarray(Y)      # a Y that lives in HBM is adopted in place (engine.DeviceArrayRef)
-    dev = open_weighted(Y.shape[0], Y.shape[1], A.shape[1], W, device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
+    device = getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0
+    # [r6] float64 arrays: the fp64 kernels, like the reference's own arithmetic (nmf.py:39-41)
+    from .engine import f64_applies
+    if all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(Y.shape[0], Y.shape[1], A.shape[1], weighted=W is not None):
+        try:
+            dev = DeviceNMF(Y.shape[0], Y.shape[1], A.shape[1], device=device, mode="f64" if W is None else "f64mfma")
+        except NotImplementedError:
+            dev = None
+        if dev is not None:
+            dev.set_Y(Y)
+            if W is not None:
+                dev.set_W(W)
+            dev.set_factors(A, S)
+            return dev
+    if isinstance(Y, DeviceArrayRef) and Y.dtype == np.float64:
+        raise NotImplementedError("a float64 device-resident Y goes with float64 factors (the fp64 kernels, K <= 128)")
+    dev = open_weighted(Y.shape[0], Y.shape[1], A.shape[1], W, device=device)
     dev.set_Y(Y)
     dev.set_factors(A, S)
     return dev
@@ -85,7 +101,7 @@ class _Locked:
         return False
 
 
-def _factors_only(A, S):
+def _factors_only(A, S, f64_ok=False):
     """Context holding just the factors (the step rules never touch Y: nothing M x N is allocated or uploaded).  [r5] The last one is
     kept: the reference's FISTA idiom `step=lambda *X, it=None: tuple(.5 * s for s in step_pgm(*X))` calls this once per iteration,
     and a context per call (allocations, a stream, two uploads) cost more than the rule itself.  One shape and device at a time; the
@@ -94,7 +110,10 @@ def _factors_only(A, S):
     (PMX_DEVICE, default 0) as well, and closed by an atexit hook."""
     A, S = np.asarray(A), np.asarray(S)
     device = int(os.environ.get("PMX_DEVICE", "0"))
-    key = (device, A.shape[0], S.shape[1], A.shape[1])
+    # [r6] float64 factors: lambda_max from fp64 Gram matrices (the reference calls LAPACK on float64 arrays, utils.py:14-35)
+    from .engine import f64_applies
+    mode = "f64" if (f64_ok and A.dtype == np.float64 and S.dtype == np.float64 and f64_applies(A.shape[0], S.shape[1], A.shape[1])) else "f32"
+    key = (device, A.shape[0], S.shape[1], A.shape[1], mode)
     _FACTOR_LOCK.acquire()
     try:
         dev = _FACTOR_CTX.get(key)
@@ -102,7 +121,7 @@ def _factors_only(A, S):
             for old in _FACTOR_CTX.values():
                 old.close()
             _FACTOR_CTX.clear()
-            dev = _FACTOR_CTX[key] = DeviceNMF(key[1], key[2], key[3], device=device, mode="f32")
+            dev = _FACTOR_CTX[key] = DeviceNMF(key[1], key[2], key[3], device=device, mode=mode)
         dev.set_factors(A, S)
     except BaseException:
         _FACTOR_LOCK.release()
@@ -146,7 +165,7 @@ def step_pgm(*X, it=None, W=1):
     if W != 1:
         raise NotImplementedError("the weighted step rule of nmf.step_pgm (nmf.py:64-88) is not implemented; pass `step`")
     A, S = X
-    with _factors_only(A, S) as dev:       # no Y: the rule needs the two K x K Gram matrices only
+    with _factors_only(A, S, f64_ok=True) as dev:       # no Y: the rule needs the two K x K Gram matrices only
         return dev.step_pgm()
 
 

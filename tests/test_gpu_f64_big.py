@@ -321,6 +321,28 @@ def test_weighted_likelihood(pm, orc, monkeypatch, M, N, K):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
 
 
+def test_the_helper_functions_keep_float64(pm, orc):
+    """nmf.grad_likelihood / log_likelihood / step_pgm called by the caller's own code on float64 arrays (the reference: NumPy in float64)"""
+    M, N, K = 700, 900, 48
+    Y, A, S = orc.synthetic_problem(M, N, K, np.float64, seed=8)
+    W = 0.5 + np.random.default_rng(1).random((M, N))
+    for w in (None, W):
+        kw = {} if w is None else {"W": w}
+        gA, gS = pm.nmf.grad_likelihood(A, S, Y=Y, **kw)
+        rA, rS = orc.residual_gradients(A, S, Y, w)
+        assert gA.dtype == np.float64
+        np.testing.assert_allclose(gA, rA, rtol=1e-12, atol=1e-12 * np.abs(rA).max())
+        np.testing.assert_allclose(gS, rS, rtol=1e-12, atol=1e-12 * np.abs(rS).max())
+        assert pm.nmf.log_likelihood(A, S, Y=Y, **kw) == pytest.approx(orc.half_sq_residual(A, S, Y, w), rel=1e-12)
+    sA, sS = pm.nmf.step_pgm(A, S)
+    LA, LS = orc.lipschitz_steps(A, S)
+    assert sA == pytest.approx(LA, rel=1e-11) and sS == pytest.approx(LS, rel=1e-11)
+    sA2, sS2 = pm.nmf.step_pgm(A, S)                    # the cached factors-only context: a function of its arguments
+    assert (sA2, sS2) == (sA, sS)
+    s32 = pm.nmf.step_pgm(A.astype(np.float32), S.astype(np.float32))
+    assert s32[0] == pytest.approx(LA, rel=1e-5)
+
+
 def test_a_float64_Y_that_lives_on_the_gpu(pm, orc):
     """a torch float64 tensor (or a pitched view of one) as Y: copied into the fp64 context's array on the device -- the same bits as the host array"""
     import torch
