@@ -321,6 +321,24 @@ def test_weighted_likelihood(pm, orc, monkeypatch, M, N, K):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
 
 
+@pytest.mark.parametrize("backend", ["pgm", "adaprox", "bsdmm"])
+def test_runs_are_bit_reproducible(pm, orc, backend):
+    """no atomics, fixed summation order everywhere (slabs folded in order, partial sums folded in order): the same call gives the same bits"""
+    ops = pm.operators
+    M, N, K = 900, 1300, 72
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, unity_S=True, seed=12)
+    kw = {"pgm": dict(accelerated=True, step=pm.nmf.scaled_step_pgm(0.5)),
+          "adaprox": dict(algorithm=pm.adaprox, scheme="amsgrad", prox_S=partial(ops.prox_unity_plus, axis=0), check_convergence=False),
+          "bsdmm": dict(algorithm=pm.bsdmm, proxs_g=[[ops.prox_plus, partial(ops.prox_soft, thresh=1e-3)]] * 2)}[backend]
+    outs = []
+    for _ in range(3):
+        A, S = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A, S, max_iter=7, e_rel=1e-6, **kw)
+        outs.append((A, S))
+    for A, S in outs[1:]:
+        assert np.array_equal(A, outs[0][0]) and np.array_equal(S, outs[0][1])
+
+
 def test_the_helper_functions_keep_float64(pm, orc):
     """nmf.grad_likelihood / log_likelihood / step_pgm called by the caller's own code on float64 arrays (the reference: NumPy in float64)"""
     M, N, K = 700, 900, 48
