@@ -67,9 +67,9 @@ enum {
     PMX_MODE_F64 = 4,    /* [ABI v3] fp64 operands, products and sums -- what the reference computes for fp64 inputs
                             (nmf.py:39-41 keeps the dtype of its arguments).  The fused loops of the three back-ends with this
                             library's operators and step rules: pmx_set_Y_host_f64, pmx_upload_f64 / pmx_download_f64,
-                            pmx_pgm_begin / _run (pgm, FISTA), pmx_adaprox_begin / _run (all six schemes, warm start, constant
-                            steps), pmx_bsdmm_begin / _run, pmx_grad, pmx_loglike, pmx_step_pgm, pmx_iter_result; every other
-                            entry point (line search, Barzilai-Borwein, the *_split pieces for user callables, weights,
+                            pmx_pgm_begin / _run (pgm, FISTA; [r6] with the Beck-Teboulle line search on the matrix-core kernels), pmx_adaprox_begin / _run
+                            (all six schemes, warm start, constant steps), pmx_bsdmm_begin / _run, pmx_grad, pmx_loglike, pmx_step_pgm,
+                            pmx_iter_result; every other entry point (Barzilai-Borwein, the *_split pieces for user callables,
                             sharding) returns PMX_E_UNSUPPORTED in such a context -- the host wrappers compute those cases in
                             fp32 (and say so).  Two sets of kernels behind the same entry points: SMALL problems (K <= 16,
                             M N <= 2^20, M, N <= 8192: the reference's own examples and BASELINE cfg1) run fused launches of
@@ -77,8 +77,8 @@ enum {
                             v_mfma_f64_16x16x4_f64 pass per gradient and the updates as plain launches (k_grad_f64.hip,
                             k_big_f64.hip; PMX_F64_BIG=0 in the environment restores the fp32 computation of those shapes),
                             which also take WEIGHTS (pmx_set_W_host_f64) */
-    PMX_MODE_F64_MFMA = 6 /* [ABI v5] PMX_MODE_F64 on the matrix-core kernels whatever the shape (a weighted likelihood on a small
-                            problem; tests) */
+    PMX_MODE_F64_MFMA = 6 /* [ABI v5] PMX_MODE_F64 on the matrix-core kernels whatever the shape (a weighted likelihood or the line search on a
+                            small problem; tests) */
 };
 
 /* ---- proximal operators: proxmin/operators.py:20-160 ---------------------------------- */

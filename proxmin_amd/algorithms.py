@@ -68,13 +68,13 @@ def _host_gradient(dev, grad, dt, accelerated_eval=True):
     return Xe
 
 
-def _open_device(Y, A, S, W, f64=False):
+def _open_device(Y, A, S, W, f64=False, f64_mfma=False):
     """Context for one solver call; weights (nmf.py:13-41): engine.open_weighted picks the kernel.  f64: the caller's
     arrays are fp64 and the call is one the fp64 kernels cover (pgm / FISTA, small problem): compute in fp64 like the
     reference does for fp64 inputs (nmf.py:39-41)."""
     if f64:
         try:                            # (a weighted likelihood: the matrix-core kernels whatever the shape -- the small-problem ones take no weights)
-            dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64" if W is None else "f64mfma", device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
+            dev = DeviceNMF(A.shape[0], S.shape[1], A.shape[1], mode="f64" if (W is None and not f64_mfma) else "f64mfma", device=getattr(Y, "device", 0) if isinstance(Y, DeviceArrayRef) else 0)
         except NotImplementedError:     # the library's own test (pmx_ctx_create) is the authority: compute in fp32 and cast back, as for any other fp64 call
             dev = None
         if dev is not None:
@@ -84,7 +84,7 @@ def _open_device(Y, A, S, W, f64=False):
             dev.set_factors(A, S)
             return dev
     if isinstance(Y, DeviceArrayRef) and Y.dtype == np.float64:
-        raise NotImplementedError("a float64 device-resident Y is taken by the fp64 kernels only (library operators and step rules, no line search / "
+        raise NotImplementedError("a float64 device-resident Y is taken by the fp64 kernels only (library operators and step rules, no "
                                   "Barzilai-Borwein / user callables, K <= 128); hand this call a float32 array")
     _warn_f64_in_f32(Y, A, S)
     if Y is None:                       # a user `grad`: nothing M x N on the device (engine.DeviceNMF.set_host_grad)
@@ -110,7 +110,7 @@ def _warn_f64_in_f32(Y, A, S):
     if any(getattr(x, "dtype", None) == np.float64 for x in (Y, A, S) if x is not None):
         _f64_warned.append(True)
         logger.warning("proxmin_amd: float64 arrays at %d x %d x %d are computed in float32 on the GPU and cast back (the fp64 kernels take "
-                       "library operators and step rules only: no line search, Barzilai-Borwein or user callables); the reference would keep float64 here. "
+                       "library operators and step rules only: no Barzilai-Borwein or user callables); the reference would keep float64 here. "
                        "Pass float32 arrays to silence this." % (A.shape[0], S.shape[1], A.shape[1]))
 
 
@@ -274,9 +274,10 @@ def pgm(X, grad, step, prox=None, accelerated=False, backtracking=False, f=None,
     # unweighted Lipschitz rule -- also when the likelihood carries weights)
     # [r4] fp64 inputs of a small problem, everything of the iteration on the device: fp64 arithmetic (PMX_MODE_F64)
     from .engine import f64_applies
-    f64 = (not slow and not backtracking and bb is None and Y is not None and not isinstance(W, DeviceArrayRef)
-           and all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1], weighted=W is not None))
-    with _open_device(Y, A, S, W, f64=f64) as dev:
+    # [r6] ... at any size up to K = 128, weighted or not, with the Beck-Teboulle line search (the matrix-core kernels: k_big_f64.hip)
+    f64 = (not slow and bb is None and Y is not None and not isinstance(W, DeviceArrayRef)
+           and all(x.dtype == np.float64 for x in (Y, A, S)) and f64_applies(A.shape[0], S.shape[1], A.shape[1], weighted=W is not None or backtracking))
+    with _open_device(Y, A, S, W, f64=f64, f64_mfma=backtracking) as dev:
         dev.pgm_begin(seqs, accelerated=accelerated, step_scale=scale, fixed_steps=(1.0, 1.0) if user_step is not None else fixed,
                       e_rel=e_rel, bb=(bb.type, bb.r) if bb is not None else None, backtracking=backtracking,
                       host_prox=[h is not None for h in host_prox], unweighted_rule=W is not None and user_step is None and fixed is None and bb is None)

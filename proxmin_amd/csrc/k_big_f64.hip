@@ -7,7 +7,7 @@
 // (a PMX_MODE_F64 context whose shape is outside the small kernels' takes these launches instead), so a caller with fp64
 // arrays gets fp64 results at BASELINE's sizes too.
 //
-//   k64_grad_pass<KP, TRANS>   K1 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, 78.6 TFLOP/s on this part -- the same
+//   k64_grad_pass<KP, TRANS, HASW>  (k_grad_f64.hip)  K1 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, 78.6 TFLOP/s on this part -- the same
 //                              as the vector fp64 rate, but with 16 x less operand traffic per FLOP).  ONE gradient per
 //                              launch: a workgroup owns 64 rows of the "fixed" factor F (St for gSt, A for gA: its fragments
 //                              stay in registers) and sweeps the other factor W in blocks of 64 rows through LDS;
@@ -23,8 +23,9 @@
 //                              (nmf.py:181-185), pays nothing.  MFMA-bound: 2 KP instructions of 64 cycles per wave and block
 //                              against 8 KB of Y -- the HBM stream is ~20 % of its roof at K = 64.
 //   k64_gram_partial<KP> / k64_gram_reduce   the step rule's Gram matrices from fp64 rows (nmf.py:44-65), then k_eig with
-//                              EigArgs::force_exact (lambda_max to fp64 round-off), as k64_front does for small problems;
+//                              EigArgs::force_exact = 2 (power steps on the fp64 matrix: lambda_max to fp64 round-off without the O(K^3) exact solver);
 //   k64b_pgm_update<NC>        k64_pgm_update for K <= 128 (a row = half a wave, NC = ceil(K / 32) values per lane);
+//   k64b_bt_update / _bt_finish  the Beck-Teboulle line search's trial update and the next evaluation point (host-driven trials);
 //   k64b_bsdmm_update<NC>      k64_bsdmm_block spread over the grid + k_bsdmm_decide (the fp32 path's, it only ever saw fp64 sums);
 //   k64b_colsum / _alpha / _ada_moment / _ada_sub / _ada_finish / _ada_decide
 //                              k64_ada_iter as a chain of launches.  The proximal sub-iteration loop (algorithms.py:380-400)
@@ -218,6 +219,95 @@ __global__ __launch_bounds__(256) void k64b_fold(Fold64Args a) {
     }
 }
 void launch_fold64b(const Fold64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64b_fold, dim3(1024, 2), dim3(256), 0, s, a); }
+
+// ------------------------------------------------------------------------------------------------
+// pgm with the Beck-Teboulle line search (algorithms.py:110-128) in fp64: the trial update of the blocks in `do_block`,
+//   X_j = prox_j(E_j - T_j s_j G_j, T_j s_j)                                   (:108, :125)
+// and what the test and the choice of the block to shrink need of it: sum (X - X_).G, sum (X - X_)^2, sum X^2, max |G|, max |X_|
+// (slots SL_BT0, SL_DIFF2, SL_NORM2, SL_BT0 + 1, SL_BT0 + 2; the host folds them: the loop is data-dependent and every trial ends
+// in an evaluation of the likelihood anyway -- pmx_api.hip: pgm64_bt_iteration).  grid (EW_BLOCKS, 2)
+// ------------------------------------------------------------------------------------------------
+struct Bt64Args {
+    double* X[2];
+    const double* E[2];      // evaluation point _X (algorithms.py:93-99)
+    const double* Xp[2];     // X_ : the iterate before this iteration
+    const double* G[2];      // gradient at E (folded)
+    int64_t rows[2];
+    int K;
+    ProxSeq prox[2];
+    const DevStatus* status;
+    double T[2];
+    int do_block[2];
+    double* partials;
+};
+template <int NC>
+__global__ __launch_bounds__(EW_THREADS) void k64b_bt_update(Bt64Args a) {
+    __shared__ double scratch[3 * EW_WAVES];
+    __shared__ double smax[2][EW_WAVES];
+    const int j = blockIdx.y;
+    if (chain_halted(a.status) || !a.do_block[j]) return;
+    const double ts = a.T[j] * a.status->step[j];
+    const int64_t rows = a.rows[j];
+    const int K = a.K, l32 = threadIdx.x & 31;
+    bool ok[NC];
+    double sk[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ok[c] = l32 + 32 * c < K; sk[c] = ts; }
+    double red[3] = {0.0, 0.0, 0.0}, mg = 0.0, mx = 0.0;
+    const int64_t hw = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 5, nhw = ((int64_t)gridDim.x * EW_THREADS) >> 5;
+    for (int64_t r = hw; r < rows; r += nhw) {
+        double g[NC], xp[NC], v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int64_t e = r * K + l32 + 32 * c;
+            g[c] = ok[c] ? a.G[j][e] : 0.0;
+            xp[c] = ok[c] ? a.Xp[j][e] : 0.0;
+            v[c] = (ok[c] ? a.E[j][e] : 0.0) - ts * g[c];
+        }
+        prox64b_row<NC>(v, ok, a.prox[j], sk);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (!ok[c]) continue;
+            a.X[j][r * K + l32 + 32 * c] = v[c];
+            const double d = v[c] - xp[c];
+            red[0] += d * g[c];
+            red[1] += d * d;
+            red[2] += v[c] * v[c];
+            mg = nanmax(mg, fabs(g[c]));
+            mx = nanmax(mx, fabs(xp[c]));
+        }
+    }
+    mg = wave_nanmax(mg);
+    mx = wave_nanmax(mx);
+    if ((threadIdx.x & 63) == 0) { smax[0][threadIdx.x >> 6] = mg; smax[1][threadIdx.x >> 6] = mx; }
+    double r0[1] = {red[0]}, r12[2] = {red[1], red[2]};
+    block_sum_store<1>(r0, part_ptr(a.partials, SL_BT0, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    __syncthreads();
+    block_sum_store<2>(r12, part_ptr(a.partials, SL_DIFF2, j) + blockIdx.x, (int64_t)2 * EW_BLOCKS, scratch);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m0 = smax[0][0], m1 = smax[1][0];
+        for (int qw = 1; qw < EW_WAVES; ++qw) { m0 = nanmax(m0, smax[0][qw]); m1 = nanmax(m1, smax[1][qw]); }
+        part_ptr(a.partials, SL_BT0 + 1, j)[blockIdx.x] = m0;
+        part_ptr(a.partials, SL_BT0 + 2, j)[blockIdx.x] = m1;
+    }
+}
+// after the line search settled: the next iteration's evaluation point E = X + omega (X - X_) (algorithms.py:93-99; omega = 0: a copy); grid (1024, 2)
+struct BtFin64Args { const double* X[2]; const double* Xp[2]; double* E[2]; int64_t count[2]; double omega; const DevStatus* status; };
+__global__ __launch_bounds__(256) void k64b_bt_finish(BtFin64Args a) {
+    const int j = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.count[j]; e += (int64_t)gridDim.x * 256) {
+        const double x = a.X[j][e];
+        a.E[j][e] = x + a.omega * (x - a.Xp[j][e]);
+    }
+}
+void launch_bt64_update(const Bt64Args& a, hipStream_t s) {
+    const dim3 grid(EW_BLOCKS, 2), block(EW_THREADS);
+    if (a.K <= 32) hipLaunchKernelGGL(k64b_bt_update<1>, grid, block, 0, s, a);
+    else if (a.K <= 64) hipLaunchKernelGGL(k64b_bt_update<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k64b_bt_update<4>, grid, block, 0, s, a);
+}
+void launch_bt64_finish(const BtFin64Args& a, hipStream_t s) { hipLaunchKernelGGL(k64b_bt_finish, dim3(1024, 2), dim3(256), 0, s, a); }
 
 // ------------------------------------------------------------------------------------------------
 // bSDMM block update (algorithms.py:805-844, utils.py:269-391; identity L) over the grid; its sums go to the reduction slots

@@ -115,6 +115,7 @@ struct pmx_ctx {
     int nsplit64[2] = {1, 1}, bps64[2] = {1, 1};   // sweep plan of the gradient pass of block j (0: gA, fixed factor A; 1: gSt, fixed factor St)
     int nsub64 = 4;                        // adaprox: proximal passes enqueued per iteration (follows the loops' lengths)
     bool Wd_on = false;
+    double* Xprevd[2] = {nullptr, nullptr}; // pgm line search in fp64: X_ (algorithms.py:102)
     double* Wd = nullptr;                  // weights of the likelihood (pmx_set_W_host_f64), Yd's shape and pitch; nullptr: W == 1
     double* Xk64[2] = {nullptr, nullptr};  // K1's padded operands (ceil64(rows) x KP), when the factors are not already that shape
     int64_t ldY64 = 0;                     // row pitch of Yd (ceil64(N): K1 loads without tests)
@@ -1554,6 +1555,100 @@ static int pgm64_enqueue_iteration(pmx_ctx* c) {
     return PMX_OK;
 }
 
+// [r6] one pgm iteration with the Beck-Teboulle line search (algorithms.py:93-135) in fp64: host-driven -- every trial ends in an evaluation
+// of the likelihood whose value decides the next step, so the chain cannot run ahead anyway
+static int loss64_now(pmx_ctx* c, const double* A, const double* St, double* out) {
+    int rc = enqueue_front64(c, A, St, 0, 0, true, false, 1.0);
+    if (rc != PMX_OK) return rc;
+    std::vector<double> h(c->nloss);
+    HIP_CHECK(hipMemcpyAsync(h.data(), c->lossPart, c->nloss * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *out = 0.5 * s;
+    return PMX_OK;
+}
+static int pgm64_bt_iteration(pmx_ctx* c) {
+    const pmx_pgm_params& p = c->pgm;
+    int rc = PMX_OK;
+    if (c->it == 0) {                                            // f_prev = f(X_) (algorithms.py:113-114)
+        rc = loss64_now(c, c->Xd[0], c->Xd[1], &c->bt_fprev);
+        if (rc != PMX_OK) return rc;
+    }
+    for (int j = 0; j < 2; ++j)                                  // X_ = copy of X (:102)
+        HIP_CHECK(hipMemcpyAsync(c->Xprevd[j], c->Xd[j], c->rows[j] * c->K * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    rc = enqueue_front64(c, c->Xed[0], c->Xed[1], 1, 1, true, !p.use_fixed_steps, (double)p.step_scale);      // G, S at _X (:105-106)
+    if (rc != PMX_OK) return rc;
+    Fold64Args f{};
+    for (int j = 0; j < 2; ++j) { f.slab[j] = c->slabd[j]; f.nslab[j] = j == 0 ? c->nSlabA : c->nSlabS; f.G[j] = c->Gd[j]; f.count[j] = c->rows[j] * c->K; }
+    launch_fold64b(f, c->stream);
+    Bt64Args u{};
+    for (int j = 0; j < 2; ++j) {
+        u.X[j] = c->Xd[j]; u.E[j] = c->Xed[j]; u.Xp[j] = c->Xprevd[j]; u.G[j] = c->Gd[j];
+        u.rows[j] = c->rows[j];
+        u.prox[j] = to_dev(p.prox[j]);
+        u.do_block[j] = 1;
+    }
+    u.K = (int)c->K;
+    u.status = c->dstatus;
+    u.partials = c->partials;
+    std::vector<double> hp((size_t)SL_COUNT * 2 * EW_BLOCKS);
+    double sums[2][5] = {};                                      // per block: (X - X_).G, (X - X_)^2, X^2, max |G|, max |X_|
+    double f_now = 0.0;
+    for (int trial = 0;; ++trial) {
+        u.T[0] = c->btT[0]; u.T[1] = c->btT[1];
+        launch_bt64_update(u, c->stream);                        // :108 / :125
+        HIP_CHECK(hipGetLastError());
+        rc = loss64_now(c, c->Xd[0], c->Xd[1], &f_now);          // f(*X) (:112, :126)
+        if (rc != PMX_OK) return rc;
+        HIP_CHECK(hipMemcpyAsync(hp.data(), c->partials, hp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        rc = read_status(c);
+        if (rc != PMX_OK) return rc;
+        auto slot = [&](int sl, int j) { return hp.data() + ((size_t)sl * 2 + j) * EW_BLOCKS; };
+        for (int j = 0; j < 2; ++j) {
+            if (!u.do_block[j]) continue;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, m0 = 0.0, m1 = 0.0;
+            for (int b = 0; b < EW_BLOCKS; ++b) {                // fixed order
+                s0 += slot(SL_BT0, j)[b]; s1 += slot(SL_DIFF2, j)[b]; s2 += slot(SL_NORM2, j)[b];
+                const double g = slot(SL_BT0 + 1, j)[b], x = slot(SL_BT0 + 2, j)[b];
+                m0 = (g != g || m0 != m0) ? NAN : std::max(m0, g);
+                m1 = (x != x || m1 != m1) ? NAN : std::max(m1, x);
+            }
+            sums[j][0] = s0; sums[j][1] = s1; sums[j][2] = s2; sums[j][3] = m0; sums[j][4] = m1;
+        }
+        double q = 0.0;
+        for (int j = 0; j < 2; ++j) q += sums[j][0] + 0.5 / (c->btT[j] * c->hstatus->step[j]) * sums[j][1];      // Beck & Teboulle, eq. 3.2 (:117-118)
+        if (!(f_now > c->bt_fprev + q)) break;
+        if (trial > 1100) FAIL(PMX_E_STATE, "pgm (fp64): the line search does not terminate");       // (T underflows to 0 after 1075 halvings)
+        const double r0 = c->hstatus->step[0] * sums[0][3] / sums[0][4], r1 = c->hstatus->step[1] * sums[1][3] / sums[1][4];
+        const int jm = (r1 > r0) ? 1 : 0;                        // np.argmax: the first of equals; a NaN in front wins (:121)
+        const int jmax = (r0 != r0) ? 0 : ((r1 != r1) ? 1 : jm);
+        c->btT[jmax] /= 2;                                       // :122
+        u.do_block[0] = jmax == 0; u.do_block[1] = jmax == 1;
+    }
+    c->bt_fprev = f_now;                                         // :127
+    // the stopping test (:130-135) from the sums of the accepted trial: k_pgm_decide folds the same slots
+    DecideArgs d{};
+    d.status = c->dstatus; d.partials = c->partials;
+    d.e_rel[0] = p.e_rel[0]; d.e_rel[1] = p.e_rel[1];
+    d.check = 1;
+    launch_pgm_decide(d, c->stream);
+    BtFin64Args fin{};
+    double om = 0.0;
+    if (p.accelerated) {                                         // omega the NEXT iteration reads (utils.py:198-206)
+        const double t = c->nest_t, t1 = 0.5 * (1.0 + sqrt(4.0 * t * t + 1.0));
+        om = (t - 1.0) / t1;
+        c->nest_t = t1;
+    }
+    for (int j = 0; j < 2; ++j) { fin.X[j] = c->Xd[j]; fin.Xp[j] = c->Xprevd[j]; fin.E[j] = c->Xed[j]; fin.count[j] = c->rows[j] * c->K; }
+    fin.omega = om;
+    fin.status = c->dstatus;
+    launch_bt64_finish(fin, c->stream);
+    HIP_CHECK(hipGetLastError());
+    c->it += 1;
+    return PMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // single operations
 // ------------------------------------------------------------------------------------------------
@@ -1830,20 +1925,24 @@ extern "C" int pmx_pgm_begin(pmx_ctx* c, const pmx_pgm_params* p) {
     if (c->f64) {                                // PMX_MODE_F64: plain pgm / FISTA with device operators and a device or fixed step
         if (c->Wd_on && !p->use_fixed_steps && !p->unweighted_rule)     // nmf.step_pgm with an array W raises (nmf.py:63)
             FAIL(PMX_E_INVALID, "The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()");
-        if (p->backtracking || p->bb_type || p->host_prox[0] || p->host_prox[1])
-            FAIL(PMX_E_UNSUPPORTED, "fp64 contexts run pgm / FISTA with this library's operators and step rules (no line search, Barzilai-Borwein or user prox)");
+        if ((p->backtracking && !c->f64big) || p->bb_type || p->host_prox[0] || p->host_prox[1])
+            FAIL(PMX_E_UNSUPPORTED, "fp64 contexts run pgm / FISTA with this library's operators and step rules (no Barzilai-Borwein or user prox; the line search on the matrix-core kernels only: PMX_MODE_F64_MFMA)");
         c->pgm = *p;
         c->algo = ALG_PGM;
         c->it = 0;
         c->nest_t = 1.0;
         rc = reset_status(c);
         if (rc != PMX_OK) return rc;
-        if (p->accelerated) {
+        c->btT[0] = c->btT[1] = 1.0;
+        if (p->accelerated || p->backtracking) {      // (the line search keeps the evaluation point apart from the iterate: algorithms.py:96-97)
             for (int j = 0; j < 2; ++j) {
                 rc = dallocT(c, &c->Xed[j], (size_t)c->rows[j] * c->K, false);
+                if (rc == PMX_OK && p->backtracking) rc = dallocT(c, &c->Xprevd[j], (size_t)c->rows[j] * c->K, false);
                 if (rc != PMX_OK) return rc;
                 HIP_CHECK(hipMemcpyAsync(c->Xed[j], c->Xd[j], c->rows[j] * c->K * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             }
+        }
+        if (p->accelerated) {
             c->nest_t = 0.5 * (1.0 + sqrt(4.0 * c->nest_t * c->nest_t + 1.0));       // the first omega (== 0) is consumed at it = 0
         }
         return PMX_OK;
@@ -2183,6 +2282,16 @@ extern "C" int pmx_pgm_run(pmx_ctx* c, int n_iter, pmx_result* res) {
     if (c->pgm.use_fixed_steps) {
         rc = set_fixed_steps(c, c->pgm.fixed_steps);
         if (rc != PMX_OK) return rc;
+    }
+    if (c->f64 && c->pgm.backtracking) {     // [r6] host-driven trials: one iteration at a time
+        for (int i = 0; i < n_iter && !c->hstatus->stopped; ++i) {
+            rc = pgm64_bt_iteration(c);
+            if (rc != PMX_OK) return rc;
+            rc = read_status(c);
+            if (rc != PMX_OK) return rc;
+        }
+        fill_result(c, res, it0);
+        return PMX_OK;
     }
     if (c->f64) {
         for (int left = n_iter; left > 0 && !c->hstatus->stopped; left -= 32) {

@@ -321,6 +321,66 @@ def test_weighted_likelihood(pm, orc, monkeypatch, M, N, K):
         pm.nmf.nmf(Y, A0.copy(), S0.copy(), W=W, max_iter=2)
 
 
+@pytest.mark.parametrize("M,N,K,accelerated", [(100, 50, 3, False), (100, 50, 3, True), (700, 900, 40, False), (300, 420, 128, True)])
+def test_pgm_with_the_line_search(pm, orc, monkeypatch, M, N, K, accelerated):
+    """algorithms.py:110-128 (Beck & Teboulle's backtracking, the reference's own example: examples/unmixing.py:134 on float64 arrays) in fp64:
+    factors, the returned gradient, the stopping iteration.  Fixed steps four times the Lipschitz ones force halvings; the first shape is the
+    example's (the matrix-core kernels whatever the size: mode "f64mfma")."""
+    seen = _spy(monkeypatch)
+    Y, A0, S0 = orc.synthetic_problem(M, N, K, np.float64, seed=5)
+    sA, sS = orc.lipschitz_steps(A0, S0)
+    fixed = (4 * sA, 4 * sS)
+    f = partial(pm.nmf.log_likelihood, Y=Y)
+    A, S = A0.copy(), S0.copy()
+    tb = pm.utils.Traceback()
+    conv, G, steps = pm.nmf.nmf(Y, A, S, step=pm.nmf.constant_step(*fixed), backtracking=True, f=f, accelerated=accelerated, max_iter=12, e_rel=1e-9, callback=tb)
+    assert seen[0] == ("f64mfma", "k64_grad_pass"), seen
+    Ao, So = A0.copy(), S0.copy()
+    trace = []
+    oret = orc.pgm_nmf(Y, Ao, So, step=lambda a, s, it, g: fixed, accelerated=accelerated, backtracking=True, max_iter=12, e_rel=1e-9, trace=trace)
+    assert len(tb.trace) == len(trace) and tuple(conv) == tuple(oret[0])
+    _close(A, Ao, rtol=1e-8)
+    _close(S, So, rtol=1e-8)
+    _close(G[0], oret[1][0], rtol=1e-7)
+    _close(tb.trace[2][0], trace[2][0], rtol=1e-8)
+    # chained (no callback): the same bits; the default rule (no halvings, the reference's example) against the oracle
+    Ac, Sc = A0.copy(), S0.copy()
+    pm.nmf.nmf(Y, Ac, Sc, step=pm.nmf.constant_step(*fixed), backtracking=True, f=f, accelerated=accelerated, max_iter=12, e_rel=1e-9)
+    assert np.array_equal(A, Ac) and np.array_equal(S, Sc)
+    if not accelerated:
+        A, S = A0.copy(), S0.copy()
+        pm.nmf.nmf(Y, A, S, backtracking=True, f=f, max_iter=8, e_rel=1e-9)
+        Ao, So = A0.copy(), S0.copy()
+        orc.pgm_nmf(Y, Ao, So, backtracking=True, max_iter=8, e_rel=1e-9)
+        _close(A, Ao, rtol=1e-8)
+        _close(S, So, rtol=1e-8)
+
+
+def test_the_references_example_in_its_own_dtype(pm):
+    """examples/unmixing.py: float64 arrays, PGM with backtracking to convergence.  tests/golden/unmixing.npz holds the reference's final loss and
+    iteration count; in fp32 the library lands within 0.5 % / 15 % of them (tests/test_gpu_nmf.py), in fp64 on them."""
+    from conftest import load_golden
+    from test_gpu_nmf import spec_to_prox
+    z, meta = load_golden("unmixing.npz")
+    Y, A0, S0 = z["Y"].astype(np.float64), z["A0"].astype(np.float64), z["S0"].astype(np.float64)
+    done = 0
+    for r in meta["runs"]:
+        if r["cfg"] is not None or r["mode"] != "nmf":
+            continue
+        A, S = A0.copy(), S0.copy()
+        tb = pm.utils.Traceback()
+        pm.nmf.nmf(Y, A, S, prox_A=spec_to_prox(pm, tuple(r["prox_A"])), prox_S=spec_to_prox(pm, tuple(r["prox_S"])),
+                   backtracking=True, f=partial(pm.nmf.log_likelihood, Y=Y), e_rel=1e-4, max_iter=1000, callback=tb)
+        loss = pm.nmf.log_likelihood(A, S, Y=Y)
+        if z["Y"].dtype == np.float64:
+            assert len(tb.trace) == r["iters"], (len(tb.trace), r["iters"])
+            assert loss == pytest.approx(r["loss"], rel=1e-7)
+        else:                                  # (a fixture stored in fp32: the fp32 test's bounds)
+            assert abs(loss / r["loss"] - 1) < 5e-3 and abs(len(tb.trace) - r["iters"]) <= 0.15 * r["iters"]
+        done += 1
+    assert done >= 1
+
+
 @pytest.mark.parametrize("backend", ["pgm", "adaprox", "bsdmm"])
 def test_runs_are_bit_reproducible(pm, orc, backend):
     """no atomics, fixed summation order everywhere (slabs folded in order, partial sums folded in order): the same call gives the same bits"""
@@ -386,7 +446,7 @@ def test_a_float64_Y_that_lives_on_the_gpu(pm, orc):
     pm.nmf.nmf(torch.from_numpy(Y2).to("cuda:0"), Ad, Sd, max_iter=5)
     assert np.array_equal(Ah, Ad) and np.array_equal(Sh, Sd)
     with pytest.raises(NotImplementedError):                                               # what the fp64 kernels do not cover has no float64 device path
-        pm.nmf.nmf(Yd, A0.copy(), S0.copy(), backtracking=True, f=partial(pm.nmf.log_likelihood, Y=Y), max_iter=2)
+        pm.nmf.nmf(Yd, A0.copy(), S0.copy(), prox_A=lambda X, step: np.maximum(X, 0), max_iter=2)
 
 
 def test_switching_the_large_path_off_restores_the_fp32_computation_and_its_warning(pm, orc, monkeypatch, caplog):
