@@ -6,6 +6,9 @@
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifndef PMX_CHAIN_PF
+#define PMX_CHAIN_PF 4       // pieces of a chain's previous sum in flight (k_grad_f16_v8<.., RS>'s gA waves): all four requested behind the arrival check (profiles/r06_q_chain_prefetch_ab.txt); 0 = rounds 2-5
+#endif
 constexpr int V8_NPART = 256;                // partial maxima per factor
 
 __device__ __forceinline__ void v8_split2(const float4& x, float sc, f16x4& h, f16x4& l) {
@@ -613,6 +616,26 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
             sync();
             sync();
             int s = 2;
+            // [r6] The previous sum of the panel arrives in four pieces (accumulator registers 4 p .. 4 p + 3 of all four tiles), piece p added behind the MFMAs of
+            // slot 4 + p.  Requested in FRONT of those MFMAs (rounds 2-5) a piece had 24 MFMAs = ~0.4 us to arrive -- less than a round trip to the L2 under the
+            // stream of Y, and the consumers' pole waited for the rest in four slots of every panel (the 6 % the chains cost inside K1, profiles/r05_d_chain_length.txt).
+            // Now the pieces are requested PF at a time as soon as the arrival word has been seen (behind slot 3's MFMAs) and piece p + PF behind the add of piece p:
+            // a whole slot (barrier, operand reads, MFMAs) or more per round trip.  The adds stand where they stood: the same sums in the same order, bit for bit.
+            constexpr int PF = PMX_CHAIN_PF;          // pieces in flight (buffers of 16 registers): 0 = the old placement
+            static_assert(PF >= 0 && PF <= 4, "");
+            float pv[PF > 0 ? PF : 1][2][2][4];
+            auto fetch_piece = [&](int prow_, auto p_c) {
+                constexpr int p = decltype(p_c)::value;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float* pb = gA_tile(prow_, rt) + (8 * (p & 1) + 16 * (p >> 1)) * K;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pv[PF > 0 ? p % PF : 0][rt][0][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        pv[PF > 0 ? p % PF : 0][rt][1][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
+                }
+            };
 #pragma nounroll
             for (int rp = 0; rp < nrp; ++rp) {
                 const int pnl = panel_at(rp);
@@ -624,18 +647,14 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         __builtin_amdgcn_s_barrier();
                         if constexpr (CHAIN) link.open(pnl, chainPos, a.chainL, 1, nrp, a.chainBase, (a.doA & 1) != 0);
                     }
-                    float pv[2][2][4];
                     if constexpr (CHAIN) {
                         if (cb == 3) link.look();
-                        if (cb >= 4 && link.cadd) {   // piece cb - 4 of the previous sum: accumulator registers 4 (cb - 4) .. of all four tiles
-#pragma unroll
-                            for (int rt = 0; rt < 2; ++rt) {
-                                const float* pb = gA_tile(prow, rt) + (8 * ((cb - 4) & 1) + 16 * ((cb - 4) >> 1)) * K;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    pv[rt][0][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                                    pv[rt][1][q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)(pb + q * K + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                                }
+                        if constexpr (PF == 0) {
+                            if (cb >= 4 && link.cadd) {
+                                if (cb == 4) fetch_piece(prow, std::integral_constant<int, 0>{});
+                                if (cb == 5) fetch_piece(prow, std::integral_constant<int, 1>{});
+                                if (cb == 6) fetch_piece(prow, std::integral_constant<int, 2>{});
+                                if (cb == 7) fetch_piece(prow, std::integral_constant<int, 3>{});
                             }
                         }
                     }
@@ -663,15 +682,31 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_v8(GradV4Args a) {
                         }
                     }
                     if constexpr (CHAIN) {
-                        if (cb == 3) link.wait();
+                        if (cb == 3) {
+                            link.wait();
+                            if constexpr (PF > 0) {
+                                if (link.cadd) {
+                                    fetch_piece(prow, std::integral_constant<int, 0>{});
+                                    if constexpr (PF > 1) fetch_piece(prow, std::integral_constant<int, 1>{});
+                                    if constexpr (PF > 2) fetch_piece(prow, std::integral_constant<int, 2>{});
+                                    if constexpr (PF > 3) fetch_piece(prow, std::integral_constant<int, 3>{});
+                                }
+                            }
+                        }
                         if (cb >= 4 && link.cadd) {
+                            const int b_ = PF > 0 ? (cb - 4) % PF : 0;
 #pragma unroll
                             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    accA[rt][0][4 * (cb - 4) + q] += pv[rt][0][q] * invUnA;
-                                    accA[rt][1][4 * (cb - 4) + q] += pv[rt][1][q] * invUnA;
+                                    accA[rt][0][4 * (cb - 4) + q] += pv[b_][rt][0][q] * invUnA;
+                                    accA[rt][1][4 * (cb - 4) + q] += pv[b_][rt][1][q] * invUnA;
                                 }
+                            if constexpr (PF > 0 && PF < 4) {          // the buffer is free: the piece PF places on
+                                if (cb - 4 + PF == 1) fetch_piece(prow, std::integral_constant<int, 1>{});
+                                if (cb - 4 + PF == 2) fetch_piece(prow, std::integral_constant<int, 2>{});
+                                if (cb - 4 + PF == 3) fetch_piece(prow, std::integral_constant<int, 3>{});
+                            }
                         }
                     }
                     if (cb + 1 == NCB) {

@@ -28,6 +28,9 @@
 // place in the chain (2 where the region has the panels for it: the predecessor's sum is then a whole panel-time old when it
 // is asked for).  gA: one slab per CHAIN (N / 128 / chainL of them) instead of one per column region.
 // ------------------------------------------------------------------------------------------------
+#ifndef PMX_CHAIN_PF128
+#define PMX_CHAIN_PF128 0    // how far ahead the gA waves of <RS, CHAIN> request the pieces of a chain's previous sum (see the loop); the A/B builds set it
+#endif
 constexpr int W8_NCB = 4;
 constexpr int W8_S_HALF = 2 * V5_S_TERM;            // [h][l] images of one k half of a 32-column block
 constexpr int W8_SL_BYTES = 2 * W8_S_HALF;          // both halves: 16 KB per block
@@ -529,8 +532,38 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                 if constexpr (CHAIN) link.look();
                 consumeA(s - 2, c1{});
                 if constexpr (CHAIN) link.wait();
-                sync(); ++s;
-                if constexpr (CHAIN) {
+                // [r6] PMX_CHAIN_PF128: how far ahead of its add a piece of the previous sum is requested (the adds stand where they stood: same sums, same order).
+                //   0: in front of the half block of MFMAs it is added behind (rounds 4-5: 24 MFMAs = ~0.4 us per round trip)
+                //   1: one buffer, every piece requested as soon as the buffer is free -- the first behind the arrival check, the third behind the second's add
+                //   2: two buffers (+ 32 registers): two pieces in flight, a whole slot per round trip
+                if constexpr (CHAIN && PMX_CHAIN_PF128 == 2) {
+                    float pa[32], pb[32];
+                    if (link.cadd) { chain_fetch(prow, 0, 0, pa); chain_fetch(prow, 0, 1, pb); }
+                    sync(); ++s;
+                    consumeA_ks(s - 2, c2{}, c0{});
+                    if (link.cadd) { chain_add(0, 0, pa); chain_fetch(prow, 1, 0, pa); }
+                    consumeA_ks(s - 2, c2{}, c1{});
+                    if (link.cadd) { chain_add(0, 1, pb); chain_fetch(prow, 1, 1, pb); }
+                    sync(); ++s;
+                    consumeA_ks(s - 2, c3{}, c0{});
+                    if (link.cadd) chain_add(1, 0, pa);
+                    consumeA_ks(s - 2, c3{}, c1{});
+                    if (link.cadd) chain_add(1, 1, pb);
+                } else if constexpr (CHAIN && PMX_CHAIN_PF128 == 1) {
+                    float pv[32];
+                    if (link.cadd) chain_fetch(prow, 0, 0, pv);
+                    sync(); ++s;
+                    consumeA_ks(s - 2, c2{}, c0{});
+                    if (link.cadd) { chain_add(0, 0, pv); chain_fetch(prow, 0, 1, pv); }
+                    consumeA_ks(s - 2, c2{}, c1{});
+                    if (link.cadd) { chain_add(0, 1, pv); chain_fetch(prow, 1, 0, pv); }
+                    sync(); ++s;
+                    consumeA_ks(s - 2, c3{}, c0{});
+                    if (link.cadd) { chain_add(1, 0, pv); chain_fetch(prow, 1, 1, pv); }
+                    consumeA_ks(s - 2, c3{}, c1{});
+                    if (link.cadd) chain_add(1, 1, pv);
+                } else if constexpr (CHAIN) {
+                    sync(); ++s;
                     float pv[32];
                     if (link.cadd) chain_fetch(prow, 0, 0, pv);
                     consumeA_ks(s - 2, c2{}, c0{});
@@ -544,6 +577,7 @@ __global__ __launch_bounds__(V5_THREADS, 2) void k_grad_f16_k128(GradK128Args a)
                     consumeA_ks(s - 2, c3{}, c1{});
                     if (link.cadd) chain_add(1, 1, pv);
                 } else {
+                    sync(); ++s;
                     consumeA(s - 2, c2{}); sync(); ++s;
                     consumeA(s - 2, c3{});
                 }
