@@ -177,6 +177,14 @@ def measured_on_this_box(local):
         out["energy_floor_ms"] = ms["stream_8B+mfma28_random_lds"]
         out["energy_floor_ms_16B_fetch"] = ms["stream_16B+mfma28_random_lds"]
         out["energy_floor_with_epilogue_ms"] = ms["stream_8B+mfma28_random_lds+epilogue"]
+        # [r6] the same skeleton for the two other K1 shapes the line quotes: cfg4's 8192-row share at K = 128 (8 + 48 MFMAs per producer + consumer wave and block:
+        # the HBM roof is the wrong ruler at 192 flop per byte) and a one-gradient pass at K = 64 (bsdmm: 4 + 12)
+        try:
+            out["energy_floor_k128_share8192_ms"] = call(lib.pmxf_stream, local, 3011, 8192, 16384, 0, 20)
+            out["mfma56_random_lds_share8192_ms"] = call(lib.pmxf_stream, local, 3013, 8192, 16384, 0, 20)
+            out["energy_floor_one_gradient_pass_ms"] = call(lib.pmxf_stream, local, 4011, M, N, 0, 20)
+        except Exception as exc:                  # (an older libpmx_floor.so without these variants)
+            out["energy_floor_other_shapes_error"] = repr(exc)
         out["note"] = ("measured on this GPU just before the headline, random data, 2 x 20 launches each after a warm pass; skeleton = K1's grid / region map / barrier per "
                        "128 x 32 block / 4 + 24 MFMAs per producer + consumer wave and block, no gradient computed (proxmin_amd/csrc/bench_floor.hip)")
     except Exception as exc:                      # a side measurement must never take the headline down
@@ -487,6 +495,11 @@ def main():
             except Exception as exc:
                 side[key] = {"error": repr(exc)}
         side["other_configs"] = other_configs(Y, local)
+        for cfg_name, key in (("cfg4_share8192", "energy_floor_k128_share8192_ms"), ("cfg5", "energy_floor_one_gradient_pass_ms")):
+            oc, fl = side["other_configs"].get(cfg_name, {}), side["measured"].get(key)
+            if fl and oc.get("k1_ms"):           # K1 against the floor of ITS job (stream + its own MFMA count on random operands, under this package's cap)
+                oc["energy_floor_ms"] = fl
+                oc["frac_of_energy_floor"] = fl / oc["k1_ms"]
         side["nmf_call"] = nmf_call_leg(Y, A0, S0, unity)
 
     assert proxmin_amd.get_default_mode() == proxmin_amd.LIBRARY_DEFAULT_MODE or os.environ.get("PMX_MODE"), "bench.py must not change the library's default mode"

@@ -298,7 +298,7 @@ static int time_launches(Kern kern, int lds, int grid, int reps, const float* Y,
 extern "C" const char* pmxf_last_error() { return g_err; }
 
 // K1's skeleton on a fresh M x N fp32 matrix (M % 2048 == 0, N % 2048 == 0; 16384 x 16384 = cfg3), average ms per launch over 2 x reps launches.
-// variant = fetch + 10 * ops + 100 * epi + 1000 * mfma   (fetch 0..3 as FETCH; ops 0 / 2; epi 0 / 1; mfma 0: none, 1: today's 4 + 24, 2: round 3's 12 + 24)
+// variant = fetch + 10 * ops + 100 * epi + 1000 * mfma   (fetch 0..3 as FETCH; ops 0 / 2; epi 0 / 1; mfma 0: none, 1: today's 4 + 24, 2: round 3's 12 + 24, 3: K = 128's 8 + 48, 4: a one-gradient pass's 4 + 12)
 extern "C" int pmxf_stream(int device, int variant, int M, int N, int zero_data, int reps, double* ms) {
     if (!ms || M <= 0 || N <= 0 || M % 2048 || N % 2048 || reps <= 0) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
     FCHECK(hipSetDevice(device));
@@ -328,6 +328,9 @@ extern "C" int pmxf_stream(int device, int variant, int M, int N, int zero_data,
     case 1012: VAR(2, 4, 12, 2, false); break;
     case 1111: VAR(1, 4, 12, 2, true); break;    // + an epilogue's VALU and LDS stores
     case 1112: VAR(2, 4, 12, 2, true); break;
+    case 3011: VAR(1, 8, 24, 2, false); break;   // [r6] K = 128 (k_grad_f16_k128<HH, RS>): 8 + 48 MFMAs per producer + consumer wave and 128 x 32 block
+    case 3013: VAR(3, 8, 24, 2, false); break;   //      ... its MFMAs alone
+    case 4011: VAR(1, 4, 6, 2, false); break;    // [r6] a one-gradient pass at K = 64 (bsdmm's K1s): 4 + 12
     case 2001: VAR(1, 12, 12, 0, false); break;  // round 3's 36 MFMAs (mode f16x2), for continuity with profiles/r03_a_ystream2_sweep.txt
     case 2002: VAR(2, 12, 12, 0, false); break;
     default: snprintf(g_err, sizeof g_err, "unknown variant %d", variant); rc = -1;
