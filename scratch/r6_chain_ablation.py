@@ -7,7 +7,7 @@ import torch
 import bench
 from proxmin_amd.engine import DeviceNMF
 M, N, K = (16384, 16384, 64) if len(sys.argv) < 2 else tuple(int(x) for x in sys.argv[1].split("x"))
-Y, A0, S0 = bench.make_problem_device(M, N, K, True, 1234, torch.device("cuda", 0))
+Y, A0, S0 = bench.make_problem_device(M, N, K, K == 64, 1234, torch.device("cuda", 0))
 dev = DeviceNMF(M, N, K, device=0, mode="f16x2r")
 dev.set_Y_device(Y.data_ptr(), ld=N, copy=False, keepalive=Y)
 dev.set_factors(A0, S0)
